@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py — quadrature-points/s of the fused von Mises return-map + consistent tangent on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic quadrature data already resident in
+HBM: the kernel behind `external_function((1,))(deps)` (dxo_von_mises, device pointers) and, for N > 1,
+the RCCL all-gather that reassembles the flat coefficient vectors (BASELINE north_star).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nqp POINTS_PER_GPU] [--d 6]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (named in config.workload): 3-D hex mesh, 8 quadrature points per cell (degree-2 rule), Mandel
+d = 6, fp64; 1 250 000 cells = 10^7 quadrature points per GPU — the size BASELINE.json's north_star quotes
+the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, small enough that its 104 MB of
+inputs stay in the 256 MB Infinity Cache between steps; it is reported too, under "also"). Scaling is weak:
+every rank owns its own cell block of 10^7 points (config 3 is 1.25*10^7 per GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import statistics
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_QP = {4: 240, 6: 448}  # algorithmic fp64 traffic per point, SURVEY.md 8(d)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def synth_inputs(torch, n, d, seed, device):
+    """deps ~ N(0, 3e-3) (Mandel shear x sqrt 2), sigma_n ~ N(0, 100), p = |N(0, 1e-3)|."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    deps = torch.randn(n, d, generator=g, device=device, dtype=torch.float64) * 3e-3
+    deps[:, 3:] *= 2.0 ** 0.5
+    sigma_n = torch.randn(n, d, generator=g, device=device, dtype=torch.float64) * 100.0
+    p = (torch.randn(n, generator=g, device=device, dtype=torch.float64) * 1e-3).abs()
+    return deps.contiguous(), sigma_n.contiguous(), p.contiguous()
+
+
+def cpu_baseline(d, n_sample, budget_s=12.0):
+    """Time the CPU oracle (oracle/dxo_oracle.c, a statement-by-statement port of the reference's
+    Numba kernel, OpenMP over points) on this host, on a bounded sample of the same distribution."""
+    import numpy as np
+
+    from oracle import load_oracle
+
+    o = load_oracle()
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rng = np.random.Generator(np.random.PCG64(1))
+    deps = rng.normal(0.0, 3e-3, size=(n_sample, d))
+    deps[:, 3:] *= np.sqrt(2.0)
+    sigma_n = rng.normal(0.0, 100.0, size=(n_sample, d))
+    p = np.abs(rng.normal(0.0, 1e-3, size=n_sample))
+    o.von_mises(deps[:1000], sigma_n[:1000], p[:1000], nthreads=threads)  # thread-pool warm-up
+    rates, t_all = [], time.perf_counter()
+    while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 40):
+        t0 = time.perf_counter()
+        o.von_mises(deps, sigma_n, p, nthreads=threads)
+        rates.append(n_sample / (time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    n1 = max(n_sample // 8, 1000)
+    o.von_mises(deps[:n1], sigma_n[:n1], p[:n1], nthreads=1)
+    one_core = n1 / (time.perf_counter() - t0)
+    return {
+        "value": statistics.median(rates), "unit": "qp/s", "cores": threads, "kind": "port",
+        "sample": f"{n_sample} points x {len(rates)} passes (median), d={d}, same distribution, "
+                  f"oracle/dxo_oracle.c OpenMP incl. output allocation",
+        "value_1core": one_core,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nqp", type=int, default=10_000_000, help="quadrature points per GPU")
+    ap.add_argument("--d", type=int, default=6, choices=(4, 6))
+    ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
+    ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--nontemporal", type=int, default=-1)
+    ap.add_argument("--blocks-per-cu", type=int, default=-1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to benchmark (only the cpu_baseline leg uses the oracle)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
+    from dolfinx_external_operator_amd._build import build_library
+    from dolfinx_external_operator_amd.sharding import WAVE_TILE, all_gather_flat_into
+
+    if rank == 0:
+        build_library()
+    if world > 1:
+        dist.barrier()
+
+    d, K, W = args.d, args.steps, args.warmup
+    n = (args.nqp + WAVE_TILE - 1) // WAVE_TILE * WAVE_TILE  # shard borders on wave tiles
+    gather = (world > 1) if args.gather < 0 else bool(args.gather)
+    E, nu, sigma_0 = 70e3, 0.3, 250.0
+    H = E * (E / 100.0) / (E - E / 100.0)
+    prm = VmParams(E, nu, sigma_0, H)
+
+    ctx = Context(local_rank)
+    info = ctx.device_info()
+    ctx.set_option("vm_variant", args.variant)
+    if args.nontemporal >= 0:
+        ctx.set_option("nontemporal", args.nontemporal)
+    if args.blocks_per_cu >= 0:
+        ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    stream = torch.cuda.current_stream(device)
+    ctx.set_stream(stream.cuda_stream)
+
+    seed = 1 if world == 1 else 100 + rank
+    deps, sigma_n, p = synth_inputs(torch, n, d, seed, device)
+    C_tang = torch.empty(n * d * d, dtype=torch.float64, device=device)
+    sigma = torch.empty(n * d, dtype=torch.float64, device=device)
+    dp = torch.empty(n, dtype=torch.float64, device=device)
+    full = None
+    if gather and world > 1:
+        full = [torch.empty(world * t.numel(), dtype=torch.float64, device=device) for t in (C_tang, sigma, dp)]
+
+    ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs)
+        if ev is not None:
+            ev[1].record(stream)
+        if full is not None:
+            for out, loc in zip(full, (C_tang, sigma, dp)):
+                all_gather_flat_into(out, loc)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(W):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms_avg], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
+    else:
+        kernel_ms_avg_max = kernel_ms_avg
+
+    # quick correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface
+    s_chk = sigma.view(n, d)[:4096]
+    dev_chk = s_chk.clone()
+    dev_chk[:, :3] -= s_chk[:, :3].mean(dim=1, keepdim=True)
+    f_chk = (1.5 * (dev_chk * dev_chk).sum(1)).sqrt() - sigma_0 - H * (p[:4096] + dp[:4096])
+    plastic = dp[:4096] > 0
+    if plastic.any() and float(f_chk[plastic].abs().max()) > 1e-8 * sigma_0:
+        raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
+    if full is not None:
+        lo = rank * C_tang.numel()
+        if not torch.equal(full[0][lo:lo + 1024], C_tang[:1024]):
+            raise SystemExit("bench: gathered C_tang does not contain this rank's block")
+
+    total_points = n * world
+    value = total_points * K / elapsed
+    bytes_per_launch = BYTES_PER_QP[d] * n
+    achieved = bytes_per_launch / (kernel_ms_avg_max * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                if tj.get("points_per_launch") == n and tj.get("d") == d:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "quadrature-points/sec (von Mises return-map + tangent)",
+            "value": value, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
+                            f"{n // args.nq} cells = {n} quadrature points per GPU, fp64, cell-block sharded"
+                            + (", RCCL all-gather of (C_tang, sigma, dp) every step" if full is not None else ""),
+                "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
+                "sharding": "cell-block" if world > 1 else "none",
+                "gather": "rccl_all_gather" if full is not None else "none",
+                "kernel": "vm_tile" if args.variant else "vm_point",
+                "device": info["name"], "arch": info["arch"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
+                "kernel_ms_avg": kernel_ms_avg_max, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bytes_per_qp": BYTES_PER_QP[d],
+            },
+            "kernel_only_value": total_points / (kernel_ms_avg_max * 1e-3),
+        }
+
+    # secondary sizes, N = 1 only, outside the timed region
+    if world == 1 and rank == 0:
+        also = {}
+        n2 = 1_000_000
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for _ in range(W):
+            ctx.von_mises(prm, d, n2, MEM_DEVICE, *ptrs)
+        for a, b in ev:
+            a.record(stream)
+            ctx.von_mises(prm, d, n2, MEM_DEVICE, *ptrs)
+            b.record(stream)
+        torch.cuda.synchronize(device)
+        ms2 = statistics.mean(a.elapsed_time(b) for a, b in ev)
+        also["config2_1e6_points"] = {"qp_per_s": n2 / (ms2 * 1e-3), "kernel_ms": ms2,
+                                      "GBps": BYTES_PER_QP[d] * n2 / (ms2 * 1e-3) / 1e9,
+                                      "note": "448 MB working set; inputs (104 MB) stay in the 256 MB Infinity Cache"}
+        # PCIe-inclusive end-to-end through the host entry point (never `value`)
+        import numpy as np
+        nh = 1_000_000
+        hd, hs, hp = (t[:nh].cpu().numpy() for t in (deps, sigma_n, p))
+        oC, os_, odp = np.empty(nh * d * d), np.empty(nh * d), np.empty(nh)
+        from dolfinx_external_operator_amd import MEM_HOST
+        ctx.von_mises(prm, d, nh, MEM_HOST, hd, hs, hp, oC, os_, odp)
+        t1 = time.perf_counter()
+        ctx.von_mises(prm, d, nh, MEM_HOST, hd, hs, hp, oC, os_, odp)
+        also["host_end_to_end_1e6_points"] = {"qp_per_s": nh / (time.perf_counter() - t1), **ctx.last_timing(),
+                                              "note": "pageable NumPy arrays, H2D + kernel + D2H, PCIe-inclusive"}
+        result["also"] = also
+        if not args.no_cpu:
+            del C_tang, sigma, dp
+            result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

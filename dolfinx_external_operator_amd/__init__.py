@@ -1,0 +1,25 @@
+"""dolfinx_external_operator_amd — MI355X (gfx950) kernels behind dolfinx-external-operator's
+`FEMExternalOperator.external_function` callback.
+
+Product path: `operators.make_*` -> ctypes (`_lib`) -> libdxo_hip.so (hand-written HIP, include/dxo.h).
+There is no CPU fallback; `oracle/` is test infrastructure and is never imported from here.
+"""
+from ._lib import MEM_DEVICE, MEM_HOST, Context, DxoError, VmParams, default_context, load_library
+from .evaluation import (
+    Coefficient,
+    Operand,
+    QuadratureExternalOperator,
+    evaluate_external_operators,
+    evaluate_operands,
+    get_unrolled_dofmap,
+)
+from .operators import make_heat, make_von_mises
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "Context", "DxoError", "VmParams", "MEM_HOST", "MEM_DEVICE", "default_context", "load_library",
+    "make_von_mises", "make_heat",
+    "QuadratureExternalOperator", "Operand", "Coefficient",
+    "evaluate_operands", "evaluate_external_operators", "get_unrolled_dofmap",
+]

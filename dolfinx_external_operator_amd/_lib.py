@@ -1,0 +1,214 @@
+"""ctypes binding of libdxo_hip.so (the C ABI declared in include/dxo.h).
+
+There is deliberately no CPU fallback: if the HIP library cannot be loaded, or no GPU context
+can be created, the operators raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import threading
+
+import numpy as np
+
+PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = PKG / "libdxo_hip.so"
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+ERRORS = {
+    -1: "DXO_E_NULL", -2: "DXO_E_DIM", -3: "DXO_E_SIZE", -4: "DXO_E_MEM",
+    -5: "DXO_E_ALIGN", -6: "DXO_E_OPTION", -7: "DXO_E_NODEVICE",
+}
+
+
+class VmParams(C.Structure):
+    """dxo_vm_params — demo_plasticity_von_mises.py:185-188."""
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("sigma_0", C.c_double), ("H", C.c_double)]
+
+
+class McParams(C.Structure):
+    """dxo_mc_params — demo_plasticity_mohr_coulomb.py:110-116, 469."""
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("c", C.c_double), ("phi", C.c_double),
+                ("psi", C.c_double), ("theta_T", C.c_double), ("a", C.c_double), ("tol", C.c_double),
+                ("nitermax", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
+                ("wavefront_size", C.c_int32), ("total_mem_bytes", C.c_int64)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "dxo_abi_version": (C.c_int, []),
+    "dxo_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dxo_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "dxo_ctx_destroy": (C.c_int, [_P]),
+    "dxo_last_error": (C.c_char_p, [_P]),
+    "dxo_ctx_device_info": (C.c_int, [_P, C.POINTER(DeviceInfo)]),
+    "dxo_ctx_set_stream": (C.c_int, [_P, _P]),
+    "dxo_ctx_synchronize": (C.c_int, [_P]),
+    "dxo_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "dxo_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "dxo_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
+    "dxo_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "dxo_host_free": (C.c_int, [_P, _P]),
+    "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
+    "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class DxoError(RuntimeError):
+    pass
+
+
+def load_library(path: str | pathlib.Path | None = None) -> C.CDLL:
+    """dlopen libdxo_hip.so and type every entry point. Raises if the library is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = pathlib.Path(path) if path is not None else LIB_PATH
+        if not p.exists():
+            raise DxoError(
+                f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the quadrature-point kernels."
+            )
+        lib = C.CDLL(str(p))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dxo_abi_version() != 1:
+            raise DxoError(f"ABI version mismatch: library {lib.dxo_abi_version()}, binding 1")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def declared_symbols() -> list[str]:
+    return list(_SIGNATURES)
+
+
+def _ptr(a) -> int | None:
+    """Address of a NumPy array, a raw int address, or None."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return int(a)
+    return a.ctypes.data
+
+
+class Context:
+    """One dxo_ctx: a (process, GPU) pair owning streams and device scratch."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _P()
+        rc = self.lib.dxo_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise DxoError(
+                f"dxo_ctx_create(device={device}) failed with {ERRORS.get(rc, rc)}: no usable MI355X/HIP device. "
+                "The HIP path is the only implementation; it does not fall back to the CPU."
+            )
+        self._h = h
+        self.device = int(device)
+        self._pinned: list[tuple[int, np.ndarray]] = []
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def check(self, rc: int, what: str) -> None:
+        if rc == 0:
+            return
+        msg = self.lib.dxo_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc < 0:
+            raise ValueError(f"{what}: {ERRORS.get(rc, rc)}: {msg}")
+        raise DxoError(f"{what}: HIP error {rc}: {msg}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            for addr, _ in self._pinned:
+                self.lib.dxo_host_free(self._h, _P(addr))
+            self._pinned.clear()
+            self.lib.dxo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, key: str, value: int) -> None:
+        self.check(self.lib.dxo_ctx_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        self.check(self.lib.dxo_ctx_get_option(self._h, key.encode(), C.byref(v)), f"get_option({key})")
+        return v.value
+
+    def set_stream(self, stream_handle: int | None) -> None:
+        self.check(self.lib.dxo_ctx_set_stream(self._h, _P(stream_handle)), "set_stream")
+
+    def synchronize(self) -> None:
+        self.check(self.lib.dxo_ctx_synchronize(self._h), "synchronize")
+
+    def device_info(self) -> dict:
+        info = DeviceInfo()
+        self.check(self.lib.dxo_ctx_device_info(self._h, C.byref(info)), "device_info")
+        return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+                "wavefront_size": info.wavefront_size, "total_mem_bytes": info.total_mem_bytes}
+
+    def last_timing(self) -> dict:
+        t = Timing()
+        self.check(self.lib.dxo_last_timing(self._h, C.byref(t)), "last_timing")
+        return {"h2d_ms": t.h2d_ms, "kernel_ms": t.kernel_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms}
+
+    def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """NumPy array backed by hipHostMalloc memory owned by this context."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        p = _P()
+        self.check(self.lib.dxo_host_alloc(self._h, n * dtype.itemsize, C.byref(p)), "host_alloc")
+        buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+        self._pinned.append((p.value, arr))
+        return arr
+
+    # -- kernels -------------------------------------------------------------------------------
+    def von_mises(self, prm: VmParams, d: int, n: int, mem: int, deps, sigma_n, p, C_tang, sigma, dp) -> None:
+        rc = self.lib.dxo_von_mises(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(deps), _ptr(sigma_n),
+                                    _ptr(p), _ptr(C_tang), _ptr(sigma), _ptr(dp))
+        self.check(rc, "dxo_von_mises")
+
+    def heat(self, A: float, B: float, gdim: int, n: int, mem: int, T, sigma, q, dqdT, dqdsigma) -> None:
+        rc = self.lib.dxo_heat(self._h, float(A), float(B), int(gdim), int(n), int(mem), _ptr(T), _ptr(sigma),
+                               _ptr(q), _ptr(dqdT), _ptr(dqdsigma))
+        self.check(rc, "dxo_heat")
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx._h is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,89 @@
+// dxo_common.h — internal declarations shared by the HIP translation units of libdxo_hip.so.
+// Not part of the ABI (that is include/dxo.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dxo.h"
+
+typedef double dxo_f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int DXO_WAVE = 64;          // gfx950 wavefront
+constexpr int DXO_BLOCK = 256;        // 4 waves per workgroup
+constexpr int DXO_HOST_SLOTS = 3;     // H2D / kernel / D2H pipeline depth
+
+struct dxo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // library-owned compute stream
+    hipStream_t user_stream = nullptr;  // borrowed (dxo_ctx_set_stream)
+    bool use_user_stream = false;
+    hipStream_t slot_stream[DXO_HOST_SLOTS] = {nullptr, nullptr, nullptr};
+    void* slot_buf[DXO_HOST_SLOTS] = {nullptr, nullptr, nullptr};
+    size_t slot_bytes = 0;              // capacity of each slot buffer
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_pending = false;            // device-path events recorded, not yet read
+    int compute_units = 256;
+    // options
+    int64_t vm_variant = 1;
+    int64_t host_chunk_points = 1 << 18;
+    int64_t nontemporal = 1;
+    int64_t timing = 0;
+    int64_t blocks_per_cu = 0;          // 0: one wave-tile per wave (no grid stride)
+    dxo_timing last = {0, 0, 0, 0};
+    std::string err;
+};
+
+inline hipStream_t dxo_launch_stream(dxo_ctx* c) { return c->use_user_stream ? c->user_stream : c->stream; }
+
+inline int dxo_fail(dxo_ctx* c, int code, const char* what) {
+    if (c) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "%s (code %d)", what, code);
+        c->err = buf;
+    }
+    return code;
+}
+
+inline int dxo_hip_fail(dxo_ctx* c, hipError_t e, const char* where) {
+    if (c) {
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s: %s (hipError %d)", where, hipGetErrorString(e), (int)e);
+        c->err = buf;
+    }
+    return (int)e > 0 ? (int)e : 999;
+}
+
+#define DXO_HIP(ctx, call)                                             \
+    do {                                                               \
+        hipError_t _e = (call);                                        \
+        if (_e != hipSuccess) return dxo_hip_fail((ctx), _e, #call);   \
+    } while (0)
+
+// One array of a pointwise map: host/device base pointer and bytes per quadrature point.
+struct dxo_span {
+    const void* in = nullptr;   // for inputs
+    void* out = nullptr;        // for outputs
+    size_t bytes_pp = 0;
+};
+
+// Launch callback for the chunked host pipeline: device pointers of the chunk, in the same
+// order as the spans that were passed, and the number of points in the chunk.
+typedef int (*dxo_chunk_launch)(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const* d_in,
+                                void* const* d_out, hipStream_t stream);
+
+// H2D -> kernel -> D2H, chunked over points and rotated over DXO_HOST_SLOTS streams so copies
+// of one chunk overlap the kernel of another. Blocks until every output byte is on the host.
+int dxo_run_host_pipeline(dxo_ctx* ctx, int64_t n, const std::vector<dxo_span>& inputs,
+                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user);
+
+// Device-path bracket: optional event timing around a launch sequence.
+int dxo_device_begin(dxo_ctx* ctx, hipStream_t s);
+int dxo_device_end(dxo_ctx* ctx, hipStream_t s);
+
+int dxo_grid_for_tiles(const dxo_ctx* ctx, int64_t n_tiles, int tiles_per_block);

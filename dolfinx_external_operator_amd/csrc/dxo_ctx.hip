@@ -1,0 +1,289 @@
+// dxo_ctx.hip — context, options, pinned host memory, the chunked host pipeline.
+// Host-side runtime of libdxo_hip.so; the kernels live in von_mises.hip / heat.hip / ...
+#include <chrono>
+
+#include "dxo_common.h"
+
+namespace {
+
+struct SlotEvents {
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};  // h2d start, kernel start, kernel end, d2h end
+    bool used = false;
+};
+
+size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int dxo_abi_version(void) { return DXO_ABI_VERSION; }
+
+int dxo_device_count(int* count) {
+    if (!count) return DXO_E_NULL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        (void)hipGetLastError();
+        return DXO_E_NODEVICE;
+    }
+    *count = n;
+    return DXO_OK;
+}
+
+int dxo_ctx_create(int device, dxo_ctx** out) {
+    if (!out) return DXO_E_NULL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        (void)hipGetLastError();
+        return DXO_E_NODEVICE;
+    }
+    dxo_ctx* c = new dxo_ctx();
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < DXO_HOST_SLOTS && e == hipSuccess; ++i)
+        e = hipStreamCreateWithFlags(&c->slot_stream[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        int code = dxo_hip_fail(nullptr, e, "dxo_ctx_create");
+        dxo_ctx_destroy(c);
+        return code;
+    }
+    c->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return DXO_OK;
+}
+
+int dxo_ctx_destroy(dxo_ctx* c) {
+    if (!c) return DXO_E_NULL;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < DXO_HOST_SLOTS; ++i) {
+        if (c->slot_buf[i]) (void)hipFree(c->slot_buf[i]);
+        if (c->slot_stream[i]) (void)hipStreamDestroy(c->slot_stream[i]);
+    }
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DXO_OK;
+}
+
+const char* dxo_last_error(const dxo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int dxo_ctx_device_info(dxo_ctx* c, dxo_device_info* info) {
+    if (!c || !info) return DXO_E_NULL;
+    hipDeviceProp_t prop;
+    DXO_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    std::memset(info, 0, sizeof *info);
+    std::strncpy(info->name, prop.name, sizeof info->name - 1);
+    std::strncpy(info->arch, prop.gcnArchName, sizeof info->arch - 1);
+    info->compute_units = prop.multiProcessorCount;
+    info->wavefront_size = prop.warpSize;
+    info->total_mem_bytes = (int64_t)prop.totalGlobalMem;
+    return DXO_OK;
+}
+
+int dxo_ctx_set_stream(dxo_ctx* c, void* hip_stream) {
+    if (!c) return DXO_E_NULL;
+    c->user_stream = (hipStream_t)hip_stream;
+    c->use_user_stream = true;  // NULL selects the legacy default stream explicitly
+    return DXO_OK;
+}
+
+int dxo_ctx_synchronize(dxo_ctx* c) {
+    if (!c) return DXO_E_NULL;
+    DXO_HIP(c, hipSetDevice(c->device));
+    DXO_HIP(c, hipStreamSynchronize(dxo_launch_stream(c)));
+    for (int i = 0; i < DXO_HOST_SLOTS; ++i) DXO_HIP(c, hipStreamSynchronize(c->slot_stream[i]));
+    return DXO_OK;
+}
+
+static int64_t* option_slot(dxo_ctx* c, const char* key) {
+    if (!std::strcmp(key, "vm_variant")) return &c->vm_variant;
+    if (!std::strcmp(key, "host_chunk_points")) return &c->host_chunk_points;
+    if (!std::strcmp(key, "nontemporal")) return &c->nontemporal;
+    if (!std::strcmp(key, "timing")) return &c->timing;
+    if (!std::strcmp(key, "blocks_per_cu")) return &c->blocks_per_cu;
+    return nullptr;
+}
+
+int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return DXO_E_NULL;
+    int64_t* slot = option_slot(c, key);
+    if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
+    if (value < 0) return dxo_fail(c, DXO_E_OPTION, "option value must be >= 0");
+    if (slot == &c->host_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "host_chunk_points < 64");
+    *slot = value;
+    return DXO_OK;
+}
+
+int dxo_ctx_get_option(dxo_ctx* c, const char* key, int64_t* value) {
+    if (!c || !key || !value) return DXO_E_NULL;
+    int64_t* slot = option_slot(c, key);
+    if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
+    *value = *slot;
+    return DXO_OK;
+}
+
+int dxo_last_timing(dxo_ctx* c, dxo_timing* t) {
+    if (!c || !t) return DXO_E_NULL;
+    if (c->ev_pending) {
+        DXO_HIP(c, hipEventSynchronize(c->ev_stop));
+        float ms = 0.f;
+        DXO_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        c->last = {0.0, (double)ms, 0.0, (double)ms};
+        c->ev_pending = false;
+    }
+    *t = c->last;
+    return DXO_OK;
+}
+
+int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
+    if (!c || !ptr) return DXO_E_NULL;
+    if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
+    *ptr = nullptr;
+    DXO_HIP(c, hipSetDevice(c->device));
+    DXO_HIP(c, hipHostMalloc(ptr, bytes > 0 ? (size_t)bytes : 1, hipHostMallocDefault));
+    return DXO_OK;
+}
+
+int dxo_host_free(dxo_ctx* c, void* ptr) {
+    if (!c) return DXO_E_NULL;
+    if (!ptr) return DXO_OK;
+    DXO_HIP(c, hipHostFree(ptr));
+    return DXO_OK;
+}
+
+}  // extern "C"
+
+int dxo_device_begin(dxo_ctx* c, hipStream_t s) {
+    DXO_HIP(c, hipSetDevice(c->device));
+    if (c->timing) DXO_HIP(c, hipEventRecord(c->ev_start, s));
+    return DXO_OK;
+}
+
+int dxo_device_end(dxo_ctx* c, hipStream_t s) {
+    DXO_HIP(c, hipGetLastError());
+    if (c->timing) {
+        DXO_HIP(c, hipEventRecord(c->ev_stop, s));
+        c->ev_pending = true;
+    }
+    return DXO_OK;
+}
+
+int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {
+    int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    if (blocks < 1) blocks = 1;
+    if (c->blocks_per_cu > 0) {
+        int64_t cap = (int64_t)c->compute_units * c->blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+    }
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    return (int)blocks;
+}
+
+int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& inputs,
+                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user) {
+    DXO_HIP(c, hipSetDevice(c->device));
+    c->last = {0, 0, 0, 0};
+    c->ev_pending = false;
+    if (n == 0) return DXO_OK;
+    int64_t chunk = c->host_chunk_points;
+    if (chunk > n) chunk = n;
+    if (chunk < n) chunk = chunk / DXO_WAVE * DXO_WAVE;  // interior chunk borders on whole wave tiles
+    // slot layout: every span starts on a 256-byte border
+    size_t need = 0;
+    for (const auto& s : inputs) need += round_up(s.bytes_pp * (size_t)chunk, 256);
+    for (const auto& s : outputs) need += round_up(s.bytes_pp * (size_t)chunk, 256);
+    if (need > c->slot_bytes) {
+        for (int i = 0; i < DXO_HOST_SLOTS; ++i) {
+            DXO_HIP(c, hipStreamSynchronize(c->slot_stream[i]));
+            if (c->slot_buf[i]) DXO_HIP(c, hipFree(c->slot_buf[i]));
+            c->slot_buf[i] = nullptr;
+        }
+        c->slot_bytes = 0;
+        for (int i = 0; i < DXO_HOST_SLOTS; ++i) DXO_HIP(c, hipMalloc(&c->slot_buf[i], need));
+        c->slot_bytes = need;
+    }
+    SlotEvents ev[DXO_HOST_SLOTS];
+    int rc = DXO_OK;
+    auto destroy_events = [&]() {
+        for (auto& s : ev)
+            for (auto& e : s.e)
+                if (e) (void)hipEventDestroy(e);
+    };
+    for (auto& s : ev)
+        for (auto& e : s.e) {
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) {
+                destroy_events();
+                return dxo_hip_fail(c, err, "hipEventCreate");
+            }
+        }
+    auto harvest = [&](int slot) -> int {
+        if (!ev[slot].used) return DXO_OK;
+        DXO_HIP(c, hipEventSynchronize(ev[slot].e[3]));
+        float a = 0, b = 0, d = 0;
+        DXO_HIP(c, hipEventElapsedTime(&a, ev[slot].e[0], ev[slot].e[1]));
+        DXO_HIP(c, hipEventElapsedTime(&b, ev[slot].e[1], ev[slot].e[2]));
+        DXO_HIP(c, hipEventElapsedTime(&d, ev[slot].e[2], ev[slot].e[3]));
+        c->last.h2d_ms += a;
+        c->last.kernel_ms += b;
+        c->last.d2h_ms += d;
+        ev[slot].used = false;
+        return DXO_OK;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<void*> d_in(inputs.size()), d_out(outputs.size());
+    int64_t done = 0;
+    for (int64_t i = 0; done < n && rc == DXO_OK; ++i) {
+        const int slot = (int)(i % DXO_HOST_SLOTS);
+        const int64_t m = (n - done < chunk) ? (n - done) : chunk;
+        hipStream_t s = c->slot_stream[slot];
+        if ((rc = harvest(slot)) != DXO_OK) break;
+        char* base = (char*)c->slot_buf[slot];
+        size_t off = 0;
+        hipError_t e = hipEventRecord(ev[slot].e[0], s);
+        for (size_t k = 0; k < inputs.size() && e == hipSuccess; ++k) {
+            d_in[k] = base + off;
+            off += round_up(inputs[k].bytes_pp * (size_t)chunk, 256);
+            e = hipMemcpyAsync(d_in[k], (const char*)inputs[k].in + (size_t)done * inputs[k].bytes_pp,
+                               inputs[k].bytes_pp * (size_t)m, hipMemcpyHostToDevice, s);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev[slot].e[1], s);
+        if (e != hipSuccess) { rc = dxo_hip_fail(c, e, "host pipeline H2D"); break; }
+        for (size_t k = 0; k < outputs.size(); ++k) {
+            d_out[k] = base + off;
+            off += round_up(outputs[k].bytes_pp * (size_t)chunk, 256);
+        }
+        rc = launch(c, user, m, d_in.data(), d_out.data(), s);
+        if (rc != DXO_OK) break;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ev[slot].e[2], s);
+        for (size_t k = 0; k < outputs.size() && e == hipSuccess; ++k) {
+            if (!outputs[k].out) continue;
+            e = hipMemcpyAsync((char*)outputs[k].out + (size_t)done * outputs[k].bytes_pp, d_out[k],
+                               outputs[k].bytes_pp * (size_t)m, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev[slot].e[3], s);
+        if (e != hipSuccess) { rc = dxo_hip_fail(c, e, "host pipeline D2H"); break; }
+        ev[slot].used = true;
+        done += m;
+    }
+    for (int slot = 0; slot < DXO_HOST_SLOTS; ++slot) {
+        int r2 = harvest(slot);
+        if (rc == DXO_OK) rc = r2;
+        hipError_t e = hipStreamSynchronize(c->slot_stream[slot]);
+        if (rc == DXO_OK && e != hipSuccess) rc = dxo_hip_fail(c, e, "host pipeline sync");
+    }
+    destroy_events();
+    c->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}

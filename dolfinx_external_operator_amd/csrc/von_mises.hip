@@ -1,0 +1,315 @@
+// von_mises.hip — von Mises radial return + consistent tangent, fused (C_tang, sigma, dp).
+//
+// Algorithm: the reference's per-point `_kernel`, doc/demo/demo_plasticity_von_mises.py:307-326
+// (constants :185-204, batched caller return_mapping :298-332, wrapper C_tang_impl :343-352).
+//
+// Roofline: HBM. Algorithmic traffic per quadrature point (fp64):
+//   d = 4: read 4+4+1, write 16+4+1 doubles = 240 B      d = 6: read 6+6+1, write 36+6+1 = 448 B
+// against ~150 flop — < 1 flop/B, so the design goal is: every global access a fully coalesced
+// 16 B/lane (1 KiB per wave-instruction) transaction, nothing read or written twice.
+//
+// Two kernels:
+//   vm_point  (variant 0)  one lane = one point, strided 8-byte AoS accesses. Needs only 8-byte
+//                          alignment; the fallback and the on-GPU cross-check of variant 1.
+//   vm_tile   (variant 1)  one WAVE = one tile of 64 consecutive points.
+//     A  the tile's deps / sigma_n blocks (64*d contiguous doubles each) are fetched with
+//        lane-linear 16-byte loads, parked in the wave's private LDS slice and re-read
+//        point-per-lane (an AoS->per-lane transpose through LDS).
+//     B  each lane does the radial return of its own point in registers.
+//     C  sigma goes back through LDS to lane-linear 16-byte stores. For the d*d tangent the
+//        wave does NOT transpose 64*d*d doubles through LDS: each lane leaves only
+//        (n[0..d), a, b) — d+2 doubles — in LDS, and the wave then walks the tile's C_tang block
+//        in OUTPUT order: chunk q = it*64 + lane covers entries (pt, i, j0), (pt, i, j0+1) with
+//        pt = q / (d*d/2); the lane rebuilds both from C_elas(i,j) - a n_i n_j - b dev(i,j).
+//        LDS per wave: 7 KiB (d=6) / 5 KiB (d=4) instead of 18 KiB, so 16+ waves stay resident
+//        per CU, and every C_tang store instruction writes 1 KiB of consecutive bytes.
+//   No cross-wave communication, hence no __syncthreads(): LDS slices are wave-private and DS
+//   operations of one wave execute in order; only the compiler must be kept from reordering.
+#include "dxo_common.h"
+
+namespace {
+
+struct VmConst {
+    double lmbda, mu2, mu3;   // lambda, 2 mu, 3 mu
+    double sigma_0, H;
+    double mu3_H;             // 3 mu + H
+    double ratio;             // 3 mu / (3 mu + H)
+};
+
+VmConst make_const(const dxo_vm_params& p) {
+    VmConst c;
+    // demo_plasticity_von_mises.py:190-191
+    c.lmbda = p.E * p.nu / (1.0 + p.nu) / (1.0 - 2.0 * p.nu);
+    const double mu = p.E / 2.0 / (1.0 + p.nu);
+    c.mu2 = 2.0 * mu;
+    c.mu3 = 3 * mu;
+    c.sigma_0 = p.sigma_0;
+    c.H = p.H;
+    c.mu3_H = 3 * mu + p.H;
+    c.ratio = 3 * mu / (3 * mu + p.H);
+    return c;
+}
+
+// Per-point radial return. Outputs: sigma[D], dp, direction n[D], and the two scalars of the
+// tangent C_tang = C_elas - a n(x)n - b dev  (a = 3mu(3mu/(3mu+H) - beta), b = 2 mu beta).
+template <int D>
+__device__ __forceinline__ void vm_return_map(const VmConst& c, const double (&deps)[D], const double (&sn)[D],
+                                              double p, double (&sig)[D], double& dp, double (&nrm)[D],
+                                              double& a, double& b) {
+    // sigma_elastic = sigma_n + C_elas @ deps  (:309); C_elas = lmbda * 1(x)1 + 2 mu I on the Mandel vector
+    const double tr_e = deps[0] + deps[1] + deps[2];
+    double se[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) se[i] = sn[i] + ((i < 3 ? c.lmbda * tr_e : 0.0) + c.mu2 * deps[i]);
+    // s = deviatoric @ sigma_elastic (:310)
+    const double mean = (se[0] + se[1] + se[2]) * (1.0 / 3.0);
+    double s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = i < 3 ? se[i] - mean : se[i];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ss += s[i] * s[i];
+    const double sigma_eq = sqrt(3.0 / 2.0 * ss);                 // :311
+    const double f_el = sigma_eq - c.sigma_0 - c.H * p;          // :313
+    const double f_plus = (f_el + sqrt(f_el * f_el)) / 2.0;      // :314
+    dp = f_plus / c.mu3_H;                                       // :316
+    // n_elas = s / sigma_eq * f_plus / f_el (:318); 0/0 -> NaN exactly as the reference
+    const double beta = c.mu3 * dp / sigma_eq;                   // :319
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        nrm[i] = s[i] / sigma_eq * f_plus / f_el;
+        sig[i] = se[i] - beta * s[i];                            // :321
+    }
+    a = c.mu3 * (c.ratio - beta);                                // :324
+    b = c.mu2 * beta;
+}
+
+// Entry (i, j) of C_elas and of `deviatoric` on the Mandel vector (:193-204).
+__device__ __forceinline__ double c_elas_ij(const VmConst& c, int i, int j) {
+    return ((i < 3 && j < 3) ? c.lmbda : 0.0) + (i == j ? c.mu2 : 0.0);
+}
+__device__ __forceinline__ double dev_ij(int i, int j) {
+    return (i == j ? 1.0 : 0.0) - ((i < 3 && j < 3) ? 1.0 / 3.0 : 0.0);
+}
+
+// ------------------------------------------------------------------ variant 0: lane = point
+template <int D>
+__global__ __launch_bounds__(DXO_BLOCK) void vm_point(VmConst c, int64_t n, const double* __restrict__ deps,
+                                                      const double* __restrict__ sigma_n,
+                                                      const double* __restrict__ p, double* __restrict__ C_tang,
+                                                      double* __restrict__ sigma, double* __restrict__ dp_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double e[D], sn[D], sig[D], nrm[D], dp, a, b;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            e[k] = deps[i * D + k];
+            sn[k] = sigma_n[i * D + k];
+        }
+        vm_return_map<D>(c, e, sn, p[i], sig, dp, nrm, a, b);
+#pragma unroll
+        for (int k = 0; k < D; ++k) sigma[i * D + k] = sig[k];
+        dp_out[i] = dp;
+        double* Ct = C_tang + i * (D * D);
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int q = 0; q < D; ++q) Ct[r * D + q] = c_elas_ij(c, r, q) - a * (nrm[r] * nrm[q]) - b * dev_ij(r, q);
+    }
+}
+
+// ------------------------------------------------------------------ variant 1: wave = 64-point tile
+__device__ __forceinline__ void wave_lds_fence() {
+    // Orders this wave's LDS traffic for the compiler; the hardware already executes one wave's DS
+    // instructions in issue order, so no s_barrier and no cross-wave wait is involved.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool NT>
+__device__ __forceinline__ void store16(dxo_f64x2* ptr, dxo_f64x2 v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, ptr);
+    else
+        *ptr = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store8(double* ptr, double v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, ptr);
+    else
+        *ptr = v;
+}
+
+template <int D>
+struct VmTile {
+    static constexpr int PTS = DXO_WAVE;            // points per wave tile
+    static constexpr int CH_VEC = D / 2;            // 16-byte chunks per lane for one [PTS][D] block
+    static constexpr int CH_CT = D * D / 2;         // 16-byte chunks per point of C_tang = per lane per tile
+    static constexpr int ST = D + 2;                // LDS state doubles per point: n[D], a, b
+    static constexpr int X_DOUBLES = PTS * D;       // deps staging, later sigma staging
+    static constexpr int Y_DOUBLES = PTS * (D > ST ? D : ST);  // sigma_n staging, later state
+    static constexpr int WAVE_DOUBLES = X_DOUBLES + Y_DOUBLES;
+    static constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+};
+
+template <int D, bool NT>
+__global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
+                                                     const double* __restrict__ sigma_n,
+                                                     const double* __restrict__ p, double* __restrict__ C_tang,
+                                                     double* __restrict__ sigma, double* __restrict__ dp_out) {
+    using T = VmTile<D>;
+    __shared__ __attribute__((aligned(16))) double lds[T::WAVES * T::WAVE_DOUBLES];
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* X = lds + wave * T::WAVE_DOUBLES;
+    double* Y = X + T::X_DOUBLES;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
+    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
+
+    const int64_t n_tiles = (n + T::PTS - 1) / T::PTS;
+    const int64_t tile_stride = (int64_t)gridDim.x * T::WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave; tile < n_tiles; tile += tile_stride) {
+        const int64_t p0 = tile * T::PTS;
+        const int npts = (n - p0 < T::PTS) ? (int)(n - p0) : T::PTS;  // wave-uniform
+        const int nvec = npts * T::CH_VEC;                              // valid 16-byte chunks of a [npts][D] block
+
+        // ---- A: lane-linear global loads -> LDS -> point-per-lane registers
+        const dxo_f64x2* g_e = reinterpret_cast<const dxo_f64x2*>(deps + p0 * D);
+        const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
+        dxo_f64x2 ve[T::CH_VEC], vs[T::CH_VEC];
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            const bool ok = idx < nvec;
+            ve[k] = ok ? g_e[idx] : dxo_f64x2{0.0, 0.0};
+            vs[k] = ok ? g_s[idx] : dxo_f64x2{0.0, 0.0};
+        }
+        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            X2[k * DXO_WAVE + lane] = ve[k];
+            Y2[k * DXO_WAVE + lane] = vs[k];
+        }
+        wave_lds_fence();
+        double e[D], sn[D];
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            const dxo_f64x2 a2 = X2[lane * T::CH_VEC + k];
+            const dxo_f64x2 b2 = Y2[lane * T::CH_VEC + k];
+            e[2 * k] = a2.x;
+            e[2 * k + 1] = a2.y;
+            sn[2 * k] = b2.x;
+            sn[2 * k + 1] = b2.y;
+        }
+        wave_lds_fence();  // staging slices are about to be reused
+
+        // ---- B: radial return of this lane's point
+        double sig[D], nrm[D], dp, a, b;
+        vm_return_map<D>(c, e, sn, p_l, sig, dp, nrm, a, b);
+
+        // ---- C: sigma -> X (point-per-lane), state -> Y, then output-ordered coalesced stores
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
+            Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+        }
+        Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+        wave_lds_fence();
+
+        if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);
+        dxo_f64x2* g_o = reinterpret_cast<dxo_f64x2*>(sigma + p0 * D);
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
+        }
+        dxo_f64x2* g_c = reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D));
+        const int nct = npts * T::CH_CT;
+        // partial unroll: a full unroll lets the scheduler hoist all 3*CH_CT LDS reads and spill
+#pragma unroll T::CH_VEC
+        for (int it = 0; it < T::CH_CT; ++it) {
+            const int q = it * DXO_WAVE + lane;     // 16-byte chunk index inside the tile's C_tang block
+            const int pt = q / T::CH_CT;            // local point
+            const int k = q - pt * T::CH_CT;        // chunk inside the point's d x d block
+            const int i = k / T::CH_VEC;            // row
+            const int j0 = (k - i * T::CH_VEC) * 2; // first of two columns
+            const double n_i = Y[pt * T::ST + i];
+            const dxo_f64x2 n_j = Y2[pt * (T::ST / 2) + (j0 >> 1)];
+            const dxo_f64x2 ab = Y2[pt * (T::ST / 2) + T::CH_VEC];
+            dxo_f64x2 out;
+            out.x = c_elas_ij(c, i, j0) - ab.x * (n_i * n_j.x) - ab.y * dev_ij(i, j0);
+            out.y = c_elas_ij(c, i, j0 + 1) - ab.x * (n_i * n_j.y) - ab.y * dev_ij(i, j0 + 1);
+            if (q < nct) store16<NT>(g_c + q, out);
+        }
+        wave_lds_fence();  // next tile overwrites X / Y
+    }
+}
+
+struct VmLaunch {
+    VmConst c;
+    int d;
+};
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, const double* sigma_n,
+              const double* p, double* C_tang, double* sigma, double* dp, hipStream_t s) {
+    if (n == 0) return DXO_OK;
+    const bool can_tile = aligned16(deps) && aligned16(sigma_n) && aligned16(C_tang) && aligned16(sigma);
+    const bool tiled = ctx->vm_variant != 0 && can_tile;
+    if (tiled) {
+        const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+        const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        const bool nt = ctx->nontemporal != 0;
+        if (L.d == 4) {
+            if (nt) hipLaunchKernelGGL((vm_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            else    hipLaunchKernelGGL((vm_tile<4, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+        } else {
+            if (nt) hipLaunchKernelGGL((vm_tile<6, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            else    hipLaunchKernelGGL((vm_tile<6, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+        }
+    } else {
+        const int grid = dxo_grid_for_tiles(ctx, (n + DXO_BLOCK - 1) / DXO_BLOCK, 1);
+        if (L.d == 4) hipLaunchKernelGGL((vm_point<4>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+        else          hipLaunchKernelGGL((vm_point<6>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+    }
+    return DXO_OK;
+}
+
+int vm_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
+    const VmLaunch& L = *static_cast<const VmLaunch*>(user);
+    return vm_launch(ctx, L, m, (const double*)d_in[0], (const double*)d_in[1], (const double*)d_in[2],
+                     (double*)d_out[0], (double*)d_out[1], (double*)d_out[2], s);
+}
+
+}  // namespace
+
+extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
+                             const double* deps, const double* sigma_n, const double* p, double* C_tang,
+                             double* sigma, double* dp) {
+    if (!ctx) return DXO_E_NULL;
+    if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises: params is NULL");
+    if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_von_mises: d must be 4 or 6");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises: n < 0");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises: bad mem");
+    if (n > 0 && (!deps || !sigma_n || !p || !C_tang || !sigma || !dp))
+        return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises: NULL array");
+    const uintptr_t all = (uintptr_t)deps | (uintptr_t)sigma_n | (uintptr_t)p | (uintptr_t)C_tang |
+                          (uintptr_t)sigma | (uintptr_t)dp;
+    if (all & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises: arrays must be 8-byte aligned");
+    VmLaunch L{make_const(*prm), d};
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = vm_launch(ctx, L, n, deps, sigma_n, p, C_tang, sigma, dp, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    const size_t sd = sizeof(double);
+    std::vector<dxo_span> in = {{deps, nullptr, d * sd}, {sigma_n, nullptr, d * sd}, {p, nullptr, sd}};
+    std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
+    return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
+}

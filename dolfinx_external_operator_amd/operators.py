@@ -1,0 +1,210 @@
+"""Drop-in `external_function` factories backed by the HIP kernels in libdxo_hip.so.
+
+The reference's contract (src/dolfinx_external_operator/external_operator.py:432):
+
+    values = external_operator.external_function(external_operator.derivatives)(*operand_arrays)
+
+`external_function` maps the derivative multi-index to a callable; the callable receives one ndarray
+per operand, shaped (num_cells, nq, *ufl_shape), and returns a flat array (or a tuple whose first
+entry is assigned to the coefficient, :435-438). The factories below return objects that honour exactly
+that contract, so a user of the reference only swaps
+
+    sigma.external_function = sigma_external                 # demo_plasticity_von_mises.py:371
+for
+    sigma.external_function = make_von_mises(sigma_n, p)     # same call sites, same tuple order
+
+State variables are NOT operands in the reference: `C_tang_impl` reads `sigma_n.x.array` / `p.x.array`
+through its closure at every call (demo_plasticity_von_mises.py:347-348) because the load-stepping loop
+mutates them (:564-565). The factories therefore take the *holders* (a `fem.Function`, an ndarray, or a
+zero-argument callable) and re-read them at every evaluation.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+from ._lib import MEM_DEVICE, MEM_HOST, Context, VmParams, default_context
+
+
+def _state_array(holder):
+    """Current value of a closure-captured state variable (fem.Function | ndarray | callable | tensor)."""
+    if callable(holder) and not hasattr(holder, "x") and not hasattr(holder, "data_ptr"):
+        holder = holder()
+    x = getattr(holder, "x", None)
+    if x is not None and hasattr(x, "array"):
+        return x.array  # dolfinx.fem.Function
+    return holder
+
+
+def _is_device_tensor(a) -> bool:
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _as_f64_host(a, what: str) -> np.ndarray:
+    arr = np.asarray(a)
+    if arr.dtype != np.float64:
+        raise TypeError(f"{what}: the HIP kernels are fp64 (reference default PETSc.ScalarType); got {arr.dtype}")
+    return np.ascontiguousarray(arr)
+
+
+class _Outputs:
+    """Output buffers for host calls. With reuse=True the same pinned buffers are handed out on every
+    call (the reference's callers copy the results into coefficient arrays immediately,
+    demo_plasticity_von_mises.py:451-456); reuse=False returns fresh pageable arrays like NumPy would."""
+
+    def __init__(self, ctx: Context, reuse: bool):
+        self.ctx = ctx
+        self.reuse = reuse
+        self._cache: dict[tuple[str, int], np.ndarray] = {}
+
+    def get(self, key: str, size: int) -> np.ndarray:
+        if not self.reuse:
+            return np.empty(size, dtype=np.float64)
+        buf = self._cache.get((key, size))
+        if buf is None:
+            buf = self.ctx.pinned_empty(size)
+            self._cache = {k: v for k, v in self._cache.items() if k[0] != key}
+            self._cache[(key, size)] = buf
+        return buf
+
+
+def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
+                   H: float | None = None, ctx: Context | None = None, device: int = 0,
+                   reuse_outputs: bool = False) -> Callable:
+    """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
+
+    Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
+    in the reference's order (:352). Any other multi-index raises NotImplementedError as in :367-368.
+    `deps` has shape (num_cells, nq, d), d = 4 (reference) or 6 (3-D Mandel). Default constants: :185-188.
+    Host ndarrays go through the chunked H2D/kernel/D2H pipeline; torch CUDA tensors stay on the device
+    (outputs are then CUDA tensors on the same device, launched on torch's current stream).
+    """
+    if H is None:
+        E_tangent = E / 100.0                      # :186
+        H = E * E_tangent / (E - E_tangent)        # :187
+    prm = VmParams(float(E), float(nu), float(sigma_0), float(H))
+    holder = {"ctx": ctx, "out": None}
+
+    def _ctx() -> Context:
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        if holder["out"] is None:
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+        return holder["ctx"]
+
+    def C_tang_impl(deps):
+        c = _ctx()
+        if _is_device_tensor(deps):
+            return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p))
+        num_cells, num_quadrature_points, d = deps.shape      # :344
+        if d not in (4, 6):
+            raise ValueError(f"von Mises kernel supports Mandel vectors of length 4 or 6, got {d}")
+        n = num_cells * num_quadrature_points
+        deps_ = _as_f64_host(deps, "deps").reshape(n, d)
+        sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape(-1)
+        p_ = _as_f64_host(_state_array(p), "p").reshape(-1)
+        if sigma_n_.size != n * d or p_.size != n:
+            # the reference's reshape at :347-348 raises ValueError on a size mismatch
+            raise ValueError(f"state size mismatch: sigma_n {sigma_n_.size} (want {n * d}), p {p_.size} (want {n})")
+        out = holder["out"]
+        C_tang_ = out.get("C_tang", n * d * d)
+        sigma_ = out.get("sigma", n * d)
+        dp_ = out.get("dp", n)
+        c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
+        return C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1)   # :352
+
+    def sigma_external(derivatives):
+        if derivatives == (1,):
+            return C_tang_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    sigma_external.params = prm
+    sigma_external.context = _ctx
+    return sigma_external
+
+
+def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p):
+    import torch
+
+    if deps.dtype != torch.float64:
+        raise TypeError(f"deps: the HIP kernels are fp64, got {deps.dtype}")
+    num_cells, nq, d = deps.shape
+    n = num_cells * nq
+    deps = deps.contiguous()
+    sigma_n = sigma_n.contiguous()
+    p = p.contiguous()
+    if sigma_n.numel() != n * d or p.numel() != n:
+        raise ValueError("state size mismatch")
+    C_tang = torch.empty(n * d * d, dtype=torch.float64, device=deps.device)
+    sigma = torch.empty(n * d, dtype=torch.float64, device=deps.device)
+    dp = torch.empty(n, dtype=torch.float64, device=deps.device)
+    c.set_stream(torch.cuda.current_stream(deps.device).cuda_stream)
+    c.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(),
+                sigma.data_ptr(), dp.data_ptr())
+    return C_tang, sigma, dp
+
+
+def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, device: int = 0,
+              fuse_by_identity: bool = False) -> Callable:
+    """`q_external` of the nonlinear-heat demo (demo_nonlinear_heat_equation_part2.py:276-284) on the GPU.
+
+    external_function((0, 0))(T, sigma) -> q        flat (N*gdim,)        (:219-230)
+    external_function((1, 0))(T, sigma) -> dq/dT    flat (N*gdim,)        (:243-247)
+    external_function((0, 1))(T, sigma) -> dq/dsig  flat (N*gdim*gdim,)   (:259-261)
+    T: (num_cells, nq); sigma: (num_cells, nq*gdim) or (num_cells, nq, gdim) (:222-225); gdim is
+    sigma.size / T.size.
+
+    By default every call launches the kernel with only the requested output (the other output pointers
+    are NULL). With fuse_by_identity=True the first call for a given pair of operand OBJECTS computes all
+    three outputs in one launch and the next two calls (part2.py:307-309 evaluates F- and J-operators
+    from the same `evaluated_operands` dict) are served from that result. Only enable it if the operand
+    arrays are not modified in place between those calls (evaluate_operands returns fresh arrays).
+    """
+    holder = {"ctx": ctx, "keep": None, "val": None}
+
+    def _eval(T, sigma, which: int):
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        c = holder["ctx"]
+        if fuse_by_identity and holder["keep"] is not None and holder["keep"][0] is T and holder["keep"][1] is sigma:
+            return holder["val"][which]
+        T_ = _as_f64_host(T, "T").reshape(-1)
+        n = T_.size
+        sig_ = _as_f64_host(sigma, "sigma").reshape(-1)
+        if n == 0:
+            gdim = sigma.shape[-1] if np.ndim(sigma) == 3 and sigma.shape[-1] in (1, 2, 3) else 2
+        else:
+            if sig_.size % n:
+                raise ValueError(f"sigma size {sig_.size} is not a multiple of the number of points {n}")
+            gdim = sig_.size // n
+        sizes = (n * gdim, n * gdim, n * gdim * gdim)
+        outs = [np.empty(sz) if (fuse_by_identity or k == which) else None for k, sz in enumerate(sizes)]
+        c.heat(A, B, gdim, n, MEM_HOST, T_, sig_, outs[0], outs[1], outs[2])
+        if fuse_by_identity:
+            holder["keep"] = (T, sigma)
+            holder["val"] = outs
+        return outs[which]
+
+    def q_impl(T, sigma):
+        return _eval(T, sigma, 0)
+
+    def dqdT_impl(T, sigma):
+        return _eval(T, sigma, 1)
+
+    def dqdsigma_impl(T, sigma):
+        return _eval(T, sigma, 2)
+
+    def q_external(derivatives):
+        if derivatives == (0, 0):
+            return q_impl
+        elif derivatives == (1, 0):
+            return dqdT_impl
+        elif derivatives == (0, 1):
+            return dqdsigma_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    return q_external
+
+
+__all__ = ["make_von_mises", "make_heat"]

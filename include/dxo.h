@@ -1,0 +1,139 @@
+/*
+ * dxo.h — C ABI of libdxo_hip.so: MI355X (gfx950) quadrature-point kernels that stand
+ * behind dolfinx-external-operator's `external_function(derivatives)(*operand_arrays)`
+ * callback (reference: src/dolfinx_external_operator/external_operator.py:432).
+ *
+ * Every entry point is plain C: pointers, sizes, POD parameter structs. No torch / numpy /
+ * DOLFINx types cross this boundary. All arrays are C-contiguous, cell-major ->
+ * quadrature-point -> component ("AoS per point"), exactly the layout the reference hands to
+ * and expects back from the user kernel (external_operator.py:286-290, 393-402).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 for an invalid argument (DXO_E_*), >0 for a
+ *     HIP runtime error code (hipError_t). dxo_last_error(ctx) gives the text.
+ *   - `mem` says where ALL data pointers of that call live: DXO_MEM_HOST (pageable or pinned
+ *     host memory: the library does H2D -> kernel -> D2H, chunked and overlapped) or
+ *     DXO_MEM_DEVICE (device memory on the ctx's GPU: the kernel is launched on the ctx
+ *     stream and the call returns without synchronising).
+ *   - the library never frees or keeps caller memory. Scratch is owned by the ctx.
+ *   - non-convergence of a local Newton solve is NOT an error (the reference only reports
+ *     niter / norm_res, demo_plasticity_mohr_coulomb.py:584-591).
+ *   - one ctx per (process, device). Calls on one ctx are serialised by the caller
+ *     (the reference calls from a single Python thread inside the SNES callback,
+ *     petsc/petsc.py:60).
+ */
+#ifndef DXO_H
+#define DXO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DXO_ABI_VERSION 1
+
+/* error codes (negative = caller error) */
+#define DXO_OK 0
+#define DXO_E_NULL (-1)      /* required pointer is NULL            */
+#define DXO_E_DIM (-2)       /* unsupported tensor dimension d/gdim */
+#define DXO_E_SIZE (-3)      /* negative size                       */
+#define DXO_E_MEM (-4)       /* bad `mem` selector                  */
+#define DXO_E_ALIGN (-5)     /* device pointer not 8-byte aligned   */
+#define DXO_E_OPTION (-6)    /* unknown option / bad value          */
+#define DXO_E_NODEVICE (-7)  /* no usable HIP device                */
+
+#define DXO_MEM_HOST 0
+#define DXO_MEM_DEVICE 1
+
+typedef struct dxo_ctx dxo_ctx;
+
+/* Material constants of the von Mises demo (demo_plasticity_von_mises.py:185-188);
+ * lmbda, mu, C_elas, deviatoric (:190-204) are derived from them inside the kernel. */
+typedef struct dxo_vm_params {
+    double E;        /* Young modulus            (70e3)               */
+    double nu;       /* Poisson ratio            (0.3)                */
+    double sigma_0;  /* yield strength           (250)                */
+    double H;        /* hardening modulus        (E*Et/(E-Et), Et=E/100) */
+} dxo_vm_params;
+
+/* Constants of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:110-116, 469). */
+typedef struct dxo_mc_params {
+    double E;        /* 6778                                          */
+    double nu;       /* 0.25                                          */
+    double c;        /* cohesion 3.45                                 */
+    double phi;      /* friction angle  [rad]                         */
+    double psi;      /* dilatancy angle [rad]                         */
+    double theta_T;  /* Abbo-Sloan transition angle [rad]             */
+    double a;        /* tension cut-off parameter 0.26 c / tan(phi)   */
+    double tol;      /* relative residual tolerance 1e-8 (:469)       */
+    int32_t nitermax;/* 200 (:469)                                    */
+    int32_t _pad;
+} dxo_mc_params;
+
+/* Timing of the last call on a ctx, milliseconds (HIP events on the ctx streams). */
+typedef struct dxo_timing {
+    double h2d_ms;     /* DXO_MEM_HOST only, else 0                   */
+    double kernel_ms;  /* sum over chunks                             */
+    double d2h_ms;     /* DXO_MEM_HOST only, else 0                   */
+    double total_ms;   /* first enqueue -> last completion            */
+} dxo_timing;
+
+typedef struct dxo_device_info {
+    char name[128];
+    char arch[32];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int64_t total_mem_bytes;
+} dxo_device_info;
+
+/* ---- context ------------------------------------------------------------------------- */
+int dxo_abi_version(void);
+int dxo_device_count(int* count);
+int dxo_ctx_create(int device, dxo_ctx** out);
+int dxo_ctx_destroy(dxo_ctx* ctx);
+const char* dxo_last_error(const dxo_ctx* ctx);
+int dxo_ctx_device_info(dxo_ctx* ctx, dxo_device_info* info);
+/* Borrow a caller-owned hipStream_t for DXO_MEM_DEVICE launches (NULL = library stream). */
+int dxo_ctx_set_stream(dxo_ctx* ctx, void* hip_stream);
+int dxo_ctx_synchronize(dxo_ctx* ctx);
+/* Integer tuning knobs: "vm_variant" (0 scalar AoS kernel, 1 LDS-staged coalesced kernel,
+ * default 1), "host_chunk_points" (points per H2D/kernel/D2H pipeline chunk),
+ * "nontemporal" (0/1 streaming stores), "timing" (0/1 record dxo_timing on device calls). */
+int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
+int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
+int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);
+/* Pinned host buffers (hipHostMalloc) so DXO_MEM_HOST calls DMA without staging. */
+int dxo_host_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
+int dxo_host_free(dxo_ctx* ctx, void* ptr);
+
+/* ---- von Mises radial return + consistent tangent ---------------------------------------
+ * Replaces return_mapping/_kernel + C_tang_impl, demo_plasticity_von_mises.py:298-352.
+ *   d        Mandel vector length: 4 (plane strain, the reference demo) or 6 (3-D)
+ *   n        number of quadrature points (num_cells * nq)
+ *   deps     [n][d]   strain increment operand            (in)
+ *   sigma_n  [n][d]   stress at the previous load step    (in; closure state, :347)
+ *   p        [n]      cumulative plastic strain           (in; closure state, :348)
+ *   C_tang   [n][d][d] consistent tangent                 (out)
+ *   sigma    [n][d]   new stress                          (out)
+ *   dp       [n]      plastic strain increment            (out)
+ */
+int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
+                  const double* deps, const double* sigma_n, const double* p,
+                  double* C_tang, double* sigma, double* dp);
+
+/* ---- nonlinear heat flux ------------------------------------------------------------------
+ * Replaces k / q_impl / dqdT_impl / dqdsigma_impl, demo_nonlinear_heat_equation_part2.py:209-261
+ * (same code: test/test_external_operators_evaluation.py:64-86).
+ *   T [n], sigma [n][gdim] (in);  q [n][gdim], dqdT [n][gdim], dqdsigma [n][gdim][gdim] (out).
+ * Any output may be NULL (the reference evaluates the three derivatives as separate
+ * operators; one fused launch fills whichever are requested). gdim in {1,2,3}.
+ */
+int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, int mem,
+             const double* T, const double* sigma,
+             double* q, double* dqdT, double* dqdsigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXO_H */

@@ -1,0 +1,82 @@
+"""ctypes loader for liboracle (oracle/dxo_oracle.c [+ mc_oracle.cpp]). TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+LIB = HERE / "libdxo_oracle.so"
+
+
+def build_oracle(force: bool = False) -> pathlib.Path:
+    srcs = list(HERE.glob("*.c")) + list(HERE.glob("*.cpp")) + list(HERE.glob("*.hpp")) + [HERE / "Makefile"]
+    if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
+        res = subprocess.run(["make", "-C", str(HERE), "-s", "-B" if force else "-s"], stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + res.stdout)
+    return LIB
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleLib:
+    def __init__(self, path=LIB):
+        self.lib = C.CDLL(str(path))
+        P = C.c_void_p
+        self.lib.oracle_von_mises.restype = C.c_int
+        self.lib.oracle_von_mises.argtypes = [P, C.c_int, C.c_int64, P, P, P, P, P, P, C.c_int]
+        self.lib.oracle_heat.restype = C.c_int
+        self.lib.oracle_heat.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int64, P, P, P, P, P, C.c_int]
+        self.lib.oracle_max_threads.restype = C.c_int
+
+    def max_threads(self) -> int:
+        return int(self.lib.oracle_max_threads())
+
+    def von_mises(self, deps, sigma_n, p, *, E=70e3, nu=0.3, sigma_0=250.0, H=None, nthreads=1):
+        """deps (..., d), sigma_n (..., d), p (...) -> C_tang (N, d, d), sigma (N, d), dp (N,)"""
+        if H is None:
+            Et = E / 100.0
+            H = E * Et / (E - Et)
+        d = deps.shape[-1]
+        deps = np.ascontiguousarray(deps, dtype=np.float64).reshape(-1, d)
+        sigma_n = np.ascontiguousarray(sigma_n, dtype=np.float64).reshape(-1, d)
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+        n = deps.shape[0]
+        prm = np.array([E, nu, sigma_0, H], dtype=np.float64)
+        C_tang = np.empty((n, d, d))
+        sigma = np.empty((n, d))
+        dp = np.empty(n)
+        rc = self.lib.oracle_von_mises(_dp(prm), d, n, _dp(deps), _dp(sigma_n), _dp(p), _dp(C_tang), _dp(sigma),
+                                       _dp(dp), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_von_mises rc={rc}")
+        return C_tang, sigma, dp
+
+    def heat(self, T, sigma, *, A=1.0, B=1.0, gdim=2, nthreads=1):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1)
+        n = T.size
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(n, gdim)
+        q = np.empty((n, gdim))
+        dqdT = np.empty((n, gdim))
+        dqds = np.empty((n, gdim, gdim))
+        rc = self.lib.oracle_heat(A, B, gdim, n, _dp(T), _dp(sigma), _dp(q), _dp(dqdT), _dp(dqds), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_heat rc={rc}")
+        return q, dqdT, dqds
+
+
+_oracle = None
+
+
+def load_oracle() -> OracleLib:
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        _oracle = OracleLib()
+    return _oracle

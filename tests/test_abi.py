@@ -1,0 +1,77 @@
+"""The C-ABI library: builds for gfx950, loads, exports what include/dxo.h declares (not gpu)."""
+import ctypes as C
+import pathlib
+import re
+import subprocess
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+HEADER = ROOT / "include" / "dxo.h"
+
+
+def header_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(dxo_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    names = header_functions()
+    for must in ("dxo_ctx_create", "dxo_ctx_destroy", "dxo_von_mises", "dxo_heat", "dxo_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(hip_library):
+    for name in header_functions():
+        assert hasattr(hip_library, name), f"{name} declared in include/dxo.h but not exported"
+
+
+def test_binding_covers_every_declared_symbol(hip_library):
+    from dolfinx_external_operator_amd._lib import declared_symbols
+
+    assert sorted(declared_symbols()) == header_functions()
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "dxo.h"\nint main(void){ dxo_vm_params p = {70e3, 0.3, 250.0, 707.07}; (void)p; return DXO_ABI_VERSION - 1; }\n')
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", "-c", str(src), "-o",
+                          str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
+def test_code_object_targets_gfx950(hip_library):
+    from dolfinx_external_operator_amd._lib import LIB_PATH
+
+    blob = LIB_PATH.read_bytes()
+    assert b"gfx950" in blob
+    assert b"vm_tile" in blob and b"heat_g2" in blob
+
+
+def test_argument_errors_without_a_device(hip_library):
+    lib = hip_library
+    assert lib.dxo_abi_version() == 1
+    assert lib.dxo_ctx_create(0, None) == -1                       # DXO_E_NULL
+    assert lib.dxo_von_mises(None, None, 4, 0, 0, None, None, None, None, None, None) == -1
+    assert lib.dxo_heat(None, 1.0, 1.0, 2, 0, 0, None, None, None, None, None) == -1
+    assert lib.dxo_ctx_destroy(None) == -1
+    n = C.c_int(-5)
+    rc = lib.dxo_device_count(C.byref(n))
+    assert rc in (0, -7) and n.value >= 0
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = ROOT / "dolfinx_external_operator_amd"
+    for f in pkg.rglob("*.py"):
+        text = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+        assert "libdxo_oracle" not in text, f
+    for f in (pkg / "csrc").iterdir():
+        assert "oracle" not in f.read_text().lower(), f
+
+
+def test_missing_library_is_a_loud_error(tmp_path):
+    from dolfinx_external_operator_amd._lib import DxoError, load_library
+
+    with pytest.raises(DxoError, match="no CPU fallback"):
+        load_library(tmp_path / "libdxo_hip.so")

@@ -1,0 +1,161 @@
+"""Boundary semantics of evaluate_operands / evaluate_external_operators (not gpu).
+
+Mirrors what the reference's own tests pin with trivial NumPy kernels
+(test/test_external_operators_evaluation.py, test_nested_ex_op.py, test_external_operators_construction.py:202-212):
+array shapes, flattening, the tuple rule, operand de-duplication, nesting, error behaviour.
+"""
+import numpy as np
+import pytest
+
+from dolfinx_external_operator_amd import (
+    Coefficient,
+    Operand,
+    QuadratureExternalOperator,
+    evaluate_external_operators,
+    evaluate_operands,
+    get_unrolled_dofmap,
+)
+
+NC, NQ = 7, 3
+
+
+def _operands():
+    rng = np.random.default_rng(0)
+    T_full = rng.uniform(0.5, 2.0, size=(NC, NQ))
+    s_full = rng.normal(size=(NC, NQ, 2))
+    T = Operand(lambda cells: T_full[cells], "T")
+    sigma = Operand(lambda cells: s_full[cells], "grad(T)")
+    return T, sigma, T_full, s_full
+
+
+def _heat_numpy(A=1.0, B=1.0):
+    # the reference's own test kernels, restated (test/test_external_operators_evaluation.py:69-96)
+    def k(T):
+        return 1.0 / (A + B * T)
+
+    def q_impl(T, sigma):
+        return (-k(T)[:, :, None] * sigma.reshape(T.shape[0], -1, 2)).reshape(-1)
+
+    def dqdT_impl(T, sigma):
+        return (B * (k(T) ** 2)[:, :, None] * sigma.reshape(T.shape[0], -1, 2)).reshape(-1)
+
+    def dqdsigma_impl(T, sigma):
+        return (-k(T)[:, :, None, None] * np.eye(2)[None, None]).reshape(-1)
+
+    def q_external(derivatives):
+        if derivatives == (0, 0):
+            return q_impl
+        elif derivatives == (1, 0):
+            return dqdT_impl
+        elif derivatives == (0, 1):
+            return dqdsigma_impl
+        raise NotImplementedError
+
+    return q_external
+
+
+def test_empty_operator_list():
+    # test/test_external_operators_construction.py:202-212
+    assert evaluate_operands([]) == {}
+    assert evaluate_external_operators([], {}) == []
+
+
+def test_heat_operators_fill_coefficients_and_share_operands():
+    T, sigma, T_full, s_full = _operands()
+    ext = _heat_numpy()
+    q = QuadratureExternalOperator(T, sigma, num_cells=NC, num_points=NQ, value_shape=(2,), external_function=ext)
+    dqdT = QuadratureExternalOperator(T, sigma, num_cells=NC, num_points=NQ, value_shape=(2,),
+                                      external_function=ext, derivatives=(1, 0))
+    dqds = QuadratureExternalOperator(T, sigma, num_cells=NC, num_points=NQ, value_shape=(2, 2),
+                                      external_function=ext, derivatives=(0, 1))
+    ops = [q, dqdT, dqds]
+    evaluated = evaluate_operands(ops)
+    assert set(evaluated) == {T, sigma}
+    assert T.eval_count == 1 and sigma.eval_count == 1          # unique operands evaluated once (:374-403)
+    assert evaluated[T].shape == (NC, NQ) and evaluated[sigma].shape == (NC, NQ, 2)
+    out = evaluate_external_operators(ops, evaluated)
+    k = 1.0 / (1.0 + T_full)
+    assert np.allclose(q.ref_coefficient.x.array, (-k[..., None] * s_full).reshape(-1))
+    assert np.allclose(dqdT.ref_coefficient.x.array, (k[..., None] ** 2 * s_full).reshape(-1))
+    assert dqds.ref_coefficient.x.array.size == NC * NQ * 4
+    assert all(op.ref_coefficient.x.scatter_count == 1 for op in ops)  # scatter_forward per operator (:445)
+    assert len(out) == 3 and out[0] is not q.ref_coefficient.x.array
+
+
+def test_entities_subset_and_default_cache():
+    T, sigma, T_full, _ = _operands()
+    op = QuadratureExternalOperator(T, sigma, num_cells=NC, num_points=NQ, value_shape=(2,),
+                                    external_function=_heat_numpy())
+    cells = np.array([1, 4], dtype=np.int32)
+    ev = evaluate_operands([op], cells)
+    assert np.array_equal(ev[T], T_full[cells])
+    evaluate_operands([op])
+    assert op._full_cells is not None and op._full_cells.dtype == np.int32 and op._full_cells.size == NC
+
+
+def test_tuple_result_assigns_first_and_returns_all():
+    # demo_plasticity_von_mises.py:352, external_operator.py:435-438,446
+    deps = Operand(lambda cells: np.ones((len(cells), NQ, 4)), "eps(Du)")
+
+    def impl(d):
+        n = d.shape[0] * d.shape[1]
+        return np.full(n * 16, 2.0), np.full(n * 4, 3.0), np.full(n, 4.0)
+
+    def ext(derivatives):
+        if derivatives == (1,):
+            return impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    C_tang = QuadratureExternalOperator(deps, num_cells=NC, num_points=NQ, value_shape=(4, 4),
+                                        external_function=ext, derivatives=(1,))
+    ((C, s, dp),) = evaluate_external_operators([C_tang], evaluate_operands([C_tang]))
+    assert np.all(C_tang.ref_coefficient.x.array == 2.0)
+    assert s.shape == (NC * NQ * 4,) and dp.shape == (NC * NQ,)
+    sigma_op = QuadratureExternalOperator(deps, num_cells=NC, num_points=NQ, value_shape=(4,), external_function=ext)
+    with pytest.raises(NotImplementedError, match=r"\(0,\)"):
+        evaluate_external_operators([sigma_op], evaluate_operands([sigma_op]))
+
+
+def test_wrong_size_raises_value_error():
+    deps = Operand(lambda cells: np.ones((len(cells), NQ, 4)))
+    op = QuadratureExternalOperator(deps, num_cells=NC, num_points=NQ, value_shape=(4,),
+                                    external_function=lambda d: (lambda a: np.zeros(5)))
+    with pytest.raises(ValueError):
+        evaluate_external_operators([op], evaluate_operands([op]))
+
+
+def test_nested_operator_is_evaluated_recursively():
+    # test/test_nested_ex_op.py:124-137: N2(N1(u)) ; the inner operator's result feeds the outer kernel
+    u_full = np.arange(NC * NQ, dtype=float).reshape(NC, NQ)
+    u = Operand(lambda cells: u_full[cells], "u")
+    inner = QuadratureExternalOperator(u, num_cells=NC, num_points=NQ,
+                                       external_function=lambda d: (lambda a: (a ** 2).reshape(-1)))
+    outer = QuadratureExternalOperator(inner, num_cells=NC, num_points=NQ,
+                                       external_function=lambda d: (lambda a: (a + 1.0).reshape(-1)))
+    ev = evaluate_operands([outer])
+    assert isinstance(ev[inner], dict) and u in ev[inner]
+    evaluate_external_operators([outer], ev)
+    assert np.array_equal(inner.ref_coefficient.x.array, (u_full ** 2).reshape(-1))
+    assert np.array_equal(outer.ref_coefficient.x.array, (u_full ** 2 + 1.0).reshape(-1))
+
+
+def test_unrolled_dofmap_assignment():
+    # external_operator.py:18-26, 286-287: blocked dofmap, bs = 2
+    dofmap = np.array([[0, 1, 2], [2, 1, 3]], dtype=np.int32)
+    un = get_unrolled_dofmap(dofmap, 2)
+    assert np.array_equal(un, [0, 1, 2, 3, 4, 5, 4, 5, 2, 3, 6, 7])
+    assert get_unrolled_dofmap(np.empty((0, 3), dtype=np.int32), 2).size == 0
+    u = Operand(lambda cells: np.ones((len(cells), 3, 2)))
+    op = QuadratureExternalOperator(u, num_cells=2, num_points=3, value_shape=(2,), unrolled_dofmap=un,
+                                    coefficient_size=8,
+                                    external_function=lambda d: (lambda a: np.arange(12, dtype=float)))
+    evaluate_external_operators([op], evaluate_operands([op]))
+    expect = np.zeros(8)
+    expect[un] = np.arange(12, dtype=float)
+    assert np.array_equal(op.ref_coefficient.x.array, expect)
+
+
+def test_coefficient_must_match_space():
+    u = Operand(lambda cells: np.ones((len(cells), NQ)))
+    with pytest.raises(TypeError):
+        QuadratureExternalOperator(u, num_cells=NC, num_points=NQ, coefficient=Coefficient(5))

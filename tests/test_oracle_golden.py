@@ -1,0 +1,71 @@
+"""The CPU oracle against golden vectors produced by the reference's own kernels (not gpu)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, vm_inputs
+
+# The oracle repeats the reference's statements in the same order; what is left is BLAS-internal
+# summation order inside np.dot / `@` (a few ulp).
+ORACLE_RTOL = 2e-15
+
+
+@pytest.mark.parametrize("name,d", [("von_mises_d4.npz", 4), ("von_mises_d6.npz", 6)])
+def test_von_mises_oracle_matches_reference_golden(oracle, golden, name, d):
+    g = golden(name)
+    E, nu, sigma_0, H = g["params"]
+    C, s, dp = oracle.von_mises(g["deps"], g["sigma_n"], g["p"], E=E, nu=nu, sigma_0=sigma_0, H=H)
+    assert g["deps"].shape[-1] == d
+    assert_close_scaled(C, g["C_tang"], ORACLE_RTOL, "C_tang")
+    assert_close_scaled(s, g["sigma"], ORACLE_RTOL, "sigma")
+    assert_close_scaled(dp, g["dp"], ORACLE_RTOL, "dp")
+    # the all-zero special point is the reference's 0/0 case (demo_plasticity_von_mises.py:318-319)
+    assert np.isnan(C[4]).all() and np.isnan(s[4]).all() and dp[4] == 0.0
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_von_mises_oracle_elastic_points_return_c_elas(oracle, golden, d):
+    g = golden(f"von_mises_d{d}.npz")
+    C, s, dp = oracle.von_mises(g["deps"], g["sigma_n"], g["p"])
+    elastic = (dp == 0.0) & np.isfinite(s).all(axis=1)
+    assert elastic.sum() > 10
+    assert np.array_equal(C[elastic], np.broadcast_to(g["C_elas"], C[elastic].shape))
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_von_mises_oracle_threads_agree(oracle, d):
+    deps, sigma_n, p = vm_inputs(5000, d, seed=7)
+    a = oracle.von_mises(deps, sigma_n, p, nthreads=1)
+    b = oracle.von_mises(deps, sigma_n, p, nthreads=4)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_von_mises_oracle_plastic_points_land_on_yield_surface(oracle, d):
+    """Independent check with the pure-UFL statement of the same model
+    (demo_plasticity_von_mises_pure_ufl.py:105-124): f(sigma_new, p + dp) = 0 on plastic points."""
+    deps, sigma_n, p = vm_inputs(20000, d, seed=11)
+    C, s, dp = oracle.von_mises(deps, sigma_n, p)
+    E, sigma_0 = 70e3, 250.0
+    H = E * (E / 100.0) / (E - E / 100.0)
+    dev = s.copy()
+    dev[:, :3] -= s[:, :3].mean(axis=1, keepdims=True)
+    seq = np.sqrt(1.5 * np.sum(dev * dev, axis=1))
+    plastic = dp > 0
+    assert plastic.mean() > 0.5 and (~plastic).sum() > 100
+    f = seq - sigma_0 - H * (p + dp)
+    assert np.max(np.abs(f[plastic])) < 1e-9 * sigma_0
+    assert np.all(f[~plastic] <= 1e-9)
+    # tangent is symmetric
+    assert np.max(np.abs(C - np.transpose(C, (0, 2, 1)))) < 1e-9 * E
+
+
+def test_heat_oracle_matches_reference_golden_bitwise(oracle, golden):
+    g = golden("heat_c1.npz")
+    q, dqdT, dqds = oracle.heat(g["T"], g["sigma"], A=float(g["A"]), B=float(g["B"]), gdim=2)
+    assert g["T"].size == 6144  # BASELINE config 1: 32x32 unit square, 2048 triangles x 3 points
+    assert np.array_equal(q.reshape(-1), g["q"])
+    assert np.array_equal(dqdT.reshape(-1), g["dqdT"])
+    assert np.array_equal(dqds.reshape(-1), g["dqdsigma"])
+    # -k * 0 is a negative zero in the reference (part2.py:260); the oracle keeps the sign
+    assert np.array_equal(np.signbit(dqds.reshape(-1)), np.signbit(g["dqdsigma"]))

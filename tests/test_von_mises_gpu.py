@@ -1,0 +1,258 @@
+"""Parity of the HIP von Mises kernels (through the C ABI) with the CPU oracle and the reference goldens."""
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, vm_inputs
+from dolfinx_external_operator_amd import (
+    MEM_DEVICE,
+    MEM_HOST,
+    Operand,
+    QuadratureExternalOperator,
+    VmParams,
+    evaluate_external_operators,
+    evaluate_operands,
+    make_von_mises,
+)
+
+pytestmark = pytest.mark.gpu
+
+# fp64. The HIP kernel uses the sparse structure of C_elas / deviatoric and FMA contraction, the oracle
+# follows NumPy's dense mat-vecs: differences are rounding-level, measured against the array's scale.
+RTOL = 1e-13
+
+E, NU, SIGMA_0 = 70e3, 0.3, 250.0
+H = E * (E / 100.0) / (E - E / 100.0)
+PRM = VmParams(E, NU, SIGMA_0, H)
+
+
+def run_host(ctx, deps, sigma_n, p, variant=1):
+    n, d = deps.shape
+    C = np.empty(n * d * d)
+    s = np.empty(n * d)
+    dp = np.empty(n)
+    ctx.set_option("vm_variant", variant)
+    ctx.von_mises(PRM, d, n, MEM_HOST, deps, sigma_n, p, C, s, dp)
+    return C.reshape(n, d, d), s.reshape(n, d), dp
+
+
+def run_device(ctx, deps, sigma_n, p, variant=1):
+    import torch
+
+    n, d = deps.shape
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (deps, sigma_n, p)]
+    C = torch.empty(n * d * d, dtype=torch.float64, device=dev)
+    s = torch.empty(n * d, dtype=torch.float64, device=dev)
+    dp = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.set_option("vm_variant", variant)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, *(x.data_ptr() for x in t), C.data_ptr(), s.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    return C.cpu().numpy().reshape(n, d, d), s.cpu().numpy().reshape(n, d), dp.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", ["von_mises_d4.npz", "von_mises_d6.npz"])
+def test_reference_golden(ctx, golden, name, variant):
+    g = golden(name)
+    d = g["deps"].shape[-1]
+    deps, sigma_n, p = g["deps"].reshape(-1, d), g["sigma_n"].reshape(-1, d), g["p"].reshape(-1)
+    for runner in (run_host, run_device):
+        C, s, dp = runner(ctx, deps, sigma_n, p, variant)
+        assert_close_scaled(C, g["C_tang"], RTOL, f"C_tang {runner.__name__}")
+        assert_close_scaled(s, g["sigma"], RTOL, f"sigma {runner.__name__}")
+        assert_close_scaled(dp, g["dp"], RTOL, f"dp {runner.__name__}")
+        assert np.isnan(C[4]).all() and np.isnan(s[4]).all()      # the reference's 0/0 point stays NaN
+        elastic = (g["dp"].reshape(-1) == 0.0) & np.isfinite(s).all(axis=1)
+        assert np.array_equal(C[elastic], np.broadcast_to(g["C_elas"], C[elastic].shape))  # exact C_elas
+
+
+@pytest.mark.parametrize("d", [4, 6])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 1000, 4097])
+def test_ragged_sizes_against_oracle(ctx, oracle, d, n):
+    deps, sigma_n, p = vm_inputs(n, d, seed=100 + n, plastic_scale=0.6)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    for variant in (0, 1):
+        C, s, dp = run_device(ctx, deps, sigma_n, p, variant)
+        if n == 0:
+            assert C.size == 0 and s.size == 0 and dp.size == 0
+            continue
+        assert_close_scaled(C, Co, RTOL, "C_tang")
+        assert_close_scaled(s, so, RTOL, "sigma")
+        assert_close_scaled(dp, dpo, RTOL, "dp")
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_outputs_do_not_overrun(ctx, d):
+    """Guard words after each output must survive (partial last tile)."""
+    import torch
+
+    n = 130
+    deps, sigma_n, p = vm_inputs(n, d, seed=3)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(a).to(dev) for a in (deps, sigma_n, p)]
+    guard = 64
+    outs = [torch.full((n * k + guard,), -7.0, dtype=torch.float64, device=dev) for k in (d * d, d, 1)]
+    ctx.set_option("vm_variant", 1)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, *(x.data_ptr() for x in t), *(o.data_ptr() for o in outs))
+    torch.cuda.synchronize()
+    for o, k in zip(outs, (d * d, d, 1)):
+        assert torch.all(o[n * k:] == -7.0)
+        assert not torch.any(o[: n * k] == -7.0)
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_tiled_and_scalar_kernels_agree_at_scale(ctx, oracle, d):
+    n = 200_000
+    deps, sigma_n, p = vm_inputs(n, d, seed=5)
+    C1, s1, dp1 = run_device(ctx, deps, sigma_n, p, 1)
+    C0, s0, dp0 = run_device(ctx, deps, sigma_n, p, 0)
+    assert_close_scaled(C1, C0, 1e-14, "C_tang v1 vs v0")
+    assert_close_scaled(s1, s0, 1e-14, "sigma v1 vs v0")
+    assert np.array_equal(dp1, dp0)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p, nthreads=8)
+    assert_close_scaled(C1, Co, RTOL, "C_tang")
+    assert_close_scaled(s1, so, RTOL, "sigma")
+    assert_close_scaled(dp1, dpo, RTOL, "dp")
+
+
+def test_unaligned_pointers_fall_back_to_scalar_kernel(ctx, oracle):
+    import torch
+
+    n, d = 777, 6
+    deps, sigma_n, p = vm_inputs(n, d, seed=9)
+    dev = torch.device("cuda:0")
+    big = torch.zeros(n * d + 1, dtype=torch.float64, device=dev)
+    big[1:] = torch.from_numpy(deps.reshape(-1)).to(dev)   # 8-byte aligned, not 16
+    sn = torch.from_numpy(sigma_n).to(dev)
+    pp = torch.from_numpy(p).to(dev)
+    C = torch.empty(n * d * d, dtype=torch.float64, device=dev)
+    s = torch.empty(n * d, dtype=torch.float64, device=dev)
+    dp = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.set_option("vm_variant", 1)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, big.data_ptr() + 8, sn.data_ptr(), pp.data_ptr(), C.data_ptr(),
+                  s.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C.cpu().numpy(), Co, RTOL, "C_tang")
+    with pytest.raises(ValueError, match="ALIGN"):
+        ctx.von_mises(PRM, d, n, MEM_DEVICE, big.data_ptr() + 4, sn.data_ptr(), pp.data_ptr(), C.data_ptr(),
+                      s.data_ptr(), dp.data_ptr())
+
+
+def test_argument_validation(ctx):
+    a = np.zeros(16)
+    with pytest.raises(ValueError, match="DIM"):
+        ctx.von_mises(PRM, 5, 1, MEM_HOST, a, a, a, a, a, a)
+    with pytest.raises(ValueError, match="SIZE"):
+        ctx.von_mises(PRM, 4, -1, MEM_HOST, a, a, a, a, a, a)
+    with pytest.raises(ValueError, match="NULL"):
+        ctx.von_mises(PRM, 4, 1, MEM_HOST, a, None, a, a, a, a)
+    with pytest.raises(ValueError, match="MEM"):
+        ctx.von_mises(PRM, 4, 1, 7, a, a, a, a, a, a)
+    with pytest.raises(ValueError, match="OPTION"):
+        ctx.set_option("no_such_knob", 1)
+
+
+def test_host_pipeline_chunking(ctx, oracle):
+    """Many small chunks through the 3-slot H2D/kernel/D2H ring must equal one big call."""
+    n, d = 10_000, 6
+    deps, sigma_n, p = vm_inputs(n, d, seed=21)
+    old = ctx.get_option("host_chunk_points")
+    try:
+        ctx.set_option("host_chunk_points", 640)
+        C, s, dp = run_host(ctx, deps, sigma_n, p)
+        t = ctx.last_timing()
+        assert t["kernel_ms"] > 0 and t["h2d_ms"] > 0 and t["d2h_ms"] > 0 and t["total_ms"] > 0
+    finally:
+        ctx.set_option("host_chunk_points", old)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C, Co, RTOL, "C_tang")
+    assert_close_scaled(s, so, RTOL, "sigma")
+    assert_close_scaled(dp, dpo, RTOL, "dp")
+
+
+def test_drop_in_external_function_through_evaluate_external_operators(ctx, oracle):
+    """The demo's call sequence (demo_plasticity_von_mises.py:445-456) with the HIP-backed callback."""
+    nc, nq, d = 50, 3, 4
+    deps_full, sigma_n, p = vm_inputs(nc * nq, d, seed=33)
+    deps_full = deps_full.reshape(nc, nq, d)
+    state = {"sigma_n": sigma_n.reshape(-1).copy(), "p": p.copy()}
+    sigma_external = make_von_mises(lambda: state["sigma_n"], lambda: state["p"], ctx=ctx)
+    eps = Operand(lambda cells: deps_full[cells], "eps(Du)")
+    sigma = QuadratureExternalOperator(eps, num_cells=nc, num_points=nq, value_shape=(d,),
+                                       external_function=sigma_external)
+    C_tang = QuadratureExternalOperator(eps, num_cells=nc, num_points=nq, value_shape=(d, d),
+                                        external_function=sigma_external, derivatives=(1,))
+    evaluated_operands = evaluate_operands([sigma])
+    ((_, sigma_new, dp_new),) = evaluate_external_operators([C_tang], evaluated_operands)
+    sigma.ref_coefficient.x.array[:] = sigma_new
+    Co, so, dpo = oracle.von_mises(deps_full, sigma_n, p)
+    assert_close_scaled(C_tang.ref_coefficient.x.array, Co, RTOL, "C_tang coefficient")
+    assert_close_scaled(sigma.ref_coefficient.x.array, so, RTOL, "sigma coefficient")
+    assert_close_scaled(dp_new, dpo, RTOL, "dp")
+    with pytest.raises(NotImplementedError, match="No external function is defined"):
+        evaluate_external_operators([sigma], evaluated_operands)
+    # the closure state is re-read at every call (load stepping mutates it, :564-565)
+    state["p"] = p + dp_new
+    state["sigma_n"] = sigma_new.copy()
+    ((C2, s2, dp2),) = evaluate_external_operators([C_tang], evaluated_operands)
+    Co2, so2, dpo2 = oracle.von_mises(deps_full, sigma_new.reshape(-1, d), p + dp_new)
+    assert_close_scaled(s2, so2, RTOL, "sigma step 2")
+    assert_close_scaled(dp2, dpo2, RTOL, "dp step 2")
+
+
+def test_device_resident_tensors(ctx, oracle):
+    import torch
+
+    nc, nq, d = 1000, 8, 6
+    deps, sigma_n, p = vm_inputs(nc * nq, d, seed=44)
+    dev = torch.device("cuda:0")
+    sn_t = torch.from_numpy(sigma_n).to(dev)
+    p_t = torch.from_numpy(p).to(dev)
+    ext = make_von_mises(sn_t, p_t, ctx=ctx)
+    C, s, dp = ext((1,))(torch.from_numpy(deps.reshape(nc, nq, d)).to(dev))
+    assert C.is_cuda and C.shape == (nc * nq * d * d,)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C.cpu().numpy(), Co, RTOL, "C_tang")
+    assert_close_scaled(s.cpu().numpy(), so, RTOL, "sigma")
+
+
+@pytest.mark.parametrize("d", [6])
+def test_full_size_properties(ctx, d):
+    """BASELINE config 2 size (10^6 points, d = 6): properties that need no oracle.
+    plastic points land on the yield surface, elastic points return C_elas exactly, tangent symmetric,
+    trace(sigma) is the elastic trace (the return is purely deviatoric)."""
+    import torch
+
+    n = 1_000_000
+    deps, sigma_n, p = vm_inputs(n, d, seed=0, plastic_scale=0.7)
+    C, s, dp = run_device(ctx, deps, sigma_n, p, 1)
+    dev = s.copy()
+    dev[:, :3] -= s[:, :3].mean(axis=1, keepdims=True)
+    seq = np.sqrt(1.5 * np.sum(dev * dev, axis=1))
+    plastic = dp > 0
+    assert 0.05 < plastic.mean() < 0.999
+    f = seq - SIGMA_0 - H * (p + dp)
+    assert np.max(np.abs(f[plastic])) < 1e-9 * SIGMA_0
+    assert np.all(f[~plastic] <= 1e-9)
+    lmbda = E * NU / (1 + NU) / (1 - 2 * NU)
+    mu = E / 2 / (1 + NU)
+    C_el = np.zeros((d, d))
+    C_el[:3, :3] = lmbda
+    C_el[np.arange(d), np.arange(d)] += 2 * mu
+    assert np.array_equal(C[~plastic], np.broadcast_to(C_el, C[~plastic].shape))
+    assert np.max(np.abs(C - np.transpose(C, (0, 2, 1)))) < 1e-10 * E
+    tr_el = sigma_n[:, :3].sum(1) + (3 * lmbda + 2 * mu) * deps[:, :3].sum(1)
+    assert np.max(np.abs(s[:, :3].sum(1) - tr_el)) < 1e-10 * np.max(np.abs(tr_el))
+    # consistent tangent: finite-difference check of d sigma / d eps on a handful of plastic points
+    idx = np.flatnonzero(plastic)[:64]
+    h = 1e-7
+    for k in range(d):
+        e2 = deps[idx].copy()
+        e2[:, k] += h
+        _, s2, _ = run_device(ctx, e2, sigma_n[idx], p[idx], 1)
+        fd = (s2 - s[idx]) / h
+        assert np.max(np.abs(fd - C[idx][:, :, k])) < 2e-5 * E
