@@ -11,11 +11,11 @@ the RCCL all-gather that reassembles the flat coefficient vectors (BASELINE nort
 
 Workload (named in config.workload): 3-D hex mesh, 8 quadrature points per cell (degree-2 rule), Mandel
 d = 6, fp64; 1 250 000 cells = 10^7 quadrature points per GPU — the size BASELINE.json's north_star quotes
-the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, small enough that its 104 MB of
-inputs stay in the 256 MB Infinity Cache between steps; it is reported too, under "also"). Scaling is weak:
-every rank owns its own cell block of 10^7 points (config 3 is 1.25*10^7 per GPU).
+the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, of which the 104 MB of inputs stay
+in the 256 MB Infinity Cache between steps; scripts/bench_extra.py reports it). Scaling is weak: every rank
+owns its own cell block of 10^7 points (config 3 is 1.25*10^7 per GPU).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (contract: task statement).
 """
 from __future__ import annotations
 
@@ -33,6 +33,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_QP = {4: 240, 6: 448}  # algorithmic fp64 traffic per point, SURVEY.md 8(d)
+PROBE_MIX = {4: (9, 21), 6: (13, 43)}  # 16-byte chunks read / written per pair of points
 
 
 def log(*a):
@@ -40,19 +41,27 @@ def log(*a):
 
 
 def synth_inputs(torch, n, d, seed, device):
-    """deps ~ N(0, 3e-3) (Mandel shear x sqrt 2), sigma_n ~ N(0, 100), p = |N(0, 1e-3)|."""
+    """deps ~ N(0, 3e-3) (Mandel shear x sqrt 2), sigma_n ~ N(0, 100), p = |N(0, 1e-3)|.
+    All three live in ONE slab (13 doubles per point at d = 6) so the stream probe can read exactly the
+    same memory the kernel reads."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    deps = torch.randn(n, d, generator=g, device=device, dtype=torch.float64) * 3e-3
+    slab = torch.empty(n * (2 * d + 1), dtype=torch.float64, device=device)
+    deps = slab[: n * d].view(n, d)
+    sigma_n = slab[n * d: 2 * n * d].view(n, d)
+    p = slab[2 * n * d:]
+    deps.normal_(0.0, 3e-3, generator=g)
     deps[:, 3:] *= 2.0 ** 0.5
-    sigma_n = torch.randn(n, d, generator=g, device=device, dtype=torch.float64) * 100.0
-    p = (torch.randn(n, generator=g, device=device, dtype=torch.float64) * 1e-3).abs()
-    return deps.contiguous(), sigma_n.contiguous(), p.contiguous()
+    sigma_n.normal_(0.0, 100.0, generator=g)
+    p.normal_(0.0, 1e-3, generator=g)
+    p.abs_()
+    return slab, deps, sigma_n, p
 
 
-def cpu_baseline(d, n_sample, budget_s=12.0):
-    """Time the CPU oracle (oracle/dxo_oracle.c, a statement-by-statement port of the reference's
-    Numba kernel, OpenMP over points) on this host, on a bounded sample of the same distribution."""
+def cpu_baseline(d, n_sample, budget_s=10.0):
+    """Time the CPU oracle (oracle/dxo_oracle.c, a statement-by-statement port of the reference's Numba
+    kernel, OpenMP over points) on this host's cores, on a bounded sample of the same distribution.
+    Output arrays are allocated and touched once, outside the timed passes."""
     import numpy as np
 
     from oracle import load_oracle
@@ -64,21 +73,25 @@ def cpu_baseline(d, n_sample, budget_s=12.0):
     deps[:, 3:] *= np.sqrt(2.0)
     sigma_n = rng.normal(0.0, 100.0, size=(n_sample, d))
     p = np.abs(rng.normal(0.0, 1e-3, size=n_sample))
-    o.von_mises(deps[:1000], sigma_n[:1000], p[:1000], nthreads=threads)  # thread-pool warm-up
+    out = (np.zeros((n_sample, d, d)), np.zeros((n_sample, d)), np.zeros(n_sample))
+    o.von_mises(deps, sigma_n, p, nthreads=threads, out=out)  # thread-pool + page warm-up
     rates, t_all = [], time.perf_counter()
-    while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 40):
+    while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 200):
         t0 = time.perf_counter()
-        o.von_mises(deps, sigma_n, p, nthreads=threads)
+        o.von_mises(deps, sigma_n, p, nthreads=threads, out=out)
         rates.append(n_sample / (time.perf_counter() - t0))
-    t0 = time.perf_counter()
     n1 = max(n_sample // 8, 1000)
-    o.von_mises(deps[:n1], sigma_n[:n1], p[:n1], nthreads=1)
-    one_core = n1 / (time.perf_counter() - t0)
+    out1 = tuple(a[:n1] for a in out)
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o.von_mises(deps[:n1], sigma_n[:n1], p[:n1], nthreads=1, out=out1)
+        one.append(n1 / (time.perf_counter() - t0))
     return {
         "value": statistics.median(rates), "unit": "qp/s", "cores": threads, "kind": "port",
-        "sample": f"{n_sample} points x {len(rates)} passes (median), d={d}, same distribution, "
-                  f"oracle/dxo_oracle.c OpenMP incl. output allocation",
-        "value_1core": one_core,
+        "sample": f"{n_sample} points x {len(rates)} passes (median of passes), d={d}, same input distribution; "
+                  f"oracle/dxo_oracle.c (C port of the reference's Numba kernel) with OpenMP over points",
+        "value_1core": statistics.median(one),
     }
 
 
@@ -92,6 +105,7 @@ def main():
     ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
     ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-probe", action="store_true", help="skip the stream-ceiling probe")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
@@ -125,7 +139,7 @@ def main():
         dist.barrier()
 
     d, K, W = args.d, args.steps, args.warmup
-    n = (args.nqp + WAVE_TILE - 1) // WAVE_TILE * WAVE_TILE  # shard borders on wave tiles
+    n = (args.nqp + 2 * WAVE_TILE - 1) // (2 * WAVE_TILE) * (2 * WAVE_TILE)  # shard borders on wave tiles
     gather = (world > 1) if args.gather < 0 else bool(args.gather)
     E, nu, sigma_0 = 70e3, 0.3, 250.0
     H = E * (E / 100.0) / (E - E / 100.0)
@@ -142,10 +156,12 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     seed = 1 if world == 1 else 100 + rank
-    deps, sigma_n, p = synth_inputs(torch, n, d, seed, device)
-    C_tang = torch.empty(n * d * d, dtype=torch.float64, device=device)
-    sigma = torch.empty(n * d, dtype=torch.float64, device=device)
-    dp = torch.empty(n, dtype=torch.float64, device=device)
+    in_slab, deps, sigma_n, p = synth_inputs(torch, n, d, seed, device)
+    # outputs carved from one slab too (C_tang | sigma | dp), 43 doubles per point at d = 6
+    out_slab = torch.empty(n * (d * d + d + 1), dtype=torch.float64, device=device)
+    C_tang = out_slab[: n * d * d]
+    sigma = out_slab[n * d * d: n * (d * d + d)]
+    dp = out_slab[n * (d * d + d):]
     full = None
     if gather and world > 1:
         full = [torch.empty(world * t.numel(), dtype=torch.float64, device=device) for t in (C_tang, sigma, dp)]
@@ -187,7 +203,7 @@ def main():
     else:
         kernel_ms_avg_max = kernel_ms_avg
 
-    # quick correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface
+    # correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface
     s_chk = sigma.view(n, d)[:4096]
     dev_chk = s_chk.clone()
     dev_chk[:, :3] -= s_chk[:, :3].mean(dim=1, keepdim=True)
@@ -205,6 +221,22 @@ def main():
     bytes_per_launch = BYTES_PER_QP[d] * n
     achieved = bytes_per_launch / (kernel_ms_avg_max * 1e-3) / 1e9
 
+    # stream ceiling: a no-arithmetic kernel moving the same read:write mix over the SAME two slabs
+    ceiling = None
+    if rank == 0 and not args.no_probe:
+        R, Wc = PROBE_MIX[d]
+        tiles = n // (2 * WAVE_TILE)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for _ in range(W):
+            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), out_slab.data_ptr())
+        for a, b in ev:
+            a.record(stream)
+            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), out_slab.data_ptr())
+            b.record(stream)
+        torch.cuda.synchronize(device)
+        ms = statistics.mean(a.elapsed_time(b) for a, b in ev)
+        ceiling = tiles * (R + Wc) * 1024 / (ms * 1e-3) / 1e9
+
     result = None
     if rank == 0:
         traffic = None
@@ -212,7 +244,8 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("points_per_launch") == n and tj.get("d") == d:
+                # the counter pass records the launch's grid size in threads = points rounded up to whole workgroups
+                if 0 <= tj.get("grid_threads", -1) - n < 256 and tj.get("d") == d:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -223,13 +256,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
-                            f"{n // args.nq} cells = {n} quadrature points per GPU, fp64, cell-block sharded"
-                            + (", RCCL all-gather of (C_tang, sigma, dp) every step" if full is not None else ""),
+                            f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
+                            + (", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step" if full is not None
+                               else (", cell-block sharded, no gather" if world > 1 else "")),
                 "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
                 "sharding": "cell-block" if world > 1 else "none",
                 "gather": "rccl_all_gather" if full is not None else "none",
                 "kernel": "vm_tile" if args.variant else "vm_point",
-                "device": info["name"], "arch": info["arch"],
+                "arch": info["arch"], "compute_units": info["compute_units"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -237,42 +271,14 @@ def main():
                 "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
                 "kernel_ms_avg": kernel_ms_avg_max, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "bytes_per_qp": BYTES_PER_QP[d],
+                "stream_ceiling_GBps": ceiling,
+                "frac_of_stream_ceiling": (achieved / ceiling) if ceiling else None,
             },
             "kernel_only_value": total_points / (kernel_ms_avg_max * 1e-3),
         }
-
-    # secondary sizes, N = 1 only, outside the timed region
-    if world == 1 and rank == 0:
-        also = {}
-        n2 = 1_000_000
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-        for _ in range(W):
-            ctx.von_mises(prm, d, n2, MEM_DEVICE, *ptrs)
-        for a, b in ev:
-            a.record(stream)
-            ctx.von_mises(prm, d, n2, MEM_DEVICE, *ptrs)
-            b.record(stream)
-        torch.cuda.synchronize(device)
-        ms2 = statistics.mean(a.elapsed_time(b) for a, b in ev)
-        also["config2_1e6_points"] = {"qp_per_s": n2 / (ms2 * 1e-3), "kernel_ms": ms2,
-                                      "GBps": BYTES_PER_QP[d] * n2 / (ms2 * 1e-3) / 1e9,
-                                      "note": "448 MB working set; inputs (104 MB) stay in the 256 MB Infinity Cache"}
-        # PCIe-inclusive end-to-end through the host entry point (never `value`)
-        import numpy as np
-        nh = 1_000_000
-        hd, hs, hp = (t[:nh].cpu().numpy() for t in (deps, sigma_n, p))
-        oC, os_, odp = np.empty(nh * d * d), np.empty(nh * d), np.empty(nh)
-        from dolfinx_external_operator_amd import MEM_HOST
-        ctx.von_mises(prm, d, nh, MEM_HOST, hd, hs, hp, oC, os_, odp)
-        t1 = time.perf_counter()
-        ctx.von_mises(prm, d, nh, MEM_HOST, hd, hs, hp, oC, os_, odp)
-        also["host_end_to_end_1e6_points"] = {"qp_per_s": nh / (time.perf_counter() - t1), **ctx.last_timing(),
-                                              "note": "pageable NumPy arrays, H2D + kernel + D2H, PCIe-inclusive"}
-        result["also"] = also
-        if not args.no_cpu:
-            del C_tang, sigma, dp
+        if world == 1 and not args.no_cpu:
+            del out_slab, C_tang, sigma, dp
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
-    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

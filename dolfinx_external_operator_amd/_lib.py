@@ -62,6 +62,7 @@ _SIGNATURES = {
     "dxo_host_free": (C.c_int, [_P, _P]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
+    "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
 _lib = None
@@ -70,6 +71,34 @@ _lib_lock = threading.Lock()
 
 class DxoError(RuntimeError):
     pass
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP/HSA runtime per process.
+
+    PyTorch-ROCm wheels bundle their own `libamdhip64.so` (SONAME libamdhip64.so.7) and load it by the
+    unversioned name, so if libdxo_hip.so pulled in /opt/rocm's copy first, a later `import torch` would
+    load a SECOND runtime whose hsa_init sees no GPU ("No HIP GPUs are available"). When torch is
+    installed but not yet imported, map its bundled runtime first: libdxo_hip.so's NEEDED
+    `libamdhip64.so.7` then resolves to that same object (SONAME match) and torch later finds its own file
+    already mapped. Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = pathlib.Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load_library(path: str | pathlib.Path | None = None) -> C.CDLL:
@@ -84,6 +113,7 @@ def load_library(path: str | pathlib.Path | None = None) -> C.CDLL:
                 f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the quadrature-point kernels."
             )
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(str(p))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
@@ -197,6 +227,10 @@ class Context:
                                     _ptr(p), _ptr(C_tang), _ptr(sigma), _ptr(dp))
         self.check(rc, "dxo_von_mises")
 
+    def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
+        rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))
+        self.check(rc, "dxo_stream_probe")
+
     def heat(self, A: float, B: float, gdim: int, n: int, mem: int, T, sigma, q, dqdT, dqdsigma) -> None:
         rc = self.lib.dxo_heat(self._h, float(A), float(B), int(gdim), int(n), int(mem), _ptr(T), _ptr(sigma),
                                _ptr(q), _ptr(dqdT), _ptr(dqdsigma))
@@ -204,6 +238,7 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+
 
 
 def default_context(device: int = 0) -> Context:

@@ -133,6 +133,15 @@ int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, int mem,
              const double* T, const double* sigma,
              double* q, double* dqdT, double* dqdsigma);
 
+/* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
+ * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
+ * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte
+ * stores. Supported mixes (read, write): (13,43) von Mises d=6, (9,21) von Mises d=4, (8,20)
+ * Mohr-Coulomb, (3,8) heat, (1,1) and (4,4) plain copy. src needs n_tiles*read_chunks*1024 bytes, dst
+ * n_tiles*write_chunks*1024 bytes. bench.py reports its GB/s beside the 8 TB/s spec peak. */
+int dxo_stream_probe(dxo_ctx* ctx, int read_chunks, int write_chunks, int64_t n_tiles,
+                     const void* src, void* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,8 +38,9 @@ class OracleLib:
     def max_threads(self) -> int:
         return int(self.lib.oracle_max_threads())
 
-    def von_mises(self, deps, sigma_n, p, *, E=70e3, nu=0.3, sigma_0=250.0, H=None, nthreads=1):
-        """deps (..., d), sigma_n (..., d), p (...) -> C_tang (N, d, d), sigma (N, d), dp (N,)"""
+    def von_mises(self, deps, sigma_n, p, *, E=70e3, nu=0.3, sigma_0=250.0, H=None, nthreads=1, out=None):
+        """deps (..., d), sigma_n (..., d), p (...) -> C_tang (N, d, d), sigma (N, d), dp (N,).
+        `out=(C_tang, sigma, dp)` reuses caller buffers (timing runs: keeps page faults out of the loop)."""
         if H is None:
             Et = E / 100.0
             H = E * Et / (E - Et)
@@ -49,9 +50,13 @@ class OracleLib:
         p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
         n = deps.shape[0]
         prm = np.array([E, nu, sigma_0, H], dtype=np.float64)
-        C_tang = np.empty((n, d, d))
-        sigma = np.empty((n, d))
-        dp = np.empty(n)
+        if out is None:
+            C_tang = np.empty((n, d, d))
+            sigma = np.empty((n, d))
+            dp = np.empty(n)
+        else:
+            C_tang, sigma, dp = out
+            assert C_tang.size == n * d * d and sigma.size == n * d and dp.size == n
         rc = self.lib.oracle_von_mises(_dp(prm), d, n, _dp(deps), _dp(sigma_n), _dp(p), _dp(C_tang), _dp(sigma),
                                        _dp(dp), int(nthreads))
         if rc != 0:

@@ -15,7 +15,7 @@ from dolfinx_external_operator_amd import (
 pytestmark = pytest.mark.gpu
 
 # k = 1/(A + B T) uses the GPU's correctly-rounded fp64 division; products may be FMA-contracted.
-RTOL = 4e-16
+RTOL = 1e-15
 
 
 def rel(a, b):
