@@ -67,31 +67,39 @@ def cpu_baseline(d, n_sample, budget_s=10.0):
     from oracle import load_oracle
 
     o = load_oracle()
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     rng = np.random.Generator(np.random.PCG64(1))
     deps = rng.normal(0.0, 3e-3, size=(n_sample, d))
     deps[:, 3:] *= np.sqrt(2.0)
     sigma_n = rng.normal(0.0, 100.0, size=(n_sample, d))
     p = np.abs(rng.normal(0.0, 1e-3, size=n_sample))
     out = (np.zeros((n_sample, d, d)), np.zeros((n_sample, d)), np.zeros(n_sample))
-    o.von_mises(deps, sigma_n, p, nthreads=threads, out=out)  # thread-pool + page warm-up
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def one_pass(nt):
+        t0 = time.perf_counter()
+        o.von_mises(deps, sigma_n, p, nthreads=nt, out=out)
+        return n_sample / (time.perf_counter() - t0)
+
+    # The visible core count can exceed what the container may actually run (cgroup quota): scan thread
+    # counts and keep the fastest; `cores` reports the thread count actually used for the quoted value.
+    one_pass(avail)  # thread-pool + page warm-up
+    scan = {}
+    nt = 1
+    while nt <= avail:
+        scan[nt] = max(one_pass(nt), one_pass(nt))
+        nt *= 2
+    if avail not in scan:
+        scan[avail] = max(one_pass(avail), one_pass(avail))
+    threads = max(scan, key=scan.get)
     rates, t_all = [], time.perf_counter()
     while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 200):
-        t0 = time.perf_counter()
-        o.von_mises(deps, sigma_n, p, nthreads=threads, out=out)
-        rates.append(n_sample / (time.perf_counter() - t0))
-    n1 = max(n_sample // 8, 1000)
-    out1 = tuple(a[:n1] for a in out)
-    one = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        o.von_mises(deps[:n1], sigma_n[:n1], p[:n1], nthreads=1, out=out1)
-        one.append(n1 / (time.perf_counter() - t0))
+        rates.append(one_pass(threads))
     return {
         "value": statistics.median(rates), "unit": "qp/s", "cores": threads, "kind": "port",
         "sample": f"{n_sample} points x {len(rates)} passes (median of passes), d={d}, same input distribution; "
-                  f"oracle/dxo_oracle.c (C port of the reference's Numba kernel) with OpenMP over points",
-        "value_1core": statistics.median(one),
+                  f"oracle/dxo_oracle.c (C port of the reference's Numba kernel) with OpenMP over points, "
+                  f"fastest of thread counts {sorted(scan)} on {avail} visible cores",
+        "value_1core": scan[1], "thread_scan": {str(k): v for k, v in scan.items()},
     }
 
 
