@@ -62,6 +62,7 @@ _SIGNATURES = {
     "dxo_host_free": (C.c_int, [_P, _P]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
+    "dxo_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [_P] * 8),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
@@ -226,6 +227,12 @@ class Context:
         rc = self.lib.dxo_von_mises(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(deps), _ptr(sigma_n),
                                     _ptr(p), _ptr(C_tang), _ptr(sigma), _ptr(dp))
         self.check(rc, "dxo_von_mises")
+
+    def mohr_coulomb(self, prm: McParams, n: int, mem: int, deps, sigma_n, C_tang, sigma, niter=None, yielding=None,
+                     norm_res=None, dlambda=None) -> None:
+        rc = self.lib.dxo_mohr_coulomb(self._h, C.byref(prm), int(n), int(mem), _ptr(deps), _ptr(sigma_n), _ptr(C_tang),
+                                       _ptr(sigma), _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
+        self.check(rc, "dxo_mohr_coulomb")
 
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))

@@ -1,0 +1,481 @@
+// mc_core.h — per-point Mohr-Coulomb (Abbo-Sloan) return mapping with the forward-mode-through-Newton
+// tangent, written for one GPU lane. Host/device compilable (the host build exists only so the math can
+// be unit-tested against the oracle without a GPU; the product path is mohr_coulomb.hip).
+//
+// Reference: doc/demo/demo_plasticity_mohr_coulomb.py — surface/f/g :282-391, r/drdy :420-462,
+// return_mapping :474-533, dsigma_ddeps = jacfwd(return_mapping) :555.
+//
+// The reference gets every derivative from JAX forward-mode AD: dg/dsigma inside r, dr/dy inside the
+// Newton loop, and the tangent by differentiating THROUGH the loop. A GPU lane cannot afford nested
+// dual numbers (a triple-nested 4-direction dual is 20+ doubles per scalar), so the same quantities are
+// obtained in closed form:
+//
+//  1. g(sigma) = sin(a) I1/3 + F(J2, J3) - c cos(a),  F = sqrt(J2 K(theta)^2 + a_g^2 sin^2 a),
+//     theta = asin(clip(-3 sqrt3 J3 / (2 J2^1.5)))/3. F is evaluated ONCE per iterate on a truncated Taylor
+//     type in the two invariants (T23: all partials of F up to third order, 10 numbers). Tensor
+//     derivatives follow from the chain rule with grad J2 = s, hess J2 = dev, grad/hess J3 polynomial in s.
+//  2. Newton step on y = (sigma, dlambda) in compliance form: with S = C^-1, M = S + dlambda H_g (SPD),
+//     J^-1 reduces to solves with M (LDL^T, no pivoting, fully unrolled) plus a scalar Schur complement.
+//  3. Tangent recursion of jacfwd-through-while_loop (Y_k = d y_k / d deps, Y_0 = 0, step t = J^-1 r):
+//         Y_{k+1} = J^-1 ( [C; 0] + (D J [Y_k]) t ),
+//     (D J[v, dl] t)_sigma  = C ( dl H t_s + dlambda T(t_s) v + t_l H v ),   T(t) = D_t H (third derivatives)
+//     (D J[v, dl] t)_lambda = (H_f t_s) . v
+//     which is exactly what forward-mode AD of `y + solve(drdy(y), -r(y))` computes.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DXO_HD __host__ __device__ __forceinline__
+#else
+#define DXO_HD inline
+#endif
+
+namespace mc {
+
+struct Const {  // derived once on the host from dxo_mc_params
+    double lmbda, mu2;              // C_elas = lmbda 1(x)1 + 2 mu I (Mandel), :405-415
+    double inv_E, nu;               // S = C^-1: (1/E) [[1,-nu,-nu,0],...,[0,0,0,1+nu]]
+    double c, theta_T, tol;
+    int32_t nitermax, same_angle;   // same_angle: phi == psi -> f and g share every derivative
+    // per angle (index 0: phi -> f, 1: psi -> g)
+    double sin_a[2], cos_a[2], k_lin[2];       // k_lin = sin(a)/sqrt(3)
+    double ag2s2[2];                           // a_g(a)^2 sin^2 a, :348-349, :371
+    double A[2][2], B[2][2], Cc[2][2];         // Abbo-Sloan coefficients for sign(theta) = -1 / +1, :302-331
+};
+
+// ---- truncated Taylor type in (x, y) = (J2, J3): f, fx, fy, fxx, fxy, fyy, fxxx, fxxy, fxyy, fyyy
+struct T23 { double c[10]; };
+
+DXO_HD T23 t_mul(const T23& u, const T23& v) {
+    T23 w;
+    w.c[0] = u.c[0] * v.c[0];
+    w.c[1] = u.c[1] * v.c[0] + u.c[0] * v.c[1];
+    w.c[2] = u.c[2] * v.c[0] + u.c[0] * v.c[2];
+    w.c[3] = u.c[3] * v.c[0] + 2.0 * u.c[1] * v.c[1] + u.c[0] * v.c[3];
+    w.c[4] = u.c[4] * v.c[0] + u.c[1] * v.c[2] + u.c[2] * v.c[1] + u.c[0] * v.c[4];
+    w.c[5] = u.c[5] * v.c[0] + 2.0 * u.c[2] * v.c[2] + u.c[0] * v.c[5];
+    w.c[6] = u.c[6] * v.c[0] + 3.0 * (u.c[3] * v.c[1] + u.c[1] * v.c[3]) + u.c[0] * v.c[6];
+    w.c[7] = u.c[7] * v.c[0] + u.c[3] * v.c[2] + 2.0 * (u.c[4] * v.c[1] + u.c[1] * v.c[4]) + u.c[2] * v.c[3] + u.c[0] * v.c[7];
+    w.c[8] = u.c[8] * v.c[0] + u.c[5] * v.c[1] + 2.0 * (u.c[4] * v.c[2] + u.c[2] * v.c[4]) + u.c[1] * v.c[5] + u.c[0] * v.c[8];
+    w.c[9] = u.c[9] * v.c[0] + 3.0 * (u.c[5] * v.c[2] + u.c[2] * v.c[5]) + u.c[0] * v.c[9];
+    return w;
+}
+
+// w = h(u) given h and its first three derivatives at u.c[0] (Faa di Bruno to third order)
+DXO_HD T23 t_compose(const T23& u, double h0, double h1, double h2, double h3) {
+    T23 w;
+    const double ux = u.c[1], uy = u.c[2];
+    w.c[0] = h0;
+    w.c[1] = h1 * ux;
+    w.c[2] = h1 * uy;
+    w.c[3] = h1 * u.c[3] + h2 * ux * ux;
+    w.c[4] = h1 * u.c[4] + h2 * ux * uy;
+    w.c[5] = h1 * u.c[5] + h2 * uy * uy;
+    w.c[6] = h1 * u.c[6] + 3.0 * h2 * u.c[3] * ux + h3 * ux * ux * ux;
+    w.c[7] = h1 * u.c[7] + h2 * (u.c[3] * uy + 2.0 * u.c[4] * ux) + h3 * ux * ux * uy;
+    w.c[8] = h1 * u.c[8] + h2 * (u.c[5] * ux + 2.0 * u.c[4] * uy) + h3 * ux * uy * uy;
+    w.c[9] = h1 * u.c[9] + 3.0 * h2 * u.c[5] * uy + h3 * uy * uy * uy;
+    return w;
+}
+
+DXO_HD T23 t_scale(const T23& u, double k) {
+    T23 w;
+    for (int i = 0; i < 10; ++i) w.c[i] = k * u.c[i];
+    return w;
+}
+
+DXO_HD T23 t_sqrt(const T23& u) {
+    const double h0 = sqrt(u.c[0]);
+    const double h1 = 0.5 / h0;
+    const double h2 = -0.5 * h1 / u.c[0];
+    const double h3 = -1.5 * h2 / u.c[0];
+    return t_compose(u, h0, h1, h2, h3);
+}
+
+// ---- 4-vector helpers on the Mandel vector (xx, yy, zz, sqrt2 xy)
+DXO_HD void devv(const double* v, double* out) {  // dev @ v, :352-360
+    const double m = (v[0] + v[1] + v[2]) * (1.0 / 3.0);
+    out[0] = v[0] - m;
+    out[1] = v[1] - m;
+    out[2] = v[2] - m;
+    out[3] = v[3];
+}
+DXO_HD double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+DXO_HD void C_times(const Const& k, const double* x, double* out) {  // C_elas @ x
+    const double t = k.lmbda * (x[0] + x[1] + x[2]);
+    out[0] = t + k.mu2 * x[0];
+    out[1] = t + k.mu2 * x[1];
+    out[2] = t + k.mu2 * x[2];
+    out[3] = k.mu2 * x[3];
+}
+DXO_HD void S_times(const Const& k, const double* x, double* out) {  // C_elas^-1 @ x
+    const double t = k.nu * (x[0] + x[1] + x[2]);
+    out[0] = k.inv_E * ((1.0 + k.nu) * x[0] - t);
+    out[1] = k.inv_E * ((1.0 + k.nu) * x[1] - t);
+    out[2] = k.inv_E * ((1.0 + k.nu) * x[2] - t);
+    out[3] = k.inv_E * (1.0 + k.nu) * x[3];
+}
+// hess_s J3 (s) applied to w; linear in s (so it also serves D_t hess J3 with s -> dev t)
+DXO_HD void Qs_times(const double* s, const double* w, double* out) {
+    out[0] = s[2] * w[1] + s[1] * w[2];
+    out[1] = s[2] * w[0] + s[0] * w[2];
+    out[2] = s[1] * w[0] + s[0] * w[1] - s[3] * w[3];
+    out[3] = -s[3] * w[2] - s[2] * w[3];
+}
+
+// Everything the Newton step needs about the yield surface / plastic potential at one stress state.
+struct Surf {
+    double s[4], q[4];     // grad J2 = s, grad J3 = dev q_s
+    double I1;
+    double f, g;           // f(sigma), g(sigma)
+    T23 F[2];              // F for angle phi (f) and psi (g)
+    bool finite_branch;    // false when J2 == 0 produced NaN (kept, like the reference)
+};
+
+// theta(J2, J3) as a Taylor object, :290-295
+DXO_HD T23 theta_taylor(double J2, double J3) {
+    const double r = sqrt(J2);
+    const double h0 = 1.0 / (J2 * r);   // J2^-1.5
+    const double h1 = -1.5 * h0 / J2;
+    const double h2 = -2.5 * h1 / J2;
+    const double h3 = -3.5 * h2 / J2;
+    const double kk = -(3.0 * sqrt(3.0)) / 2.0;
+    T23 a;
+    a.c[0] = kk * J3 * h0;
+    a.c[1] = kk * J3 * h1;
+    a.c[2] = kk * h0;
+    a.c[3] = kk * J3 * h2;
+    a.c[4] = kk * h1;
+    a.c[5] = 0.0;
+    a.c[6] = kk * J3 * h3;
+    a.c[7] = kk * h2;
+    a.c[8] = 0.0;
+    a.c[9] = 0.0;
+    if (a.c[0] < -1.0 || a.c[0] > 1.0) {  // jnp.clip: constant outside, no tangent
+        const double v = a.c[0] < 0.0 ? -1.0 : 1.0;
+        for (int i = 1; i < 10; ++i) a.c[i] = 0.0;
+        a.c[0] = v;
+    }
+    const double u = a.c[0];
+    const double w = 1.0 / sqrt(1.0 - u * u);
+    const double w3 = w * w * w;
+    T23 th = t_compose(a, asin(u), w, u * w3, w3 + 3.0 * u * u * w3 * w * w);
+    return t_scale(th, 1.0 / 3.0);
+}
+
+// F(J2, J3) = sqrt(J2 K(theta)^2 + a_g^2 sin^2 a) for angle index ia, :334-345, :364-374
+DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th) {
+    T23 K;
+    const double t0 = th.c[0];
+    if (fabs(t0) > k.theta_T) {
+        const int sg = t0 < 0.0 ? 0 : 1;  // sign(theta), :298-299
+        const T23 u = t_scale(th, 3.0);
+        const double sn = sin(u.c[0]), cs = cos(u.c[0]);
+        const T23 S3 = t_compose(u, sn, cs, -sn, -cs);
+        const T23 S3S3 = t_mul(S3, S3);
+        for (int i = 0; i < 10; ++i) K.c[i] = k.B[ia][sg] * S3.c[i] + k.Cc[ia][sg] * S3S3.c[i];
+        K.c[0] += k.A[ia][sg];
+    } else {
+        const double sn = sin(t0), cs = cos(t0);
+        const T23 Ct = t_compose(th, cs, -sn, -cs, sn);
+        const T23 St = t_compose(th, sn, cs, -sn, -cs);
+        for (int i = 0; i < 10; ++i) K.c[i] = Ct.c[i] - k.k_lin[ia] * St.c[i];
+    }
+    const T23 KK = t_mul(K, K);
+    T23 w;  // x * KK + const, x = J2 (dx = 1)
+    w.c[0] = J2 * KK.c[0] + k.ag2s2[ia];
+    w.c[1] = KK.c[0] + J2 * KK.c[1];
+    w.c[2] = J2 * KK.c[2];
+    w.c[3] = 2.0 * KK.c[1] + J2 * KK.c[3];
+    w.c[4] = KK.c[2] + J2 * KK.c[4];
+    w.c[5] = J2 * KK.c[5];
+    w.c[6] = 3.0 * KK.c[3] + J2 * KK.c[6];
+    w.c[7] = 2.0 * KK.c[4] + J2 * KK.c[7];
+    w.c[8] = KK.c[5] + J2 * KK.c[8];
+    w.c[9] = J2 * KK.c[9];
+    return t_sqrt(w);
+}
+
+DXO_HD void surf_eval(const Const& k, const double* sig, Surf& o) {
+    devv(sig, o.s);
+    o.I1 = sig[0] + sig[1] + sig[2];
+    const double* s = o.s;
+    const double J2 = 0.5 * dot4(s, s);                       // :286-287
+    const double J3 = s[2] * (s[0] * s[1] - s[3] * s[3] / 2.0);  // :282-283
+    const double qs[4] = {s[1] * s[2], s[0] * s[2], s[0] * s[1] - s[3] * s[3] / 2.0, -s[2] * s[3]};
+    devv(qs, o.q);
+    const T23 th = theta_taylor(J2, J3);
+    o.F[1] = F_taylor(k, 1, J2, th);
+    o.g = o.I1 / 3.0 * k.sin_a[1] + o.F[1].c[0] - k.c * k.cos_a[1];
+    if (k.same_angle) {
+        o.F[0] = o.F[1];
+        o.f = o.g;
+    } else {
+        o.F[0] = F_taylor(k, 0, J2, th);
+        o.f = o.I1 / 3.0 * k.sin_a[0] + o.F[0].c[0] - k.c * k.cos_a[0];
+    }
+}
+
+// value of f only (trial-stress check), same arithmetic as surf_eval's value path
+DXO_HD double f_value(const Const& k, const double* sig) {
+    Surf tmp;
+    surf_eval(k, sig, tmp);
+    return tmp.f;
+}
+
+DXO_HD void grad_surface(const Const& k, const Surf& e, int ia, double* out) {  // d surface / d sigma
+    const double Fx = e.F[ia].c[1], Fy = e.F[ia].c[2];
+    const double h = k.sin_a[ia] / 3.0;
+    out[0] = h + Fx * e.s[0] + Fy * e.q[0];
+    out[1] = h + Fx * e.s[1] + Fy * e.q[1];
+    out[2] = h + Fx * e.s[2] + Fy * e.q[2];
+    out[3] = Fx * e.s[3] + Fy * e.q[3];
+}
+
+// H v = hess(surface) v
+DXO_HD void hess_apply(const Surf& e, int ia, const double* v, double* out) {
+    const double* F = e.F[ia].c;
+    double Pv[4], Qv[4], tmp[4];
+    devv(v, Pv);
+    Qs_times(e.s, Pv, tmp);
+    devv(tmp, Qv);
+    const double al = dot4(e.s, v), be = dot4(e.q, v);
+    const double cp = F[3] * al + F[4] * be, cq = F[4] * al + F[5] * be;
+    for (int i = 0; i < 4; ++i) out[i] = F[1] * Pv[i] + F[2] * Qv[i] + cp * e.s[i] + cq * e.q[i];
+}
+
+// Precomputed pieces of T(t) = D_t hess(surface) for a fixed direction t
+struct Third {
+    double Pt[4], Qt[4], dPt[4];  // dev t, (hess J3) t, dev t again for R_t
+    double a, b;                  // s.t, q.t
+    double dFx, dFy, dFxx, dFxy, dFyy;
+};
+DXO_HD void third_setup(const Surf& e, int ia, const double* t, Third& o) {
+    const double* F = e.F[ia].c;
+    double tmp[4];
+    devv(t, o.Pt);
+    Qs_times(e.s, o.Pt, tmp);
+    devv(tmp, o.Qt);
+    o.a = dot4(e.s, t);
+    o.b = dot4(e.q, t);
+    o.dFx = F[3] * o.a + F[4] * o.b;
+    o.dFy = F[4] * o.a + F[5] * o.b;
+    o.dFxx = F[6] * o.a + F[7] * o.b;
+    o.dFxy = F[7] * o.a + F[8] * o.b;
+    o.dFyy = F[8] * o.a + F[9] * o.b;
+}
+// T(t) v = D_t (H v)
+DXO_HD void third_apply(const Surf& e, int ia, const Third& T, const double* v, double* out) {
+    const double* F = e.F[ia].c;
+    double Pv[4], Qv[4], Rv[4], tmp[4];
+    devv(v, Pv);
+    Qs_times(e.s, Pv, tmp);
+    devv(tmp, Qv);
+    Qs_times(T.Pt, Pv, tmp);  // hess_s J3 is linear in s: D_t -> s replaced by dev t
+    devv(tmp, Rv);
+    const double al = dot4(e.s, v), be = dot4(e.q, v);
+    const double dal = dot4(T.Pt, v), dbe = dot4(T.Qt, v);
+    const double cp = T.dFxx * al + F[3] * dal + T.dFxy * be + F[4] * dbe;
+    const double cq = T.dFxy * al + F[4] * dal + T.dFyy * be + F[5] * dbe;
+    const double ep = F[3] * al + F[4] * be, eq = F[4] * al + F[5] * be;
+    for (int i = 0; i < 4; ++i)
+        out[i] = T.dFx * Pv[i] + T.dFy * Qv[i] + F[2] * Rv[i] + cp * e.s[i] + ep * T.Pt[i] + cq * e.q[i] + eq * T.Qt[i];
+}
+
+// LDL^T of a symmetric 4x4 (lower triangle in m[10]: 00,10,11,20,21,22,30,31,32,33), no pivoting
+struct Ldl { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3; };
+DXO_HD void ldl_factor(const double (*M)[4], Ldl& f) {
+    f.d0 = M[0][0];
+    f.l10 = M[1][0] / f.d0;
+    f.l20 = M[2][0] / f.d0;
+    f.l30 = M[3][0] / f.d0;
+    f.d1 = M[1][1] - f.l10 * f.l10 * f.d0;
+    f.l21 = (M[2][1] - f.l20 * f.l10 * f.d0) / f.d1;
+    f.l31 = (M[3][1] - f.l30 * f.l10 * f.d0) / f.d1;
+    f.d2 = M[2][2] - f.l20 * f.l20 * f.d0 - f.l21 * f.l21 * f.d1;
+    f.l32 = (M[3][2] - f.l30 * f.l20 * f.d0 - f.l31 * f.l21 * f.d1) / f.d2;
+    f.d3 = M[3][3] - f.l30 * f.l30 * f.d0 - f.l31 * f.l31 * f.d1 - f.l32 * f.l32 * f.d2;
+}
+DXO_HD void ldl_solve(const Ldl& f, const double* b, double* x) {
+    const double z0 = b[0];
+    const double z1 = b[1] - f.l10 * z0;
+    const double z2 = b[2] - f.l20 * z0 - f.l21 * z1;
+    const double z3 = b[3] - f.l30 * z0 - f.l31 * z1 - f.l32 * z2;
+    const double w3 = z3 / f.d3;
+    const double w2 = z2 / f.d2 - f.l32 * w3;
+    const double w1 = z1 / f.d1 - f.l21 * w2 - f.l31 * w3;
+    const double w0 = z0 / f.d0 - f.l10 * w1 - f.l20 * w2 - f.l30 * w3;
+    x[0] = w0; x[1] = w1; x[2] = w2; x[3] = w3;
+}
+
+struct Result {
+    double sigma[4];
+    double C_tang[16];  // row-major d sigma_i / d deps_j
+    int32_t niter;
+    double yielding, norm_res, dlambda;
+};
+
+// residual r(y) (:451-459) for the plastic branch, also returns rho = S r_sigma (compliance form)
+DXO_HD double residual(const Const& k, const Surf& e, const double* sig, double dl, const double* deps, const double* sn,
+                       const double* gradg, double* r_sig, double* r_f) {
+    double de[4], Cd[4];
+    for (int i = 0; i < 4; ++i) de[i] = deps[i] - dl * gradg[i];   // deps - deps_p, :427-435
+    C_times(k, de, Cd);
+    double acc = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        r_sig[i] = sig[i] - sn[i] - Cd[i];
+        acc += r_sig[i] * r_sig[i];
+    }
+    *r_f = e.f;                                                     // :446
+    acc += e.f * e.f;
+    return sqrt(acc);
+}
+
+DXO_HD void return_map(const Const& k, const double* deps, const double* sn, Result& R) {
+    double Ce[4], trial[4];
+    C_times(k, deps, Ce);
+    for (int i = 0; i < 4; ++i) trial[i] = sn[i] + Ce[i];
+    R.yielding = f_value(k, trial);                                  // :422, :531
+    if (R.yielding <= 0.0) {
+        // elastic branch: r = [sigma - sigma_n - C deps, dlambda], J = I  (:424-425, :442-443)
+        // res0 = -(C deps); norm_res0 == 0 (deps == 0) -> 0/0 = NaN > tol is false: zero iterations, C_tang = 0
+        const double n0 = sqrt(dot4(Ce, Ce));
+        if (!(n0 / n0 > k.tol)) {  // covers n0 == 0 (NaN) exactly like cond_fun :503-505
+            for (int i = 0; i < 4; ++i) R.sigma[i] = sn[i];
+            for (int i = 0; i < 16; ++i) R.C_tang[i] = 0.0;
+            R.niter = 0;
+            R.norm_res = n0;
+            R.dlambda = 0.0;
+            return;
+        }
+        double acc = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            R.sigma[i] = trial[i];
+            const double ri = trial[i] - sn[i] - Ce[i];
+            acc += ri * ri;
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                R.C_tang[i * 4 + j] = ((i < 3 && j < 3) ? k.lmbda : 0.0) + (i == j ? k.mu2 : 0.0);
+        R.niter = 1;
+        R.norm_res = sqrt(acc);
+        R.dlambda = 0.0;
+        return;
+    }
+    // ---- plastic branch: Newton on y = (sigma, dlambda), tangent Y = d y / d deps (5 x 4)
+    double sig[4] = {sn[0], sn[1], sn[2], sn[3]}, dl = 0.0;  // :496-498
+    double Y[5][4];
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 4; ++j) Y[i][j] = 0.0;
+    Surf e;
+    surf_eval(k, sig, e);
+    double gradg[4], r_sig[4], r_f;
+    grad_surface(k, e, 1, gradg);
+    double norm_res = residual(k, e, sig, dl, deps, sn, gradg, r_sig, &r_f);
+    const double norm_res0 = norm_res;                          // :501
+    int niter = 0;
+    while ((norm_res / norm_res0 > k.tol) && (niter < k.nitermax)) {  // :503-505
+        // M = S + dlambda H_g (symmetric)
+        double M[4][4];
+        for (int j = 0; j < 4; ++j) {
+            double ej[4] = {0.0, 0.0, 0.0, 0.0}, Hj[4], Sj[4];
+            ej[j] = 1.0;
+            hess_apply(e, 1, ej, Hj);
+            S_times(k, ej, Sj);
+            for (int i = 0; i < 4; ++i) M[i][j] = Sj[i] + dl * Hj[i];
+        }
+        Ldl L;
+        ldl_factor(M, L);
+        double gradf[4];
+        if (k.same_angle) { for (int i = 0; i < 4; ++i) gradf[i] = gradg[i]; }
+        else grad_surface(k, e, 0, gradf);
+        // Newton step t = J^-1 r
+        double rho[4], xh[4], bh[4];
+        S_times(k, r_sig, rho);
+        ldl_solve(L, rho, xh);
+        ldl_solve(L, gradg, bh);
+        const double cb = dot4(gradf, bh);
+        const double t_l = (dot4(gradf, xh) - r_f) / cb;
+        double t_s[4];
+        for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
+        // tangent recursion (skipped algebraically when Y == 0: first iteration)
+        double Ht[4], Hft[4];
+        hess_apply(e, 1, t_s, Ht);
+        if (k.same_angle) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
+        else hess_apply(e, 0, t_s, Hft);
+        Third T;
+        third_setup(e, 1, t_s, T);
+        double Ynew[5][4];
+        for (int m = 0; m < 4; ++m) {
+            double v[4] = {Y[0][m], Y[1][m], Y[2][m], Y[3][m]};
+            const double dlm = Y[4][m];
+            double Tv[4], Hv[4], rhs[4], zh[4];
+            third_apply(e, 1, T, v, Tv);
+            hess_apply(e, 1, v, Hv);
+            for (int i = 0; i < 4; ++i) rhs[i] = (i == m ? 1.0 : 0.0) + dlm * Ht[i] + dl * Tv[i] + t_l * Hv[i];
+            const double nu_m = dot4(Hft, v);
+            ldl_solve(L, rhs, zh);
+            const double mu_m = (dot4(gradf, zh) - nu_m) / cb;
+            for (int i = 0; i < 4; ++i) Ynew[i][m] = zh[i] - bh[i] * mu_m;
+            Ynew[4][m] = mu_m;
+        }
+        for (int i = 0; i < 5; ++i)
+            for (int m = 0; m < 4; ++m) Y[i][m] = Ynew[i][m];
+        // y <- y - t  (:514)
+        for (int i = 0; i < 4; ++i) sig[i] -= t_s[i];
+        dl -= t_l;
+        surf_eval(k, sig, e);
+        grad_surface(k, e, 1, gradg);
+        norm_res = residual(k, e, sig, dl, deps, sn, gradg, r_sig, &r_f);  // :516-517
+        niter += 1;
+    }
+    for (int i = 0; i < 4; ++i) {
+        R.sigma[i] = sig[i];
+        for (int j = 0; j < 4; ++j) R.C_tang[i * 4 + j] = Y[i][j];
+    }
+    R.niter = niter;
+    R.norm_res = norm_res;
+    R.dlambda = dl;
+}
+
+// Host-side constant folding of the model parameters (dxo_mc_params field order).
+inline Const make_const(double E, double nu, double c, double phi, double psi, double theta_T, double a, double tol,
+                        int32_t nitermax) {
+    Const k;
+    k.lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));   // :405
+    k.mu2 = 2.0 * (E / (2.0 * (1.0 + nu)));                // :406
+    k.inv_E = 1.0 / E;
+    k.nu = nu;
+    k.c = c;
+    k.theta_T = theta_T;
+    k.tol = tol;
+    k.nitermax = nitermax;
+    k.same_angle = (phi == psi) ? 1 : 0;
+    const double ang[2] = {phi, psi};
+    const double coeff3 = 18.0 * cos(3.0 * theta_T) * cos(3.0 * theta_T) * cos(3.0 * theta_T);  // :310
+    for (int ia = 0; ia < 2; ++ia) {
+        const double al = ang[ia];
+        k.sin_a[ia] = sin(al);
+        k.cos_a[ia] = cos(al);
+        k.k_lin[ia] = (1.0 / sqrt(3.0)) * sin(al);
+        const double ag = a * tan(phi) / tan(al);           // :348-349
+        k.ag2s2[ia] = ag * ag * sin(al) * sin(al);
+        const double coeff1 = cos(theta_T) - (1.0 / sqrt(3.0)) * sin(al) * sin(theta_T);  // :302-303
+        for (int sg = 0; sg < 2; ++sg) {
+            const double sign = sg == 0 ? -1.0 : 1.0;
+            const double coeff2 = sign * sin(theta_T) + (1.0 / sqrt(3.0)) * sin(al) * cos(theta_T);  // :306-307
+            const double Cc = (-cos(3.0 * theta_T) * coeff1 - 3.0 * sign * sin(3.0 * theta_T) * coeff2) / coeff3;  // :313-316
+            const double Bc = (sign * sin(6.0 * theta_T) * coeff1 - 6.0 * cos(6.0 * theta_T) * coeff2) / coeff3;   // :319-322
+            const double Ac = -(1.0 / sqrt(3.0)) * sin(al) * sign * sin(theta_T) - Bc * sign * sin(3 * theta_T) -
+                              Cc * sin(3.0 * theta_T) * sin(3.0 * theta_T) + cos(theta_T);                          // :325-331
+            k.A[ia][sg] = Ac;
+            k.B[ia][sg] = Bc;
+            k.Cc[ia][sg] = Cc;
+        }
+    }
+    return k;
+}
+
+}  // namespace mc

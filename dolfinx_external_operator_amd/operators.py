@@ -24,7 +24,7 @@ from typing import Callable
 
 import numpy as np
 
-from ._lib import MEM_DEVICE, MEM_HOST, Context, VmParams, default_context
+from ._lib import MEM_DEVICE, MEM_HOST, Context, McParams, VmParams, default_context
 
 
 def _state_array(holder):
@@ -207,4 +207,60 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     return q_external
 
 
-__all__ = ["make_von_mises", "make_heat"]
+def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float = 3.45,
+                      phi: float = 30 * np.pi / 180, psi: float = 30 * np.pi / 180, theta_T: float = 26 * np.pi / 180,
+                      a: float | None = None, tol: float = 1e-8, Nitermax: int = 200, diagnostics: bool = True,
+                      on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0) -> Callable:
+    """`sigma_external` of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:604-608) on the GPU.
+
+    `external_function((1,))(deps) -> (C_tang, sigma)`, flat arrays, the reference's order (:593); any other
+    multi-index raises NotImplementedError (:607-608). `deps` is reshaped to (-1, 4) (:578); `sigma_n` is the
+    closure state (a fem.Function, ndarray or callable), re-read at every call (:579, :728).
+    Defaults are the demo's constants (:110-116) and Newton controls (:469).
+
+    The reference prints an "Inner Newton summary" at every call (:584-591). Here the four per-point aux
+    arrays (niter, yielding, norm_res, dlambda; :533) are kept on `external_function.last_state` when
+    `diagnostics=True`, and `on_summary(dict)` — if given — receives the same numbers the reference prints:
+    unique iteration counts, their multiplicities, max f, max residual.
+    """
+    if a is None:
+        a = 0.26 * c / np.tan(phi)   # :116
+    prm = McParams(float(E), float(nu), float(c), float(phi), float(psi), float(theta_T), float(a), float(tol),
+                   int(Nitermax), 0)
+    holder = {"ctx": ctx}
+
+    def C_tang_impl(deps):
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        cx = holder["ctx"]
+        deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
+        sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape((-1, 4))   # :579
+        n = deps_.shape[0]
+        if sigma_n_.shape[0] != n:
+            raise ValueError(f"state size mismatch: sigma_n has {sigma_n_.shape[0]} points, deps {n}")
+        C_tang = np.empty(n * 16)
+        sigma = np.empty(n * 4)
+        if diagnostics or on_summary is not None:
+            niter = np.empty(n, dtype=np.int32)
+            yielding, norm_res, dlambda = np.empty(n), np.empty(n), np.empty(n)
+        else:
+            niter = yielding = norm_res = dlambda = None
+        cx.mohr_coulomb(prm, n, MEM_HOST, deps_, sigma_n_, C_tang, sigma, niter, yielding, norm_res, dlambda)
+        sigma_external.last_state = (niter, yielding, norm_res, dlambda)
+        if on_summary is not None and n > 0:
+            unique_iters, counts = np.unique(niter, return_counts=True)   # :584
+            on_summary({"unique_iters": unique_iters, "counts": counts, "max_yielding": float(np.max(yielding)),
+                        "max_norm_res": float(np.nanmax(norm_res)) if np.isfinite(norm_res).any() else float("nan")})
+        return C_tang.reshape(-1), sigma.reshape(-1)                    # :593
+
+    def sigma_external(derivatives):
+        if derivatives == (1,):
+            return C_tang_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    sigma_external.params = prm
+    sigma_external.last_state = None
+    return sigma_external
+
+
+__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb"]

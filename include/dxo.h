@@ -133,6 +133,22 @@ int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, int mem,
              const double* T, const double* sigma,
              double* q, double* dqdT, double* dqdsigma);
 
+/* ---- Mohr-Coulomb (Abbo-Sloan) return mapping + AD-through-Newton tangent ----------------------
+ * Replaces return_mapping / dsigma_ddeps_vec / C_tang_impl,
+ * demo_plasticity_mohr_coulomb.py:282-391, 405-462, 469-533, 555, 574-593.
+ *   deps [n][4], sigma_n [n][4] (in; sigma_n is closure state, :579);
+ *   C_tang [n][4][4] = d sigma / d deps differentiated THROUGH the Newton iterations (jacfwd of the
+ *   while_loop, :555), sigma [n][4] (out).
+ *   optional diagnostics (NULL to skip) = the reference's aux outputs (:533, :582):
+ *   niter [n] int32, yielding [n] = f(sigma_n + C deps), norm_res [n], dlambda [n].
+ * A point that does not converge within prm->nitermax iterations is not an error: niter == nitermax
+ * and norm_res tell (the reference prints the same, :584-591).
+ * DXO_MEM_DEVICE needs 16-byte aligned deps/sigma_n/C_tang/sigma. */
+int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, int mem,
+                     const double* deps, const double* sigma_n,
+                     double* C_tang, double* sigma,
+                     int32_t* niter, double* yielding, double* norm_res, double* dlambda);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

@@ -21,6 +21,24 @@ def build_oracle(force: bool = False) -> pathlib.Path:
     return LIB
 
 
+MC_DEFAULTS = dict(E=6778.0, nu=0.25, c=3.45, phi=30 * np.pi / 180, psi=30 * np.pi / 180, theta_T=26 * np.pi / 180,
+                   a=None, tol=1e-8, nitermax=200)  # demo_plasticity_mohr_coulomb.py:110-116, 469
+
+
+class _McParams(C.Structure):
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("c", C.c_double), ("phi", C.c_double), ("psi", C.c_double),
+                ("theta_T", C.c_double), ("a", C.c_double), ("tol", C.c_double), ("nitermax", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+def mc_params(**kw) -> _McParams:
+    d = dict(MC_DEFAULTS)
+    d.update(kw)
+    if d["a"] is None:
+        d["a"] = 0.26 * d["c"] / np.tan(d["phi"])  # :116
+    return _McParams(d["E"], d["nu"], d["c"], d["phi"], d["psi"], d["theta_T"], d["a"], d["tol"], int(d["nitermax"]), 0)
+
+
 def _dp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -34,6 +52,13 @@ class OracleLib:
         self.lib.oracle_heat.restype = C.c_int
         self.lib.oracle_heat.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int64, P, P, P, P, P, C.c_int]
         self.lib.oracle_max_threads.restype = C.c_int
+        if hasattr(self.lib, "oracle_mohr_coulomb"):
+            self.lib.oracle_mohr_coulomb.restype = C.c_int
+            self.lib.oracle_mohr_coulomb.argtypes = [P, C.c_int64] + [P] * 8 + [C.c_int]
+            self.lib.oracle_mohr_coulomb_sigma.restype = C.c_int
+            self.lib.oracle_mohr_coulomb_sigma.argtypes = [P, C.c_int64] + [P] * 7 + [C.c_int]
+            self.lib.oracle_mc_surface.restype = C.c_int
+            self.lib.oracle_mc_surface.argtypes = [P, C.c_int64, P, P, P, P]
 
     def max_threads(self) -> int:
         return int(self.lib.oracle_max_threads())
@@ -74,6 +99,37 @@ class OracleLib:
         if rc != 0:
             raise ValueError(f"oracle_heat rc={rc}")
         return q, dqdT, dqds
+
+
+    def mohr_coulomb(self, deps, sigma_n, *, nthreads=1, tangent=True, **params):
+        """deps (N,4), sigma_n (N,4) -> C_tang (N,4,4) [None if tangent=False], sigma (N,4), niter (N,) int32,
+        yielding (N,), norm_res (N,), dlambda (N,)"""
+        prm = mc_params(**params)
+        deps = np.ascontiguousarray(deps, dtype=np.float64).reshape(-1, 4)
+        sigma_n = np.ascontiguousarray(sigma_n, dtype=np.float64).reshape(-1, 4)
+        n = deps.shape[0]
+        sigma = np.empty((n, 4)); niter = np.empty(n, dtype=np.int32)
+        yielding = np.empty(n); norm_res = np.empty(n); dlambda = np.empty(n)
+        if tangent:
+            C_tang = np.empty((n, 4, 4))
+            rc = self.lib.oracle_mohr_coulomb(C.byref(prm), n, _dp(deps), _dp(sigma_n), _dp(C_tang), _dp(sigma),
+                                              _dp(niter), _dp(yielding), _dp(norm_res), _dp(dlambda), int(nthreads))
+        else:
+            C_tang = None
+            rc = self.lib.oracle_mohr_coulomb_sigma(C.byref(prm), n, _dp(deps), _dp(sigma_n), _dp(sigma), _dp(niter),
+                                                    _dp(yielding), _dp(norm_res), _dp(dlambda), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_mohr_coulomb rc={rc}")
+        return C_tang, sigma, niter, yielding, norm_res, dlambda
+
+    def mc_surface(self, sigma, **params):
+        """f(sigma), g(sigma), dg/dsigma for sigma (N,4)."""
+        prm = mc_params(**params)
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(-1, 4)
+        n = sigma.shape[0]
+        f = np.empty(n); g = np.empty(n); dg = np.empty((n, 4))
+        self.lib.oracle_mc_surface(C.byref(prm), n, _dp(sigma), _dp(f), _dp(g), _dp(dg))
+        return f, g, dg
 
 
 _oracle = None

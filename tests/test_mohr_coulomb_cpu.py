@@ -1,0 +1,157 @@
+"""Mohr-Coulomb on the CPU (not gpu): the oracle against the reference-source goldens, known-answer
+checks converted from the demo's printed/plotted verifications, and the per-lane device
+math (csrc/mc_core.h, host build) against the oracle."""
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import mc_compare as _compare
+from conftest import mc_elastic_matrices, mc_path_increment, mc_tracing_inputs
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+GOLD = ROOT / "tests" / "golden" / "mohr_coulomb.npz"
+
+
+
+@pytest.fixture(scope="module")
+def mc_core(tmp_path_factory):
+    """Host build of the per-lane math (test aid only, never shipped)."""
+    out = tmp_path_factory.mktemp("mc") / "mc_core_cpu.so"
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+                    f"-I{ROOT / 'dolfinx_external_operator_amd' / 'csrc'}", str(ROOT / "tests" / "helpers" / "mc_core_cpu.cpp"),
+                    "-o", str(out)], check=True)
+    lib = C.CDLL(str(out))
+    lib.mc_core_cpu.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+
+    def run(deps, sn, **kw):
+        from oracle.loader import mc_params
+
+        prm = mc_params(**kw)
+        deps = np.ascontiguousarray(deps, dtype=np.float64)
+        sn = np.ascontiguousarray(sn, dtype=np.float64)
+        n = len(deps)
+        Ct, s = np.empty((n, 4, 4)), np.empty((n, 4))
+        it, y, nr, dl = np.empty(n, dtype=np.int32), np.empty(n), np.empty(n), np.empty(n)
+        lib.mc_core_cpu(C.byref(prm), n, *(a.ctypes.data for a in (deps, sn, Ct, s, it, y, nr, dl)))
+        return Ct, s, it, y, nr, dl
+
+    return run
+
+
+@pytest.mark.skipif(not GOLD.exists(), reason="golden not generated yet")
+def test_oracle_matches_reference_source_golden(oracle):
+    g = np.load(GOLD)
+    prm = {k[4:]: g[k].item() for k in g.files if k.startswith("prm_")}
+    prm["nitermax"] = int(prm["nitermax"])
+    got = oracle.mohr_coulomb(g["deps"], g["sigma_n"], **prm)
+    ref = (g["C_tang"], g["sigma"], g["niter"], g["yielding"], g["norm_res"], g["dlambda"])
+    _compare(got, ref, "oracle vs reference golden", g["sigma_n"])
+    # the golden covers elastic (1 iteration), plastic (2..) and the deps == 0 point (0 iterations, C_tang = 0)
+    assert {0, 1, 2, 3} <= set(np.unique(g["niter"]).tolist())
+    zero = np.flatnonzero(g["tag"] == -2)[0]
+    assert g["niter"][zero] == 0 and np.all(g["C_tang"][zero] == 0.0)
+
+
+@pytest.mark.skipif(not GOLD.exists(), reason="golden not generated yet")
+def test_lane_math_matches_reference_source_golden(mc_core):
+    g = np.load(GOLD)
+    prm = {k[4:]: g[k].item() for k in g.files if k.startswith("prm_")}
+    prm["nitermax"] = int(prm["nitermax"])
+    got = mc_core(g["deps"], g["sigma_n"], **prm)
+    ref = (g["C_tang"], g["sigma"], g["niter"], g["yielding"], g["norm_res"], g["dlambda"])
+    _compare(got, ref, "mc_core vs reference golden", g["sigma_n"])
+
+
+def test_lane_math_matches_oracle_on_tracing_distribution(oracle, mc_core):
+    deps, sn = mc_tracing_inputs(oracle, 6000, seed=2)
+    ref = oracle.mohr_coulomb(deps, sn, nthreads=8)
+    got = mc_core(deps, sn)
+    assert ref[2].max() <= 12 and (ref[3] > 0).mean() > 0.2      # converged mix of elastic and plastic points
+    assert _compare(got, ref, "mc_core vs oracle (tracing)", sn) > 0.5
+
+
+def test_lane_math_matches_oracle_with_shear_and_non_associated_flow(oracle, mc_core):
+    deps, sn = mc_tracing_inputs(oracle, 3000, seed=5, shear=0.3)
+    for kw in ({}, {"psi": 20 * np.pi / 180}, {"phi": 25 * np.pi / 180, "psi": 10 * np.pi / 180, "theta_T": 20 * np.pi / 180}):
+        ref = oracle.mohr_coulomb(deps, sn, nthreads=8, **kw)
+        got = mc_core(deps, sn, **kw)
+        conv = ref[2] < 30
+        assert conv.mean() > 0.95
+        _compare(tuple(a[conv] for a in got), tuple(a[conv] for a in ref), f"mc_core vs oracle {kw}", sn[conv])
+
+
+def test_elastic_points_return_c_elas_and_one_iteration(oracle):
+    # demo_plasticity_mohr_coulomb.py:639-649: a small increment gives the elastic tangent
+    Cel, S = mc_elastic_matrices()
+    rng = np.random.default_rng(0)
+    deps = rng.normal(0, 1e-6, (200, 4))
+    sn = np.tile([-1.0, -1.2, -0.8, 0.1], (200, 1))
+    Ct, s, it, y, nr, dl = oracle.mohr_coulomb(deps, sn)
+    assert np.all(it == 1) and np.all(y < 0) and np.all(dl == 0)
+    assert np.array_equal(Ct, np.broadcast_to(Cel, Ct.shape))
+    assert np.allclose(s, sn + deps @ Cel.T, rtol=0, atol=1e-15)
+
+
+def test_zero_increment_takes_zero_iterations(oracle):
+    # deps == 0 -> norm_res0 == 0 -> 0/0 -> no iteration, C_tang = 0 (:500-505)
+    Ct, s, it, y, nr, dl = oracle.mohr_coulomb(np.zeros((1, 4)), np.array([[0.1, 0.2, 0.1, 0.0]]))
+    assert it[0] == 0 and np.all(Ct == 0.0) and np.array_equal(s[0], [0.1, 0.2, 0.1, 0.0])
+
+
+def test_yield_surface_tracing_lands_on_the_surface(oracle):
+    """Known-answer check converted from the demo's tracing block (:854-929): after the return the stress
+    sits on f = 0 (the demo prints `max f`), elastic paths are untouched."""
+    _, S = mc_elastic_matrices()
+    n_angles = 50
+    theta = np.linspace(-np.pi / 6 + 1e-5, np.pi / 6 - 1e-5, n_angles)
+    tr = np.array([1.0, 1.0, 1.0, 0.0])
+    sn = np.zeros((n_angles, 4))
+    sn[:, :3] = 0.1
+    saw_plastic = False
+    for load in range(9):
+        d = mc_path_increment(theta, 0.7)
+        _, s, it, y, nr, dl = oracle.mohr_coulomb(d @ S.T, sn, tangent=False)
+        f_after = oracle.mc_surface(s)[0]
+        plastic = y > 0
+        saw_plastic |= plastic.any()
+        assert np.all(np.abs(f_after[plastic]) < 1e-7)
+        assert np.all(it[~plastic] == 1) and np.allclose(s[~plastic], sn[~plastic] + d[~plastic])
+        assert it.max() <= 6
+        sn = s - np.outer(s @ tr / 3.0 - 0.1, tr)
+    assert saw_plastic
+
+
+def test_surface_is_continuous_across_the_abbo_sloan_transition(oracle):
+    # K switches formula at |theta| = theta_T (:334-345); value and gradient are continuous there
+    theta_T = 26 * np.pi / 180
+    for sgn in (-1.0, 1.0):
+        th = sgn * theta_T + np.array([-1e-7, 1e-7])
+        rho, p = 2.0, -1.0
+        s = np.stack([p + np.sqrt(2 / 3) * rho * np.cos(th_ - np.array([0, 2, 4])[k] * np.pi / 3 + np.pi / 6 * 0)
+                      for th_ in th for k in range(3)]).reshape(2, 3)
+        sig = np.zeros((2, 4))
+        sig[:, :3] = s
+        f, g, dg = oracle.mc_surface(sig)
+        assert abs(f[1] - f[0]) < 1e-5 and np.max(np.abs(dg[1] - dg[0])) < 1e-4
+
+
+def test_tangent_is_the_derivative_of_the_stress_map(oracle):
+    """Kernel-level analogue of the demo's Taylor test (:1149-1235): sigma(deps + h v) - sigma(deps) - h C_tang v
+    is second order in h on converged plastic points."""
+    deps, sn = mc_tracing_inputs(oracle, 400, seed=9)
+    Ct, s, it, y, nr, dl = oracle.mohr_coulomb(deps, sn)
+    pl = (y > 0) & (it < 10)
+    deps, sn, Ct, s = deps[pl][:100], sn[pl][:100], Ct[pl][:100], s[pl][:100]
+    rng = np.random.default_rng(1)
+    v = rng.normal(size=deps.shape)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    errs = []
+    for h in (1e-6, 5e-7):
+        s2 = oracle.mohr_coulomb(deps + h * v, sn, tangent=False)[1]
+        errs.append(np.linalg.norm(s2 - s - h * np.einsum("nij,nj->ni", Ct, v), axis=1))
+    rate = np.log2(np.median(errs[0]) / np.median(errs[1]))
+    assert np.median(errs[0]) < 1e-5 * np.median(np.linalg.norm(h * np.einsum("nij,nj->ni", Ct, v), axis=1)) * 1e3
+    assert rate > 1.5
