@@ -131,11 +131,14 @@ struct Surf {
     double I1;
     double f, g;           // f(sigma), g(sigma)
     T23 F[2];              // F for angle phi (f) and psi (g)
-    bool finite_branch;    // false when J2 == 0 produced NaN (kept, like the reference)
 };
 
-// theta(J2, J3) as a Taylor object, :290-295
-DXO_HD T23 theta_taylor(double J2, double J3) {
+// theta(J2, J3) as a Taylor object, :290-295. Also hands back the clipped argument `arg` itself:
+// sin(3 theta) = sin(asin(arg)) = arg, which F_taylor uses in the rounded branch instead of composing
+// asin and sin — their derivatives grow like (1 - arg^2)^(-1/2, -3/2, -5/2) towards the compression /
+// extension meridians and cancel against cos(3 theta) -> 0; composed numerically that cancellation costs
+// up to 1e-2 of the tangent at 1 - |arg| ~ 1e-5, while arg is a smooth rational function of (J2, J3).
+DXO_HD T23 theta_taylor(double J2, double J3, T23& arg_out) {
     const double r = sqrt(J2);
     const double h0 = 1.0 / (J2 * r);   // J2^-1.5
     const double h1 = -1.5 * h0 / J2;
@@ -158,6 +161,7 @@ DXO_HD T23 theta_taylor(double J2, double J3) {
         for (int i = 1; i < 10; ++i) a.c[i] = 0.0;
         a.c[0] = v;
     }
+    arg_out = a;
     const double u = a.c[0];
     const double w = 1.0 / sqrt(1.0 - u * u);
     const double w3 = w * w * w;
@@ -166,14 +170,12 @@ DXO_HD T23 theta_taylor(double J2, double J3) {
 }
 
 // F(J2, J3) = sqrt(J2 K(theta)^2 + a_g^2 sin^2 a) for angle index ia, :334-345, :364-374
-DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th) {
+DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th, const T23& arg) {
     T23 K;
     const double t0 = th.c[0];
     if (fabs(t0) > k.theta_T) {
         const int sg = t0 < 0.0 ? 0 : 1;  // sign(theta), :298-299
-        const T23 u = t_scale(th, 3.0);
-        const double sn = sin(u.c[0]), cs = cos(u.c[0]);
-        const T23 S3 = t_compose(u, sn, cs, -sn, -cs);
+        const T23& S3 = arg;              // sin(3 theta) == clip(arg), see theta_taylor
         const T23 S3S3 = t_mul(S3, S3);
         for (int i = 0; i < 10; ++i) K.c[i] = k.B[ia][sg] * S3.c[i] + k.Cc[ia][sg] * S3S3.c[i];
         K.c[0] += k.A[ia][sg];
@@ -206,14 +208,15 @@ DXO_HD void surf_eval(const Const& k, const double* sig, Surf& o) {
     const double J3 = s[2] * (s[0] * s[1] - s[3] * s[3] / 2.0);  // :282-283
     const double qs[4] = {s[1] * s[2], s[0] * s[2], s[0] * s[1] - s[3] * s[3] / 2.0, -s[2] * s[3]};
     devv(qs, o.q);
-    const T23 th = theta_taylor(J2, J3);
-    o.F[1] = F_taylor(k, 1, J2, th);
+    T23 arg;
+    const T23 th = theta_taylor(J2, J3, arg);
+    o.F[1] = F_taylor(k, 1, J2, th, arg);
     o.g = o.I1 / 3.0 * k.sin_a[1] + o.F[1].c[0] - k.c * k.cos_a[1];
     if (k.same_angle) {
         o.F[0] = o.F[1];
         o.f = o.g;
     } else {
-        o.F[0] = F_taylor(k, 0, J2, th);
+        o.F[0] = F_taylor(k, 0, J2, th, arg);
         o.f = o.I1 / 3.0 * k.sin_a[0] + o.F[0].c[0] - k.c * k.cos_a[0];
     }
 }

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Mohr-Coulomb kernel timing on the GPU box (BASELINE config 4: ~10^7 points, tracing distribution).
+usage: python3 scripts/bench_mc.py [--n 10000000] [--diag 1] [--launches 5]"""
+import argparse
+import json
+import pathlib
+import statistics
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from conftest import mc_tracing_inputs  # noqa: E402
+from dolfinx_external_operator_amd import MEM_DEVICE, Context, McParams  # noqa: E402
+from oracle import load_oracle  # noqa: E402  (input generation only: states after k tracing loads)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--diag", type=int, default=1)
+ap.add_argument("--launches", type=int, default=5)
+ap.add_argument("--pool", type=int, default=50_000)
+args = ap.parse_args()
+n = args.n
+o = load_oracle()
+pool_d, pool_s = mc_tracing_inputs(o, args.pool, seed=2)
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev)
+g.manual_seed(2)
+idx = torch.randint(0, args.pool, (n,), generator=g, device=dev)
+scale = torch.rand(n, 1, generator=g, device=dev, dtype=torch.float64) * 0.5 + 0.5
+deps = (torch.from_numpy(pool_d).to(dev)[idx] * scale).contiguous()
+sn = torch.from_numpy(pool_s).to(dev)[idx].contiguous()
+Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
+s = torch.empty(n * 4, dtype=torch.float64, device=dev)
+it = torch.empty(n, dtype=torch.int32, device=dev)
+y, nr, dl = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+prm = McParams(6778.0, 0.25, 3.45, np.pi / 6, np.pi / 6, 26 * np.pi / 180, 0.26 * 3.45 / np.tan(np.pi / 6), 1e-8, 200, 0)
+ctx = Context(0)
+stream = torch.cuda.current_stream()
+ctx.set_stream(stream.cuda_stream)
+diag = (it.data_ptr(), y.data_ptr(), nr.data_ptr(), dl.data_ptr()) if args.diag else (None, None, None, None)
+
+
+def run():
+    ctx.mohr_coulomb(prm, n, MEM_DEVICE, deps.data_ptr(), sn.data_ptr(), Ct.data_ptr(), s.data_ptr(), *diag)
+
+
+run()
+torch.cuda.synchronize()
+evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launches)]
+for a, b in evs:
+    a.record(stream)
+    run()
+    b.record(stream)
+torch.cuda.synchronize()
+ms = statistics.median(a.elapsed_time(b) for a, b in evs)
+bpp = 224 + (28 if args.diag else 0)
+out = {"case": "Mohr-Coulomb return map + AD tangent, tracing distribution", "n": n, "kernel_ms": ms,
+       "qp_per_s": n / ms * 1e3, "GBps_algorithmic": bpp * n / ms / 1e6, "bytes_per_qp": bpp}
+if args.diag:
+    u, c = torch.unique(it, return_counts=True)
+    out["iteration_histogram"] = {int(a): int(b) for a, b in zip(u.tolist(), c.tolist())}
+    out["plastic_fraction"] = float((y > 0).double().mean())
+    out["max_norm_res_converged"] = float(nr[it < 200].max())
+print(json.dumps(out))

@@ -125,9 +125,7 @@ def mc_tracing_inputs(oracle, n, seed, shear=0.0):
     return dsig @ S.T, sn
 
 
-# C_tang entries are O(E) = 8e3; the AD-through-loop tangent involves third derivatives of the surface,
-# so agreement is asked relative to the tangent's scale.
-RTOL_C = 1e-9
+# C_tang entries are O(E) = 8e3: agreement is asked relative to the tangent's scale (see mc_compare).
 RTOL_S = 1e-12
 
 
@@ -142,29 +140,32 @@ def lode_arg(sig):
 
 
 def mc_compare(got, ref, what, sigma_n):
-    """Parity of (C_tang, sigma, niter, yielding, norm_res, dlambda).
+    """Parity of (C_tang, sigma, niter, yielding, norm_res, dlambda), fp64.
 
-    theta = asin(arg)/3 has derivatives ~ (1-arg^2)^(-1/2), (-3/2), (-5/2): at the compression/extension
-    meridians (|arg| -> 1, where the demo's tracing paths end up) the third-derivative terms of the tangent
-    are evaluated at condition numbers of 1e10 and more, and ANY two correct implementations (JAX, torch,
-    nested duals, closed form) differ there. The tight tolerance is therefore asked of points whose start
-    and end states keep 1-|arg| > 1e-4; the ill-conditioned rest must still agree to 1e-6 of the scale."""
+    C_tang: |err| <= 1e-9 * max|C_tang| on every point, and <= 1e-12 * max|C_tang| on points whose start and
+    end states keep margin = 1 - |arg| > 1e-3 (arg = the asin argument of the Lode angle, :292). The looser
+    bound only matters at the compression / extension meridians where the demo's tracing paths end
+    (margin -> 0): there the REFERENCE's own derivative chain sin(3 asin(arg)/3) cancels terms of size
+    (1 - arg^2)^(-5/2); the HIP lane math uses sin(3 theta) = arg instead (csrc/mc_core.h) and is the more
+    accurate side. Measured between oracle and lane math: 2e-15 at margin > 0.1, 5e-13 at 1e-5, 3e-10 below
+    1e-7. sigma 1e-12, yielding 1e-12, dlambda 1e-12 (absolute), norm_res 1e-10 (absolute; it is rounding
+    noise at convergence), iteration counts exact. Returns the fraction of points held to 1e-12."""
     Cg, sg, itg, yg, nrg, dlg = got
     Cr, sr, itr, yr, nrr, dlr = ref
     assert np.array_equal(itg, itr), f"{what}: iteration counts differ at {np.flatnonzero(itg != itr)[:10]}"
     scale_C = np.max(np.abs(Cr))
     with np.errstate(all="ignore"):
         margin = np.minimum(1.0 - np.abs(lode_arg(np.asarray(sigma_n, dtype=float).reshape(-1, 4))), 1.0 - np.abs(lode_arg(sr)))
-    well = ~(margin < 1e-4) | (yr <= 0)   # elastic points never touch theta's derivatives; NaN margin (J2 = 0) -> well
-    errC = np.max(np.abs(Cg - Cr).reshape(len(Cr), -1), axis=1)
-    assert np.max(errC[well], initial=0.0) <= RTOL_C * scale_C, f"{what}: C_tang err {np.max(errC[well]):.3e} (well-conditioned points)"
-    assert np.max(errC, initial=0.0) <= 1e-6 * scale_C, f"{what}: C_tang err {np.max(errC):.3e} (all points)"
+        margin = np.where(np.isfinite(margin) & (yr > 0), margin, 1.0)  # elastic / J2 = 0: theta's derivatives are not involved
+    tol = np.where(margin > 1e-3, 1e-12, 1e-9)
+    errC = np.max(np.abs(Cg - Cr).reshape(len(Cr), -1), axis=1) / scale_C
+    bad = errC > tol
+    assert not bad.any(), (f"{what}: C_tang rel err {errC[bad].max():.3e} at margin {margin[bad][np.argmax(errC[bad])]:.2e} "
+                           f"(allowed {tol[bad][np.argmax(errC[bad])]:.0e}); {bad.sum()} points")
     assert np.max(np.abs(sg - sr)) <= RTOL_S * max(np.max(np.abs(sr)), 1.0), f"{what}: sigma"
     assert np.max(np.abs(yg - yr)) <= 1e-12 * max(np.max(np.abs(yr)), 1.0), f"{what}: yielding"
     assert np.max(np.abs(dlg - dlr)) <= 1e-12, f"{what}: dlambda"
     fin = np.isfinite(nrr)
     assert np.array_equal(fin, np.isfinite(nrg))
     assert np.max(np.abs(nrg[fin] - nrr[fin]), initial=0.0) <= 1e-10, f"{what}: norm_res"
-    return float(well.mean())
-
-
+    return float((tol <= 1e-12).mean())
