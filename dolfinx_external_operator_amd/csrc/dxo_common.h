@@ -35,6 +35,10 @@ struct dxo_ctx {
     int64_t nontemporal = 1;
     int64_t timing = 0;
     int64_t blocks_per_cu = 0;          // 0: one wave-tile per wave (no grid stride)
+    int64_t mc_variant = 1;             // 0: lane = point; 1: classify + compacted Newton with lane refill
+    int64_t mc_blocks_per_cu = 2;       // persistent Newton workgroups per CU
+    void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     dxo_timing last = {0, 0, 0, 0};
     std::string err;
 };

@@ -68,6 +68,8 @@ int dxo_ctx_destroy(dxo_ctx* c) {
         if (c->slot_buf[i]) (void)hipFree(c->slot_buf[i]);
         if (c->slot_stream[i]) (void)hipStreamDestroy(c->slot_stream[i]);
     }
+    for (int i = 0; i <= DXO_HOST_SLOTS; ++i)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -111,6 +113,8 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "nontemporal")) return &c->nontemporal;
     if (!std::strcmp(key, "timing")) return &c->timing;
     if (!std::strcmp(key, "blocks_per_cu")) return &c->blocks_per_cu;
+    if (!std::strcmp(key, "mc_variant")) return &c->mc_variant;
+    if (!std::strcmp(key, "mc_blocks_per_cu")) return &c->mc_blocks_per_cu;
     return nullptr;
 }
 
@@ -119,6 +123,7 @@ int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
     int64_t* slot = option_slot(c, key);
     if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
     if (value < 0) return dxo_fail(c, DXO_E_OPTION, "option value must be >= 0");
+    if (slot == &c->mc_blocks_per_cu && value < 1) return dxo_fail(c, DXO_E_OPTION, "mc_blocks_per_cu < 1");
     if (slot == &c->host_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "host_chunk_points < 64");
     *slot = value;
     return DXO_OK;

@@ -96,6 +96,11 @@ DXO_HD T23 t_sqrt(const T23& u) {
 
 // ---- 4-vector helpers on the Mandel vector (xx, yy, zz, sqrt2 xy)
 DXO_HD void devv(const double* v, double* out) {  // dev @ v, :352-360
+    // no FMA contraction here: a hydrostatic stress must give s == 0 exactly (then J2 == 0 and f is NaN, as in
+    // the reference); fma(-(v0+v1+v2), 1/3, v0) would leave a 1e-17 residue instead
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const double m = (v[0] + v[1] + v[2]) * (1.0 / 3.0);
     out[0] = v[0] - m;
     out[1] = v[1] - m;
@@ -221,13 +226,6 @@ DXO_HD void surf_eval(const Const& k, const double* sig, Surf& o) {
     }
 }
 
-// value of f only (trial-stress check), same arithmetic as surf_eval's value path
-DXO_HD double f_value(const Const& k, const double* sig) {
-    Surf tmp;
-    surf_eval(k, sig, tmp);
-    return tmp.f;
-}
-
 DXO_HD void grad_surface(const Const& k, const Surf& e, int ia, double* out) {  // d surface / d sigma
     const double Fx = e.F[ia].c[1], Fy = e.F[ia].c[2];
     const double h = k.sin_a[ia] / 3.0;
@@ -336,111 +334,158 @@ DXO_HD double residual(const Const& k, const Surf& e, const double* sig, double 
     return sqrt(acc);
 }
 
+// f(sigma) only — the trial-stress test (:422, :440, :531). Same expressions as the value path of
+// surf_eval / F_taylor, without carrying derivatives.
+DXO_HD double f_value(const Const& k, const double* sig) {
+    double s[4];
+    devv(sig, s);
+    const double I1 = sig[0] + sig[1] + sig[2];
+    const double J2 = 0.5 * dot4(s, s);
+    const double J3 = s[2] * (s[0] * s[1] - s[3] * s[3] / 2.0);
+    const double r = sqrt(J2);
+    double arg = (-(3.0 * sqrt(3.0)) / 2.0) * J3 * (1.0 / (J2 * r));
+    if (arg < -1.0 || arg > 1.0) arg = arg < 0.0 ? -1.0 : 1.0;
+    const double th = asin(arg) * (1.0 / 3.0);
+    double K;
+    if (fabs(th) > k.theta_T) {
+        const int sg = th < 0.0 ? 0 : 1;
+        K = k.A[0][sg] + k.B[0][sg] * arg + k.Cc[0][sg] * (arg * arg);
+    } else {
+        K = cos(th) - k.k_lin[0] * sin(th);
+    }
+    return I1 / 3.0 * k.sin_a[0] + sqrt(J2 * (K * K) + k.ag2s2[0]) - k.c * k.cos_a[0];
+}
+
+// Elastic branch (:424-425, :442-443): r = [sigma - sigma_n - C deps, dlambda], J = I, one iteration.
+// res0 = -(C deps); deps == 0 gives norm_res0 == 0 and 0/0 = NaN > tol is false: ZERO iterations, sigma =
+// sigma_n, C_tang = 0 — the reference's behaviour (:500-505), kept.
+DXO_HD void elastic_point(const Const& k, const double* sn, const double* Ce, const double* trial, Result& R) {
+    const double n0 = sqrt(dot4(Ce, Ce));
+    R.dlambda = 0.0;
+    if (!(n0 / n0 > k.tol)) {
+        for (int i = 0; i < 4; ++i) R.sigma[i] = sn[i];
+        for (int i = 0; i < 16; ++i) R.C_tang[i] = 0.0;
+        R.niter = 0;
+        R.norm_res = n0;
+        return;
+    }
+    double acc = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        R.sigma[i] = trial[i];
+        const double ri = trial[i] - sn[i] - Ce[i];
+        acc += ri * ri;
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) R.C_tang[i * 4 + j] = ((i < 3 && j < 3) ? k.lmbda : 0.0) + (i == j ? k.mu2 : 0.0);
+    R.niter = 1;
+    R.norm_res = sqrt(acc);
+}
+
+// State of one plastic point between Newton passes: y = (sig, dl), Y = d y / d deps (5 x 4).
+struct Lane {
+    double deps[4], sn[4];
+    double sig[4], dl;
+    double Y[5][4];
+    double norm0, norm;   // norm_res0 (:501) and the current residual norm
+    int32_t niter;
+};
+
+DXO_HD void lane_init(Lane& L, const double* deps, const double* sn) {
+    for (int i = 0; i < 4; ++i) {
+        L.deps[i] = deps[i];
+        L.sn[i] = sn[i];
+        L.sig[i] = sn[i];   // :496-498
+    }
+    L.dl = 0.0;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 4; ++j) L.Y[i][j] = 0.0;
+    L.norm0 = -1.0;  // "not evaluated yet"
+    L.norm = 0.0;
+    L.niter = 0;
+}
+
+// One pass = evaluate the surface at the current iterate, form r and its norm, test cond_fun (:503-505);
+// if the loop continues, do body_fun (:507-522): Newton step + tangent recursion. Returns true when the
+// point is finished (converged, NaN, or niter == nitermax); L then holds the reference's outputs.
+DXO_HD bool lane_pass(const Const& k, Lane& L) {
+    Surf e;
+    surf_eval(k, L.sig, e);
+    double gradg[4], r_sig[4], r_f;
+    grad_surface(k, e, 1, gradg);
+    L.norm = residual(k, e, L.sig, L.dl, L.deps, L.sn, gradg, r_sig, &r_f);   // :500 / :516-517
+    if (L.norm0 < 0.0 || L.norm0 != L.norm0) L.norm0 = (L.niter == 0) ? L.norm : L.norm0;  // :501
+    if (!((L.norm / L.norm0 > k.tol) && (L.niter < k.nitermax))) return true;
+    // M = S + dlambda H_g (symmetric)
+    double M[4][4];
+    for (int j = 0; j < 4; ++j) {
+        double ej[4] = {0.0, 0.0, 0.0, 0.0}, Hj[4], Sj[4];
+        ej[j] = 1.0;
+        hess_apply(e, 1, ej, Hj);
+        S_times(k, ej, Sj);
+        for (int i = 0; i < 4; ++i) M[i][j] = Sj[i] + L.dl * Hj[i];
+    }
+    Ldl F;
+    ldl_factor(M, F);
+    double gradf[4];
+    if (k.same_angle) { for (int i = 0; i < 4; ++i) gradf[i] = gradg[i]; }
+    else grad_surface(k, e, 0, gradf);
+    // Newton step t = J^-1 r
+    double rho[4], xh[4], bh[4];
+    S_times(k, r_sig, rho);
+    ldl_solve(F, rho, xh);
+    ldl_solve(F, gradg, bh);
+    const double cb = dot4(gradf, bh);
+    const double t_l = (dot4(gradf, xh) - r_f) / cb;
+    double t_s[4];
+    for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
+    // tangent recursion Y <- J^-1 ([C; 0] + (D J[Y]) t)
+    double Ht[4], Hft[4];
+    hess_apply(e, 1, t_s, Ht);
+    if (k.same_angle) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
+    else hess_apply(e, 0, t_s, Hft);
+    Third T;
+    third_setup(e, 1, t_s, T);
+    double Ynew[5][4];
+    for (int m = 0; m < 4; ++m) {
+        const double v[4] = {L.Y[0][m], L.Y[1][m], L.Y[2][m], L.Y[3][m]};
+        const double dlm = L.Y[4][m];
+        double Tv[4], Hv[4], rhs[4], zh[4];
+        third_apply(e, 1, T, v, Tv);
+        hess_apply(e, 1, v, Hv);
+        for (int i = 0; i < 4; ++i) rhs[i] = (i == m ? 1.0 : 0.0) + dlm * Ht[i] + L.dl * Tv[i] + t_l * Hv[i];
+        const double nu_m = dot4(Hft, v);
+        ldl_solve(F, rhs, zh);
+        const double mu_m = (dot4(gradf, zh) - nu_m) / cb;
+        for (int i = 0; i < 4; ++i) Ynew[i][m] = zh[i] - bh[i] * mu_m;
+        Ynew[4][m] = mu_m;
+    }
+    for (int i = 0; i < 5; ++i)
+        for (int m = 0; m < 4; ++m) L.Y[i][m] = Ynew[i][m];
+    for (int i = 0; i < 4; ++i) L.sig[i] -= t_s[i];   // y <- y + solve(j, -r), :513-514
+    L.dl -= t_l;
+    L.niter += 1;                                      // :520
+    return false;
+}
+
 DXO_HD void return_map(const Const& k, const double* deps, const double* sn, Result& R) {
     double Ce[4], trial[4];
     C_times(k, deps, Ce);
     for (int i = 0; i < 4; ++i) trial[i] = sn[i] + Ce[i];
     R.yielding = f_value(k, trial);                                  // :422, :531
     if (R.yielding <= 0.0) {
-        // elastic branch: r = [sigma - sigma_n - C deps, dlambda], J = I  (:424-425, :442-443)
-        // res0 = -(C deps); norm_res0 == 0 (deps == 0) -> 0/0 = NaN > tol is false: zero iterations, C_tang = 0
-        const double n0 = sqrt(dot4(Ce, Ce));
-        if (!(n0 / n0 > k.tol)) {  // covers n0 == 0 (NaN) exactly like cond_fun :503-505
-            for (int i = 0; i < 4; ++i) R.sigma[i] = sn[i];
-            for (int i = 0; i < 16; ++i) R.C_tang[i] = 0.0;
-            R.niter = 0;
-            R.norm_res = n0;
-            R.dlambda = 0.0;
-            return;
-        }
-        double acc = 0.0;
-        for (int i = 0; i < 4; ++i) {
-            R.sigma[i] = trial[i];
-            const double ri = trial[i] - sn[i] - Ce[i];
-            acc += ri * ri;
-        }
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j)
-                R.C_tang[i * 4 + j] = ((i < 3 && j < 3) ? k.lmbda : 0.0) + (i == j ? k.mu2 : 0.0);
-        R.niter = 1;
-        R.norm_res = sqrt(acc);
-        R.dlambda = 0.0;
+        elastic_point(k, sn, Ce, trial, R);
         return;
     }
-    // ---- plastic branch: Newton on y = (sigma, dlambda), tangent Y = d y / d deps (5 x 4)
-    double sig[4] = {sn[0], sn[1], sn[2], sn[3]}, dl = 0.0;  // :496-498
-    double Y[5][4];
-    for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 4; ++j) Y[i][j] = 0.0;
-    Surf e;
-    surf_eval(k, sig, e);
-    double gradg[4], r_sig[4], r_f;
-    grad_surface(k, e, 1, gradg);
-    double norm_res = residual(k, e, sig, dl, deps, sn, gradg, r_sig, &r_f);
-    const double norm_res0 = norm_res;                          // :501
-    int niter = 0;
-    while ((norm_res / norm_res0 > k.tol) && (niter < k.nitermax)) {  // :503-505
-        // M = S + dlambda H_g (symmetric)
-        double M[4][4];
-        for (int j = 0; j < 4; ++j) {
-            double ej[4] = {0.0, 0.0, 0.0, 0.0}, Hj[4], Sj[4];
-            ej[j] = 1.0;
-            hess_apply(e, 1, ej, Hj);
-            S_times(k, ej, Sj);
-            for (int i = 0; i < 4; ++i) M[i][j] = Sj[i] + dl * Hj[i];
-        }
-        Ldl L;
-        ldl_factor(M, L);
-        double gradf[4];
-        if (k.same_angle) { for (int i = 0; i < 4; ++i) gradf[i] = gradg[i]; }
-        else grad_surface(k, e, 0, gradf);
-        // Newton step t = J^-1 r
-        double rho[4], xh[4], bh[4];
-        S_times(k, r_sig, rho);
-        ldl_solve(L, rho, xh);
-        ldl_solve(L, gradg, bh);
-        const double cb = dot4(gradf, bh);
-        const double t_l = (dot4(gradf, xh) - r_f) / cb;
-        double t_s[4];
-        for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
-        // tangent recursion (skipped algebraically when Y == 0: first iteration)
-        double Ht[4], Hft[4];
-        hess_apply(e, 1, t_s, Ht);
-        if (k.same_angle) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
-        else hess_apply(e, 0, t_s, Hft);
-        Third T;
-        third_setup(e, 1, t_s, T);
-        double Ynew[5][4];
-        for (int m = 0; m < 4; ++m) {
-            double v[4] = {Y[0][m], Y[1][m], Y[2][m], Y[3][m]};
-            const double dlm = Y[4][m];
-            double Tv[4], Hv[4], rhs[4], zh[4];
-            third_apply(e, 1, T, v, Tv);
-            hess_apply(e, 1, v, Hv);
-            for (int i = 0; i < 4; ++i) rhs[i] = (i == m ? 1.0 : 0.0) + dlm * Ht[i] + dl * Tv[i] + t_l * Hv[i];
-            const double nu_m = dot4(Hft, v);
-            ldl_solve(L, rhs, zh);
-            const double mu_m = (dot4(gradf, zh) - nu_m) / cb;
-            for (int i = 0; i < 4; ++i) Ynew[i][m] = zh[i] - bh[i] * mu_m;
-            Ynew[4][m] = mu_m;
-        }
-        for (int i = 0; i < 5; ++i)
-            for (int m = 0; m < 4; ++m) Y[i][m] = Ynew[i][m];
-        // y <- y - t  (:514)
-        for (int i = 0; i < 4; ++i) sig[i] -= t_s[i];
-        dl -= t_l;
-        surf_eval(k, sig, e);
-        grad_surface(k, e, 1, gradg);
-        norm_res = residual(k, e, sig, dl, deps, sn, gradg, r_sig, &r_f);  // :516-517
-        niter += 1;
-    }
+    Lane L;
+    lane_init(L, deps, sn);
+    while (!lane_pass(k, L)) {}
     for (int i = 0; i < 4; ++i) {
-        R.sigma[i] = sig[i];
-        for (int j = 0; j < 4; ++j) R.C_tang[i * 4 + j] = Y[i][j];
+        R.sigma[i] = L.sig[i];
+        for (int j = 0; j < 4; ++j) R.C_tang[i * 4 + j] = L.Y[i][j];
     }
-    R.niter = niter;
-    R.norm_res = norm_res;
-    R.dlambda = dl;
+    R.niter = L.niter;
+    R.norm_res = L.norm;
+    R.dlambda = L.dl;
 }
 
 // Host-side constant folding of the model parameters (dxo_mc_params field order).

@@ -18,6 +18,8 @@
 
 namespace {
 
+constexpr int MC_PENDING = 512;  // per-wave buffer of plastic point indices (mc_classify)
+constexpr int MC_BATCH = 256;    // list entries a wave reserves per cursor atomic (mc_newton)
 constexpr int MC_ROW = 18;  // LDS doubles per point: 16 C_tang + 2 pad (144 B stride: conflict-free b128 writes)
 
 template <bool NT>
@@ -92,18 +94,235 @@ __global__ __launch_bounds__(DXO_BLOCK) void mc_point(mc::Const k, int64_t n, co
     }
 }
 
+// ------------------------------------------------------------------ variant 1: classify + compacted Newton
+// The simple kernel above makes every wave run as many Newton passes as its slowest lane while elastic
+// lanes (1 "iteration") idle. On a mixed workload (BASELINE config 4: ~30 % plastic, 2-5 iterations) that
+// is < 20 % lane utilisation. Variant 1 splits the work:
+//   mc_classify  lane = point, HBM-bound: trial stress, f(trial); elastic points are finished here
+//                (C_elas written in output order straight from constants — no LDS transposition needed —
+//                sigma through LDS); plastic points are appended to a compact index list
+//                (one wave-aggregated atomic per wave).
+//   mc_newton    FP64-bound: waves pull plastic points from the list through a shared cursor. A lane keeps
+//                its point until cond_fun fails, writes the point's outputs and is REFILLED with the next
+//                list entry while its neighbours keep iterating: every Newton pass runs on (nearly) full
+//                waves regardless of how iteration counts are distributed.
+// Scratch (ctx-owned): header {uint32 n_plastic, uint32 cursor} + int32 list[n].
+struct McScratchHeader {
+    unsigned int n_plastic;
+    unsigned int cursor;
+    unsigned int pad[62];
+};
+
+__global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n, const double* __restrict__ deps,
+                                                         const double* __restrict__ sigma_n, double* __restrict__ C_tang,
+                                                         double* __restrict__ sigma, int32_t* __restrict__ niter,
+                                                         double* __restrict__ yielding, double* __restrict__ norm_res,
+                                                         double* __restrict__ dlambda, McScratchHeader* __restrict__ hdr,
+                                                         int32_t* __restrict__ list) {
+    constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * DXO_WAVE * 4];
+    __shared__ int32_t pending[WAVES * MC_PENDING];   // plastic indices waiting for one batched list append
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(lds + wave * (DXO_WAVE * 4));
+    int32_t* pend = pending + wave * MC_PENDING;
+    int n_pend = 0;                                    // wave-uniform
+    auto flush = [&]() {
+        // ONE global atomic per ~MC_PENDING plastic points (a per-tile atomic on one address serialises:
+        // 156 k same-address atomics cost 1.8 ms at 10^7 points), and the list append is lane-linear.
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&hdr->n_plastic, (unsigned int)n_pend);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int j = lane; j < n_pend; j += DXO_WAVE) list[base + j] = pend[j];
+        n_pend = 0;
+    };
+    const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += stride) {
+        const int64_t p0 = tile * DXO_WAVE;
+        const int npts = (n - p0 < DXO_WAVE) ? (int)(n - p0) : DXO_WAVE;
+        const bool live = lane < npts;
+        const int64_t i = p0 + (live ? lane : 0);
+        const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + i * 4);
+        const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + i * 4);
+        const dxo_f64x2 e01 = ge[0], e23 = ge[1], s01 = gs[0], s23 = gs[1];
+        const double e[4] = {e01.x, e01.y, e23.x, e23.y};
+        const double sn[4] = {s01.x, s01.y, s23.x, s23.y};
+        double Ce[4], trial[4];
+        mc::C_times(k, e, Ce);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) trial[c] = sn[c] + Ce[c];
+        const double yld = mc::f_value(k, trial);                      // :422
+        const bool elastic = yld <= 0.0;                               // NaN -> plastic branch, as lax.cond does
+        mc::Result R;
+        mc::elastic_point(k, sn, Ce, trial, R);
+        const unsigned long long el_mask = __ballot(live && elastic);
+        const unsigned long long zero_mask = __ballot(live && elastic && R.niter == 0);
+        const unsigned long long pl_mask = __ballot(live && !elastic);
+        // plastic points -> the wave's pending buffer (ballot-compacted), flushed in batches
+        if (pl_mask) {
+            if (n_pend + DXO_WAVE > MC_PENDING) flush();
+            if (live && !elastic) pend[n_pend + __popcll(pl_mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+            n_pend += __popcll(pl_mask);
+        }
+        if (live) {
+            if (yielding) yielding[i] = yld;
+            if (elastic) {
+                if (niter) niter[i] = R.niter;
+                if (norm_res) norm_res[i] = R.norm_res;
+                if (dlambda) dlambda[i] = 0.0;
+            }
+        }
+        // sigma of elastic points: point-per-lane rows -> lane-linear stores, masked by the owner's branch
+        X2[lane * 2] = dxo_f64x2{R.sigma[0], R.sigma[1]};
+        X2[lane * 2 + 1] = dxo_f64x2{R.sigma[2], R.sigma[3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        dxo_f64x2* gg = reinterpret_cast<dxo_f64x2*>(sigma + p0 * 4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = it * DXO_WAVE + lane;
+            if ((el_mask >> (q >> 1)) & 1ull) st16<true>(gg + q, X2[q]);
+        }
+        // C_tang of elastic points: constants in output order (chunk q = point q/8, entries 2(q%8), 2(q%8)+1)
+        dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + p0 * 16);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int q = it * DXO_WAVE + lane;
+            const int pt = q >> 3, c = q & 7;
+            const int row = c >> 1, col = (c & 1) * 2;
+            dxo_f64x2 v;
+            v.x = ((row < 3 && col < 3) ? k.lmbda : 0.0) + (row == col ? k.mu2 : 0.0);
+            v.y = ((row < 3 && col + 1 < 3) ? k.lmbda : 0.0) + (row == col + 1 ? k.mu2 : 0.0);
+            if ((zero_mask >> pt) & 1ull) v = dxo_f64x2{0.0, 0.0};
+            if ((el_mask >> pt) & 1ull) st16<true>(gc + q, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (n_pend) flush();
+}
+
+__global__ __launch_bounds__(DXO_BLOCK) void mc_newton(mc::Const k, const double* __restrict__ deps,
+                                                       const double* __restrict__ sigma_n, double* __restrict__ C_tang,
+                                                       double* __restrict__ sigma, int32_t* __restrict__ niter,
+                                                       double* __restrict__ norm_res, double* __restrict__ dlambda,
+                                                       McScratchHeader* __restrict__ hdr, const int32_t* __restrict__ list) {
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const unsigned int total = hdr->n_plastic;   // written by mc_classify, earlier on the same stream
+    mc::Lane L;
+    bool active = false, exhausted = false;
+    int64_t idx = 0;
+    unsigned int lo = 0, hi = 0;   // the wave's reserved slice of the list (wave-uniform)
+    for (;;) {
+        // ---- refill idle lanes from the wave's reserved slice; reserve MC_BATCH more entries with ONE atomic
+        // when it runs dry (a cursor atomic per pass per wave serialises on one address like n_plastic did)
+        const unsigned long long idle = __ballot(!active);
+        if (idle && lo == hi && !exhausted) {
+            unsigned int start = 0;
+            if (lane == 0) start = atomicAdd(&hdr->cursor, (unsigned int)MC_BATCH);
+            start = __builtin_amdgcn_readfirstlane(start);
+            if (start >= total) exhausted = true;
+            else { lo = start; hi = (start + MC_BATCH < total) ? start + MC_BATCH : total; }
+        }
+        if (idle && lo < hi) {
+            const unsigned int mine = lo + (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned int take = ((unsigned int)__popcll(idle) < hi - lo) ? (unsigned int)__popcll(idle) : hi - lo;
+            lo += take;
+            if (!active && mine < hi) {
+                idx = list[mine];
+                const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + idx * 4);
+                const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + idx * 4);
+                const dxo_f64x2 e01 = ge[0], e23 = ge[1], s01 = gs[0], s23 = gs[1];
+                const double e[4] = {e01.x, e01.y, e23.x, e23.y};
+                const double sn[4] = {s01.x, s01.y, s23.x, s23.y};
+                mc::lane_init(L, e, sn);
+                active = true;
+            }
+        }
+        if (!__ballot(active)) break;
+        // ---- one Newton pass on every lane that holds a point
+        if (active) {
+            if (mc::lane_pass(k, L)) {
+                dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + idx * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gc[2 * r] = dxo_f64x2{L.Y[r][0], L.Y[r][1]};
+                    gc[2 * r + 1] = dxo_f64x2{L.Y[r][2], L.Y[r][3]};
+                }
+                dxo_f64x2* gg = reinterpret_cast<dxo_f64x2*>(sigma + idx * 4);
+                gg[0] = dxo_f64x2{L.sig[0], L.sig[1]};
+                gg[1] = dxo_f64x2{L.sig[2], L.sig[3]};
+                if (niter) niter[idx] = L.niter;
+                if (norm_res) norm_res[idx] = L.norm;
+                if (dlambda) dlambda[idx] = L.dl;
+                active = false;
+            }
+        }
+    }
+}
+
 struct McLaunch {
     mc::Const k;
     bool d_niter, d_yield, d_res, d_dl;
 };
 
+// ctx-owned scratch, one buffer per stream slot (3 host-pipeline slots + the device path)
+void* mc_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes) {
+    int slot = DXO_HOST_SLOTS;
+    for (int i = 0; i < DXO_HOST_SLOTS; ++i)
+        if (ctx->slot_stream[i] == s) slot = i;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+            (void)hipFree(ctx->scratch[slot]);
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) return nullptr;
+        ctx->scratch_bytes[slot] = want;
+    }
+    return ctx->scratch[slot];
+}
+
 int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, const double* sigma_n, double* C_tang,
               double* sigma, int32_t* niter, double* yielding, double* norm_res, double* dlambda, hipStream_t s) {
     if (n == 0) return DXO_OK;
-    const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
-    const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
-    hipLaunchKernelGGL(mc_point, dim3(grid), dim3(DXO_BLOCK), 0, s, L.k, n, deps, sigma_n, C_tang, sigma, niter, yielding,
-                       norm_res, dlambda);
+    if (ctx->mc_variant == 0) {
+        const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+        const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        hipLaunchKernelGGL(mc_point, dim3(grid), dim3(DXO_BLOCK), 0, s, L.k, n, deps, sigma_n, C_tang, sigma, niter,
+                           yielding, norm_res, dlambda);
+        return DXO_OK;
+    }
+    // int32 list entries: split gigantic batches
+    const int64_t max_part = (int64_t)1 << 30;
+    for (int64_t off = 0; off < n; off += max_part) {
+        const int64_t m = (n - off < max_part) ? (n - off) : max_part;
+        void* scratch = mc_scratch(ctx, s, sizeof(McScratchHeader) + (size_t)m * sizeof(int32_t));
+        if (!scratch) return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_mohr_coulomb: scratch allocation");
+        McScratchHeader* hdr = static_cast<McScratchHeader*>(scratch);
+        int32_t* list = reinterpret_cast<int32_t*>(hdr + 1);
+        DXO_HIP(ctx, hipMemsetAsync(hdr, 0, sizeof(McScratchHeader), s));
+        // persistent classify waves (grid-stride) so the batched list append amortises its atomic
+        int64_t cgrid = (m + DXO_BLOCK - 1) / DXO_BLOCK;
+        const int64_t ccap = (int64_t)ctx->compute_units * 6;
+        if (cgrid > ccap) cgrid = ccap;
+        const int grid = (int)cgrid;
+        hipLaunchKernelGGL(mc_classify, dim3(grid), dim3(DXO_BLOCK), 0, s, L.k, m, deps + off * 4, sigma_n + off * 4,
+                           C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
+                           yielding ? yielding + off : nullptr, norm_res ? norm_res + off : nullptr,
+                           dlambda ? dlambda + off : nullptr, hdr, list);
+        int64_t newton_blocks = (int64_t)ctx->compute_units * ctx->mc_blocks_per_cu;
+        const int64_t enough = (m + DXO_BLOCK - 1) / DXO_BLOCK;
+        if (newton_blocks > enough) newton_blocks = enough;
+        hipLaunchKernelGGL(mc_newton, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
+                           C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
+                           norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
+    }
     return DXO_OK;
 }
 

@@ -99,7 +99,10 @@ int dxo_ctx_set_stream(dxo_ctx* ctx, void* hip_stream);
 int dxo_ctx_synchronize(dxo_ctx* ctx);
 /* Integer tuning knobs: "vm_variant" (0 scalar AoS kernel, 1 LDS-staged coalesced kernel,
  * default 1), "host_chunk_points" (points per H2D/kernel/D2H pipeline chunk),
- * "nontemporal" (0/1 streaming stores), "timing" (0/1 record dxo_timing on device calls). */
+ * "nontemporal" (0/1 streaming stores), "timing" (0/1 record dxo_timing on device calls),
+ * "blocks_per_cu" (0 = one tile per wave, k = grid-stride over k workgroups per CU),
+ * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
+ * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 2). */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
 int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);

@@ -68,10 +68,15 @@ def test_reference_source_golden(ctx):
     assert got[2][zero] == 0 and np.all(got[0][zero] == 0.0)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 20000])
-def test_tracing_distribution_against_oracle(ctx, oracle, n):
+def test_tracing_distribution_against_oracle(ctx, oracle, n, variant):
     deps, sn = mc_tracing_inputs(oracle, n, seed=50 + n)
-    got = run_device(ctx, deps, sn)
+    ctx.set_option("mc_variant", variant)
+    try:
+        got = run_device(ctx, deps, sn)
+    finally:
+        ctx.set_option("mc_variant", 1)
     if n == 0:
         assert got[0].size == 0
         return
@@ -145,6 +150,17 @@ def test_drop_in_external_function(ctx, oracle):
     assert abs(seen[0]["max_yielding"] - ref[3].max()) < 1e-12
     with pytest.raises(NotImplementedError, match="No external function is defined"):
         evaluate_external_operators([sigma], evaluated_operands)
+
+
+def test_both_kernel_variants_agree_bitwise_on_sigma(ctx, oracle):
+    deps, sn = mc_tracing_inputs(oracle, 50_000, seed=8, shear=0.2)
+    ctx.set_option("mc_variant", 0)
+    a = run_device(ctx, deps, sn)
+    ctx.set_option("mc_variant", 1)
+    b = run_device(ctx, deps, sn)
+    assert np.array_equal(a[2], b[2])                       # iteration counts
+    for x, y in zip(a, b):                                  # same per-lane arithmetic in both schedules
+        assert np.array_equal(x, y, equal_nan=True)
 
 
 def test_full_size_properties(ctx, oracle):
