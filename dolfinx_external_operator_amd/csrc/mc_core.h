@@ -88,9 +88,10 @@ DXO_HD T23 t_scale(const T23& u, double k) {
 
 DXO_HD T23 t_sqrt(const T23& u) {
     const double h0 = sqrt(u.c[0]);
-    const double h1 = 0.5 / h0;
-    const double h2 = -0.5 * h1 / u.c[0];
-    const double h3 = -1.5 * h2 / u.c[0];
+    const double iu = 1.0 / u.c[0];
+    const double h1 = 0.5 * h0 * iu;      // 1 / (2 sqrt u)
+    const double h2 = -0.5 * h1 * iu;
+    const double h3 = -1.5 * h2 * iu;
     return t_compose(u, h0, h1, h2, h3);
 }
 
@@ -145,10 +146,11 @@ struct Surf {
 // up to 1e-2 of the tangent at 1 - |arg| ~ 1e-5, while arg is a smooth rational function of (J2, J3).
 DXO_HD T23 theta_taylor(double J2, double J3, T23& arg_out) {
     const double r = sqrt(J2);
-    const double h0 = 1.0 / (J2 * r);   // J2^-1.5
-    const double h1 = -1.5 * h0 / J2;
-    const double h2 = -2.5 * h1 / J2;
-    const double h3 = -3.5 * h2 / J2;
+    const double iJ2 = 1.0 / J2;
+    const double h0 = 1.0 / (J2 * r);   // J2^-1.5 (kept as one division: the value path must match f_value)
+    const double h1 = -1.5 * h0 * iJ2;
+    const double h2 = -2.5 * h1 * iJ2;
+    const double h3 = -3.5 * h2 * iJ2;
     const double kk = -(3.0 * sqrt(3.0)) / 2.0;
     T23 a;
     a.c[0] = kk * J3 * h0;
@@ -180,17 +182,17 @@ DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th, const T23&
     const double t0 = th.c[0];
     if (fabs(t0) > k.theta_T) {
         const int sg = t0 < 0.0 ? 0 : 1;  // sign(theta), :298-299
-        const T23& S3 = arg;              // sin(3 theta) == clip(arg), see theta_taylor
-        const T23 S3S3 = t_mul(S3, S3);
-        for (int i = 0; i < 10; ++i) K.c[i] = k.B[ia][sg] * S3.c[i] + k.Cc[ia][sg] * S3S3.c[i];
-        K.c[0] += k.A[ia][sg];
+        // sin(3 theta) == clip(arg) (see theta_taylor): K = A + B arg + C arg^2 is a quadratic in arg
+        const double a0 = arg.c[0];
+        K = t_compose(arg, k.A[ia][sg] + (k.B[ia][sg] + k.Cc[ia][sg] * a0) * a0, k.B[ia][sg] + 2.0 * k.Cc[ia][sg] * a0,
+                      2.0 * k.Cc[ia][sg], 0.0);
     } else {
         const double sn = sin(t0), cs = cos(t0);
         const T23 Ct = t_compose(th, cs, -sn, -cs, sn);
         const T23 St = t_compose(th, sn, cs, -sn, -cs);
         for (int i = 0; i < 10; ++i) K.c[i] = Ct.c[i] - k.k_lin[ia] * St.c[i];
     }
-    const T23 KK = t_mul(K, K);
+    const T23 KK = t_compose(K, K.c[0] * K.c[0], 2.0 * K.c[0], 2.0, 0.0);   // K^2
     T23 w;  // x * KK + const, x = J2 (dx = 1)
     w.c[0] = J2 * KK.c[0] + k.ag2s2[ia];
     w.c[1] = KK.c[0] + J2 * KK.c[1];
@@ -286,28 +288,33 @@ DXO_HD void third_apply(const Surf& e, int ia, const Third& T, const double* v, 
 }
 
 // LDL^T of a symmetric 4x4 (lower triangle in m[10]: 00,10,11,20,21,22,30,31,32,33), no pivoting
-struct Ldl { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3; };
+// (the four pivots are inverted once: a pass does 6 solves, and an fp64 division is ~12 instructions)
+struct Ldl { double l10, l20, l21, l30, l31, l32, i0, i1, i2, i3; };
 DXO_HD void ldl_factor(const double (*M)[4], Ldl& f) {
-    f.d0 = M[0][0];
-    f.l10 = M[1][0] / f.d0;
-    f.l20 = M[2][0] / f.d0;
-    f.l30 = M[3][0] / f.d0;
-    f.d1 = M[1][1] - f.l10 * f.l10 * f.d0;
-    f.l21 = (M[2][1] - f.l20 * f.l10 * f.d0) / f.d1;
-    f.l31 = (M[3][1] - f.l30 * f.l10 * f.d0) / f.d1;
-    f.d2 = M[2][2] - f.l20 * f.l20 * f.d0 - f.l21 * f.l21 * f.d1;
-    f.l32 = (M[3][2] - f.l30 * f.l20 * f.d0 - f.l31 * f.l21 * f.d1) / f.d2;
-    f.d3 = M[3][3] - f.l30 * f.l30 * f.d0 - f.l31 * f.l31 * f.d1 - f.l32 * f.l32 * f.d2;
+    const double d0 = M[0][0];
+    f.i0 = 1.0 / d0;
+    f.l10 = M[1][0] * f.i0;
+    f.l20 = M[2][0] * f.i0;
+    f.l30 = M[3][0] * f.i0;
+    const double d1 = M[1][1] - f.l10 * f.l10 * d0;
+    f.i1 = 1.0 / d1;
+    f.l21 = (M[2][1] - f.l20 * f.l10 * d0) * f.i1;
+    f.l31 = (M[3][1] - f.l30 * f.l10 * d0) * f.i1;
+    const double d2 = M[2][2] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
+    f.i2 = 1.0 / d2;
+    f.l32 = (M[3][2] - f.l30 * f.l20 * d0 - f.l31 * f.l21 * d1) * f.i2;
+    const double d3 = M[3][3] - f.l30 * f.l30 * d0 - f.l31 * f.l31 * d1 - f.l32 * f.l32 * d2;
+    f.i3 = 1.0 / d3;
 }
 DXO_HD void ldl_solve(const Ldl& f, const double* b, double* x) {
     const double z0 = b[0];
     const double z1 = b[1] - f.l10 * z0;
     const double z2 = b[2] - f.l20 * z0 - f.l21 * z1;
     const double z3 = b[3] - f.l30 * z0 - f.l31 * z1 - f.l32 * z2;
-    const double w3 = z3 / f.d3;
-    const double w2 = z2 / f.d2 - f.l32 * w3;
-    const double w1 = z1 / f.d1 - f.l21 * w2 - f.l31 * w3;
-    const double w0 = z0 / f.d0 - f.l10 * w1 - f.l20 * w2 - f.l30 * w3;
+    const double w3 = z3 * f.i3;
+    const double w2 = z2 * f.i2 - f.l32 * w3;
+    const double w1 = z1 * f.i1 - f.l21 * w2 - f.l31 * w3;
+    const double w0 = z0 * f.i0 - f.l10 * w1 - f.l20 * w2 - f.l30 * w3;
     x[0] = w0; x[1] = w1; x[2] = w2; x[3] = w3;
 }
 
