@@ -133,7 +133,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to benchmark (only the cpu_baseline leg uses the oracle)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is always brought up (also for a single rank, which
+    # lets the RCCL path be exercised on a 1-GPU box with --gather 1)
+    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
@@ -143,7 +146,7 @@ def main():
 
     if rank == 0:
         build_library()
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     d, K, W = args.d, args.steps, args.warmup
@@ -171,7 +174,7 @@ def main():
     sigma = out_slab[n * d * d: n * (d * d + d)]
     dp = out_slab[n * (d * d + d):]
     full = None
-    if gather and world > 1:
+    if gather and dist_on:
         full = [torch.empty(world * t.numel(), dtype=torch.float64, device=device) for t in (C_tang, sigma, dp)]
 
     ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
@@ -188,7 +191,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -204,7 +207,7 @@ def main():
 
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed, kernel_ms_avg], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
@@ -288,7 +291,7 @@ def main():
             del out_slab, C_tang, sigma, dp
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -115,6 +115,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "blocks_per_cu")) return &c->blocks_per_cu;
     if (!std::strcmp(key, "mc_variant")) return &c->mc_variant;
     if (!std::strcmp(key, "mc_blocks_per_cu")) return &c->mc_blocks_per_cu;
+    if (!std::strcmp(key, "mc_waves_per_simd")) return &c->mc_waves_per_simd;
     return nullptr;
 }
 

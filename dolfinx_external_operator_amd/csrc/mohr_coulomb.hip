@@ -205,7 +205,8 @@ __global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n,
     if (n_pend) flush();
 }
 
-__global__ __launch_bounds__(DXO_BLOCK) void mc_newton(mc::Const k, const double* __restrict__ deps,
+template <int MINW>
+__global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const double* __restrict__ deps,
                                                        const double* __restrict__ sigma_n, double* __restrict__ C_tang,
                                                        double* __restrict__ sigma, int32_t* __restrict__ niter,
                                                        double* __restrict__ norm_res, double* __restrict__ dlambda,
@@ -319,9 +320,14 @@ int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, co
         int64_t newton_blocks = (int64_t)ctx->compute_units * ctx->mc_blocks_per_cu;
         const int64_t enough = (m + DXO_BLOCK - 1) / DXO_BLOCK;
         if (newton_blocks > enough) newton_blocks = enough;
-        hipLaunchKernelGGL(mc_newton, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
-                           C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
-                           norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
+        if (ctx->mc_waves_per_simd >= 2)
+            hipLaunchKernelGGL(mc_newton<2>, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
+                               C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
+                               norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
+        else
+            hipLaunchKernelGGL(mc_newton<1>, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
+                               C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
+                               norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
     }
     return DXO_OK;
 }

@@ -25,6 +25,7 @@ ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--pool", type=int, default=50_000)
 ap.add_argument("--variant", type=int, default=1)
 ap.add_argument("--bpc", type=int, default=2)
+ap.add_argument("--wps", type=int, default=1)
 args = ap.parse_args()
 n = args.n
 o = load_oracle()
@@ -46,6 +47,7 @@ stream = torch.cuda.current_stream()
 ctx.set_stream(stream.cuda_stream)
 ctx.set_option("mc_variant", args.variant)
 ctx.set_option("mc_blocks_per_cu", args.bpc)
+ctx.set_option("mc_waves_per_simd", args.wps)
 diag = (it.data_ptr(), y.data_ptr(), nr.data_ptr(), dl.data_ptr()) if args.diag else (None, None, None, None)
 
 
@@ -63,7 +65,7 @@ for a, b in evs:
 torch.cuda.synchronize()
 ms = statistics.median(a.elapsed_time(b) for a, b in evs)
 bpp = 224 + (28 if args.diag else 0)
-out = {"case": "Mohr-Coulomb return map + AD tangent, tracing distribution", "variant": args.variant, "bpc": args.bpc, "n": n, "kernel_ms": ms,
+out = {"case": "Mohr-Coulomb return map + AD tangent, tracing distribution", "variant": args.variant, "bpc": args.bpc, "wps": args.wps, "n": n, "kernel_ms": ms,
        "qp_per_s": n / ms * 1e3, "GBps_algorithmic": bpp * n / ms / 1e6, "bytes_per_qp": bpp}
 if args.diag:
     u, c = torch.unique(it, return_counts=True)
