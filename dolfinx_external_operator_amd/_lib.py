@@ -35,6 +35,13 @@ class McParams(C.Structure):
                 ("nitermax", C.c_int32), ("_pad", C.c_int32)]
 
 
+class IcnnWeights(C.Structure):
+    """dxo_icnn_weights — the reference's state_dict tensors (demo_hyperelasticity.py:302-315), fp32."""
+    _fields_ = [(k, C.c_void_p) for k in ("layers0_weight", "layers0_bias", "layers1_weights", "skip1_weight", "skip1_bias",
+                                            "layers2_weights", "skip2_weight", "skip2_bias", "layers3_weights",
+                                            "skip3_weights")] + [("n_hidden", C.c_int32), ("_pad", C.c_int32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("total_ms", C.c_double)]
@@ -63,6 +70,10 @@ _SIGNATURES = {
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
     "dxo_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [_P] * 8),
+    "dxo_icnn_create": (C.c_int, [_P, C.POINTER(IcnnWeights), C.POINTER(_P)]),
+    "dxo_icnn_destroy": (C.c_int, [_P, _P]),
+    "dxo_icnn_correction": (C.c_int, [_P, _P, _P]),
+    "dxo_icnn_eval": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
@@ -233,6 +244,48 @@ class Context:
         rc = self.lib.dxo_mohr_coulomb(self._h, C.byref(prm), int(n), int(mem), _ptr(deps), _ptr(sigma_n), _ptr(C_tang),
                                        _ptr(sigma), _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
         self.check(rc, "dxo_mohr_coulomb")
+
+    # state_dict key -> dxo_icnn_weights field (shapes as torch stores them)
+    ICNN_KEYS = {
+        "layers.0.weight": ("layers0_weight", (64, 3)), "layers.0.bias": ("layers0_bias", (64,)),
+        "layers.1.weights": ("layers1_weights", (64, 64)), "skip_layers.1.weight": ("skip1_weight", (64, 3)),
+        "skip_layers.1.bias": ("skip1_bias", (64,)), "layers.2.weights": ("layers2_weights", (64, 64)),
+        "skip_layers.2.weight": ("skip2_weight", (64, 3)), "skip_layers.2.bias": ("skip2_bias", (64,)),
+        "layers.3.weights": ("layers3_weights", (1, 64)), "skip_layers.3.weights": ("skip3_weights", (1, 3)),
+    }
+
+    def icnn_create(self, state_dict) -> int:
+        """Upload an ICNN from a mapping {state_dict key: array-like} (keys with '.' or '__'). Returns a handle."""
+        w = IcnnWeights()
+        keep = []
+        norm = {str(k).replace("__", "."): v for k, v in state_dict.items()}
+        for key, (field, shape) in self.ICNN_KEYS.items():
+            if key not in norm:
+                raise ValueError(f"ICNN state_dict lacks {key!r}")
+            v = norm[key]
+            v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            if a.shape != shape:
+                raise ValueError(f"{key}: shape {a.shape}, expected {shape} (the demo's 3-64-64-64-1 network)")
+            keep.append(a)
+            setattr(w, field, a.ctypes.data)
+        w.n_hidden = 64
+        h = _P()
+        self.check(self.lib.dxo_icnn_create(self._h, C.byref(w), C.byref(h)), "dxo_icnn_create")
+        return h.value
+
+    def icnn_destroy(self, model: int) -> None:
+        if self._h and model:
+            self.lib.dxo_icnn_destroy(self._h, _P(model))
+
+    def icnn_correction(self, model: int) -> np.ndarray:
+        out = np.empty(4)
+        self.check(self.lib.dxo_icnn_correction(self._h, _P(model), _ptr(out)), "dxo_icnn_correction")
+        return out
+
+    def icnn_eval(self, model: int, precision: int, n: int, mem: int, F, dP, P) -> None:
+        rc = self.lib.dxo_icnn_eval(self._h, _P(model), int(precision), int(n), int(mem), _ptr(F), _ptr(dP), _ptr(P))
+        self.check(rc, "dxo_icnn_eval")
 
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))

@@ -1,0 +1,336 @@
+// icnn.hip — hyperelastic stress P = dW/dF and tangent dP/dF of the input-convex neural network (ICNN)
+// surrogate of the reference's hyperelasticity demo, one lane per quadrature point.
+//
+// Reference: doc/demo/demo_hyperelasticity.py — convexLinear :221-239, ICNN.forward :256-300,
+// H correction :362-381, compute_stress_local :429-443, vmap(jacfwd(.)) :448, dP_dF_impl :451-456.
+// The reference evaluates the network in fp32 (`.float()`, :286) and differentiates it with torch.func
+// (reverse mode for P, forward-over-reverse for the tangent). Here the derivatives are closed form:
+//
+//   features (fp64)   x = (K1, K2, K3)(F) depend on F only through t = |F|^2 and D = det F, so
+//                     dx/dF and d2x/dF2 are rank-structured in grad t = 2F and grad D = cof F.
+//   network (fp32 by default, fp64 for the tolerance study)
+//                     layer 0 is linear with NO activation (:289), so layer 1's pre-activation is affine in x:
+//                     a1 = A1 x + d1 with A1 = softplus(W1) W0 + S1 folded once on the host. Then
+//                       h1 = phi(a1), a2 = W2p h1 + S2 x + c2, y = w3p . phi(a2) + s3p . x,  phi(a) = softplus(a)^2/12
+//                       grad_x y = sum_j delta_j g_j + s3p,    g_j = sum_i W2p_ji phi'(a1_i) A1_i + S2_j,  delta_j = w3p_j phi'(a2_j)
+//                       hess_x y = sum_j w3p_j phi''(a2_j) g_j g_j^T + sum_i beta_i phi''(a1_i) A1_i A1_i^T,  beta = W2p^T delta
+//                     i.e. three mat-vec shaped products with the 64x64 matrix W2p per point: ~20.5 k FMA.
+//
+// Roofline: compute (fp32 VALU). 192 B/point of HBM traffic against ~45 kflop/point: > 200 flop/B.
+// Weights are wave-uniform: they are read through the scalar path (s_load into SGPRs) and enter the FMAs
+// as scalar operands; the per-point vectors h1, phi'(a1), beta live in VGPRs (3 x 64 floats per lane).
+// The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here);
+// gfx950's fp32-input MFMA runs at the fp32 VALU rate, so round 1 keeps the VALU form.
+#include <cmath>
+
+#include "dxo_common.h"
+
+namespace {
+
+constexpr int NH = 64;
+
+template <typename T>
+struct IcnnDev {
+    const T* A1;    // [64][4]: A1[i][0..2], d1[i]
+    const T* W2B;   // [64][64][4]: W2p[j][i], W2p[j][i] * A1[i][0..2]
+    const T* S2;    // [64][4]: S2[j][0..2], c2[j]
+    const T* w3;    // [64]: w3p
+    T s3[3];        // s3p
+    double H[4];    // H_flat (:371)
+};
+
+struct dxo_icnn_impl {
+    void* dev = nullptr;  // one slab holding both precisions
+    IcnnDev<float> f32;
+    IcnnDev<double> f64;
+};
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_log1p(T x);
+template <> __device__ __forceinline__ float t_log1p<float>(float x) { return log1pf(x); }
+template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
+
+// softplus (beta = 1, threshold = 20 as torch.nn.functional.softplus) with first and second derivative
+template <typename T>
+__device__ __forceinline__ void softplus3(T a, T& sp, T& s1, T& s2) {
+    if (a > T(20)) {
+        sp = a; s1 = T(1); s2 = T(0);
+    } else {
+        const T e = t_exp<T>(a);
+        const T r = T(1) / (T(1) + e);
+        sp = t_log1p<T>(e);
+        s1 = e * r;
+        s2 = s1 * r;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n, const double* __restrict__ F,
+                                                        double* __restrict__ dP, double* __restrict__ P) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const dxo_f64x2 f01 = reinterpret_cast<const dxo_f64x2*>(F + p * 4)[0];
+        const dxo_f64x2 f23 = reinterpret_cast<const dxo_f64x2*>(F + p * 4)[1];
+        const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};
+        // ---- features and their (t, D) partials, fp64 (:263-283)
+        const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+        const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+        const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
+        const double m = pow(aD, -2.0 / 3.0), nn = m * m;
+        const double K[3] = {(t + 1.0) * m - 3.0, (t + D * D) * nn - 3.0, (aD - 1.0) * (aD - 1.0)};
+        const double kt[3] = {m, nn, 0.0};
+        const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
+                              2.0 * (aD - 1.0) * sg};
+        const double ktD[3] = {(-2.0 / 3.0) * m * iD, (-4.0 / 3.0) * nn * iD, 0.0};
+        const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
+                               -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
+        const T x0 = (T)K[0], x1 = (T)K[1], x2 = (T)K[2];   // the `.float()` of :286 when T = float
+        // ---- layer 1 (layer 0 folded in): h1 = phi(a1), u = phi'(a1)
+        T h1[NH], u[NH], beta[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const T a = w.A1[i * 4 + 0] * x0 + w.A1[i * 4 + 1] * x1 + w.A1[i * 4 + 2] * x2 + w.A1[i * 4 + 3];
+            T sp, s1, s2;
+            softplus3<T>(a, sp, s1, s2);
+            h1[i] = sp * sp * T(1.0 / 12.0);      // :293-294
+            u[i] = sp * s1 * T(1.0 / 6.0);
+            beta[i] = T(0);
+        }
+        // ---- layer 2 neuron by neuron: a2_j, g_j = grad_x a2_j, then the contributions of neuron j
+        T y1[3] = {w.s3[0], w.s3[1], w.s3[2]};              // grad_x y
+        T hx[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};      // hess_x y: 00, 01, 02, 11, 12, 22
+#pragma unroll 1
+        for (int j = 0; j < NH; ++j) {
+            const T* row = w.W2B + (size_t)j * NH * 4;
+            T a2 = w.S2[j * 4 + 0] * x0 + w.S2[j * 4 + 1] * x1 + w.S2[j * 4 + 2] * x2 + w.S2[j * 4 + 3];
+            T g0 = w.S2[j * 4 + 0], g1 = w.S2[j * 4 + 1], g2 = w.S2[j * 4 + 2];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                a2 += row[i * 4 + 0] * h1[i];
+                g0 += row[i * 4 + 1] * u[i];
+                g1 += row[i * 4 + 2] * u[i];
+                g2 += row[i * 4 + 3] * u[i];
+            }
+            T sp, s1, s2;
+            softplus3<T>(a2, sp, s1, s2);
+            const T w3 = w.w3[j];
+            const T delta = w3 * sp * s1 * T(1.0 / 6.0);                    // w3p_j phi'(a2_j)
+            const T curv = w3 * (s1 * s1 + sp * s2) * T(1.0 / 6.0);         // w3p_j phi''(a2_j)
+            y1[0] += delta * g0; y1[1] += delta * g1; y1[2] += delta * g2;
+            hx[0] += curv * g0 * g0; hx[1] += curv * g0 * g1; hx[2] += curv * g0 * g2;
+            hx[3] += curv * g1 * g1; hx[4] += curv * g1 * g2; hx[5] += curv * g2 * g2;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) beta[i] += delta * row[i * 4 + 0];
+        }
+        // ---- second Hessian term: sum_i beta_i phi''(a1_i) A1_i A1_i^T
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const T A0 = w.A1[i * 4 + 0], A1v = w.A1[i * 4 + 1], A2 = w.A1[i * 4 + 2];
+            const T a = A0 * x0 + A1v * x1 + A2 * x2 + w.A1[i * 4 + 3];
+            T sp, s1, s2;
+            softplus3<T>(a, sp, s1, s2);
+            const T c = beta[i] * (s1 * s1 + sp * s2) * T(1.0 / 6.0);
+            hx[0] += c * A0 * A0; hx[1] += c * A0 * A1v; hx[2] += c * A0 * A2;
+            hx[3] += c * A1v * A1v; hx[4] += c * A1v * A2; hx[5] += c * A2 * A2;
+        }
+        // ---- chain rule to F (fp64): dK_k = kt_k gt + kD_k gD, gt = 2F, gD = cof F
+        const double Wk[3] = {(double)y1[0], (double)y1[1], (double)y1[2]};
+        const double Hk[3][3] = {{(double)hx[0], (double)hx[1], (double)hx[2]},
+                                 {(double)hx[1], (double)hx[3], (double)hx[4]},
+                                 {(double)hx[2], (double)hx[4], (double)hx[5]}};
+        double ca = 0, cb = 0, cc = 0, cd = 0, ett = 0, etD = 0, eDD = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ca += Wk[k] * kt[k]; cb += Wk[k] * kD[k]; cc += Wk[k] * ktD[k]; cd += Wk[k] * kDD[k];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                ett += Hk[k][l] * kt[k] * kt[l];
+                etD += Hk[k][l] * kt[k] * kD[l];
+                eDD += Hk[k][l] * kD[k] * kD[l];
+            }
+        }
+        const double gt[4] = {2.0 * Fv[0], 2.0 * Fv[1], 2.0 * Fv[2], 2.0 * Fv[3]};
+        const double gD[4] = {Fv[3], -Fv[2], -Fv[1], Fv[0]};
+        // P = grad_F W_NN + F @ H (:433-439); H = [[h0,h1,0,0],[h2,h3,0,0],[0,0,h0,h1],[0,0,h2,h3]]
+        const double FH[4] = {Fv[0] * w.H[0] + Fv[1] * w.H[2], Fv[0] * w.H[1] + Fv[1] * w.H[3],
+                              Fv[2] * w.H[0] + Fv[3] * w.H[2], Fv[2] * w.H[1] + Fv[3] * w.H[3]};
+        double Pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Pv[i] = ca * gt[i] + cb * gD[i] + FH[i];
+        reinterpret_cast<dxo_f64x2*>(P + p * 4)[0] = dxo_f64x2{Pv[0], Pv[1]};
+        reinterpret_cast<dxo_f64x2*>(P + p * 4)[1] = dxo_f64x2{Pv[2], Pv[3]};
+        const double ctD = cc + etD, cDD = cd + eDD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double rowv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double hD = ((i == 0 && jj == 3) || (i == 3 && jj == 0)) ? 1.0 : (((i == 1 && jj == 2) || (i == 2 && jj == 1)) ? -1.0 : 0.0);
+                // d(F @ H)_i / dF_j = H[j][i]
+                const int bi = i >> 1, bj = jj >> 1;
+                const double Hji = (bi == bj) ? w.H[(jj & 1) * 2 + (i & 1)] : 0.0;
+                rowv[jj] = (i == jj ? 2.0 * ca : 0.0) + cb * hD + ett * gt[i] * gt[jj] + ctD * (gt[i] * gD[jj] + gD[i] * gt[jj]) +
+                           cDD * gD[i] * gD[jj] + Hji;
+            }
+            reinterpret_cast<dxo_f64x2*>(dP + p * 16 + i * 4)[0] = dxo_f64x2{rowv[0], rowv[1]};
+            reinterpret_cast<dxo_f64x2*>(dP + p * 16 + i * 4)[1] = dxo_f64x2{rowv[2], rowv[3]};
+        }
+    }
+}
+
+double softplus_host(double x) { return x > 20.0 ? x : std::log1p(std::exp(x)); }
+
+struct IcnnLaunch {
+    const dxo_icnn_impl* m;
+    int precision;
+};
+
+int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, double* dP, double* P, hipStream_t s) {
+    if (n == 0) return DXO_OK;
+    int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    if (L.precision == 0) hipLaunchKernelGGL((icnn_point<float>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, L.m->f32, n, F, dP, P);
+    else hipLaunchKernelGGL((icnn_point<double>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, L.m->f64, n, F, dP, P);
+    return DXO_OK;
+}
+
+int icnn_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
+    const IcnnLaunch& L = *static_cast<const IcnnLaunch*>(user);
+    return icnn_launch(ctx, L, m, (const double*)d_in[0], (double*)d_out[0], (double*)d_out[1], s);
+}
+
+}  // namespace
+
+struct dxo_icnn : dxo_icnn_impl {};
+
+extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn** out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!w || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_create: NULL argument");
+    *out = nullptr;
+    if (w->n_hidden != NH) return dxo_fail(ctx, DXO_E_DIM, "dxo_icnn_create: n_hidden must be 64 (the reference's [64, 64, 64])");
+    if (!w->layers0_weight || !w->layers0_bias || !w->layers1_weights || !w->skip1_weight || !w->skip1_bias ||
+        !w->layers2_weights || !w->skip2_weight || !w->skip2_bias || !w->layers3_weights || !w->skip3_weights)
+        return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_create: NULL weight tensor");
+    // ---- fold in double: softplus on the convex layers (:238), layer 0 into layer 1
+    std::vector<double> A1(NH * 4), W2B((size_t)NH * NH * 4), S2(NH * 4), w3(NH);
+    for (int o = 0; o < NH; ++o) {
+        double acc[4] = {w->skip1_weight[o * 3 + 0], w->skip1_weight[o * 3 + 1], w->skip1_weight[o * 3 + 2], w->skip1_bias[o]};
+        for (int i = 0; i < NH; ++i) {
+            const double wp = softplus_host(w->layers1_weights[o * NH + i]);
+            for (int k = 0; k < 3; ++k) acc[k] += wp * w->layers0_weight[i * 3 + k];
+            acc[3] += wp * w->layers0_bias[i];
+        }
+        for (int k = 0; k < 4; ++k) A1[o * 4 + k] = acc[k];
+    }
+    for (int j = 0; j < NH; ++j) {
+        for (int i = 0; i < NH; ++i) {
+            const double wp = softplus_host(w->layers2_weights[j * NH + i]);
+            W2B[((size_t)j * NH + i) * 4 + 0] = wp;
+            for (int k = 0; k < 3; ++k) W2B[((size_t)j * NH + i) * 4 + 1 + k] = wp * A1[i * 4 + k];
+        }
+        for (int k = 0; k < 3; ++k) S2[j * 4 + k] = w->skip2_weight[j * 3 + k];
+        S2[j * 4 + 3] = w->skip2_bias[j];
+        w3[j] = softplus_host(w->layers3_weights[j]);
+    }
+    const size_t cnt = A1.size() + W2B.size() + S2.size() + w3.size();
+    std::vector<float> h32(cnt);
+    std::vector<double> h64(cnt);
+    size_t o = 0;
+    const size_t oA1 = o; for (double v : A1) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t oW = o; for (double v : W2B) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t oS2 = o; for (double v : S2) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t ow3 = o; for (double v : w3) { h64[o] = v; h32[o++] = (float)v; }
+    dxo_icnn* m = new dxo_icnn();
+    hipError_t e = hipSetDevice(ctx->device);
+    const size_t bytes64 = cnt * sizeof(double), bytes32 = (cnt * sizeof(float) + 255) / 256 * 256;
+    if (e == hipSuccess) e = hipMalloc(&m->dev, bytes64 + bytes32);
+    if (e == hipSuccess) e = hipMemcpy(m->dev, h64.data(), bytes64, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((char*)m->dev + bytes64, h32.data(), cnt * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->dev) (void)hipFree(m->dev);
+        delete m;
+        return dxo_hip_fail(ctx, e, "dxo_icnn_create");
+    }
+    const double* d64 = (const double*)m->dev;
+    const float* d32 = (const float*)((char*)m->dev + bytes64);
+    m->f64 = {d64 + oA1, d64 + oW, d64 + oS2, d64 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
+    m->f32 = {d32 + oA1, d32 + oW, d32 + oS2, d32 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
+    for (int k = 0; k < 3; ++k) {
+        const double s3 = softplus_host(w->skip3_weights[k]);
+        m->f64.s3[k] = s3;
+        m->f32.s3[k] = (float)s3;
+    }
+    // ---- H correction (:362-381): H_flat = -P_NN(F = I), with the fp32 network like the reference
+    double *dF = nullptr, *ddP = nullptr, *dPp = nullptr;
+    const double FI[4] = {1.0, 0.0, 0.0, 1.0};
+    double P0[4] = {0, 0, 0, 0};
+    e = hipMalloc(&dF, (4 + 16 + 4) * sizeof(double));
+    if (e == hipSuccess) {
+        ddP = dF + 4;
+        dPp = ddP + 16;
+        e = hipMemcpy(dF, FI, sizeof FI, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((icnn_point<float>), dim3(1), dim3(DXO_BLOCK), 0, ctx->stream, m->f32, (int64_t)1, dF, ddP, dPp);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(P0, dPp, sizeof P0, hipMemcpyDeviceToHost);
+    if (dF) (void)hipFree(dF);
+    if (e != hipSuccess) {
+        (void)hipFree(m->dev);
+        delete m;
+        return dxo_hip_fail(ctx, e, "dxo_icnn_create: H correction");
+    }
+    for (int k = 0; k < 4; ++k) {
+        m->f32.H[k] = -(double)(float)P0[k];
+        m->f64.H[k] = m->f32.H[k];
+    }
+    *out = m;
+    return DXO_OK;
+}
+
+extern "C" int dxo_icnn_destroy(dxo_ctx* ctx, dxo_icnn* m) {
+    if (!ctx) return DXO_E_NULL;
+    if (!m) return DXO_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+    return DXO_OK;
+}
+
+extern "C" int dxo_icnn_correction(dxo_ctx* ctx, const dxo_icnn* m, double* H_flat) {
+    if (!ctx) return DXO_E_NULL;
+    if (!m || !H_flat) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_correction: NULL argument");
+    for (int k = 0; k < 4; ++k) H_flat[k] = m->f32.H[k];
+    return DXO_OK;
+}
+
+extern "C" int dxo_icnn_eval(dxo_ctx* ctx, const dxo_icnn* m, int precision, int64_t n, int mem, const double* F,
+                             double* dP, double* P) {
+    if (!ctx) return DXO_E_NULL;
+    if (!m) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_eval: model is NULL");
+    if (precision != 0 && precision != 1) return dxo_fail(ctx, DXO_E_OPTION, "dxo_icnn_eval: precision must be 0 (fp32 network) or 1 (fp64)");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_icnn_eval: n < 0");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_icnn_eval: bad mem");
+    if (n > 0 && (!F || !dP || !P)) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_eval: NULL array");
+    const uintptr_t all = (uintptr_t)F | (uintptr_t)dP | (uintptr_t)P;
+    if (all & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_icnn_eval: arrays must be 8-byte aligned");
+    if (mem == DXO_MEM_DEVICE && (all & 15u)) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_icnn_eval: device arrays must be 16-byte aligned");
+    IcnnLaunch L{m, precision};
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = icnn_launch(ctx, L, n, F, dP, P, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    const size_t sd = sizeof(double);
+    std::vector<dxo_span> in = {{F, nullptr, 4 * sd}};
+    std::vector<dxo_span> out = {{nullptr, dP, 16 * sd}, {nullptr, P, 4 * sd}};
+    return dxo_run_host_pipeline(ctx, n, in, out, icnn_chunk, &L);
+}

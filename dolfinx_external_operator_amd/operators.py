@@ -263,4 +263,41 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
     return sigma_external
 
 
-__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb"]
+def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None, device: int = 0) -> Callable:
+    """`P_external` of the hyperelasticity demo (demo_hyperelasticity.py:459-466) on the GPU.
+
+    `external_function((1,))(Fvals) -> (dP, P)`, flat arrays in the reference's order (:456); other
+    multi-indices raise NotImplementedError. `Fvals` is (num_cells, nq, 2, 2) (or anything reshaping to
+    (-1, 4), :452). `state_dict` is the model's `state_dict()` (torch tensors or arrays; keys as torch names
+    them or with '__' for '.'), e.g. `torch.load("Isihara_noise=high.pth")` (:314).
+    precision "fp32" evaluates the network in fp32 like the reference (:286); "fp64" is the tolerance-study
+    variant (BASELINE config 5). The stress correction H (:362-381) is computed once at creation.
+    """
+    prec = {"fp32": 0, "fp64": 1}[precision]
+    holder = {"ctx": ctx, "model": None}
+
+    def _model():
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        if holder["model"] is None:
+            holder["model"] = holder["ctx"].icnn_create(state_dict)
+        return holder["ctx"], holder["model"]
+
+    def dP_dF_impl(Fvals):
+        cx, model = _model()
+        F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)      # :452
+        n = F.shape[0]
+        dP, P = np.empty(n * 16), np.empty(n * 4)
+        cx.icnn_eval(model, prec, n, MEM_HOST, F, dP, P)
+        return dP.reshape(-1), P.reshape(-1)                 # :456
+
+    def P_external(derivatives):
+        if derivatives == (1,):
+            return dP_dF_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    P_external.correction = lambda: _model()[0].icnn_correction(_model()[1])
+    return P_external
+
+
+__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn"]

@@ -152,6 +152,38 @@ int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, int mem,
                      double* C_tang, double* sigma,
                      int32_t* niter, double* yielding, double* norm_res, double* dlambda);
 
+/* ---- ICNN hyperelastic surrogate: stress P = dW/dF and tangent dP/dF --------------------------
+ * Replaces ICNN.forward + compute_stress_local + vmap(jacfwd(.)) + dP_dF_impl,
+ * demo_hyperelasticity.py:256-300, 362-381, 429-456. The weight struct takes the tensors of the
+ * reference's state_dict as they are stored (fp32, row-major [out][in]); softplus on the convex
+ * layers (:238) and the fold of the activation-free layer 0 into layer 1 happen inside create().
+ * Architecture is the demo's: n_input 3, n_hidden [64, 64, 64], n_output 1 (:302-307).
+ *   F  [n][4] = (F11, F12, F21, F22) (in);  dP [n][4][4] with dP[i][j] = dP_i/dF_j, P [n][4] (out),
+ *   the reference's return order is (dP, P) (:456).
+ *   precision 0: network in fp32 like the reference (`.float()`, :286); 1: network in fp64
+ *   (BASELINE config 5's fp64-vs-fp32 tolerance study). Features and chain rule are fp64 in both. */
+typedef struct dxo_icnn_weights {
+    const float* layers0_weight;   /* layers.0.weight        [64][3]  */
+    const float* layers0_bias;     /* layers.0.bias          [64]     */
+    const float* layers1_weights;  /* layers.1.weights       [64][64] */
+    const float* skip1_weight;     /* skip_layers.1.weight   [64][3]  */
+    const float* skip1_bias;       /* skip_layers.1.bias     [64]     */
+    const float* layers2_weights;  /* layers.2.weights       [64][64] */
+    const float* skip2_weight;     /* skip_layers.2.weight   [64][3]  */
+    const float* skip2_bias;       /* skip_layers.2.bias     [64]     */
+    const float* layers3_weights;  /* layers.3.weights       [1][64]  */
+    const float* skip3_weights;    /* skip_layers.3.weights  [1][3]   */
+    int32_t n_hidden;              /* 64                               */
+    int32_t _pad;
+} dxo_icnn_weights;
+typedef struct dxo_icnn dxo_icnn;
+int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn** out);
+int dxo_icnn_destroy(dxo_ctx* ctx, dxo_icnn* model);
+/* H_flat[4] of the stress correction P_cor = F @ H (:371), computed by create() at F = I. */
+int dxo_icnn_correction(dxo_ctx* ctx, const dxo_icnn* model, double* H_flat);
+int dxo_icnn_eval(dxo_ctx* ctx, const dxo_icnn* model, int precision, int64_t n, int mem,
+                  const double* F, double* dP, double* P);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

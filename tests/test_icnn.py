@@ -1,0 +1,139 @@
+"""ICNN hyperelastic operator: oracle vs reference goldens (CPU) and HIP kernel vs both (gpu)."""
+import numpy as np
+import pytest
+
+from oracle.icnn_oracle import features, icnn_stress_tangent
+
+# The reference runs the network in fp32 (`.float()`, demo_hyperelasticity.py:286); two correct fp32
+# implementations differ by summation order. Tolerances are relative to max|dP| resp. max|P| of the batch.
+RTOL_FP32 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def weights(golden):
+    return dict(golden("icnn_isihara_weights.npz"))
+
+
+def relerr(a, b):
+    return np.max(np.abs(np.asarray(a).reshape(-1) - np.asarray(b).reshape(-1))) / np.max(np.abs(b))
+
+
+def test_weight_fixture_is_the_reference_state_dict(weights):
+    assert sum(v.size for v in weights.values()) == 9027          # 9 027 fp32 parameters
+    assert weights["layers__1__weights"].shape == (64, 64) and weights["layers__0__weight"].shape == (64, 3)
+    assert all(v.dtype == np.float32 for v in weights.values())
+
+
+def test_oracle_matches_reference_golden(golden, weights):
+    g = golden("icnn_isihara.npz")
+    dP, P = icnn_stress_tangent(g["F"], weights)
+    assert dP.dtype == np.float64
+    assert relerr(dP, g["dP"]) <= RTOL_FP32 and relerr(P, g["P"]) <= RTOL_FP32
+    dP32, P32 = icnn_stress_tangent(g["F"].astype(np.float32), weights)     # dtype follows the input (:452-456)
+    assert dP32.dtype == np.float32
+    assert relerr(dP32, g["dP_f32in"]) <= 5e-6 and relerr(P32, g["P_f32in"]) <= 5e-6
+
+
+def test_feature_derivatives_by_finite_differences():
+    rng = np.random.default_rng(0)
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.15 * rng.normal(size=(50, 4))
+    K, dK, d2K = features(F)
+    h = 1e-6
+    for j in range(4):
+        Fp, Fm = F.copy(), F.copy()
+        Fp[:, j] += h
+        Fm[:, j] -= h
+        Kp, dKp, _ = features(Fp)
+        Km, dKm, _ = features(Fm)
+        assert np.max(np.abs((Kp - Km) / (2 * h) - dK[:, :, j])) < 1e-7
+        assert np.max(np.abs((dKp - dKm) / (2 * h) - d2K[:, :, :, j])) < 1e-6
+
+
+def test_stress_vanishes_in_the_undeformed_state(golden, weights):
+    # what the H correction is for (:362-381): P(F = I) = 0 up to fp32 noise
+    dP, P = icnn_stress_tangent(np.array([[1.0, 0.0, 0.0, 1.0]]), weights)
+    assert np.max(np.abs(P)) < 1e-6
+    assert np.allclose(dP[0], dP[0].T, atol=1e-5)          # hyperelastic tangent is symmetric
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def state_dict(weights):
+    return {k.replace("__", "."): v for k, v in weights.items()}
+
+
+@pytest.mark.gpu
+def test_hip_matches_reference_golden(ctx, golden, weights):
+    from dolfinx_external_operator_amd import make_icnn
+
+    g = golden("icnn_isihara.npz")
+    ext = make_icnn(state_dict(weights), ctx=ctx)
+    dP, P = ext((1,))(g["F"].reshape(-1, 1, 2, 2))
+    assert dP.shape == (g["F"].shape[0] * 16,) and P.shape == (g["F"].shape[0] * 4,)
+    assert relerr(dP, g["dP"]) <= RTOL_FP32 and relerr(P, g["P"]) <= RTOL_FP32
+    assert np.max(np.abs(ext.correction() - np.array([g["H"][0, 0], g["H"][0, 1], g["H"][1, 0], g["H"][1, 1]]))) < 1e-6
+    with pytest.raises(NotImplementedError, match="No external function is defined"):
+        ext((0,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 63, 257, 5000])
+def test_hip_against_oracle_sizes(ctx, weights, n):
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(n)
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    model = ctx.icnn_create(state_dict(weights))
+    try:
+        dP, P = np.full(n * 16 + 8, -7.0), np.full(n * 4 + 8, -7.0)
+        ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
+        assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
+        if n:
+            dPo, Po = icnn_stress_tangent(F, weights)
+            assert relerr(dP[: n * 16], dPo) <= RTOL_FP32 and relerr(P[: n * 4], Po) <= RTOL_FP32
+    finally:
+        ctx.icnn_destroy(model)
+
+
+@pytest.mark.gpu
+def test_fp64_network_variant_tolerance_study(ctx, weights):
+    """BASELINE config 5: the fp64 network differs from the fp32 one only by fp32 rounding (~1e-7), and
+    matches the fp64-network oracle to fp64 accuracy."""
+    from dolfinx_external_operator_amd import make_icnn
+
+    rng = np.random.default_rng(5)
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(4000, 4))
+    dP32, P32 = make_icnn(state_dict(weights), ctx=ctx, precision="fp32")((1,))(F)
+    dP64, P64 = make_icnn(state_dict(weights), ctx=ctx, precision="fp64")((1,))(F)
+    dPo, Po = icnn_stress_tangent(F, weights, net_dtype=np.float64)
+    assert relerr(dP64, dPo) <= 1e-11 and relerr(P64, Po) <= 1e-11
+    assert 1e-9 < relerr(dP32, dP64) <= RTOL_FP32
+
+
+@pytest.mark.gpu
+def test_device_pointers_and_validation(ctx, weights):
+    import torch
+
+    from dolfinx_external_operator_amd import MEM_DEVICE
+
+    n = 10_000
+    rng = np.random.default_rng(1)
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    dev = torch.device("cuda:0")
+    Ft = torch.from_numpy(F).to(dev)
+    dP = torch.empty(n * 16, dtype=torch.float64, device=dev)
+    P = torch.empty(n * 4, dtype=torch.float64, device=dev)
+    model = ctx.icnn_create(state_dict(weights))
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.icnn_eval(model, 0, n, MEM_DEVICE, Ft.data_ptr(), dP.data_ptr(), P.data_ptr())
+        torch.cuda.synchronize()
+        dPo, Po = icnn_stress_tangent(F, weights)
+        assert relerr(dP.cpu().numpy(), dPo) <= RTOL_FP32
+        with pytest.raises(ValueError, match="OPTION"):
+            ctx.icnn_eval(model, 2, n, MEM_DEVICE, Ft.data_ptr(), dP.data_ptr(), P.data_ptr())
+    finally:
+        ctx.icnn_destroy(model)
+    bad = state_dict(weights)
+    bad["layers.1.weights"] = bad["layers.1.weights"][:32]
+    with pytest.raises(ValueError, match="shape"):
+        ctx.icnn_create(bad)
