@@ -32,7 +32,8 @@ constexpr int NH = 64;
 template <typename T>
 struct IcnnDev {
     const T* A1;    // [64][4]: A1[i][0..2], d1[i]
-    const T* W2B;   // [64][64][4]: W2p[j][i], W2p[j][i] * A1[i][0..2]
+    const T* W2B;   // [64][4][64]: row j = { W2p[j][:], W2p[j][:] * A1[:][0], * A1[:][1], * A1[:][2] } (four 64-vectors,
+                    // each fetched with s_load_dwordx16 bursts)
     const T* S2;    // [64][4]: S2[j][0..2], c2[j]
     const T* w3;    // [64]: w3p
     T s3[3];        // s3p
@@ -67,8 +68,22 @@ __device__ __forceinline__ void softplus3(T a, T& sp, T& s1, T& s2) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n, const double* __restrict__ F,
+struct IcnnSmall {  // by-value kernel argument: lands in SGPRs
+    T s3[3];
+    double H[4];
+};
+
+// The weight arrays are separate `const T* __restrict__` kernel arguments on purpose: only then can the
+// compiler prove they are never written and fetch them through the scalar path (s_load -> SGPR operands).
+// Passed as pointers inside a struct they were loaded with per-lane global_load_dwordx4 (64x redundant,
+// 256 VGPRs for one weight row, h1/u spilled to scratch).
+template <typename T>
+__global__ __launch_bounds__(DXO_BLOCK) void icnn_point(const T* __restrict__ wA1, const T* __restrict__ wW2B,
+                                                        const T* __restrict__ wS2, const T* __restrict__ ww3,
+                                                        IcnnSmall<T> small, int64_t n, const double* __restrict__ F,
                                                         double* __restrict__ dP, double* __restrict__ P) {
+    struct { const T* A1; const T* W2B; const T* S2; const T* w3; const T* s3; const double* H; } w =
+        {wA1, wW2B, wS2, ww3, small.s3, small.H};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const dxo_f64x2 f01 = reinterpret_cast<const dxo_f64x2*>(F + p * 4)[0];
@@ -97,6 +112,10 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n,
             h1[i] = sp * sp * T(1.0 / 12.0);      // :293-294
             u[i] = sp * s1 * T(1.0 / 6.0);
             beta[i] = T(0);
+            // Pin both in registers: without this the compiler SINKS the whole softplus chain into the
+            // 64-iteration neuron loop below (it can recompute h1[i] from x) and evaluates 64 x 64 exp/log1p
+            // per point instead of 64 — measured 14x slower.
+            asm volatile("" : "+v"(h1[i]), "+v"(u[i]));
         }
         // ---- layer 2 neuron by neuron: a2_j, g_j = grad_x a2_j, then the contributions of neuron j
         T y1[3] = {w.s3[0], w.s3[1], w.s3[2]};              // grad_x y
@@ -107,12 +126,13 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n,
             T a2 = w.S2[j * 4 + 0] * x0 + w.S2[j * 4 + 1] * x1 + w.S2[j * 4 + 2] * x2 + w.S2[j * 4 + 3];
             T g0 = w.S2[j * 4 + 0], g1 = w.S2[j * 4 + 1], g2 = w.S2[j * 4 + 2];
 #pragma unroll
-            for (int i = 0; i < NH; ++i) {
-                a2 += row[i * 4 + 0] * h1[i];
-                g0 += row[i * 4 + 1] * u[i];
-                g1 += row[i * 4 + 2] * u[i];
-                g2 += row[i * 4 + 3] * u[i];
-            }
+            for (int i = 0; i < NH; ++i) a2 += row[i] * h1[i];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) g0 += row[NH + i] * u[i];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) g1 += row[2 * NH + i] * u[i];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) g2 += row[3 * NH + i] * u[i];
             T sp, s1, s2;
             softplus3<T>(a2, sp, s1, s2);
             const T w3 = w.w3[j];
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n,
             hx[0] += curv * g0 * g0; hx[1] += curv * g0 * g1; hx[2] += curv * g0 * g2;
             hx[3] += curv * g1 * g1; hx[4] += curv * g1 * g2; hx[5] += curv * g2 * g2;
 #pragma unroll
-            for (int i = 0; i < NH; ++i) beta[i] += delta * row[i * 4 + 0];
+            for (int i = 0; i < NH; ++i) beta[i] += delta * row[i];
         }
         // ---- second Hessian term: sum_i beta_i phi''(a1_i) A1_i A1_i^T
 #pragma unroll
@@ -180,6 +200,14 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(IcnnDev<T> w, int64_t n,
     }
 }
 
+template <typename T>
+void launch_icnn(const IcnnDev<T>& m, int blocks, hipStream_t s, int64_t n, const double* F, double* dP, double* P) {
+    IcnnSmall<T> small;
+    for (int k = 0; k < 3; ++k) small.s3[k] = m.s3[k];
+    for (int k = 0; k < 4; ++k) small.H[k] = m.H[k];
+    hipLaunchKernelGGL((icnn_point<T>), dim3(blocks), dim3(DXO_BLOCK), 0, s, m.A1, m.W2B, m.S2, m.w3, small, n, F, dP, P);
+}
+
 double softplus_host(double x) { return x > 20.0 ? x : std::log1p(std::exp(x)); }
 
 struct IcnnLaunch {
@@ -192,8 +220,8 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
     int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
-    if (L.precision == 0) hipLaunchKernelGGL((icnn_point<float>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, L.m->f32, n, F, dP, P);
-    else hipLaunchKernelGGL((icnn_point<double>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, L.m->f64, n, F, dP, P);
+    if (L.precision == 0) launch_icnn<float>(L.m->f32, (int)blocks, s, n, F, dP, P);
+    else launch_icnn<double>(L.m->f64, (int)blocks, s, n, F, dP, P);
     return DXO_OK;
 }
 
@@ -228,8 +256,8 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
     for (int j = 0; j < NH; ++j) {
         for (int i = 0; i < NH; ++i) {
             const double wp = softplus_host(w->layers2_weights[j * NH + i]);
-            W2B[((size_t)j * NH + i) * 4 + 0] = wp;
-            for (int k = 0; k < 3; ++k) W2B[((size_t)j * NH + i) * 4 + 1 + k] = wp * A1[i * 4 + k];
+            W2B[(size_t)j * NH * 4 + i] = wp;
+            for (int k = 0; k < 3; ++k) W2B[(size_t)j * NH * 4 + (1 + k) * NH + i] = wp * A1[i * 4 + k];
         }
         for (int k = 0; k < 3; ++k) S2[j * 4 + k] = w->skip2_weight[j * 3 + k];
         S2[j * 4 + 3] = w->skip2_bias[j];
@@ -274,7 +302,7 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
         e = hipMemcpy(dF, FI, sizeof FI, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL((icnn_point<float>), dim3(1), dim3(DXO_BLOCK), 0, ctx->stream, m->f32, (int64_t)1, dF, ddP, dPp);
+        launch_icnn<float>(m->f32, 1, ctx->stream, (int64_t)1, dF, ddP, dPp);
         e = hipStreamSynchronize(ctx->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(P0, dPp, sizeof P0, hipMemcpyDeviceToHost);

@@ -92,4 +92,16 @@ q = torch.empty(n * 2, device=dev, dtype=torch.float64); dT = torch.empty_like(q
 ms = ev_time(lambda: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr()))
 print(json.dumps({"case": "heat fused q, dq/dT, dq/dsigma, gdim=2, 5e7 points", "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
                   "GBps": 88 * n / ms / 1e6}), flush=True)
+# ICNN (BASELINE config 5): F = I + 0.1 N(0,1), det F > 0.2
+w = {k.replace("__", "."): v for k, v in np.load(ROOT / "tests" / "golden" / "icnn_isihara_weights.npz").items()}
+model = ctx.icnn_create(w)
+for n, prec, label in ((4_000_000, 0, "fp32 network (reference precision)"), (1_000_000, 1, "fp64 network (tolerance study)")):
+    Ft = torch.randn(n, 4, device=dev, dtype=torch.float64) * 0.1 + torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
+    det = Ft[:, 0] * Ft[:, 3] - Ft[:, 1] * Ft[:, 2]
+    Ft[det <= 0.2] = torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
+    dPt = torch.empty(n * 16, device=dev, dtype=torch.float64); Pt = torch.empty(n * 4, device=dev, dtype=torch.float64)
+    ms = ev_time(lambda: ctx.icnn_eval(model, prec, n, MEM_DEVICE, Ft.data_ptr(), dPt.data_ptr(), Pt.data_ptr()), launches=5, warm=1)
+    print(json.dumps({"case": f"ICNN stress + tangent, {label}", "n": n, "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
+                      "GBps_algorithmic": 192 * n / ms / 1e6, "approx_TFLOPs": 45e3 * n / ms / 1e9}), flush=True)
+ctx.icnn_destroy(model)
 ctx.close()
