@@ -37,6 +37,7 @@ struct dxo_ctx {
     int64_t blocks_per_cu = 0;          // 0: one wave-tile per wave (no grid stride)
     int64_t mc_variant = 1;             // 0: lane = point; 1: classify + compacted Newton with lane refill
     int64_t mc_blocks_per_cu = 2;       // persistent Newton workgroups per CU
+    int64_t icnn_variant = 1;           // fp32 network: 0 VALU lane-per-point kernel, 1 MFMA wave-per-64-points kernel
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};

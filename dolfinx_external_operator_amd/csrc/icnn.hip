@@ -34,6 +34,7 @@ struct IcnnDev {
     const T* A1;    // [64][4]: A1[i][0..2], d1[i]
     const T* W2B;   // [64][4][64]: row j = { W2p[j][:], W2p[j][:] * A1[:][0], * A1[:][1], * A1[:][2] } (four 64-vectors,
                     // each fetched with s_load_dwordx16 bursts)
+    const T* W2;    // [64][64]: W2p[j][i] (dense, the MFMA kernel's operand source)
     const T* S2;    // [64][4]: S2[j][0..2], c2[j]
     const T* w3;    // [64]: w3p
     T s3[3];        // s3p
@@ -54,6 +55,17 @@ template <> __device__ __forceinline__ float t_log1p<float>(float x) { return lo
 template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
 
 // softplus (beta = 1, threshold = 20 as torch.nn.functional.softplus) with first and second derivative
+// fp32 softplus on the hardware transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp): ~10 instructions instead of
+// ~120 for expf + log1pf. log(1 + e) loses RELATIVE accuracy for e < 1e-4, but there softplus < 1e-4 and only
+// enters through softplus^2/12 — absolute error < 1e-12 of the network output.
+__device__ __forceinline__ void softplus3_fast(float a, float& sp, float& s1, float& s2) {
+    const float e = __expf(fminf(a, 20.0f));
+    const float r = __frcp_rn(1.0f + e);
+    sp = a > 20.0f ? a : __logf(1.0f + e);
+    s1 = a > 20.0f ? 1.0f : e * r;
+    s2 = a > 20.0f ? 0.0f : e * r * r;
+}
+
 template <typename T>
 __device__ __forceinline__ void softplus3(T a, T& sp, T& s1, T& s2) {
     if (a > T(20)) {
@@ -64,6 +76,55 @@ __device__ __forceinline__ void softplus3(T a, T& sp, T& s1, T& s2) {
         sp = t_log1p<T>(e);
         s1 = e * r;
         s2 = s1 * r;
+    }
+}
+
+// Chain rule from the network input x = (K1, K2, K3) to F in fp64 (shared by both kernels).
+// dK_k = kt_k gt + kD_k gD with gt = grad |F|^2 = 2F, gD = grad det F = cof F; W = grad_x y, hx = hess_x y packed
+// (00, 01, 02, 11, 12, 22). Writes P = grad_F W_NN + F @ H (:433-439) and dP[i][j] = dP_i/dF_j.
+template <typename T>
+__device__ __forceinline__ void icnn_chain(const double (&Fv)[4], const double (&kt)[3], const double (&kD)[3],
+                                           const double (&ktD)[3], const double (&kDD)[3], const T* y1, const T* hx,
+                                           const double* Hc, double* __restrict__ dPp, double* __restrict__ Pp) {
+    const double Wk[3] = {(double)y1[0], (double)y1[1], (double)y1[2]};
+    const double Hk[3][3] = {{(double)hx[0], (double)hx[1], (double)hx[2]},
+                             {(double)hx[1], (double)hx[3], (double)hx[4]},
+                             {(double)hx[2], (double)hx[4], (double)hx[5]}};
+    double ca = 0, cb = 0, cc = 0, cd = 0, ett = 0, etD = 0, eDD = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ca += Wk[k] * kt[k]; cb += Wk[k] * kD[k]; cc += Wk[k] * ktD[k]; cd += Wk[k] * kDD[k];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            ett += Hk[k][l] * kt[k] * kt[l];
+            etD += Hk[k][l] * kt[k] * kD[l];
+            eDD += Hk[k][l] * kD[k] * kD[l];
+        }
+    }
+    const double gt[4] = {2.0 * Fv[0], 2.0 * Fv[1], 2.0 * Fv[2], 2.0 * Fv[3]};
+    const double gD[4] = {Fv[3], -Fv[2], -Fv[1], Fv[0]};
+    // H = [[h0,h1,0,0],[h2,h3,0,0],[0,0,h0,h1],[0,0,h2,h3]] (:371-380)
+    const double FH[4] = {Fv[0] * Hc[0] + Fv[1] * Hc[2], Fv[0] * Hc[1] + Fv[1] * Hc[3],
+                          Fv[2] * Hc[0] + Fv[3] * Hc[2], Fv[2] * Hc[1] + Fv[3] * Hc[3]};
+    double Pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Pv[i] = ca * gt[i] + cb * gD[i] + FH[i];
+    reinterpret_cast<dxo_f64x2*>(Pp)[0] = dxo_f64x2{Pv[0], Pv[1]};
+    reinterpret_cast<dxo_f64x2*>(Pp)[1] = dxo_f64x2{Pv[2], Pv[3]};
+    const double ctD = cc + etD, cDD = cd + eDD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double rowv[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double hD = ((i == 0 && jj == 3) || (i == 3 && jj == 0)) ? 1.0 : (((i == 1 && jj == 2) || (i == 2 && jj == 1)) ? -1.0 : 0.0);
+            const int bi = i >> 1, bj = jj >> 1;
+            const double Hji = (bi == bj) ? Hc[(jj & 1) * 2 + (i & 1)] : 0.0;   // d(F @ H)_i / dF_j = H[j][i]
+            rowv[jj] = (i == jj ? 2.0 * ca : 0.0) + cb * hD + ett * gt[i] * gt[jj] + ctD * (gt[i] * gD[jj] + gD[i] * gt[jj]) +
+                       cDD * gD[i] * gD[jj] + Hji;
+        }
+        reinterpret_cast<dxo_f64x2*>(dPp + i * 4)[0] = dxo_f64x2{rowv[0], rowv[1]};
+        reinterpret_cast<dxo_f64x2*>(dPp + i * 4)[1] = dxo_f64x2{rowv[2], rowv[3]};
     }
 }
 
@@ -155,47 +216,192 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(const T* __restrict__ wA
             hx[0] += c * A0 * A0; hx[1] += c * A0 * A1v; hx[2] += c * A0 * A2;
             hx[3] += c * A1v * A1v; hx[4] += c * A1v * A2; hx[5] += c * A2 * A2;
         }
-        // ---- chain rule to F (fp64): dK_k = kt_k gt + kD_k gD, gt = 2F, gD = cof F
-        const double Wk[3] = {(double)y1[0], (double)y1[1], (double)y1[2]};
-        const double Hk[3][3] = {{(double)hx[0], (double)hx[1], (double)hx[2]},
-                                 {(double)hx[1], (double)hx[3], (double)hx[4]},
-                                 {(double)hx[2], (double)hx[4], (double)hx[5]}};
-        double ca = 0, cb = 0, cc = 0, cd = 0, ett = 0, etD = 0, eDD = 0;
+        T y1v[3] = {y1[0], y1[1], y1[2]};
+        icnn_chain(Fv, kt, kD, ktD, kDD, y1v, hx, w.H, dP + p * 16, P + p * 4);
+    }
+}
+
+// ------------------------------------------------------------------ fp32 MFMA kernel (variant 1)
+// One wave = 64 points. The three mat-vec shaped products with W2p become five 64x64x64 GEMMs per wave on
+// v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf chain), everything else runs on the VALU meanwhile:
+//   [a2 | g0 | g1 | g2](j, pt) = W2p(j, i) @ [h1 | u A1_0 | u A1_1 | u A1_2](i, pt)      4 GEMMs
+//   beta(i, pt)                = W2p^T(i, j) @ delta(j, pt)                                1 GEMM
+// Lane l = (h = l >> 5, p = l & 31). Points are processed in two tiles of 32 (pt = 32 t + p).
+//   A operand (lane: row = l & 31, k = l >> 5):  A[jt][r]      = W2p[32 jt + p][r + 32 h]        K-step r covers i in {r, r + 32}
+//                                                AT[it][jt][q] = W2p[jlo(jt,q) + 4 h][32 it + p]  K-step (jt,q) covers j in {jlo, jlo + 4}
+//     — 128 weight registers, loaded ONCE per wave and kept resident across the grid-stride loop.
+//   B operand (lane: k = l >> 5, col = l & 31): the lane evaluates layer-1 neuron i = r + 32 h for point 32 t + p
+//     itself (softplus on the VALU while the matrix pipe works), so B never has to be shuffled into place.
+//   C/D (lane: col = l & 31, row = (q & 3) + 8 (q >> 2) + 4 h): delta is produced in exactly the layout the
+//     beta GEMM wants as its B operand (k = h selects row jlo + 4 h), again without a shuffle.
+// The only cross-lane traffic is x of the partner half (3 values) and the final 9-value half-wave sums.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only the compiler needs ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(DXO_BLOCK) void icnn_mfma(const float* __restrict__ wA1, const float* __restrict__ wW2,
+                                                       const float* __restrict__ wS2, const float* __restrict__ ww3,
+                                                       IcnnSmall<float> small, int64_t n, const double* __restrict__ F,
+                                                       double* __restrict__ dP, double* __restrict__ P) {
+    constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const float4* A1v = reinterpret_cast<const float4*>(wA1);   // A1[i] = (A1_i0, A1_i1, A1_i2, d1_i)
+    const float4* S2v = reinterpret_cast<const float4*>(wS2);   // S2[j] = (S2_j0, S2_j1, S2_j2, c2_j)
+    // The A operands of all five GEMMs, pre-arranged in MFMA lane order, live in LDS (32 KiB per workgroup,
+    // filled once): sA[jt][r][lane], sAT[it][jt][q][lane]. Keeping them in registers instead (128 VGPRs)
+    // forced the K loop to be fully unrolled and spilled 2.3 KB per lane.
+    __shared__ float sA[2 * 32 * 64];
+    __shared__ float sAT[2 * 2 * 16 * 64];
+    __shared__ float sStage[WAVES * 64 * 64];   // per wave: 4 accumulator tiles (later beta) parked lane-linear
+    __shared__ float sDelta[WAVES * 32 * 64];   // per wave: delta in C layout = B operand of the beta GEMM
+    float* stage = sStage + wave * (64 * 64);
+    float* sdlt = sDelta + wave * (32 * 64);
+    for (int e = threadIdx.x; e < 2 * 32 * 64; e += DXO_BLOCK) {
+        const int l = e & 63, r = (e >> 6) & 31, jt = e >> 11;
+        sA[e] = wW2[(32 * jt + (l & 31)) * NH + r + 32 * (l >> 5)];
+    }
+    for (int e = threadIdx.x; e < 2 * 2 * 16 * 64; e += DXO_BLOCK) {
+        const int l = e & 63, q = (e >> 6) & 15, jt = (e >> 10) & 1, it = e >> 11;
+        sAT[e] = wW2[(32 * jt + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)) * NH + 32 * it + (l & 31)];
+    }
+    __syncthreads();
+
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t pidx = tile * 64 + lane;
+        const int64_t pl = pidx < n ? pidx : n - 1;   // tail lanes recompute the last point, never store
+        const dxo_f64x2 f01 = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[0];
+        const dxo_f64x2 f23 = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[1];
+        const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};
+        const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+        const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+        const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
+        const double m = pow(aD, -2.0 / 3.0), nn = m * m;
+        const float x0 = (float)((t + 1.0) * m - 3.0), x1 = (float)((t + D * D) * nn - 3.0), x2 = (float)((aD - 1.0) * (aD - 1.0));
+        const float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
+        float mine[9];
+#pragma unroll 1
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool own = (tt == h);
+            const float xs0 = own ? x0 : xp0, xs1 = own ? x1 : xp1, xs2 = own ? x2 : xp2;
+            // Everything below runs in ROLLED loops: the MFMA results are parked in a wave-private LDS slice
+            // (lane-linear, each lane re-reads only its own column) purely so that the softplus passes can
+            // index them dynamically. Fully unrolled they were scheduled for ILP and spilled > 300 VGPRs.
+            float res[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc[2][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            ca += Wk[k] * kt[k]; cb += Wk[k] * kD[k]; cc += Wk[k] * ktD[k]; cd += Wk[k] * kDD[k];
+            for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                ett += Hk[k][l] * kt[k] * kt[l];
-                etD += Hk[k][l] * kt[k] * kD[l];
-                eDD += Hk[k][l] * kD[k] * kD[l];
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[jt][c][q] = 0.f;
+#pragma unroll 2
+            for (int r = 0; r < 32; ++r) {
+                const float4 a1 = A1v[r + 32 * h];
+                const float Ar0 = sA[(0 * 32 + r) * 64 + lane], Ar1 = sA[(1 * 32 + r) * 64 + lane];
+                const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
+                float sp, s1, s2;
+                softplus3_fast(a, sp, s1, s2);
+                const float hv = sp * sp * (1.0f / 12.0f);
+                const float uv = sp * s1 * (1.0f / 6.0f);
+                const float B1 = uv * a1.x, B2 = uv * a1.y, B3 = uv * a1.z;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, hv, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, hv, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B1, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B2, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B2, acc[1][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B3, acc[0][3], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B3, acc[1][3], 0, 0, 0);
+            }
+#pragma unroll 1
+            for (int jt = 0; jt < 2; ++jt) {
+                if (jt == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) stage[(c * 16 + q) * 64 + lane] = acc[0][c][q];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) stage[(c * 16 + q) * 64 + lane] = acc[1][c][q];
+                }
+                icnn_lds_fence();
+                // ---- neurons of layer 2 (C layout: q -> j): skip connection, softplus, grad / hess contributions
+#pragma unroll 2
+                for (int q = 0; q < 16; ++q) {
+                    const int j = 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    const float4 s2r = S2v[j];
+                    const float a2 = stage[(0 * 16 + q) * 64 + lane] + s2r.x * xs0 + s2r.y * xs1 + s2r.z * xs2 + s2r.w;
+                    const float g0 = stage[(1 * 16 + q) * 64 + lane] + s2r.x;
+                    const float g1 = stage[(2 * 16 + q) * 64 + lane] + s2r.y;
+                    const float g2 = stage[(3 * 16 + q) * 64 + lane] + s2r.z;
+                    float sp, s1, s2;
+                    softplus3_fast(a2, sp, s1, s2);
+                    const float w3 = ww3[j];
+                    const float delta = w3 * sp * s1 * (1.0f / 6.0f);
+                    const float curv = w3 * (s1 * s1 + sp * s2) * (1.0f / 6.0f);
+                    res[0] += delta * g0; res[1] += delta * g1; res[2] += delta * g2;
+                    res[3] += curv * g0 * g0; res[4] += curv * g0 * g1; res[5] += curv * g0 * g2;
+                    res[6] += curv * g1 * g1; res[7] += curv * g1 * g2; res[8] += curv * g2 * g2;
+                    sdlt[(jt * 16 + q) * 64 + lane] = delta;   // already the beta GEMM's B operand layout
+                }
+                icnn_lds_fence();
+            }
+            // ---- beta = W2p^T delta (K-step jq = (jt, q) covers j in {jlo, jlo + 4})
+            f32x16 bacc[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
+#pragma unroll 4
+            for (int jq = 0; jq < 32; ++jq) {
+                const float Bd = sdlt[jq * 64 + lane];
+                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sAT[(0 * 32 + jq) * 64 + lane], Bd, bacc[0], 0, 0, 0);
+                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sAT[(1 * 32 + jq) * 64 + lane], Bd, bacc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) stage[(it * 16 + q) * 64 + lane] = bacc[it][q];
+            icnn_lds_fence();
+            // ---- second Hessian term: sum_i beta_i phi''(a1_i) A1_i A1_i^T (C layout: iq -> i)
+#pragma unroll 2
+            for (int iq = 0; iq < 32; ++iq) {
+                const int q = iq & 15;
+                const int i = 32 * (iq >> 4) + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float4 a1 = A1v[i];
+                const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
+                float sp, s1, s2;
+                softplus3_fast(a, sp, s1, s2);
+                const float c = stage[iq * 64 + lane] * (s1 * s1 + sp * s2) * (1.0f / 6.0f);
+                res[3] += c * a1.x * a1.x; res[4] += c * a1.x * a1.y; res[5] += c * a1.x * a1.z;
+                res[6] += c * a1.y * a1.y; res[7] += c * a1.y * a1.z; res[8] += c * a1.z * a1.z;
+            }
+            icnn_lds_fence();
+            // both half-waves hold partial sums of the SAME 32 points: add them, keep the tile this lane owns
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float tot = res[q] + xor32(res[q]);
+                if (own) mine[q] = tot;
             }
         }
-        const double gt[4] = {2.0 * Fv[0], 2.0 * Fv[1], 2.0 * Fv[2], 2.0 * Fv[3]};
-        const double gD[4] = {Fv[3], -Fv[2], -Fv[1], Fv[0]};
-        // P = grad_F W_NN + F @ H (:433-439); H = [[h0,h1,0,0],[h2,h3,0,0],[0,0,h0,h1],[0,0,h2,h3]]
-        const double FH[4] = {Fv[0] * w.H[0] + Fv[1] * w.H[2], Fv[0] * w.H[1] + Fv[1] * w.H[3],
-                              Fv[2] * w.H[0] + Fv[3] * w.H[2], Fv[2] * w.H[1] + Fv[3] * w.H[3]};
-        double Pv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Pv[i] = ca * gt[i] + cb * gD[i] + FH[i];
-        reinterpret_cast<dxo_f64x2*>(P + p * 4)[0] = dxo_f64x2{Pv[0], Pv[1]};
-        reinterpret_cast<dxo_f64x2*>(P + p * 4)[1] = dxo_f64x2{Pv[2], Pv[3]};
-        const double ctD = cc + etD, cDD = cd + eDD;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double rowv[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const double hD = ((i == 0 && jj == 3) || (i == 3 && jj == 0)) ? 1.0 : (((i == 1 && jj == 2) || (i == 2 && jj == 1)) ? -1.0 : 0.0);
-                // d(F @ H)_i / dF_j = H[j][i]
-                const int bi = i >> 1, bj = jj >> 1;
-                const double Hji = (bi == bj) ? w.H[(jj & 1) * 2 + (i & 1)] : 0.0;
-                rowv[jj] = (i == jj ? 2.0 * ca : 0.0) + cb * hD + ett * gt[i] * gt[jj] + ctD * (gt[i] * gD[jj] + gD[i] * gt[jj]) +
-                           cDD * gD[i] * gD[jj] + Hji;
-            }
-            reinterpret_cast<dxo_f64x2*>(dP + p * 16 + i * 4)[0] = dxo_f64x2{rowv[0], rowv[1]};
-            reinterpret_cast<dxo_f64x2*>(dP + p * 16 + i * 4)[1] = dxo_f64x2{rowv[2], rowv[3]};
+        if (pidx < n) {
+            const double kt[3] = {m, nn, 0.0};
+            const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
+                                  2.0 * (aD - 1.0) * sg};
+            const double ktD[3] = {(-2.0 / 3.0) * m * iD, (-4.0 / 3.0) * nn * iD, 0.0};
+            const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
+                                   -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
+            const float y1f[3] = {mine[0] + small.s3[0], mine[1] + small.s3[1], mine[2] + small.s3[2]};
+            icnn_chain(Fv, kt, kD, ktD, kDD, y1f, mine + 3, small.H, dP + pidx * 16, P + pidx * 4);
         }
     }
 }
@@ -220,6 +426,17 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
     int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
+    if (L.precision == 0 && ctx->icnn_variant != 0) {
+        // MFMA kernel: one wave = 64 points, weights resident in registers -> persistent grid, 1 wave per SIMD
+        IcnnSmall<float> small;
+        for (int k = 0; k < 3; ++k) small.s3[k] = L.m->f32.s3[k];
+        for (int k = 0; k < 4; ++k) small.H[k] = L.m->f32.H[k];
+        int64_t mb = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+        if (mb > ctx->compute_units) mb = ctx->compute_units;
+        hipLaunchKernelGGL(icnn_mfma, dim3((int)mb), dim3(DXO_BLOCK), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
+                           small, n, F, dP, P);
+        return DXO_OK;
+    }
     if (L.precision == 0) launch_icnn<float>(L.m->f32, (int)blocks, s, n, F, dP, P);
     else launch_icnn<double>(L.m->f64, (int)blocks, s, n, F, dP, P);
     return DXO_OK;
@@ -243,7 +460,7 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
         !w->layers2_weights || !w->skip2_weight || !w->skip2_bias || !w->layers3_weights || !w->skip3_weights)
         return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_create: NULL weight tensor");
     // ---- fold in double: softplus on the convex layers (:238), layer 0 into layer 1
-    std::vector<double> A1(NH * 4), W2B((size_t)NH * NH * 4), S2(NH * 4), w3(NH);
+    std::vector<double> A1(NH * 4), W2B((size_t)NH * NH * 4), W2((size_t)NH * NH), S2(NH * 4), w3(NH);
     for (int o = 0; o < NH; ++o) {
         double acc[4] = {w->skip1_weight[o * 3 + 0], w->skip1_weight[o * 3 + 1], w->skip1_weight[o * 3 + 2], w->skip1_bias[o]};
         for (int i = 0; i < NH; ++i) {
@@ -257,18 +474,20 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
         for (int i = 0; i < NH; ++i) {
             const double wp = softplus_host(w->layers2_weights[j * NH + i]);
             W2B[(size_t)j * NH * 4 + i] = wp;
+            W2[(size_t)j * NH + i] = wp;
             for (int k = 0; k < 3; ++k) W2B[(size_t)j * NH * 4 + (1 + k) * NH + i] = wp * A1[i * 4 + k];
         }
         for (int k = 0; k < 3; ++k) S2[j * 4 + k] = w->skip2_weight[j * 3 + k];
         S2[j * 4 + 3] = w->skip2_bias[j];
         w3[j] = softplus_host(w->layers3_weights[j]);
     }
-    const size_t cnt = A1.size() + W2B.size() + S2.size() + w3.size();
+    const size_t cnt = A1.size() + W2B.size() + W2.size() + S2.size() + w3.size();
     std::vector<float> h32(cnt);
     std::vector<double> h64(cnt);
     size_t o = 0;
     const size_t oA1 = o; for (double v : A1) { h64[o] = v; h32[o++] = (float)v; }
     const size_t oW = o; for (double v : W2B) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t oW2 = o; for (double v : W2) { h64[o] = v; h32[o++] = (float)v; }
     const size_t oS2 = o; for (double v : S2) { h64[o] = v; h32[o++] = (float)v; }
     const size_t ow3 = o; for (double v : w3) { h64[o] = v; h32[o++] = (float)v; }
     dxo_icnn* m = new dxo_icnn();
@@ -284,8 +503,8 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
     }
     const double* d64 = (const double*)m->dev;
     const float* d32 = (const float*)((char*)m->dev + bytes64);
-    m->f64 = {d64 + oA1, d64 + oW, d64 + oS2, d64 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
-    m->f32 = {d32 + oA1, d32 + oW, d32 + oS2, d32 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
+    m->f64 = {d64 + oA1, d64 + oW, d64 + oW2, d64 + oS2, d64 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
+    m->f32 = {d32 + oA1, d32 + oW, d32 + oW2, d32 + oS2, d32 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
     for (int k = 0; k < 3; ++k) {
         const double s3 = softplus_host(w->skip3_weights[k]);
         m->f64.s3[k] = s3;

@@ -95,7 +95,9 @@ print(json.dumps({"case": "heat fused q, dq/dT, dq/dsigma, gdim=2, 5e7 points", 
 # ICNN (BASELINE config 5): F = I + 0.1 N(0,1), det F > 0.2
 w = {k.replace("__", "."): v for k, v in np.load(ROOT / "tests" / "golden" / "icnn_isihara_weights.npz").items()}
 model = ctx.icnn_create(w)
-for n, prec, label in ((4_000_000, 0, "fp32 network (reference precision)"), (1_000_000, 1, "fp64 network (tolerance study)")):
+for n, prec, variant, label in ((10_000_000, 0, 1, "fp32 network, MFMA kernel"), (4_000_000, 0, 0, "fp32 network, VALU kernel"),
+                                (1_000_000, 1, 0, "fp64 network (tolerance study)")):
+    ctx.set_option("icnn_variant", variant)
     Ft = torch.randn(n, 4, device=dev, dtype=torch.float64) * 0.1 + torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
     det = Ft[:, 0] * Ft[:, 3] - Ft[:, 1] * Ft[:, 2]
     Ft[det <= 0.2] = torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)

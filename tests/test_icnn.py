@@ -95,6 +95,31 @@ def test_hip_against_oracle_sizes(ctx, weights, n):
 
 
 @pytest.mark.gpu
+def test_mfma_and_valu_kernels_agree(ctx, weights):
+    """fp32 network: the MFMA kernel (variant 1, default) against the lane-per-point VALU kernel (variant 0)."""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(11)
+    n = 20_001     # ragged: last wave has one live lane
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    model = ctx.icnn_create(state_dict(weights))
+    out = {}
+    try:
+        for variant in (0, 1):
+            ctx.set_option("icnn_variant", variant)
+            dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
+            ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
+            assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
+            out[variant] = (dP[: n * 16], P[: n * 4])
+    finally:
+        ctx.set_option("icnn_variant", 1)
+        ctx.icnn_destroy(model)
+    assert relerr(out[1][0], out[0][0]) <= RTOL_FP32 and relerr(out[1][1], out[0][1]) <= RTOL_FP32
+    dPo, Po = icnn_stress_tangent(F, weights)
+    assert relerr(out[1][0], dPo) <= RTOL_FP32 and relerr(out[1][1], Po) <= RTOL_FP32
+
+
+@pytest.mark.gpu
 def test_fp64_network_variant_tolerance_study(ctx, weights):
     """BASELINE config 5: the fp64 network differs from the fp32 one only by fp32 rounding (~1e-7), and
     matches the fp64-network oracle to fp64 accuracy."""
