@@ -244,11 +244,12 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(DXO_BLOCK) void icnn_mfma(const float* __restrict__ wA1, const float* __restrict__ wW2,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* __restrict__ wA1, const float* __restrict__ wW2,
                                                        const float* __restrict__ wS2, const float* __restrict__ ww3,
                                                        IcnnSmall<float> small, int64_t n, const double* __restrict__ F,
                                                        double* __restrict__ dP, double* __restrict__ P) {
-    constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+    constexpr int BLOCK = WAVES * 64;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = threadIdx.x >> 6;
     const float4* A1v = reinterpret_cast<const float4*>(wA1);   // A1[i] = (A1_i0, A1_i1, A1_i2, d1_i)
@@ -258,15 +259,18 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_mfma(const float* __restrict__
     // forced the K loop to be fully unrolled and spilled 2.3 KB per lane.
     __shared__ float sA[2 * 32 * 64];
     __shared__ float sAT[2 * 2 * 16 * 64];
-    __shared__ float sStage[WAVES * 64 * 64];   // per wave: 4 accumulator tiles (later beta) parked lane-linear
-    __shared__ float sDelta[WAVES * 32 * 64];   // per wave: delta in C layout = B operand of the beta GEMM
-    float* stage = sStage + wave * (64 * 64);
+    // per wave: 8 KiB to park 4 accumulator tiles, 8 of their 16 registers at a time (later the 32 beta values),
+    // and 8 KiB for delta in C layout = B operand of the beta GEMM. With WAVES = 8 the workgroup uses exactly the
+    // CU's 160 KiB and runs 2 waves per SIMD, so one wave's softplus passes overlap the other's MFMAs.
+    __shared__ float sStage[WAVES * 32 * 64];
+    __shared__ float sDelta[WAVES * 32 * 64];
+    float* stage = sStage + wave * (32 * 64);
     float* sdlt = sDelta + wave * (32 * 64);
-    for (int e = threadIdx.x; e < 2 * 32 * 64; e += DXO_BLOCK) {
+    for (int e = threadIdx.x; e < 2 * 32 * 64; e += BLOCK) {
         const int l = e & 63, r = (e >> 6) & 31, jt = e >> 11;
         sA[e] = wW2[(32 * jt + (l & 31)) * NH + r + 32 * (l >> 5)];
     }
-    for (int e = threadIdx.x; e < 2 * 2 * 16 * 64; e += DXO_BLOCK) {
+    for (int e = threadIdx.x; e < 2 * 2 * 16 * 64; e += BLOCK) {
         const int l = e & 63, q = (e >> 6) & 15, jt = (e >> 10) & 1, it = e >> 11;
         sAT[e] = wW2[(32 * jt + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)) * NH + 32 * it + (l & 31)];
     }
@@ -321,28 +325,24 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_mfma(const float* __restrict__
                 acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B3, acc[1][3], 0, 0, 0);
             }
 #pragma unroll 1
-            for (int jt = 0; jt < 2; ++jt) {
-                if (jt == 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) stage[(c * 16 + q) * 64 + lane] = acc[0][c][q];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) stage[(c * 16 + q) * 64 + lane] = acc[1][c][q];
-                }
+            for (int part = 0; part < 4; ++part) {   // (jt, half): 8 accumulator registers of 4 tiles at a time
+                const int jt = part >> 1, q0 = (part & 1) * 8;
+#define DXO_PARK(JT, Q0)                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                          \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) stage[(c * 8 + q) * 64 + lane] = acc[JT][c][Q0 + q];
+                if (part == 0) { DXO_PARK(0, 0) } else if (part == 1) { DXO_PARK(0, 8) } else if (part == 2) { DXO_PARK(1, 0) } else { DXO_PARK(1, 8) }
+#undef DXO_PARK
                 icnn_lds_fence();
                 // ---- neurons of layer 2 (C layout: q -> j): skip connection, softplus, grad / hess contributions
 #pragma unroll 2
-                for (int q = 0; q < 16; ++q) {
+                for (int qq = 0; qq < 8; ++qq) {
+                    const int q = q0 + qq;
                     const int j = 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * h;
                     const float4 s2r = S2v[j];
-                    const float a2 = stage[(0 * 16 + q) * 64 + lane] + s2r.x * xs0 + s2r.y * xs1 + s2r.z * xs2 + s2r.w;
-                    const float g0 = stage[(1 * 16 + q) * 64 + lane] + s2r.x;
-                    const float g1 = stage[(2 * 16 + q) * 64 + lane] + s2r.y;
-                    const float g2 = stage[(3 * 16 + q) * 64 + lane] + s2r.z;
+                    const float a2 = stage[(0 * 8 + qq) * 64 + lane] + s2r.x * xs0 + s2r.y * xs1 + s2r.z * xs2 + s2r.w;
+                    const float g0 = stage[(1 * 8 + qq) * 64 + lane] + s2r.x;
+                    const float g1 = stage[(2 * 8 + qq) * 64 + lane] + s2r.y;
+                    const float g2 = stage[(3 * 8 + qq) * 64 + lane] + s2r.z;
                     float sp, s1, s2;
                     softplus3_fast(a2, sp, s1, s2);
                     const float w3 = ww3[j];
@@ -431,10 +431,16 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
         IcnnSmall<float> small;
         for (int k = 0; k < 3; ++k) small.s3[k] = L.m->f32.s3[k];
         for (int k = 0; k < 4; ++k) small.H[k] = L.m->f32.H[k];
-        int64_t mb = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+        // one workgroup per CU: 4 waves (1 per SIMD) or, default, 8 waves (2 per SIMD, all 160 KiB of LDS)
+        const int waves = ctx->icnn_variant == 2 ? 4 : 8;
+        int64_t mb = (n + waves * 64 - 1) / (waves * 64);
         if (mb > ctx->compute_units) mb = ctx->compute_units;
-        hipLaunchKernelGGL(icnn_mfma, dim3((int)mb), dim3(DXO_BLOCK), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
-                           small, n, F, dP, P);
+        if (waves == 8)
+            hipLaunchKernelGGL(icnn_mfma<8>, dim3((int)mb), dim3(512), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
+                               small, n, F, dP, P);
+        else
+            hipLaunchKernelGGL(icnn_mfma<4>, dim3((int)mb), dim3(256), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
+                               small, n, F, dP, P);
         return DXO_OK;
     }
     if (L.precision == 0) launch_icnn<float>(L.m->f32, (int)blocks, s, n, F, dP, P);

@@ -105,7 +105,7 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
     model = ctx.icnn_create(state_dict(weights))
     out = {}
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             ctx.set_option("icnn_variant", variant)
             dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
             ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
@@ -114,9 +114,11 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
     finally:
         ctx.set_option("icnn_variant", 1)
         ctx.icnn_destroy(model)
-    assert relerr(out[1][0], out[0][0]) <= RTOL_FP32 and relerr(out[1][1], out[0][1]) <= RTOL_FP32
     dPo, Po = icnn_stress_tangent(F, weights)
-    assert relerr(out[1][0], dPo) <= RTOL_FP32 and relerr(out[1][1], Po) <= RTOL_FP32
+    for variant in (1, 2):   # 8-wave (2 per SIMD) and 4-wave MFMA workgroups
+        assert relerr(out[variant][0], out[0][0]) <= RTOL_FP32 and relerr(out[variant][1], out[0][1]) <= RTOL_FP32
+        assert relerr(out[variant][0], dPo) <= RTOL_FP32 and relerr(out[variant][1], Po) <= RTOL_FP32
+    assert np.array_equal(out[1][0], out[2][0])    # same per-wave arithmetic in both workgroup shapes
 
 
 @pytest.mark.gpu
