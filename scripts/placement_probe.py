@@ -56,3 +56,15 @@ print("in slab sweep (best out slab", best_o, "):")
 for i in range(K):
     ms = t(lambda: run(i, best_o))
     print(f"  in {i}: vm {4.48e9 / ms / 1e6:7.1f} GB/s")
+
+# option sweep on the fastest and the slowest output slab
+rate = {o: 1.0 / t(lambda: run(0, o)) for o in range(K)}
+fast_o, slow_o = max(rate, key=rate.get), min(rate, key=rate.get)
+for name, o in (("fast", fast_o), ("slow", slow_o)):
+    for nt in (1, 0):
+        for bpc in (0, 4, 8, 16, 32):
+            ctx.set_option("nontemporal", nt)
+            ctx.set_option("blocks_per_cu", bpc)
+            ms = t(lambda: run(0, o), reps=8)
+            pm = t(lambda: ctx.stream_probe(13, 43, tiles, ins[0].data_ptr(), outs[o].data_ptr()), reps=8)
+            print(f"  {name} slab {o}: nt={nt} bpc={bpc:2d}  vm {4.48e9 / ms / 1e6:7.1f}  probe {4.48e9 / pm / 1e6:7.1f} GB/s")
