@@ -233,6 +233,15 @@ class Context:
         self._pinned.append((p.value, arr))
         return arr
 
+    def pinned_free(self, arr: np.ndarray) -> None:
+        """Release a buffer obtained from pinned_empty (the array must not be used afterwards)."""
+        addr = arr.ctypes.data
+        for k, (a, _) in enumerate(self._pinned):
+            if a == addr:
+                self._pinned.pop(k)
+                self.check(self.lib.dxo_host_free(self._h, _P(addr)), "host_free")
+                return
+
     # -- kernels -------------------------------------------------------------------------------
     def von_mises(self, prm: VmParams, d: int, n: int, mem: int, deps, sigma_n, p, C_tang, sigma, dp) -> None:
         rc = self.lib.dxo_von_mises(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(deps), _ptr(sigma_n),

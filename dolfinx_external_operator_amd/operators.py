@@ -49,9 +49,14 @@ def _as_f64_host(a, what: str) -> np.ndarray:
 
 
 class _Outputs:
-    """Output buffers for host calls. With reuse=True the same pinned buffers are handed out on every
-    call (the reference's callers copy the results into coefficient arrays immediately,
-    demo_plasticity_von_mises.py:451-456); reuse=False returns fresh pageable arrays like NumPy would."""
+    """Output buffers for host calls.
+
+    reuse=True (default of the factories): the returned flat arrays are views of pinned (hipHostMalloc) buffers
+    owned by the operator and are OVERWRITTEN BY ITS NEXT CALL. That matches how the reference consumes them —
+    `evaluate_external_operators` copies element 0 into the coefficient at once (external_operator.py:441) and
+    the demos copy the extras right after the call (demo_plasticity_von_mises.py:451-456) — and it is what makes
+    the boundary PCIe-bound instead of page-fault-bound: 7.5 ms vs 38 ms per call at 10^6 points (d = 6), because
+    a fresh 344 MB ndarray is first touched inside the D2H copy. reuse=False returns fresh pageable arrays."""
 
     def __init__(self, ctx: Context, reuse: bool):
         self.ctx = ctx
@@ -63,15 +68,16 @@ class _Outputs:
             return np.empty(size, dtype=np.float64)
         buf = self._cache.get((key, size))
         if buf is None:
+            for k in [k for k in self._cache if k[0] == key]:   # the batch size changed: release the old buffer
+                self.ctx.pinned_free(self._cache.pop(k))
             buf = self.ctx.pinned_empty(size)
-            self._cache = {k: v for k, v in self._cache.items() if k[0] != key}
             self._cache[(key, size)] = buf
         return buf
 
 
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = False) -> Callable:
+                   reuse_outputs: bool = True) -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -79,6 +85,8 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     `deps` has shape (num_cells, nq, d), d = 4 (reference) or 6 (3-D Mandel). Default constants: :185-188.
     Host ndarrays go through the chunked H2D/kernel/D2H pipeline; torch CUDA tensors stay on the device
     (outputs are then CUDA tensors on the same device, launched on torch's current stream).
+    With reuse_outputs=True (default) the returned arrays live in pinned buffers that the NEXT call of this
+    callable overwrites (see _Outputs); pass reuse_outputs=False for fresh arrays at ~5x the call time.
     """
     if H is None:
         E_tangent = E / 100.0                      # :186
@@ -210,7 +218,8 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
 def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float = 3.45,
                       phi: float = 30 * np.pi / 180, psi: float = 30 * np.pi / 180, theta_T: float = 26 * np.pi / 180,
                       a: float | None = None, tol: float = 1e-8, Nitermax: int = 200, diagnostics: bool = True,
-                      on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0) -> Callable:
+                      on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0,
+                      reuse_outputs: bool = True) -> Callable:
     """`sigma_external` of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:604-608) on the GPU.
 
     `external_function((1,))(deps) -> (C_tang, sigma)`, flat arrays, the reference's order (:593); any other
@@ -227,19 +236,21 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
         a = 0.26 * c / np.tan(phi)   # :116
     prm = McParams(float(E), float(nu), float(c), float(phi), float(psi), float(theta_T), float(a), float(tol),
                    int(Nitermax), 0)
-    holder = {"ctx": ctx}
+    holder = {"ctx": ctx, "out": None}
 
     def C_tang_impl(deps):
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         cx = holder["ctx"]
+        if holder["out"] is None:
+            holder["out"] = _Outputs(cx, reuse_outputs)
         deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
         sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape((-1, 4))   # :579
         n = deps_.shape[0]
         if sigma_n_.shape[0] != n:
             raise ValueError(f"state size mismatch: sigma_n has {sigma_n_.shape[0]} points, deps {n}")
-        C_tang = np.empty(n * 16)
-        sigma = np.empty(n * 4)
+        C_tang = holder["out"].get("C_tang", n * 16)
+        sigma = holder["out"].get("sigma", n * 4)
         if diagnostics or on_summary is not None:
             niter = np.empty(n, dtype=np.int32)
             yielding, norm_res, dlambda = np.empty(n), np.empty(n), np.empty(n)
@@ -263,7 +274,8 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
     return sigma_external
 
 
-def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None, device: int = 0) -> Callable:
+def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None, device: int = 0,
+              reuse_outputs: bool = True) -> Callable:
     """`P_external` of the hyperelasticity demo (demo_hyperelasticity.py:459-466) on the GPU.
 
     `external_function((1,))(Fvals) -> (dP, P)`, flat arrays in the reference's order (:456); other
@@ -274,20 +286,21 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
     variant (BASELINE config 5). The stress correction H (:362-381) is computed once at creation.
     """
     prec = {"fp32": 0, "fp64": 1}[precision]
-    holder = {"ctx": ctx, "model": None}
+    holder = {"ctx": ctx, "model": None, "out": None}
 
     def _model():
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["model"] is None:
             holder["model"] = holder["ctx"].icnn_create(state_dict)
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
         return holder["ctx"], holder["model"]
 
     def dP_dF_impl(Fvals):
         cx, model = _model()
         F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)      # :452
         n = F.shape[0]
-        dP, P = np.empty(n * 16), np.empty(n * 4)
+        dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
         cx.icnn_eval(model, prec, n, MEM_HOST, F, dP, P)
         return dP.reshape(-1), P.reshape(-1)                 # :456
 

@@ -188,7 +188,10 @@ def test_drop_in_external_function_through_evaluate_external_operators(ctx, orac
                                         external_function=sigma_external, derivatives=(1,))
     evaluated_operands = evaluate_operands([sigma])
     ((_, sigma_new, dp_new),) = evaluate_external_operators([C_tang], evaluated_operands)
-    sigma.ref_coefficient.x.array[:] = sigma_new
+    sigma.ref_coefficient.x.array[:] = sigma_new      # demo :453-454
+    # the extras are views of the operator's pinned output buffers (reuse_outputs=True): copy before the next call,
+    # exactly what the demo does with dp (:456)
+    sigma_new, dp_new = sigma_new.copy(), dp_new.copy()
     Co, so, dpo = oracle.von_mises(deps_full, sigma_n, p)
     assert_close_scaled(C_tang.ref_coefficient.x.array, Co, RTOL, "C_tang coefficient")
     assert_close_scaled(sigma.ref_coefficient.x.array, so, RTOL, "sigma coefficient")
