@@ -59,11 +59,14 @@ template <> __device__ __forceinline__ double t_log1p<double>(double x) { return
 // ~120 for expf + log1pf. log(1 + e) loses RELATIVE accuracy for e < 1e-4, but there softplus < 1e-4 and only
 // enters through softplus^2/12 — absolute error < 1e-12 of the network output.
 __device__ __forceinline__ void softplus3_fast(float a, float& sp, float& s1, float& s2) {
-    const float e = __expf(fminf(a, 20.0f));
-    const float r = __frcp_rn(1.0f + e);
-    sp = a > 20.0f ? a : __logf(1.0f + e);
-    s1 = a > 20.0f ? 1.0f : e * r;
-    s2 = a > 20.0f ? 0.0f : e * r * r;
+    // raw v_exp_f32 / v_log_f32 / v_rcp_f32: the arguments are bounded (e <= e^20, 1 + e >= 1), so the
+    // denormal-range fix-ups that __expf / __logf add are dead weight here
+    const float e = __builtin_amdgcn_exp2f(fminf(a, 20.0f) * 1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const bool big = a > 20.0f;
+    sp = big ? a : __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    s1 = big ? 1.0f : e * r;
+    s2 = big ? 0.0f : e * r * r;
 }
 
 template <typename T>
@@ -305,9 +308,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* 
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[jt][c][q] = 0.f;
+            // the small tables (A1, S2, w3) come from global memory through L1; every rolled loop below fetches the
+            // NEXT iteration's row before working on the current one, otherwise each iteration eats an L1 round trip
+            float4 a1n = A1v[32 * h];
 #pragma unroll 2
             for (int r = 0; r < 32; ++r) {
-                const float4 a1 = A1v[r + 32 * h];
+                const float4 a1 = a1n;
+                a1n = A1v[((r + 1) & 31) + 32 * h];
                 const float Ar0 = sA[(0 * 32 + r) * 64 + lane], Ar1 = sA[(1 * 32 + r) * 64 + lane];
                 const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
                 float sp, s1, s2;
@@ -334,18 +341,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* 
 #undef DXO_PARK
                 icnn_lds_fence();
                 // ---- neurons of layer 2 (C layout: q -> j): skip connection, softplus, grad / hess contributions
+                const int jbase = 32 * jt + 4 * h;
+                float4 s2n = S2v[jbase + (q0 & 3) + 8 * (q0 >> 2)];
+                float w3n = ww3[jbase + (q0 & 3) + 8 * (q0 >> 2)];
 #pragma unroll 2
                 for (int qq = 0; qq < 8; ++qq) {
                     const int q = q0 + qq;
-                    const int j = 32 * jt + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    const float4 s2r = S2v[j];
+                    const float4 s2r = s2n;
+                    const float w3 = w3n;
+                    {
+                        const int qn = q0 + ((qq + 1) & 7);
+                        s2n = S2v[jbase + (qn & 3) + 8 * (qn >> 2)];
+                        w3n = ww3[jbase + (qn & 3) + 8 * (qn >> 2)];
+                    }
                     const float a2 = stage[(0 * 8 + qq) * 64 + lane] + s2r.x * xs0 + s2r.y * xs1 + s2r.z * xs2 + s2r.w;
                     const float g0 = stage[(1 * 8 + qq) * 64 + lane] + s2r.x;
                     const float g1 = stage[(2 * 8 + qq) * 64 + lane] + s2r.y;
                     const float g2 = stage[(3 * 8 + qq) * 64 + lane] + s2r.z;
                     float sp, s1, s2;
                     softplus3_fast(a2, sp, s1, s2);
-                    const float w3 = ww3[j];
                     const float delta = w3 * sp * s1 * (1.0f / 6.0f);
                     const float curv = w3 * (s1 * s1 + sp * s2) * (1.0f / 6.0f);
                     res[0] += delta * g0; res[1] += delta * g1; res[2] += delta * g2;
@@ -373,11 +387,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* 
                 for (int q = 0; q < 16; ++q) stage[(it * 16 + q) * 64 + lane] = bacc[it][q];
             icnn_lds_fence();
             // ---- second Hessian term: sum_i beta_i phi''(a1_i) A1_i A1_i^T (C layout: iq -> i)
+            float4 b1n = A1v[4 * h];
 #pragma unroll 2
             for (int iq = 0; iq < 32; ++iq) {
-                const int q = iq & 15;
-                const int i = 32 * (iq >> 4) + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const float4 a1 = A1v[i];
+                const float4 a1 = b1n;
+                {
+                    const int in_ = (iq + 1) & 31, qn = in_ & 15;
+                    b1n = A1v[32 * (in_ >> 4) + (qn & 3) + 8 * (qn >> 2) + 4 * h];
+                }
                 const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
                 float sp, s1, s2;
                 softplus3_fast(a, sp, s1, s2);
