@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
     "dxo_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [_P] * 8),
+    "dxo_mc_summary": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_icnn_create": (C.c_int, [_P, C.POINTER(IcnnWeights), C.POINTER(_P)]),
     "dxo_icnn_destroy": (C.c_int, [_P, _P]),
     "dxo_icnn_correction": (C.c_int, [_P, _P, _P]),
@@ -253,6 +254,21 @@ class Context:
         rc = self.lib.dxo_mohr_coulomb(self._h, C.byref(prm), int(n), int(mem), _ptr(deps), _ptr(sigma_n), _ptr(C_tang),
                                        _ptr(sigma), _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
         self.check(rc, "dxo_mohr_coulomb")
+
+    def mc_summary(self, n: int, niter, yielding=None, norm_res=None, nbins: int = 201) -> dict:
+        """Device-side inner-Newton summary (the reference's printout, demo_plasticity_mohr_coulomb.py:584-591).
+        niter / yielding / norm_res are DEVICE pointers (or objects with data_ptr())."""
+        def dp(a):
+            return a.data_ptr() if hasattr(a, "data_ptr") else a
+        hist = np.zeros(nbins, dtype=np.int64)
+        my, mr = C.c_double(), C.c_double()
+        nans = np.zeros(2, dtype=np.int64)
+        rc = self.lib.dxo_mc_summary(self._h, int(n), _ptr(dp(niter)), _ptr(dp(yielding)), _ptr(dp(norm_res)), int(nbins),
+                                     _ptr(hist), C.byref(my), C.byref(mr), _ptr(nans))
+        self.check(rc, "dxo_mc_summary")
+        nz = np.flatnonzero(hist)
+        return {"unique_iters": nz.astype(np.int32), "counts": hist[nz], "max_yielding": my.value, "max_norm_res": mr.value,
+                "nan_yielding": int(nans[0]), "nan_norm_res": int(nans[1])}
 
     # state_dict key -> dxo_icnn_weights field (shapes as torch stores them)
     ICNN_KEYS = {

@@ -332,6 +332,58 @@ int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, co
     return DXO_OK;
 }
 
+// ------------------------------------------------------------------ inner-Newton summary on the device
+// The reference prints, at every call, the unique iteration counts with their multiplicities, max f and max
+// residual (demo_plasticity_mohr_coulomb.py:584-591). For device-resident diagnostics this kernel produces the
+// same numbers without moving 28 B/point over PCIe: wave-level __shfl_xor max reductions, a per-workgroup LDS
+// histogram, then one global atomic per non-empty bin / per maximum and workgroup.
+constexpr int MC_HIST_BINS = 1024;
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));   // fmax drops NaN like jnp.max does not —
+    return v;                                                                  // NaNs are counted separately below
+}
+
+__device__ __forceinline__ void atomic_max_double(double* addr, double v) {
+    // order-preserving map of IEEE doubles onto unsigned integers
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    bits = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), bits);
+}
+
+__global__ __launch_bounds__(DXO_BLOCK) void mc_summary(int64_t n, int nbins, const int32_t* __restrict__ niter,
+                                                        const double* __restrict__ yielding,
+                                                        const double* __restrict__ norm_res,
+                                                        unsigned long long* __restrict__ hist,
+                                                        double* __restrict__ maxima /* [2] encoded, [2] NaN counts */) {
+    __shared__ unsigned int lh[MC_HIST_BINS];
+    for (int b = threadIdx.x; b < nbins; b += DXO_BLOCK) lh[b] = 0u;
+    __syncthreads();
+    double my = -(double)INFINITY, mr = -(double)INFINITY;
+    unsigned int nan_y = 0, nan_r = 0;
+    const int64_t stride = (int64_t)gridDim.x * DXO_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * DXO_BLOCK + threadIdx.x; i < n; i += stride) {
+        int it = niter[i];
+        it = it < 0 ? 0 : (it >= nbins ? nbins - 1 : it);
+        atomicAdd(&lh[it], 1u);
+        const double y = yielding ? yielding[i] : -(double)INFINITY, r = norm_res ? norm_res[i] : -(double)INFINITY;
+        if (y != y) ++nan_y; else my = fmax(my, y);
+        if (r != r) ++nan_r; else mr = fmax(mr, r);
+    }
+    my = wave_max(my);
+    mr = wave_max(mr);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_double(maxima + 0, my);
+        atomic_max_double(maxima + 1, mr);
+    }
+    if (nan_y) atomicAdd(reinterpret_cast<unsigned long long*>(maxima + 2), (unsigned long long)nan_y);
+    if (nan_r) atomicAdd(reinterpret_cast<unsigned long long*>(maxima + 3), (unsigned long long)nan_r);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += DXO_BLOCK)
+        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
 int mc_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
     const McLaunch& L = *static_cast<const McLaunch*>(user);
     int o = 2;
@@ -376,4 +428,47 @@ extern "C" int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t 
     if (norm_res) out.push_back({nullptr, norm_res, sd});
     if (dlambda) out.push_back({nullptr, dlambda, sd});
     return dxo_run_host_pipeline(ctx, n, in, out, mc_chunk, &L);
+}
+
+extern "C" int dxo_mc_summary(dxo_ctx* ctx, int64_t n, const int32_t* niter, const double* yielding, const double* norm_res,
+                              int nbins, int64_t* hist, double* max_yielding, double* max_norm_res, int64_t* nan_counts) {
+    if (!ctx) return DXO_E_NULL;
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_summary: n < 0");
+    if (nbins < 1 || nbins > MC_HIST_BINS) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_summary: nbins must be in [1, 1024]");
+    if (!hist || (n > 0 && !niter)) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_summary: NULL array");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    const size_t bytes = (size_t)nbins * sizeof(unsigned long long) + 4 * sizeof(double);
+    void* scratch = mc_scratch(ctx, s, bytes + 256);
+    if (!scratch) return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_mc_summary: scratch allocation");
+    // the summary block sits behind a 256-byte header so it never aliases a list that mc_newton may still read
+    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch));
+    double* d_max = reinterpret_cast<double*>(d_hist + nbins);
+    DXO_HIP(ctx, hipStreamSynchronize(s));   // scratch is shared with dxo_mohr_coulomb launches on this stream
+    DXO_HIP(ctx, hipMemsetAsync(d_hist, 0, bytes, s));
+    if (n > 0) {
+        int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+        const int64_t cap = (int64_t)ctx->compute_units * 8;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(mc_summary, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, nbins, niter, yielding, norm_res, d_hist, d_max);
+        DXO_HIP(ctx, hipGetLastError());
+    }
+    std::vector<unsigned long long> h((size_t)nbins + 4);
+    DXO_HIP(ctx, hipMemcpyAsync(h.data(), d_hist, bytes, hipMemcpyDeviceToHost, s));
+    DXO_HIP(ctx, hipStreamSynchronize(s));
+    for (int b = 0; b < nbins; ++b) hist[b] = (int64_t)h[b];
+    auto decode = [](unsigned long long bits) -> double {
+        if (bits == 0ull) return -(double)INFINITY;   // nothing recorded
+        bits = (bits >> 63) ? (bits & 0x7fffffffffffffffull) : ~bits;
+        double v;
+        std::memcpy(&v, &bits, sizeof v);
+        return v;
+    };
+    if (max_yielding) *max_yielding = decode(h[nbins]);
+    if (max_norm_res) *max_norm_res = decode(h[nbins + 1]);
+    if (nan_counts) {
+        nan_counts[0] = (int64_t)h[nbins + 2];
+        nan_counts[1] = (int64_t)h[nbins + 3];
+    }
+    return DXO_OK;
 }

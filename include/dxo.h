@@ -152,6 +152,16 @@ int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, int mem,
                      double* C_tang, double* sigma,
                      int32_t* niter, double* yielding, double* norm_res, double* dlambda);
 
+/* Inner-Newton summary of a dxo_mohr_coulomb call whose diagnostics live in DEVICE memory: the numbers the
+ * reference prints at every call (unique iteration counts and their multiplicities, max f, max residual,
+ * demo_plasticity_mohr_coulomb.py:584-591), reduced on the GPU (wave __shfl_xor maxima, LDS histogram).
+ *   niter [n] int32 (device); yielding / norm_res [n] (device, may be NULL)
+ *   hist [nbins] (host, out): hist[k] = #points with niter == k (k >= nbins-1 clamps into the last bin);
+ *   nbins <= 1024, use prm->nitermax + 1.   max_* (host, out, may be NULL): maxima over non-NaN entries,
+ *   -inf if none; nan_counts[2] (host, out, may be NULL): NaN entries of yielding / norm_res. Blocking. */
+int dxo_mc_summary(dxo_ctx* ctx, int64_t n, const int32_t* niter, const double* yielding, const double* norm_res,
+                   int nbins, int64_t* hist, double* max_yielding, double* max_norm_res, int64_t* nan_counts);
+
 /* ---- ICNN hyperelastic surrogate: stress P = dW/dF and tangent dP/dF --------------------------
  * Replaces ICNN.forward + compute_stress_local + vmap(jacfwd(.)) + dP_dF_impl,
  * demo_hyperelasticity.py:256-300, 362-381, 429-456. The weight struct takes the tensors of the

@@ -188,3 +188,34 @@ def test_full_size_properties(ctx, oracle):
     lin = h * np.einsum("nij,nj->ni", Ct[sel], v)
     err = np.linalg.norm(s2 - s[sel] - lin, axis=1) / np.linalg.norm(lin, axis=1)
     assert np.median(err) < 1e-3
+
+
+def test_device_side_newton_summary(ctx, oracle):
+    """dxo_mc_summary reproduces the reference's printed summary (:584-591) from device-resident diagnostics."""
+    import torch
+
+    n = 100_000
+    pool_d, pool_s = mc_tracing_inputs(oracle, 20000, seed=4)
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 20000, n)
+    deps, sn = pool_d[idx], pool_s[idx]
+    sn[7] = [0.1, 0.1, 0.1, 0.0]          # hydrostatic trial: f = NaN like the reference
+    deps[7] = 0.0
+    dev = torch.device("cuda:0")
+    d, s0 = torch.from_numpy(deps).to(dev), torch.from_numpy(sn).to(dev)
+    Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
+    s = torch.empty(n * 4, dtype=torch.float64, device=dev)
+    it = torch.empty(n, dtype=torch.int32, device=dev)
+    y, nr, dl = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.mohr_coulomb(params(), n, MEM_DEVICE, d.data_ptr(), s0.data_ptr(), Ct.data_ptr(), s.data_ptr(), it.data_ptr(),
+                     y.data_ptr(), nr.data_ptr(), dl.data_ptr())
+    summ = ctx.mc_summary(n, it, y, nr, nbins=201)
+    it_h, y_h, nr_h = it.cpu().numpy(), y.cpu().numpy(), nr.cpu().numpy()
+    u, c = np.unique(it_h, return_counts=True)
+    assert np.array_equal(summ["unique_iters"], u) and np.array_equal(summ["counts"], c)
+    assert summ["max_yielding"] == np.nanmax(y_h) and summ["max_norm_res"] == np.nanmax(nr_h)
+    assert summ["nan_yielding"] == int(np.isnan(y_h).sum()) >= 1
+    assert summ["nan_norm_res"] == int(np.isnan(nr_h).sum())
+    with pytest.raises(ValueError, match="SIZE"):
+        ctx.mc_summary(n, it, y, nr, nbins=5000)
