@@ -7,6 +7,7 @@ There is no CPU fallback; `oracle/` is test infrastructure and is never imported
 from ._lib import MEM_DEVICE, MEM_HOST, Context, DxoError, McParams, VmParams, default_context, load_library
 from .evaluation import (
     Coefficient,
+    MixedExternalOperator,
     Operand,
     QuadratureExternalOperator,
     evaluate_external_operators,
@@ -20,6 +21,6 @@ __version__ = "0.1.0"
 __all__ = [
     "Context", "DxoError", "VmParams", "MEM_HOST", "MEM_DEVICE", "default_context", "load_library",
     "make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn", "McParams",
-    "QuadratureExternalOperator", "Operand", "Coefficient",
+    "QuadratureExternalOperator", "MixedExternalOperator", "Operand", "Coefficient",
     "evaluate_operands", "evaluate_external_operators", "get_unrolled_dofmap",
 ]

@@ -112,6 +112,58 @@ class QuadratureExternalOperator:
         self.ref_coefficient.x.array[:] = values                             # :290
 
 
+class MixedExternalOperator(QuadratureExternalOperator):
+    """Value-side stand-in of `FEMExternalOperator` on a MIXED function space (external_operator.py:139-198):
+    the evaluation points of all subspaces are concatenated, the kernel returns one padded array with
+    `comp_size = max(val_sizes)` components per point, and the assigner scatters each subspace's slice through
+    that subspace's dofmap (`_assign_mixed_2d` :292-311 when every subspace is scalar, `_assign_mixed_3d`
+    :313-335 otherwise).
+
+    subspaces: sequence of dicts {"n_pts": interpolation points of the subspace, "val_size": components per point,
+               "dofmap": int array (num_cells, n_pts * val_size) of indices into the mixed coefficient vector}
+    """
+
+    def __init__(self, *operands, num_cells: int, subspaces, coefficient_size: int, external_function=None,
+                 derivatives: tuple[int, ...] | None = None, name: str | None = None, dtype=np.float64):
+        val_sizes = [int(sp["val_size"]) for sp in subspaces]
+        self._comp_size = max(val_sizes) if val_sizes else 1                       # :161
+        self._mixed_subspace_info = []
+        offset = 0
+        for i, sp in enumerate(subspaces):
+            dofmap = np.asarray(sp["dofmap"])
+            info = {"n_pts": int(sp["n_pts"]), "val_size": int(sp["val_size"]), "dofs_per_cell": dofmap.shape[1],
+                    "flat_dofs": dofmap.flatten(), "offset": offset}              # :180-190
+            if self._comp_size < info["val_size"]:
+                raise ValueError(f"Unsupported mixed element layout for subspace {i}")   # :173-178
+            self._mixed_subspace_info.append(info)
+            offset += info["n_pts"]
+        self._n_points_total = offset                                              # :192
+        super().__init__(*operands, num_cells=num_cells, num_points=self._n_points_total,
+                         value_shape=(self._comp_size,) if self._comp_size > 1 else (), external_function=external_function,
+                         derivatives=derivatives, name=name, dtype=dtype, coefficient_size=coefficient_size)
+        self._is_mixed = True
+        self._assign_func = self._assign_mixed_2d if self._comp_size == 1 else self._assign_mixed_3d   # :195-198
+
+    def _assign_mixed_2d(self, values: np.ndarray) -> None:
+        coeff = self.ref_coefficient
+        if values.ndim == 1:
+            values = values.reshape(values.size // self._n_points_total, self._n_points_total)   # :298-300
+        for info in self._mixed_subspace_info:
+            block = values[:, info["offset"]: info["offset"] + info["n_pts"]]                    # :310
+            coeff.x.array[info["flat_dofs"]] = block.reshape(-1)                                  # :311
+
+    def _assign_mixed_3d(self, values: np.ndarray) -> None:
+        coeff = self.ref_coefficient
+        if values.ndim == 1:
+            n_cells = values.size // (self._n_points_total * self._comp_size)                     # :320
+            values = values.reshape(n_cells, self._n_points_total, self._comp_size)
+        n_cells = values.shape[0]
+        for info in self._mixed_subspace_info:
+            chunk = values[:, info["offset"]: info["offset"] + info["n_pts"], :]                  # :330
+            block = chunk[:, :, : info["val_size"]].reshape(n_cells, info["dofs_per_cell"])       # :333
+            coeff.x.array[info["flat_dofs"]] = block.reshape(-1)                                  # :335
+
+
 def _all_local_cells(op) -> np.ndarray:
     cells = getattr(op, "_full_cells", None)
     if cells is None:
@@ -175,6 +227,6 @@ def evaluate_external_operators(external_operators, evaluated_operands: dict) ->
 
 
 __all__ = [
-    "Coefficient", "Operand", "QuadratureExternalOperator", "evaluate_operands",
+    "Coefficient", "Operand", "QuadratureExternalOperator", "MixedExternalOperator", "evaluate_operands",
     "evaluate_external_operators", "get_unrolled_dofmap",
 ]

@@ -159,3 +159,48 @@ def test_coefficient_must_match_space():
     u = Operand(lambda cells: np.ones((len(cells), NQ)))
     with pytest.raises(TypeError):
         QuadratureExternalOperator(u, num_cells=NC, num_points=NQ, coefficient=Coefficient(5))
+
+
+def test_mixed_space_assigners_scalar_and_padded_vector():
+    """Conventions of test/test_external_operators_evaluation.py:185-306: concatenated points, padded component axis."""
+    from dolfinx_external_operator_amd import MixedExternalOperator
+
+    nc, p1, p2 = 4, 3, 6
+    # all-scalar mixed space (P1 x P2 like): 2-D values (n_cells, pts_total) -> _assign_mixed_2d
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(nc * (p1 + p2))
+    dm1 = perm[: nc * p1].reshape(nc, p1)
+    dm2 = perm[nc * p1:].reshape(nc, p2)
+    u_full = rng.normal(size=(nc, p1 + p2))
+    u = Operand(lambda cells: u_full[cells], "u2")
+
+    def N_impl(u_):
+        out = np.zeros_like(u_)
+        out[:, p1:] = u_[:, p1:]            # :203-206
+        return out.reshape(-1)
+
+    N = MixedExternalOperator(u, num_cells=nc, subspaces=[{"n_pts": p1, "val_size": 1, "dofmap": dm1},
+                                                          {"n_pts": p2, "val_size": 1, "dofmap": dm2}],
+                              coefficient_size=nc * (p1 + p2), external_function=lambda d: N_impl)
+    evaluate_external_operators([N], evaluate_operands([N]))
+    expect = np.zeros(nc * (p1 + p2))
+    expect[dm2.reshape(-1)] = u_full[:, p1:].reshape(-1)
+    assert np.array_equal(N.ref_coefficient.x.array, expect)
+    assert N._assign_func == N._assign_mixed_2d
+
+    # scalar + 2-vector: padded (n_cells, pts_total, 2) -> _assign_mixed_3d (:257-274)
+    perm = rng.permutation(nc * (p1 + 2 * p2))
+    dm1 = perm[: nc * p1].reshape(nc, p1)
+    dm2 = perm[nc * p1:].reshape(nc, 2 * p2)
+    vals = rng.normal(size=(nc, p1 + p2, 2))
+    M = MixedExternalOperator(u, num_cells=nc, subspaces=[{"n_pts": p1, "val_size": 1, "dofmap": dm1},
+                                                          {"n_pts": p2, "val_size": 2, "dofmap": dm2}],
+                              coefficient_size=nc * (p1 + 2 * p2), external_function=lambda d: (lambda a: vals.reshape(-1)))
+    evaluate_external_operators([M], evaluate_operands([M]))
+    expect = np.zeros(nc * (p1 + 2 * p2))
+    expect[dm1.reshape(-1)] = vals[:, :p1, 0].reshape(-1)
+    expect[dm2.reshape(-1)] = vals[:, p1:, :].reshape(-1)
+    assert np.array_equal(M.ref_coefficient.x.array, expect)
+    assert M._assign_func == M._assign_mixed_3d and M._comp_size == 2
+    with pytest.raises(ValueError):      # wrong size, as in the reference (:440-444)
+        M._assign_func(np.zeros(7))
