@@ -68,6 +68,10 @@ _SIGNATURES = {
     "dxo_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_host_free": (C.c_int, [_P, _P]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
+    "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
+    "dxo_device_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "dxo_device_free": (C.c_int, [_P, _P]),
+    "dxo_copy": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
     "dxo_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [_P] * 8),
     "dxo_mc_summary": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
@@ -315,6 +319,22 @@ class Context:
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))
         self.check(rc, "dxo_stream_probe")
+
+    def vm_commit_state(self, d: int, n: int, p, dp, sigma_n, sigma) -> None:
+        self.check(self.lib.dxo_vm_commit_state(self._h, int(d), int(n), _ptr(p), _ptr(dp), _ptr(sigma_n), _ptr(sigma)),
+                   "dxo_vm_commit_state")
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = _P()
+        self.check(self.lib.dxo_device_alloc(self._h, int(nbytes), C.byref(p)), "dxo_device_alloc")
+        return p.value
+
+    def device_free(self, ptr: int) -> None:
+        if self._h and ptr:
+            self.lib.dxo_device_free(self._h, _P(ptr))
+
+    def copy(self, dst, src, nbytes: int, kind: int) -> None:
+        self.check(self.lib.dxo_copy(self._h, _ptr(dst), _ptr(src), int(nbytes), int(kind)), "dxo_copy")
 
     def heat(self, A: float, B: float, gdim: int, n: int, mem: int, T, sigma, q, dqdT, dqdsigma) -> None:
         rc = self.lib.dxo_heat(self._h, float(A), float(B), int(gdim), int(n), int(mem), _ptr(T), _ptr(sigma),

@@ -168,6 +168,37 @@ int dxo_host_free(dxo_ctx* c, void* ptr) {
     return DXO_OK;
 }
 
+int dxo_device_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
+    if (!c || !ptr) return DXO_E_NULL;
+    if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
+    *ptr = nullptr;
+    DXO_HIP(c, hipSetDevice(c->device));
+    DXO_HIP(c, hipMalloc(ptr, bytes > 0 ? (size_t)bytes : 1));
+    return DXO_OK;
+}
+
+int dxo_device_free(dxo_ctx* c, void* ptr) {
+    if (!c) return DXO_E_NULL;
+    if (!ptr) return DXO_OK;
+    DXO_HIP(c, hipSetDevice(c->device));
+    DXO_HIP(c, hipFree(ptr));
+    return DXO_OK;
+}
+
+int dxo_copy(dxo_ctx* c, void* dst, const void* src, int64_t bytes, int kind) {
+    if (!c) return DXO_E_NULL;
+    if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
+    if (kind < 0 || kind > 2) return dxo_fail(c, DXO_E_MEM, "dxo_copy: kind must be 0 (H2D), 1 (D2H) or 2 (D2D)");
+    if (bytes == 0) return DXO_OK;
+    if (!dst || !src) return dxo_fail(c, DXO_E_NULL, "dxo_copy: NULL pointer");
+    DXO_HIP(c, hipSetDevice(c->device));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    hipStream_t s = dxo_launch_stream(c);
+    DXO_HIP(c, hipMemcpyAsync(dst, src, (size_t)bytes, k, s));
+    DXO_HIP(c, hipStreamSynchronize(s));
+    return DXO_OK;
+}
+
 }  // extern "C"
 
 int dxo_device_begin(dxo_ctx* c, hipStream_t s) {

@@ -313,3 +313,37 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
     return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
 }
+
+// ------------------------------------------------------------------ history update
+// End of a load step in the reference: `p.x.petsc_vec.axpy(1.0, dp.x.petsc_vec)` and
+// `sigma_n.x.array[:] = sigma.ref_coefficient.x.array` (demo_plasticity_von_mises.py:564-565). With the state
+// resident on the device this is one fused lane-linear pass instead of two host loops plus two uploads.
+namespace {
+__global__ __launch_bounds__(DXO_BLOCK) void vm_commit(int64_t n_p, int64_t n_s, double* __restrict__ p,
+                                                       const double* __restrict__ dp, double* __restrict__ sigma_n,
+                                                       const double* __restrict__ sigma) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i < n_p; i += stride) p[i] += dp[i];
+    for (int64_t i = i0; i < n_s; i += stride) sigma_n[i] = sigma[i];
+}
+}  // namespace
+
+extern "C" int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, const double* dp, double* sigma_n,
+                                   const double* sigma) {
+    if (!ctx) return DXO_E_NULL;
+    if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_commit_state: d must be 4 or 6");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_commit_state: n < 0");
+    if (n > 0 && (!p || !dp || !sigma_n || !sigma)) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_commit_state: NULL array");
+    if (((uintptr_t)p | (uintptr_t)dp | (uintptr_t)sigma_n | (uintptr_t)sigma) & 7u)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_vm_commit_state: arrays must be 8-byte aligned");
+    if (n == 0) return DXO_OK;
+    hipStream_t s = dxo_launch_stream(ctx);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    int64_t blocks = (n * d + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(vm_commit, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, n * d, p, dp, sigma_n, sigma);
+    return dxo_device_end(ctx, s);
+}

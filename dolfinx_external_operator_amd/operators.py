@@ -153,6 +153,24 @@ def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p):
     return C_tang, sigma, dp
 
 
+def von_mises_commit_state(p, dp, sigma_n, sigma, *, ctx: Context | None = None, device: int = 0) -> None:
+    """End-of-load-step history update for DEVICE-resident state (demo_plasticity_von_mises.py:564-565):
+    `p += dp; sigma_n[:] = sigma` in one fused launch. Arguments are torch CUDA tensors (fp64, contiguous);
+    p/dp hold n values, sigma_n/sigma n*d. Host-resident state keeps the reference's two NumPy statements."""
+    import torch
+
+    for name, t in (("p", p), ("dp", dp), ("sigma_n", sigma_n), ("sigma", sigma)):
+        if not _is_device_tensor(t) or t.dtype != torch.float64 or not t.is_contiguous():
+            raise TypeError(f"{name}: expected a contiguous fp64 CUDA tensor")
+    n = p.numel()
+    if dp.numel() != n or n == 0 and sigma.numel() != 0 or sigma_n.numel() != sigma.numel() or (n and sigma.numel() % n):
+        raise ValueError("state size mismatch")
+    d = sigma.numel() // n if n else 4
+    c = ctx if ctx is not None else default_context(device)
+    c.set_stream(torch.cuda.current_stream(p.device).cuda_stream)
+    c.vm_commit_state(d, n, p.data_ptr(), dp.data_ptr(), sigma_n.data_ptr(), sigma.data_ptr())
+
+
 def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, device: int = 0,
               fuse_by_identity: bool = False) -> Callable:
     """`q_external` of the nonlinear-heat demo (demo_nonlinear_heat_equation_part2.py:276-284) on the GPU.

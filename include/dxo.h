@@ -125,6 +125,18 @@ int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int 
                   const double* deps, const double* sigma_n, const double* p,
                   double* C_tang, double* sigma, double* dp);
 
+/* History update at the end of a load step, DEVICE memory only (demo_plasticity_von_mises.py:564-565):
+ *   p[n] += dp[n];  sigma_n[n][d] = sigma[n][d].   One fused pass, asynchronous on the ctx stream. */
+int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, const double* dp,
+                        double* sigma_n, const double* sigma);
+
+/* Device memory owned by the caller but allocated through the library (hipMalloc / hipFree / hipMemcpyAsync on
+ * the ctx stream + synchronise), so a host program without its own HIP binding can keep state on the GPU.
+ * kind: 0 host->device, 1 device->host, 2 device->device. */
+int dxo_device_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
+int dxo_device_free(dxo_ctx* ctx, void* ptr);
+int dxo_copy(dxo_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind);
+
 /* ---- nonlinear heat flux ------------------------------------------------------------------
  * Replaces k / q_impl / dqdT_impl / dqdsigma_impl, demo_nonlinear_heat_equation_part2.py:209-261
  * (same code: test/test_external_operators_evaluation.py:64-86).

@@ -259,3 +259,64 @@ def test_full_size_properties(ctx, d):
         _, s2, _ = run_device(ctx, e2, sigma_n[idx], p[idx], 1)
         fd = (s2 - s[idx]) / h
         assert np.max(np.abs(fd - C[idx][:, :, k])) < 2e-5 * E
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_device_resident_load_history(ctx, oracle, d):
+    """Five load steps with sigma_n, p resident on the device (dxo_device_alloc / dxo_copy, no torch) and the fused
+    history update dxo_vm_commit_state, against the oracle driven by the reference's two NumPy statements
+    (demo_plasticity_von_mises.py:564-565). Checks the state after every step, not only the last."""
+    n = 20_011
+    deps0, sigma_n, p = vm_inputs(n, d, seed=77)
+    sigma_n *= 0.0
+    p *= 0.0
+    nb = {"deps": n * d * 8, "sigma_n": n * d * 8, "p": n * 8, "C": n * d * d * 8, "sigma": n * d * 8, "dp": n * 8}
+    dev = {k: ctx.device_alloc(v) for k, v in nb.items()}
+    try:
+        ctx.copy(dev["sigma_n"], sigma_n, nb["sigma_n"], 0)
+        ctx.copy(dev["p"], p, nb["p"], 0)
+        s_ref, p_ref = sigma_n.copy(), p.copy()
+        got_s, got_p = np.empty_like(sigma_n), np.empty_like(p)
+        C = np.empty((n, d, d))
+        for step in range(5):
+            deps = np.ascontiguousarray(deps0 * (0.4 + 0.3 * step) * (-1.0 if step == 3 else 1.0))   # unloading at step 3
+            ctx.copy(dev["deps"], deps, nb["deps"], 0)
+            ctx.von_mises(PRM, d, n, MEM_DEVICE, dev["deps"], dev["sigma_n"], dev["p"], dev["C"], dev["sigma"], dev["dp"])
+            ctx.vm_commit_state(d, n, dev["p"], dev["dp"], dev["sigma_n"], dev["sigma"])
+            ctx.synchronize()
+            C_o, s_o, dp_o = oracle.von_mises(deps, s_ref, p_ref)
+            p_ref += dp_o.reshape(-1)                    # :564
+            s_ref[:] = s_o.reshape(n, d)                 # :565
+            ctx.copy(got_s, dev["sigma_n"], nb["sigma_n"], 1)
+            ctx.copy(got_p, dev["p"], nb["p"], 1)
+            ctx.copy(C, dev["C"], nb["C"], 1)
+            assert_close_scaled(got_s, s_ref, RTOL, f"sigma_n after step {step}")
+            assert_close_scaled(got_p, p_ref, RTOL, f"p after step {step}")
+            assert_close_scaled(C, C_o, RTOL, f"C_tang at step {step}")
+        assert (p_ref > 0).mean() > 0.5                  # the history really went plastic
+    finally:
+        for a in dev.values():
+            ctx.device_free(a)
+
+
+def test_commit_state_torch_and_errors(ctx):
+    import torch
+
+    from dolfinx_external_operator_amd import DxoError, von_mises_commit_state
+
+    n, d = 1000, 6
+    g = torch.Generator().manual_seed(1)
+    p, dp = (torch.rand(n, dtype=torch.float64, generator=g).cuda() for _ in range(2))
+    sn, s = (torch.rand(n * d, dtype=torch.float64, generator=g).cuda() for _ in range(2))
+    want_p = (p + dp).cpu()
+    von_mises_commit_state(p, dp, sn, s, ctx=ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(p.cpu(), want_p) and torch.equal(sn, s)
+    with pytest.raises(ValueError):
+        von_mises_commit_state(p, dp[:-1].contiguous(), sn, s, ctx=ctx)
+    with pytest.raises(TypeError):
+        von_mises_commit_state(p.cpu(), dp, sn, s, ctx=ctx)
+    with pytest.raises(DxoError):
+        ctx.vm_commit_state(5, n, p.data_ptr(), dp.data_ptr(), sn.data_ptr(), s.data_ptr())
+    with pytest.raises(DxoError):
+        ctx.copy(p.data_ptr(), dp.data_ptr(), 8, 7)
