@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--d", type=int, default=6, choices=(4, 6))
     ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
     ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
+    ap.add_argument("--gather-mode", choices=("compact", "full"), default="compact",
+                    help="compact: RCCL all-gather of (sigma, dp) + local rebuild of the remote tangents "
+                         "(dxo_vm_expand_tangent); full: RCCL all-gather of (C_tang, sigma, dp). The other mode is "
+                         "timed too and reported under config.gather_modes.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the stream-ceiling probe")
     ap.add_argument("--variant", type=int, default=1)
@@ -145,7 +149,7 @@ def main():
 
     from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
     from dolfinx_external_operator_amd._build import build_library
-    from dolfinx_external_operator_amd.sharding import WAVE_TILE, all_gather_flat_into
+    from dolfinx_external_operator_amd.sharding import WAVE_TILE, all_gather_in_place, gather_von_mises_compact
 
     if rank == 0:
         build_library()
@@ -178,11 +182,26 @@ def main():
     # the bench allocates a few candidate output slabs, runs the kernel once on each and keeps the fastest. The
     # first candidate is what a plain allocation would have returned; its figure is reported as
     # roofline.achieved_first_allocation.
-    placement = {"candidates": max(args.placement, 1), "kernel_GBps": []}
-    cands = [torch.empty(n * (d * d + d + 1), dtype=torch.float64, device=device) for _ in range(max(args.placement, 1))]
+    # With the gather on, every rank holds the FULL-length outputs and its kernel writes its cell block straight
+    # into them at [rank*n, (rank+1)*n): the all-gather is RCCL's in-place form and nothing is copied locally.
+    gather_on = gather and dist_on
+    blocks = world if gather_on else 1
+    own = rank if gather_on else 0
+    n_cand = max(args.placement, 1) if blocks == 1 else max(1, min(args.placement, 3, int(120e9 // (blocks * n * 344))))
+    placement = {"candidates": n_cand, "kernel_GBps": []}
+    per_pt = d * d + d + 1
+
+    def carve(slab):
+        N = blocks * n
+        return slab[: N * d * d], slab[N * d * d: N * (d * d + d)], slab[N * (d * d + d):]
+
+    def own_ptrs(slab):
+        C_f, s_f, dp_f = carve(slab)
+        return (C_f.data_ptr() + own * n * d * d * 8, s_f.data_ptr() + own * n * d * 8, dp_f.data_ptr() + own * n * 8)
+
+    cands = [torch.empty(blocks * n * per_pt, dtype=torch.float64, device=device) for _ in range(n_cand)]
     for cnd in cands:
-        pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), cnd.data_ptr(), cnd.data_ptr() + n * d * d * 8,
-              cnd.data_ptr() + n * (d * d + d) * 8)
+        pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), *own_ptrs(cnd))
         ctx.von_mises(prm, d, n, MEM_DEVICE, *pp)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -195,24 +214,33 @@ def main():
     out_slab = cands[placement["chosen"]]
     del cands, cnd
     torch.cuda.empty_cache()
-    C_tang = out_slab[: n * d * d]
-    sigma = out_slab[n * d * d: n * (d * d + d)]
-    dp = out_slab[n * (d * d + d):]
-    full = None
-    if gather and dist_on:
-        full = [torch.empty(world * t.numel(), dtype=torch.float64, device=device) for t in (C_tang, sigma, dp)]
+    C_full, sigma_full, dp_full = carve(out_slab)
+    C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]
+    sigma = sigma_full[own * n * d:(own + 1) * n * d]
+    dp = dp_full[own * n:(own + 1) * n]
 
     ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
 
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record(stream)
-        ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs)
-        if ev is not None:
-            ev[1].record(stream)
-        if full is not None:
-            for out, loc in zip(full, (C_tang, sigma, dp)):
-                all_gather_flat_into(out, loc)
+    def expand(s_view, dp_view, C_view, npts):
+        ctx.vm_expand_tangent(prm, d, npts, MEM_DEVICE, s_view.data_ptr(), dp_view.data_ptr(), C_view.data_ptr())
+
+    def make_step(mode):
+        def step(ev=None):
+            if ev is not None:
+                ev[0].record(stream)
+            ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs)
+            if ev is not None:
+                ev[1].record(stream)
+            if not gather_on:
+                return
+            if mode == "compact":
+                gather_von_mises_compact(C_full, sigma_full, dp_full, rank, d, expand)
+            else:
+                for buf in (C_full, sigma_full, dp_full):
+                    all_gather_in_place(buf, rank)
+        return step
+
+    step = make_step(args.gather_mode)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -230,12 +258,31 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # the other gather mode, same protocol, reported beside the headline (never as `value`)
+    other_mode, other_elapsed = ("full" if args.gather_mode == "compact" else "compact"), None
+    if gather_on:
+        if world > 1:   # remote tangents rebuilt from (sigma, dp) must be usable: finite and symmetric
+            nb = (rank + 1) % world
+            chk = C_full[nb * n * d * d: nb * n * d * d + 4096 * d * d].view(-1, d, d)
+            if not bool(torch.isfinite(chk).all()) or float((chk - chk.transpose(1, 2)).abs().max()) > 1e-9 * E:
+                raise SystemExit("bench: gathered/rebuilt remote C_tang block is not a finite symmetric tangent")
+        step2 = make_step(other_mode)
+        for _ in range(min(W, 2)):
+            step2()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(K):
+            step2()
+        fence()
+        other_elapsed = time.perf_counter() - t0
+
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     if dist_on:
-        t = torch.tensor([elapsed, kernel_ms_avg], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kernel_ms_avg, other_elapsed or 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
+        other_elapsed = float(t[2]) if other_elapsed is not None else None
     else:
         kernel_ms_avg_max = kernel_ms_avg
 
@@ -247,10 +294,6 @@ def main():
     plastic = dp[:4096] > 0
     if plastic.any() and float(f_chk[plastic].abs().max()) > 1e-8 * sigma_0:
         raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
-    if full is not None:
-        lo = rank * C_tang.numel()
-        if not torch.equal(full[0][lo:lo + 1024], C_tang[:1024]):
-            raise SystemExit("bench: gathered C_tang does not contain this rank's block")
 
     total_points = n * world
     value = total_points * K / elapsed
@@ -293,11 +336,18 @@ def main():
             "config": {
                 "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
                             f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
-                            + (", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step" if full is not None
+                            + ((", cell-block sharded, RCCL all-gather of (sigma, dp) + on-device rebuild of the remote "
+                                "tangents every step" if args.gather_mode == "compact" else
+                                ", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step") if gather_on
                                else (", cell-block sharded, no gather" if world > 1 else "")),
                 "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
                 "sharding": "cell-block" if world > 1 else "none",
-                "gather": "rccl_all_gather" if full is not None else "none",
+                "gather": f"rccl_all_gather_{args.gather_mode}" if gather_on else "none",
+                "gather_modes": ({args.gather_mode: {"value": value, "ms_per_step": elapsed / K * 1e3,
+                                                     "link_bytes_per_qp": 8 * (d + 1) if args.gather_mode == "compact" else 8 * per_pt},
+                                  other_mode: {"value": total_points * K / other_elapsed, "ms_per_step": other_elapsed / K * 1e3,
+                                               "link_bytes_per_qp": 8 * (d + 1) if other_mode == "compact" else 8 * per_pt}}
+                                 if gather_on and other_elapsed else None),
                 "kernel": "vm_tile" if args.variant else "vm_point",
                 "arch": info["arch"], "compute_units": info["compute_units"],
             },
@@ -315,7 +365,7 @@ def main():
             "kernel_only_value": total_points / (kernel_ms_avg_max * 1e-3),
         }
         if world == 1 and not args.no_cpu:
-            del out_slab, C_tang, sigma, dp
+            del out_slab, C_tang, sigma, dp, C_full, sigma_full, dp_full
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
         print(json.dumps(result), flush=True)
     if dist_on:

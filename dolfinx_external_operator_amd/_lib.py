@@ -68,6 +68,7 @@ _SIGNATURES = {
     "dxo_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_host_free": (C.c_int, [_P, _P]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
+    "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "dxo_device_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_device_free": (C.c_int, [_P, _P]),
@@ -319,6 +320,11 @@ class Context:
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))
         self.check(rc, "dxo_stream_probe")
+
+    def vm_expand_tangent(self, prm: VmParams, d: int, n: int, mem: int, sigma, dp, C_tang) -> None:
+        rc = self.lib.dxo_vm_expand_tangent(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(sigma), _ptr(dp),
+                                            _ptr(C_tang))
+        self.check(rc, "dxo_vm_expand_tangent")
 
     def vm_commit_state(self, d: int, n: int, p, dp, sigma_n, sigma) -> None:
         self.check(self.lib.dxo_vm_commit_state(self._h, int(d), int(n), _ptr(p), _ptr(dp), _ptr(sigma_n), _ptr(sigma)),

@@ -154,6 +154,31 @@ struct VmTile {
     static constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
 };
 
+// Phase C of a wave tile: the 64 points' tangent state (n[D], a, b per point) sits in the wave's LDS slice Y;
+// lanes walk the tile's C_tang block in OUTPUT order (16-byte chunk q = it*64 + lane), so every store
+// instruction of the wave covers 1 KiB of consecutive addresses.
+template <int D, bool NT>
+__device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double* Y, dxo_f64x2* g_c, int nct, int lane) {
+    using T = VmTile<D>;
+    const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
+    // partial unroll: a full unroll lets the scheduler hoist all 3*CH_CT LDS reads and spill
+#pragma unroll T::CH_VEC
+    for (int it = 0; it < T::CH_CT; ++it) {
+        const int q = it * DXO_WAVE + lane;     // 16-byte chunk index inside the tile's C_tang block
+        const int pt = q / T::CH_CT;            // local point
+        const int k = q - pt * T::CH_CT;        // chunk inside the point's d x d block
+        const int i = k / T::CH_VEC;            // row
+        const int j0 = (k - i * T::CH_VEC) * 2; // first of two columns
+        const double n_i = Y[pt * T::ST + i];
+        const dxo_f64x2 n_j = Y2[pt * (T::ST / 2) + (j0 >> 1)];
+        const dxo_f64x2 ab = Y2[pt * (T::ST / 2) + T::CH_VEC];
+        dxo_f64x2 out;
+        out.x = c_elas_ij(c, i, j0) - ab.x * (n_i * n_j.x) - ab.y * dev_ij(i, j0);
+        out.y = c_elas_ij(c, i, j0 + 1) - ab.x * (n_i * n_j.y) - ab.y * dev_ij(i, j0 + 1);
+        if (q < nct) store16<NT>(g_c + q, out);
+    }
+}
+
 template <int D, bool NT>
 __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
                                                      const double* __restrict__ sigma_n,
@@ -225,24 +250,7 @@ __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, co
             const int idx = k * DXO_WAVE + lane;
             if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
         }
-        dxo_f64x2* g_c = reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D));
-        const int nct = npts * T::CH_CT;
-        // partial unroll: a full unroll lets the scheduler hoist all 3*CH_CT LDS reads and spill
-#pragma unroll T::CH_VEC
-        for (int it = 0; it < T::CH_CT; ++it) {
-            const int q = it * DXO_WAVE + lane;     // 16-byte chunk index inside the tile's C_tang block
-            const int pt = q / T::CH_CT;            // local point
-            const int k = q - pt * T::CH_CT;        // chunk inside the point's d x d block
-            const int i = k / T::CH_VEC;            // row
-            const int j0 = (k - i * T::CH_VEC) * 2; // first of two columns
-            const double n_i = Y[pt * T::ST + i];
-            const dxo_f64x2 n_j = Y2[pt * (T::ST / 2) + (j0 >> 1)];
-            const dxo_f64x2 ab = Y2[pt * (T::ST / 2) + T::CH_VEC];
-            dxo_f64x2 out;
-            out.x = c_elas_ij(c, i, j0) - ab.x * (n_i * n_j.x) - ab.y * dev_ij(i, j0);
-            out.y = c_elas_ij(c, i, j0 + 1) - ab.x * (n_i * n_j.y) - ab.y * dev_ij(i, j0 + 1);
-            if (q < nct) store16<NT>(g_c + q, out);
-        }
+        vm_store_tangent<D, NT>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
         wave_lds_fence();  // next tile overwrites X / Y
     }
 }
@@ -284,7 +292,149 @@ int vm_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const
                      (double*)d_out[0], (double*)d_out[1], (double*)d_out[2], s);
 }
 
+// ------------------------------------------------------------------ tangent from (sigma, dp)
+// The consistent tangent is a function of the RETURNED state alone: radial return keeps the deviatoric direction
+// (dev sigma = (1 - beta) s_tr), so with s = dev sigma, sigma_eq = sqrt(3/2 s.s):
+//   sigma_eq_tr = sigma_eq + 3 mu dp,  beta = 3 mu dp / sigma_eq_tr,  n = s / sigma_eq (plastic) or 0 (elastic),
+// and C_tang = C_elas - 3mu(3mu/(3mu+H) - beta) n(x)n - 2 mu beta dev as in demo_plasticity_von_mises.py:318-324.
+// Used by the multi-GPU gather (sharding.py): ranks exchange (sigma, dp) = (d+1) doubles per point over xGMI
+// instead of (d*d+d+1) and rebuild the tangent of the REMOTE blocks here at HBM speed. NaN propagates as in the
+// reference (sigma NaN or 0/0 -> every entry NaN); the one difference is the reference's 0/0 at f_el == 0
+// EXACTLY (:318), which leaves no trace in (sigma, dp) and comes out as C_elas.
+template <int D>
+__device__ __forceinline__ void vm_tangent_state(const VmConst& c, const double (&sig)[D], double dp,
+                                                 double (&nrm)[D], double& a, double& b) {
+    const double mean = (sig[0] + sig[1] + sig[2]) * (1.0 / 3.0);
+    double s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = i < 3 ? sig[i] - mean : sig[i];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ss += s[i] * s[i];
+    const double sigma_eq = sqrt(3.0 / 2.0 * ss);
+    const double beta = c.mu3 * dp / (sigma_eq + c.mu3 * dp);
+    const double ind = dp > 0.0 ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) nrm[i] = s[i] / sigma_eq * ind;
+    a = c.mu3 * (c.ratio - beta);
+    b = c.mu2 * beta;
+}
+
+template <int D>
+__global__ __launch_bounds__(DXO_BLOCK) void vm_expand_point(VmConst c, int64_t n, const double* __restrict__ sigma,
+                                                             const double* __restrict__ dp_in,
+                                                             double* __restrict__ C_tang) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double sig[D], nrm[D], a, b;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sig[k] = sigma[i * D + k];
+        vm_tangent_state<D>(c, sig, dp_in[i], nrm, a, b);
+        double* Ct = C_tang + i * (D * D);
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int q = 0; q < D; ++q) Ct[r * D + q] = c_elas_ij(c, r, q) - a * (nrm[r] * nrm[q]) - b * dev_ij(r, q);
+    }
+}
+
+template <int D, bool NT>
+__global__ __launch_bounds__(DXO_BLOCK, 4) void vm_expand_tile(VmConst c, int64_t n, const double* __restrict__ sigma,
+                                                            const double* __restrict__ dp_in,
+                                                            double* __restrict__ C_tang) {
+    using T = VmTile<D>;
+    __shared__ __attribute__((aligned(16))) double lds[T::WAVES * T::WAVE_DOUBLES];
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* X = lds + wave * T::WAVE_DOUBLES;
+    double* Y = X + T::X_DOUBLES;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
+    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
+    const int64_t n_tiles = (n + T::PTS - 1) / T::PTS;
+    const int64_t tile_stride = (int64_t)gridDim.x * T::WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave; tile < n_tiles; tile += tile_stride) {
+        const int64_t p0 = tile * T::PTS;
+        const int npts = (n - p0 < T::PTS) ? (int)(n - p0) : T::PTS;
+        const int nvec = npts * T::CH_VEC;
+        const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma + p0 * D);
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            X2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{0.0, 0.0};
+        }
+        const double dp = lane < npts ? dp_in[p0 + lane] : 0.0;
+        wave_lds_fence();
+        double sig[D], nrm[D], a, b;
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) {
+            const dxo_f64x2 v = X2[lane * T::CH_VEC + k];
+            sig[2 * k] = v.x;
+            sig[2 * k + 1] = v.y;
+        }
+        vm_tangent_state<D>(c, sig, dp, nrm, a, b);
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+        Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+        wave_lds_fence();
+        vm_store_tangent<D, NT>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
+        wave_lds_fence();  // next tile overwrites X / Y
+    }
+}
+
+int vm_expand_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* sigma, const double* dp, double* C_tang,
+                     hipStream_t s) {
+    if (n == 0) return DXO_OK;
+    const bool tiled = ctx->vm_variant != 0 && aligned16(sigma) && aligned16(C_tang);
+    if (tiled) {
+        const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+        const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        const bool nt = ctx->nontemporal != 0;
+        if (L.d == 4) {
+            if (nt) hipLaunchKernelGGL((vm_expand_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+            else    hipLaunchKernelGGL((vm_expand_tile<4, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+        } else {
+            if (nt) hipLaunchKernelGGL((vm_expand_tile<6, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+            else    hipLaunchKernelGGL((vm_expand_tile<6, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+        }
+    } else {
+        const int grid = dxo_grid_for_tiles(ctx, (n + DXO_BLOCK - 1) / DXO_BLOCK, 1);
+        if (L.d == 4) hipLaunchKernelGGL((vm_expand_point<4>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+        else          hipLaunchKernelGGL((vm_expand_point<6>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);
+    }
+    return DXO_OK;
+}
+
+int vm_expand_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
+    const VmLaunch& L = *static_cast<const VmLaunch*>(user);
+    return vm_expand_launch(ctx, L, m, (const double*)d_in[0], (const double*)d_in[1], (double*)d_out[0], s);
+}
+
 }  // namespace
+
+extern "C" int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
+                                     const double* sigma, const double* dp, double* C_tang) {
+    if (!ctx) return DXO_E_NULL;
+    if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_expand_tangent: params is NULL");
+    if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_expand_tangent: d must be 4 or 6");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_expand_tangent: n < 0");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_vm_expand_tangent: bad mem");
+    if (n > 0 && (!sigma || !dp || !C_tang)) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_expand_tangent: NULL array");
+    if (((uintptr_t)sigma | (uintptr_t)dp | (uintptr_t)C_tang) & 7u)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_vm_expand_tangent: arrays must be 8-byte aligned");
+    VmLaunch L{make_const(*prm), d};
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = vm_expand_launch(ctx, L, n, sigma, dp, C_tang, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    const size_t sd = sizeof(double);
+    std::vector<dxo_span> in = {{sigma, nullptr, d * sd}, {dp, nullptr, sd}};
+    std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}};
+    return dxo_run_host_pipeline(ctx, n, in, out, vm_expand_chunk, &L);
+}
 
 extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
                              const double* deps, const double* sigma_n, const double* p, double* C_tang,

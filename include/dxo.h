@@ -125,6 +125,12 @@ int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int 
                   const double* deps, const double* sigma_n, const double* p,
                   double* C_tang, double* sigma, double* dp);
 
+/* Consistent tangent rebuilt from the RETURNED state: C_tang[n][d][d] from sigma[n][d], dp[n] (same formulas,
+ * demo_plasticity_von_mises.py:318-324, with s = dev sigma). The multi-GPU gather exchanges (sigma, dp) and rebuilds
+ * the tangent of remote cell blocks with this entry point. Agrees with dxo_von_mises' C_tang to rounding. */
+int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
+                          const double* sigma, const double* dp, double* C_tang);
+
 /* History update at the end of a load step, DEVICE memory only (demo_plasticity_von_mises.py:564-565):
  *   p[n] += dp[n];  sigma_n[n][d] = sigma[n][d].   One fused pass, asynchronous on the ctx stream. */
 int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, const double* dp,

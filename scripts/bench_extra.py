@@ -40,7 +40,7 @@ def ev_time(fn, launches=20, warm=3):
     return statistics.mean(a.elapsed_time(b) for a, b in evs)
 
 
-def vm_case(n, d, label):
+def vm_case(n, d, label, expand=False):
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     deps = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 3e-3
@@ -54,11 +54,19 @@ def vm_case(n, d, label):
                                        C.data_ptr(), s.data_ptr(), dp.data_ptr()))
     print(json.dumps({"case": label, "n": n, "d": d, "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
                       "GBps": BPP[d] * n / ms / 1e6}), flush=True)
+    if expand:
+        # the multi-GPU gather's rebuild of remote tangents from (sigma, dp): read (d+1), write d*d doubles per point
+        ms = ev_time(lambda: ctx.vm_expand_tangent(prm, d, n, MEM_DEVICE, s.data_ptr(), dp.data_ptr(), C.data_ptr()))
+        print(json.dumps({"case": f"tangent rebuild from (sigma, dp), d={d} (dxo_vm_expand_tangent)", "n": n, "kernel_ms": ms,
+                          "qp_per_s": n / ms * 1e3, "GBps": 8 * (d * d + d + 1) * n / ms / 1e6}), flush=True)
+        ms = ev_time(lambda: ctx.vm_commit_state(d, n, p.data_ptr(), dp.data_ptr(), sig.data_ptr(), s.data_ptr()))
+        print(json.dumps({"case": f"history update p += dp, sigma_n <- sigma, d={d} (dxo_vm_commit_state)", "n": n,
+                          "kernel_ms": ms, "GBps": 8 * (3 + 2 * d) * n / ms / 1e6}), flush=True)
     return deps, sig, p
 
 
 vm_case(1_000_000, 6, "von Mises d=6, config 2 size (448 MB working set, inputs fit the 256 MB Infinity Cache)")
-vm_case(10_000_000, 6, "von Mises d=6, 1e7 points")
+vm_case(10_000_000, 6, "von Mises d=6, 1e7 points", expand=True)
 vm_case(10_000_000, 4, "von Mises d=4 (reference demo layout), 1e7 points")
 vm_case(30_000_000, 4, "von Mises d=4, 3e7 points")
 

@@ -10,6 +10,7 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--variant", type=int, default=1)
 ap.add_argument("--precision", type=int, default=0)
 ap.add_argument("--launches", type=int, default=5)
+ap.add_argument("--cpu", type=int, default=0, help="also time the NumPy oracle (oracle/icnn_oracle.py) on this many points")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ctx = Context(0)
@@ -30,5 +31,24 @@ for x, y in ev:
     x.record(stream); run(); y.record(stream)
 torch.cuda.synchronize()
 ms = statistics.median(x.elapsed_time(y) for x, y in ev)
-print(json.dumps({"case": "ICNN", "variant": a.variant, "precision": a.precision, "n": a.n, "kernel_ms": ms, "qp_per_s": a.n / ms * 1e3}))
+# MFMA work actually issued by icnn_mfma: five 64x64x64 fp32 GEMMs per 64-point tile = 5 * 2 * 64^3 flop per 64 points
+mfma_flop = 5 * 2 * 64 ** 3 / 64 * a.n
+out = {"case": "ICNN", "variant": a.variant, "precision": a.precision, "n": a.n, "kernel_ms": ms, "qp_per_s": a.n / ms * 1e3,
+       "GBps_algorithmic": 192 * a.n / ms / 1e6}
+if a.variant in (1, 2) and a.precision == 0:
+    out["roofline"] = {"bound": "mfma", "achieved": mfma_flop / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
+                       "frac": mfma_flop / ms / 1e9 / 157.3,
+                       "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak; flop = the five 64^3 GEMMs per 64-point tile only"}
+if a.cpu:
+    import os
+    import time
+    sys.path.insert(0, str(ROOT))
+    from oracle.icnn_oracle import icnn_stress_tangent
+    wn = {k: v for k, v in np.load(ROOT / "tests" / "golden" / "icnn_isihara_weights.npz").items()}
+    Fh = F[: a.cpu].cpu().numpy()
+    icnn_stress_tangent(Fh[:1000], wn)
+    t0 = time.perf_counter(); icnn_stress_tangent(Fh, wn); dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": a.cpu / dt, "unit": "qp/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+                           "sample": f"{a.cpu} points of the same batch, oracle/icnn_oracle.py (NumPy jets, BLAS threads as configured)"}
+print(json.dumps(out))
 ctx.icnn_destroy(model); ctx.close()

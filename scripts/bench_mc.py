@@ -26,6 +26,7 @@ ap.add_argument("--pool", type=int, default=50_000)
 ap.add_argument("--variant", type=int, default=1)
 ap.add_argument("--bpc", type=int, default=2)
 ap.add_argument("--wps", type=int, default=1)
+ap.add_argument("--cpu", type=int, default=0, help="also time the CPU oracle (nested dual numbers, OpenMP) on this many points")
 args = ap.parse_args()
 n = args.n
 o = load_oracle()
@@ -72,4 +73,29 @@ if args.diag:
     out["iteration_histogram"] = {int(a): int(b) for a, b in zip(u.tolist(), c.tolist())}
     out["plastic_fraction"] = float((y > 0).double().mean())
     out["max_norm_res_converged"] = float(nr[it < 200].max())
+# Not HBM-bound: the binding roof is the fp64 vector pipe; both are reported.
+out["roofline"] = {"bound": "hbm", "achieved": bpp * n / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                   "frac": bpp * n / ms / 1e6 / 8000.0,
+                   "note": "fp64-VALU/divergence-bound, see profiles/r01_mc_pmc_summary.json for the VALU-pipe fraction"}
+if args.cpu:
+    import os
+    import time
+
+    m = args.cpu
+    hd, hs = deps[:m].cpu().numpy(), sn[:m].cpu().numpy()
+    avail = len(os.sched_getaffinity(0))
+    scan = {}
+    nt = 1
+    while nt <= avail:
+        t0 = time.perf_counter()
+        o.mohr_coulomb(hd, hs, nthreads=nt)
+        scan[nt] = m / (time.perf_counter() - t0)
+        if nt > 1 and scan[nt] < 0.7 * max(scan.values()):
+            break
+        nt *= 2
+    best = max(scan, key=scan.get)
+    out["cpu_baseline"] = {"value": scan[best], "unit": "qp/s", "cores": best, "kind": "port",
+                           "sample": f"{m} points of the same batch, oracle/mc_oracle.cpp (jacfwd through the Newton loop restated "
+                                     f"with nested dual numbers), OpenMP, thread scan {sorted(scan)}",
+                           "value_1core": scan[1]}
 print(json.dumps(out))

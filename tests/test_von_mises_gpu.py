@@ -302,7 +302,7 @@ def test_device_resident_load_history(ctx, oracle, d):
 def test_commit_state_torch_and_errors(ctx):
     import torch
 
-    from dolfinx_external_operator_amd import DxoError, von_mises_commit_state
+    from dolfinx_external_operator_amd import von_mises_commit_state
 
     n, d = 1000, 6
     g = torch.Generator().manual_seed(1)
@@ -316,7 +316,59 @@ def test_commit_state_torch_and_errors(ctx):
         von_mises_commit_state(p, dp[:-1].contiguous(), sn, s, ctx=ctx)
     with pytest.raises(TypeError):
         von_mises_commit_state(p.cpu(), dp, sn, s, ctx=ctx)
-    with pytest.raises(DxoError):
+    with pytest.raises(ValueError):           # argument errors (rc < 0) map to ValueError, HIP errors to DxoError
         ctx.vm_commit_state(5, n, p.data_ptr(), dp.data_ptr(), sn.data_ptr(), s.data_ptr())
-    with pytest.raises(DxoError):
+    with pytest.raises(ValueError):
         ctx.copy(p.data_ptr(), dp.data_ptr(), 8, 7)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("d,n", [(4, 1), (4, 4097), (6, 63), (6, 50_001)])
+def test_expand_tangent_from_returned_state(ctx, oracle, d, n, variant):
+    """dxo_vm_expand_tangent(sigma, dp) rebuilds what dxo_von_mises wrote as C_tang: to rounding on plastic points,
+    bit for bit on elastic ones (C_elas), same NaN pattern; and it meets the oracle's tangent at the usual 1e-13.
+    This is the property the compact multi-GPU gather rests on (sharding.gather_von_mises_compact)."""
+    deps, sigma_n, p = vm_inputs(n, d, seed=5 + n)
+    deps[: n // 3] *= 0.2
+    sigma_n[: n // 3] *= 0.2
+    if n > 10:
+        deps[7], sigma_n[7] = 0.0, 0.0
+        sigma_n[7, :3] = 40.0                      # hydrostatic trial stress: sigma_eq = 0 -> the reference's 0/0
+    C_k, s_k, dp_k = run_device(ctx, deps, sigma_n, p, variant)
+    ctx.set_option("vm_variant", variant)
+    C_x = np.empty((n, d, d))
+    ctx.vm_expand_tangent(PRM, d, n, MEM_HOST, np.ascontiguousarray(s_k), np.ascontiguousarray(dp_k), C_x)
+    assert_close_scaled(C_x, C_k, 1e-14, "expand vs kernel")
+    el = (dp_k == 0) & ~np.isnan(s_k).any(axis=1)
+    assert el.any() or n < 3
+    assert np.array_equal(C_x[el], C_k[el])
+    if n > 10:
+        assert np.isnan(C_x[7]).all() and np.isnan(C_k[7]).all()
+    with np.errstate(all="ignore"):
+        C_o, _, _ = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C_x, C_o, RTOL, "expand vs oracle")
+
+
+def test_expand_tangent_device_pointers_and_errors(ctx):
+    import torch
+
+    n, d = 100_000, 6
+    deps, sigma_n, p = vm_inputs(n, d, seed=2)
+    C_k, s_k, dp_k = run_device(ctx, deps, sigma_n, p)
+    s_t, dp_t = torch.from_numpy(s_k).cuda(), torch.from_numpy(dp_k).cuda()
+    C_t = torch.empty(n * d * d, dtype=torch.float64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.vm_expand_tangent(PRM, d, n, MEM_DEVICE, s_t.data_ptr(), dp_t.data_ptr(), C_t.data_ptr())
+    torch.cuda.synchronize()
+    assert_close_scaled(C_t.cpu().numpy(), C_k, 1e-14, "expand (device)")
+    # 8-byte-aligned but not 16-byte-aligned views take the scalar kernel
+    s_o = torch.empty(n * d + 1, dtype=torch.float64, device="cuda")
+    s_o[1:] = s_t.reshape(-1)
+    ctx.vm_expand_tangent(PRM, d, n, MEM_DEVICE, s_o.data_ptr() + 8, dp_t.data_ptr(), C_t.data_ptr())
+    torch.cuda.synchronize()
+    assert_close_scaled(C_t.cpu().numpy(), C_k, 1e-14, "expand (unaligned)")
+    with pytest.raises(ValueError):
+        ctx.vm_expand_tangent(PRM, 5, n, MEM_DEVICE, s_t.data_ptr(), dp_t.data_ptr(), C_t.data_ptr())
+    with pytest.raises(ValueError):
+        ctx.vm_expand_tangent(PRM, d, n, MEM_DEVICE, None, dp_t.data_ptr(), C_t.data_ptr())
+    ctx.vm_expand_tangent(PRM, d, 0, MEM_DEVICE, None, None, None)
