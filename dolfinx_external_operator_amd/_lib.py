@@ -35,6 +35,11 @@ class McParams(C.Structure):
                 ("nitermax", C.c_int32), ("_pad", C.c_int32)]
 
 
+class IsiharaParams(C.Structure):
+    """dxo_isihara_params — W = c1 (I1bar-3) + c2 (I2bar-3) + c3 (I1bar-3)^2 + c4 (J-1)^2 (demo_hyperelasticity.py:700)."""
+    _fields_ = [("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double), ("c4", C.c_double)]
+
+
 class IcnnWeights(C.Structure):
     """dxo_icnn_weights — the reference's state_dict tensors (demo_hyperelasticity.py:302-315), fp32."""
     _fields_ = [(k, C.c_void_p) for k in ("layers0_weight", "layers0_bias", "layers1_weights", "skip1_weight", "skip1_bias",
@@ -80,6 +85,7 @@ _SIGNATURES = {
     "dxo_icnn_destroy": (C.c_int, [_P, _P]),
     "dxo_icnn_correction": (C.c_int, [_P, _P, _P]),
     "dxo_icnn_eval": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
+    "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
@@ -316,6 +322,10 @@ class Context:
     def icnn_eval(self, model: int, precision: int, n: int, mem: int, F, dP, P) -> None:
         rc = self.lib.dxo_icnn_eval(self._h, _P(model), int(precision), int(n), int(mem), _ptr(F), _ptr(dP), _ptr(P))
         self.check(rc, "dxo_icnn_eval")
+
+    def isihara(self, prm: "IsiharaParams", n: int, mem: int, F, dP, P) -> None:
+        rc = self.lib.dxo_isihara(self._h, C.byref(prm), int(n), int(mem), _ptr(F), _ptr(dP), _ptr(P))
+        self.check(rc, "dxo_isihara")
 
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))

@@ -470,7 +470,117 @@ int icnn_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* con
     return icnn_launch(ctx, L, m, (const double*)d_in[0], (double*)d_out[0], (double*)d_out[1], s);
 }
 
+// ------------------------------------------------------------------ analytic Isihara energy (demo_hyperelasticity.py:686-703)
+// W = c1 (I1bar - 3) + c2 (I2bar - 3) + c3 (I1bar - 3)^2 + c4 (J - 1)^2 with I1bar = J^(-2/3) I1, I2bar = J^(-4/3) I2,
+// I1 = tr C + 1, I2 = I1 + J^2 - 1 (plane strain) — i.e. W is a quadratic in the SAME features (K1, K2, K3) the network
+// sees, so P = dW/dF and dP/dF come out of the same chain rule with grad_x W = (c1 + 2 c3 K1, c2, c4) and
+// hess_x W = diag(2 c3, 0, 0). The reference only has this model as UFL (`P = ufl.diff(W_Isihara, F_)`, :703); as a
+// kernel it is the HBM-bound twin of the network operator (192 B per point, a few hundred flop).
+// Unlike the network's features (J = sqrt(det C) = |det F|, :279) UFL's J = det F: for det F < 0 the real power
+// J^(-2/3) is NaN, and so is the output here.
+struct IsiPrm { double c1, c2, c3, c4; };
+
+template <bool NT>
+__global__ __launch_bounds__(DXO_BLOCK) void isihara_tile(IsiPrm prm, int64_t n, const double* __restrict__ F,
+                                                          double* __restrict__ dP, double* __restrict__ P) {
+    constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * DXO_WAVE * 20];
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* Xd = lds + wave * (DXO_WAVE * 20);     // [64][16] tangent rows of this wave's points
+    double* Xp = Xd + DXO_WAVE * 16;               // [64][4]  stresses
+    const dxo_f64x2* Xd2 = reinterpret_cast<const dxo_f64x2*>(Xd);
+    const dxo_f64x2* Xp2 = reinterpret_cast<const dxo_f64x2*>(Xp);
+    const double Hzero[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+    const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += tile_stride) {
+        const int64_t p0 = tile * DXO_WAVE;
+        const int npts = (n - p0 < DXO_WAVE) ? (int)(n - p0) : DXO_WAVE;
+        dxo_f64x2 f01{1.0, 0.0}, f23{0.0, 1.0};
+        if (lane < npts) {
+            f01 = reinterpret_cast<const dxo_f64x2*>(F + (p0 + lane) * 4)[0];
+            f23 = reinterpret_cast<const dxo_f64x2*>(F + (p0 + lane) * 4)[1];
+        }
+        const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};
+        const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+        const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+        const double iD = 1.0 / D;
+        const double m = D > 0.0 ? pow(D, -2.0 / 3.0) : __builtin_nan(""), nn = m * m;
+        const double K1 = (t + 1.0) * m - 3.0;
+        const double kt[3] = {m, nn, 0.0};
+        const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
+                              2.0 * (D - 1.0)};
+        const double ktD[3] = {(-2.0 / 3.0) * m * iD, (-4.0 / 3.0) * nn * iD, 0.0};
+        const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
+                               -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
+        const double y1[3] = {prm.c1 + 2.0 * prm.c3 * K1, prm.c2, prm.c4};
+        const double hx[6] = {2.0 * prm.c3, 0.0, 0.0, 0.0, 0.0, 0.0};
+        icnn_chain<double>(Fv, kt, kD, ktD, kDD, y1, hx, Hzero, Xd + lane * 16, Xp + lane * 4);
+        icnn_lds_fence();
+        // output-ordered stores: every store instruction of the wave covers 1 KiB of consecutive addresses
+        dxo_f64x2* g_d = reinterpret_cast<dxo_f64x2*>(dP + p0 * 16);
+        dxo_f64x2* g_p = reinterpret_cast<dxo_f64x2*>(P + p0 * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            if (idx < npts * 8) {
+                if constexpr (NT) __builtin_nontemporal_store(Xd2[idx], g_d + idx);
+                else g_d[idx] = Xd2[idx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            if (idx < npts * 2) {
+                if constexpr (NT) __builtin_nontemporal_store(Xp2[idx], g_p + idx);
+                else g_p[idx] = Xp2[idx];
+            }
+        }
+        icnn_lds_fence();
+    }
+}
+
+int isihara_launch(dxo_ctx* ctx, const IsiPrm& prm, int64_t n, const double* F, double* dP, double* P, hipStream_t s) {
+    if (n == 0) return DXO_OK;
+    const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
+    const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+    if (ctx->nontemporal != 0) hipLaunchKernelGGL(isihara_tile<true>, dim3(grid), dim3(DXO_BLOCK), 0, s, prm, n, F, dP, P);
+    else hipLaunchKernelGGL(isihara_tile<false>, dim3(grid), dim3(DXO_BLOCK), 0, s, prm, n, F, dP, P);
+    return DXO_OK;
+}
+
+int isihara_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
+    return isihara_launch(ctx, *static_cast<const IsiPrm*>(user), m, (const double*)d_in[0], (double*)d_out[0],
+                          (double*)d_out[1], s);
+}
+
 }  // namespace
+
+extern "C" int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, int mem, const double* F, double* dP,
+                           double* P) {
+    if (!ctx) return DXO_E_NULL;
+    if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_isihara: params is NULL");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_isihara: n < 0");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_isihara: bad mem");
+    if (n > 0 && (!F || !dP || !P)) return dxo_fail(ctx, DXO_E_NULL, "dxo_isihara: NULL array");
+    const uintptr_t all = (uintptr_t)F | (uintptr_t)dP | (uintptr_t)P;
+    if (all & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_isihara: arrays must be 8-byte aligned");
+    if (mem == DXO_MEM_DEVICE && (all & 15u)) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_isihara: device arrays must be 16-byte aligned");
+    IsiPrm k{prm->c1, prm->c2, prm->c3, prm->c4};
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = isihara_launch(ctx, k, n, F, dP, P, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    const size_t sd = sizeof(double);
+    std::vector<dxo_span> in = {{F, nullptr, 4 * sd}};
+    std::vector<dxo_span> out = {{nullptr, dP, 16 * sd}, {nullptr, P, 4 * sd}};
+    return dxo_run_host_pipeline(ctx, n, in, out, isihara_chunk, &k);
+}
 
 struct dxo_icnn : dxo_icnn_impl {};
 

@@ -24,7 +24,7 @@ from typing import Callable
 
 import numpy as np
 
-from ._lib import MEM_DEVICE, MEM_HOST, Context, McParams, VmParams, default_context
+from ._lib import MEM_DEVICE, MEM_HOST, Context, IsiharaParams, McParams, VmParams, default_context
 
 
 def _state_array(holder):
@@ -332,3 +332,34 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
 
 
 __all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn"]
+
+
+def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float = 1.5, ctx: Context | None = None,
+                 device: int = 0, reuse_outputs: bool = True) -> Callable:
+    """The analytic Isihara model behind the same `P_external` contract as `make_icnn`.
+
+    The reference states it in UFL only (demo_hyperelasticity.py:686-703, `P = ufl.diff(W_Isihara, F_)`) and
+    uses it as the ground truth the network is compared with (:806-817). As an external operator it takes the
+    operand `F = I + grad u` exactly like the network: `external_function((1,))(Fvals) -> (dP, P)`.
+    W = c1 (I1bar-3) + c2 (I2bar-3) + c3 (I1bar-3)^2 + c4 (J-1)^2; defaults are the reference's (:700)."""
+    prm = IsiharaParams(float(c1), float(c2), float(c3), float(c4))
+    holder = {"ctx": ctx, "out": None}
+
+    def dP_dF_impl(Fvals):
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        if holder["out"] is None:
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+        F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)
+        n = F.shape[0]
+        dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
+        holder["ctx"].isihara(prm, n, MEM_HOST, F, dP, P)
+        return dP.reshape(-1), P.reshape(-1)
+
+    def P_external(derivatives):
+        if derivatives == (1,):
+            return dP_dF_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    P_external.params = prm
+    return P_external

@@ -212,6 +212,13 @@ int dxo_icnn_correction(dxo_ctx* ctx, const dxo_icnn* model, double* H_flat);
 int dxo_icnn_eval(dxo_ctx* ctx, const dxo_icnn* model, int precision, int64_t n, int mem,
                   const double* F, double* dP, double* P);
 
+/* Analytic Isihara energy the network was trained on (demo_hyperelasticity.py:686-703; UFL-only in the reference):
+ *   W = c1 (I1bar-3) + c2 (I2bar-3) + c3 (I1bar-3)^2 + c4 (J-1)^2,  reference constants (0.5, 1.0, 1.0, 1.5).
+ * Same I/O as dxo_icnn_eval: F[n][4] -> dP[n][4][4] (dP_i/dF_j), P[n][4], fp64 throughout. det F <= 0 -> NaN. */
+typedef struct dxo_isihara_params { double c1, c2, c3, c4; } dxo_isihara_params;
+int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, int mem,
+                const double* F, double* dP, double* P);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

@@ -117,3 +117,25 @@ def icnn_stress_tangent(F, w, net_dtype=np.float32):
     P = np.einsum("nk,nki->ni", dy, dK) + F @ H                            # :433-439
     dP = np.einsum("nk,nkij->nij", dy, d2K) + np.einsum("nkl,nki,nlj->nij", d2y, dK, dK) + H.T[None]
     return dP, P
+
+
+def isihara_stress_tangent(F, c=(0.5, 1.0, 1.0, 1.5)):
+    """Analytic Isihara model, demo_hyperelasticity.py:686-703 (UFL): W = c1 K1 + c2 K2 + c3 K1^2 + c4 (J-1)^2 with
+    K1 = I1bar - 3, K2 = I2bar - 3 — the same (K1, K2, K3) as `features` for det F > 0 (UFL's J = det F; for
+    det F <= 0 the real power J^(-2/3) has no value: NaN). Returns dP (N,4,4), P (N,4) like icnn_stress_tangent.
+
+    Parity status: the reference has this model as a UFL form only, which cannot be executed here (no UFL/FFCx):
+    UNPINNED against the reference; pinned against torch.func differentiation of the energy as written at
+    :692-700 (tests/golden/make_golden_isihara.py -> tests/golden/isihara_analytic.npz)."""
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 4)
+    K, dK, d2K = features(F)
+    n = F.shape[0]
+    dy = np.stack([c[0] + 2.0 * c[2] * K[:, 0], np.full(n, c[1]), np.full(n, c[3])], axis=1)
+    d2y = np.zeros((n, 3, 3))
+    d2y[:, 0, 0] = 2.0 * c[2]
+    P = np.einsum("nk,nki->ni", dy, dK)
+    dP = np.einsum("nk,nkij->nij", dy, d2K) + np.einsum("nkl,nki,nlj->nij", d2y, dK, dK)
+    bad = (F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2]) <= 0.0
+    P[bad] = np.nan
+    dP[bad] = np.nan
+    return dP, P

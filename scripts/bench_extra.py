@@ -115,4 +115,13 @@ for n, prec, variant, label in ((10_000_000, 0, 1, "fp32 network, MFMA kernel, 8
     print(json.dumps({"case": f"ICNN stress + tangent, {label}", "n": n, "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
                       "GBps_algorithmic": 192 * n / ms / 1e6, "approx_TFLOPs": 45e3 * n / ms / 1e9}), flush=True)
 ctx.icnn_destroy(model)
+# analytic Isihara model: same I/O as the network, HBM-bound (192 B per point)
+from dolfinx_external_operator_amd import IsiharaParams  # noqa: E402
+n = 20_000_000
+Ft = torch.randn(n, 4, device=dev, dtype=torch.float64) * 0.05 + torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
+dPt = torch.empty(n * 16, device=dev, dtype=torch.float64); Pt = torch.empty(n * 4, device=dev, dtype=torch.float64)
+iprm = IsiharaParams(0.5, 1.0, 1.0, 1.5)
+ms = ev_time(lambda: ctx.isihara(iprm, n, MEM_DEVICE, Ft.data_ptr(), dPt.data_ptr(), Pt.data_ptr()))
+print(json.dumps({"case": "analytic Isihara stress + tangent (dxo_isihara), fp64, 2e7 points", "n": n, "kernel_ms": ms,
+                  "qp_per_s": n / ms * 1e3, "GBps": 192 * n / ms / 1e6}), flush=True)
 ctx.close()

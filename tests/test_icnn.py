@@ -164,3 +164,84 @@ def test_device_pointers_and_validation(ctx, weights):
     bad["layers.1.weights"] = bad["layers.1.weights"][:32]
     with pytest.raises(ValueError, match="shape"):
         ctx.icnn_create(bad)
+
+
+# ------------------------------------------------------------------ analytic Isihara model (demo_hyperelasticity.py:686-703)
+def test_isihara_oracle_matches_torch_differentiation(golden):
+    from oracle.icnn_oracle import isihara_stress_tangent
+
+    g = golden("isihara_analytic.npz")
+    dP, P = isihara_stress_tangent(g["F"])
+    assert np.abs(P - g["P"]).max() <= 1e-13 * np.abs(g["P"]).max()
+    assert np.abs(dP - g["dP"]).max() <= 1e-13 * np.abs(g["dP"]).max()
+    assert np.abs(P[0]).max() == 0.0                      # W has its minimum at F = I
+    assert np.abs(dP - dP.transpose(0, 2, 1)).max() <= 1e-13 * np.abs(dP).max()   # a Hessian
+    dPn, Pn = isihara_stress_tangent(np.array([[1.0, 0.0, 0.0, -1.0]]))
+    assert np.isnan(Pn).all() and np.isnan(dPn).all()     # det F < 0: J^(-2/3) has no real value
+
+
+def test_network_approximates_the_analytic_model_it_was_trained_on(golden, weights):
+    """End-to-end sanity of features + weights + chain rule: the shipped ICNN (trained on noisy Isihara data, :314)
+    reproduces the analytic stress within a few per cent on the BASELINE config-5 distribution (the reference
+    compares the two through the FEM solution, :806-817)."""
+    from oracle.icnn_oracle import isihara_stress_tangent
+
+    g = golden("isihara_analytic.npz")
+    _, P_a = isihara_stress_tangent(g["F"])
+    _, P_n = icnn_stress_tangent(g["F"], weights)
+    assert np.abs(P_n - P_a).max() <= 0.06 * np.abs(P_a).max()
+    assert np.median(np.abs(P_n - P_a)) <= 0.02 * np.median(np.abs(P_a))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 4097])
+def test_isihara_hip_against_golden_and_oracle(ctx, golden, n):
+    from dolfinx_external_operator_amd import MEM_HOST, IsiharaParams
+    from oracle.icnn_oracle import isihara_stress_tangent
+
+    g = golden("isihara_analytic.npz")
+    rng = np.random.Generator(np.random.PCG64(n))
+    F = g["F"][:n] if n <= 1000 else np.array([1.0, 0, 0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    if n > 1000:
+        F[5] = [1.0, 0.0, 0.0, -1.0]                      # det F < 0 -> NaN row
+    F = np.ascontiguousarray(F)
+    dP, P = np.empty((n, 4, 4)), np.empty((n, 4))
+    ctx.isihara(IsiharaParams(0.5, 1.0, 1.0, 1.5), n, MEM_HOST, F, dP, P)
+    if n == 0:
+        return
+    with np.errstate(all="ignore"):
+        dPo, Po = isihara_stress_tangent(F)
+    assert np.array_equal(np.isnan(dP), np.isnan(dPo)) and np.array_equal(np.isnan(P), np.isnan(Po))
+    ok = ~np.isnan(Po).any(axis=1)
+    # fp64 throughout; the kernel groups the chain rule by (t, D) partials, the oracle by einsum: rounding only
+    assert np.abs(P[ok] - Po[ok]).max() <= 1e-12 * np.abs(Po[ok]).max()
+    assert np.abs(dP[ok] - dPo[ok]).max() <= 1e-12 * np.abs(dPo[ok]).max()
+    if n <= 1000:
+        assert np.abs(P - g["P"][:n]).max() <= 1e-12 * np.abs(g["P"]).max()
+        assert np.abs(dP - g["dP"][:n]).max() <= 1e-12 * np.abs(g["dP"]).max()
+
+
+@pytest.mark.gpu
+def test_isihara_factory_contract_and_device_pointers(ctx, golden):
+    import torch
+
+    from dolfinx_external_operator_amd import MEM_DEVICE, IsiharaParams, make_isihara
+
+    g = golden("isihara_analytic.npz")
+    fn = make_isihara(ctx=ctx)
+    dP, P = fn((1,))(g["F"].reshape(-1, 1, 2, 2))
+    assert dP.shape == (g["F"].shape[0] * 16,) and P.shape == (g["F"].shape[0] * 4,)
+    assert np.abs(P.reshape(-1, 4) - g["P"]).max() <= 1e-12 * np.abs(g["P"]).max()
+    with pytest.raises(NotImplementedError):
+        fn((0,))
+    n = 100_003
+    Ft = torch.randn(n, 4, dtype=torch.float64, device="cuda") * 0.05 + torch.tensor([1.0, 0, 0, 1.0], dtype=torch.float64, device="cuda")
+    dPt = torch.empty(n * 16, dtype=torch.float64, device="cuda")
+    Pt = torch.empty(n * 4, dtype=torch.float64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.isihara(IsiharaParams(0.5, 1.0, 1.0, 1.5), n, MEM_DEVICE, Ft.data_ptr(), dPt.data_ptr(), Pt.data_ptr())
+    torch.cuda.synchronize()
+    from oracle.icnn_oracle import isihara_stress_tangent
+    dPo, Po = isihara_stress_tangent(Ft.cpu().numpy())
+    assert np.abs(dPt.cpu().numpy().reshape(-1, 4, 4) - dPo).max() <= 1e-12 * np.abs(dPo).max()
+    assert np.abs(Pt.cpu().numpy().reshape(-1, 4) - Po).max() <= 1e-12 * np.abs(Po).max()

@@ -332,8 +332,7 @@ def test_expand_tangent_from_returned_state(ctx, oracle, d, n, variant):
     deps[: n // 3] *= 0.2
     sigma_n[: n // 3] *= 0.2
     if n > 10:
-        deps[7], sigma_n[7] = 0.0, 0.0
-        sigma_n[7, :3] = 40.0                      # hydrostatic trial stress: sigma_eq = 0 -> the reference's 0/0
+        deps[7], sigma_n[7] = 0.0, 0.0             # zero trial stress: sigma_eq = 0 -> the reference's 0/0 (:318-319)
     C_k, s_k, dp_k = run_device(ctx, deps, sigma_n, p, variant)
     ctx.set_option("vm_variant", variant)
     C_x = np.empty((n, d, d))
