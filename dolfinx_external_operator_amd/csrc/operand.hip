@@ -1,0 +1,416 @@
+// operand.hip — operand evaluation on the device.
+//
+// Reference: evaluate_operands builds `fem.Expression(operand, quadrature_points)` and calls
+// `expr.eval(mesh, entities)` (src/dolfinx_external_operator/external_operator.py:386-402): a DOLFINx/FFCx cell loop
+// that tabulates the operand at every quadrature point of every cell. Every operand of the reference's demos is
+// a linear function of the gradient (or the value) of one Lagrange field:
+//   eps(Du) = [g00, g11, 0, sqrt(1/2)(g01 + g10)]     demo_plasticity_von_mises.py:225-227, _mohr_coulomb.py:148-157
+//   F = I + grad u                                     demo_hyperelasticity.py:479
+//   T, grad T                                          demo_nonlinear_heat_equation_part2.py (operands of q)
+// so the device version is: gather the cell's dofs through the dofmap, contract with the tabulated reference
+// gradients at the cell's quadrature points, push forward with J^-1 built from the geometry dofs, shape the
+// operand. Output layout is Expression.eval's: (num_cells, nq, value_size), C order.
+//
+// Kernel shape: lane = (cell, quadrature point); a wave owns floor(64 / nq) consecutive cells. The wave gathers
+// its cells' field dofs and geometry into wave-private LDS (the irregular part: int32 dofmap -> 8-byte loads,
+// neighbours share nodes so most hits come from L2), the reference tables sit in LDS once per workgroup, each
+// lane accumulates Gref = sum_a u_a (x) dphi_a(q), multiplies by J^-1, and the wave writes its points in output
+// order through LDS (consecutive 8-byte words per store instruction). No __syncthreads inside the cell loop.
+#include "dxo_common.h"
+
+namespace {
+
+struct OperandDev {
+    int nq, ndofs, ngeom;
+    int cells_per_wave;            // floor(64 / nq)
+    int wave_doubles;              // LDS doubles per wave
+    int table_doubles;             // LDS doubles for the tables
+    const double* phi;             // [nq][ndofs]
+    const double* dphi;            // [nq][ndofs][G]
+    const double* dpsi;            // [nq][ngeom][G]
+    const int32_t* dofmap;         // [num_cells][ndofs]
+    const int32_t* geom_dofmap;    // [num_cells][ngeom]
+    const double* x;               // [num_geom_nodes][G]
+};
+
+__device__ __forceinline__ void op_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int G>
+__device__ __forceinline__ void invert(const double (&J)[G][G], double (&K)[G][G]) {
+    if constexpr (G == 2) {
+        const double idet = 1.0 / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+        K[0][0] = J[1][1] * idet; K[0][1] = -J[0][1] * idet;
+        K[1][0] = -J[1][0] * idet; K[1][1] = J[0][0] * idet;
+    } else {
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double idet = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
+        K[0][0] = c00 * idet; K[1][0] = c01 * idet; K[2][0] = c02 * idet;
+        K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * idet;
+        K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * idet;
+        K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * idet;
+        K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * idet;
+        K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * idet;
+        K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * idet;
+    }
+}
+
+// Value size of the shaped operand.
+template <int G, int BS, int KIND>
+struct OperandShape {
+    static constexpr int D = KIND == DXO_OPERAND_VALUE ? BS
+                           : KIND == DXO_OPERAND_GRAD ? BS * G
+                           : KIND == DXO_OPERAND_EPS_MANDEL ? (G == 2 ? 4 : 6)
+                           : G * G;   // DXO_OPERAND_DEFGRAD
+};
+
+// grad u (BS x G, row = field component, column = direction) -> operand components
+template <int G, int BS, int KIND>
+__device__ __forceinline__ void shape_operand(const double (&val)[BS], const double (&g)[BS][G],
+                                              double (&o)[OperandShape<G, BS, KIND>::D]) {
+    constexpr double r2 = 0.70710678118654752440;   // sqrt(2) * 0.5, demo_plasticity_von_mises.py:227
+    if constexpr (KIND == DXO_OPERAND_VALUE) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) o[i] = val[i];
+    } else if constexpr (KIND == DXO_OPERAND_GRAD) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) o[i * G + j] = g[i][j];
+    } else if constexpr (KIND == DXO_OPERAND_EPS_MANDEL) {
+        if constexpr (G == 2) {
+            o[0] = g[0][0]; o[1] = g[1][1]; o[2] = 0.0; o[3] = r2 * (g[0][1] + g[1][0]);
+        } else {
+            o[0] = g[0][0]; o[1] = g[1][1]; o[2] = g[2][2];
+            o[3] = r2 * (g[0][1] + g[1][0]); o[4] = r2 * (g[0][2] + g[2][0]); o[5] = r2 * (g[1][2] + g[2][1]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) o[i * G + j] = g[i][j] + (i == j ? 1.0 : 0.0);
+    }
+}
+
+// One wave-group of cells: gather -> per-lane gradient -> `o` (D values of this lane's point). Returns false for
+// lanes without a point. Shared by the standalone kernel below and by kernels that consume the operand in place.
+template <int G, int BS, int KIND>
+__device__ __forceinline__ bool operand_point(const OperandDev& m, const double* tab, double* W,
+                                              const double* __restrict__ u, const int32_t* __restrict__ cells,
+                                              int64_t c0, int ncell, int lane,
+                                              double (&o)[OperandShape<G, BS, KIND>::D]) {
+    const int nd = m.ndofs, ng = m.ngeom;
+    double* U = W;                                   // [ncell][nd][BS]
+    double* X = W + m.cells_per_wave * nd * BS;      // [ncell][ng][G]
+    // ---- cooperative gather
+    for (int idx = lane; idx < ncell * nd; idx += DXO_WAVE) {
+        const int c = idx / nd, a = idx - c * nd;
+        const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
+        const int64_t node = m.dofmap[cell * nd + a];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) U[idx * BS + i] = u[node * BS + i];
+    }
+    for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
+        const int c = idx / ng, v = idx - c * ng;
+        const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
+        const int64_t node = m.geom_dofmap[cell * ng + v];
+#pragma unroll
+        for (int j = 0; j < G; ++j) X[idx * G + j] = m.x[node * G + j];
+    }
+    op_fence();
+    const int c = lane / m.nq, q = lane - c * m.nq;
+    const bool active = c < ncell;
+    if (active) {
+        const double* phi = tab + q * nd;
+        const double* dphi = tab + m.nq * nd + (q * nd) * G;
+        const double* dpsi = tab + m.nq * nd * (1 + G) + (q * ng) * G;
+        double J[G][G], K[G][G];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int k = 0; k < G; ++k) J[j][k] = 0.0;
+        for (int v = 0; v < ng; ++v) {
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int k = 0; k < G; ++k) J[j][k] += X[(c * ng + v) * G + j] * dpsi[v * G + k];
+        }
+        invert<G>(J, K);
+        double val[BS], gref[BS][G];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            val[i] = 0.0;
+#pragma unroll
+            for (int k = 0; k < G; ++k) gref[i][k] = 0.0;
+        }
+        const double* Uc = U + c * nd * BS;
+        for (int a = 0; a < nd; ++a) {
+            double ua[BS];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) ua[i] = Uc[a * BS + i];
+            if constexpr (KIND == DXO_OPERAND_VALUE) {
+                const double ph = phi[a];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) val[i] += ua[i] * ph;
+            } else {
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const double dk = dphi[a * G + k];
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) gref[i][k] += ua[i] * dk;
+                }
+            }
+        }
+        double g[BS][G];
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < G; ++k) s += gref[i][k] * K[k][j];   // d/dx_j = sum_k d/dxi_k * dxi_k/dx_j
+                g[i][j] = s;
+            }
+        shape_operand<G, BS, KIND>(val, g, o);
+    }
+    op_fence();   // W may be reused by the caller
+    return active;
+}
+
+template <int G, int BS, int KIND>
+__global__ __launch_bounds__(DXO_BLOCK) void operand_eval(OperandDev m, const double* __restrict__ u,
+                                                          const int32_t* __restrict__ cells, int64_t n_cells,
+                                                          double* __restrict__ out) {
+    constexpr int D = OperandShape<G, BS, KIND>::D;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tab = lds;
+    for (int i = threadIdx.x; i < m.nq * m.ndofs; i += blockDim.x) tab[i] = m.phi[i];
+    for (int i = threadIdx.x; i < m.nq * m.ndofs * G; i += blockDim.x) tab[m.nq * m.ndofs + i] = m.dphi[i];
+    for (int i = threadIdx.x; i < m.nq * m.ngeom * G; i += blockDim.x) tab[m.nq * m.ndofs * (1 + G) + i] = m.dpsi[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + m.table_doubles + wave * m.wave_doubles;
+    const int cpw = m.cells_per_wave;
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const int64_t stride = (int64_t)gridDim.x * (DXO_BLOCK / DXO_WAVE);
+    for (int64_t grp = (int64_t)blockIdx.x * (DXO_BLOCK / DXO_WAVE) + wave; grp < n_groups; grp += stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        double o[D];
+        const bool active = operand_point<G, BS, KIND>(m, tab, W, u, cells, c0, ncell, lane, o);
+        // output-ordered store: the wave's ncell*nq points are consecutive in `out`
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) W[lane * D + k] = o[k];
+        }
+        op_fence();
+        const int nval = ncell * m.nq * D;
+        double* g_o = out + c0 * m.nq * D;
+        for (int idx = lane; idx < nval; idx += DXO_WAVE) __builtin_nontemporal_store(W[idx], g_o + idx);
+        op_fence();
+    }
+}
+
+}  // namespace
+
+struct dxo_mesh {
+    int gdim = 0;
+    OperandDev dev{};
+    int64_t num_cells = 0, num_field_nodes = 0, num_geom_nodes = 0;
+    void* blob = nullptr;       // one device allocation holding tables + dofmaps + coordinates
+    double* d_u = nullptr;      // staging for host-resident field vectors
+    size_t u_cap = 0;
+    int32_t* d_cells = nullptr; // staging for host-resident entity lists
+    size_t cells_cap = 0;
+    double* d_out = nullptr;    // staging for host-resident outputs
+    size_t out_cap = 0;
+};
+
+namespace {
+
+template <int G, int BS, int KIND>
+void launch_operand(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, const int32_t* cells, int64_t n_cells,
+                    double* out, hipStream_t s) {
+    const int64_t n_groups = (n_cells + m->dev.cells_per_wave - 1) / m->dev.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    const size_t shm = (size_t)(m->dev.table_doubles + 4 * m->dev.wave_doubles) * sizeof(double);
+    hipLaunchKernelGGL((operand_eval<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, m->dev, u, cells, n_cells, out);
+}
+
+template <int G, int BS>
+int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double* u, const int32_t* cells,
+                  int64_t n_cells, double* out, hipStream_t s) {
+    switch (kind) {
+        case DXO_OPERAND_VALUE: launch_operand<G, BS, DXO_OPERAND_VALUE>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_GRAD: launch_operand<G, BS, DXO_OPERAND_GRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_EPS_MANDEL:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_DEFGRAD:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+    }
+    return DXO_E_OPTION;
+}
+
+int ensure(dxo_ctx* ctx, void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return DXO_OK;
+    if (*p) DXO_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    DXO_HIP(ctx, hipMalloc(p, bytes));
+    *cap = bytes;
+    return DXO_OK;
+}
+
+}  // namespace
+
+extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
+    if (gdim != 2 && gdim != 3) return DXO_E_DIM;
+    switch (kind) {
+        case DXO_OPERAND_VALUE: return bs == 1 || bs == gdim ? bs : DXO_E_DIM;
+        case DXO_OPERAND_GRAD: return bs == 1 || bs == gdim ? bs * gdim : DXO_E_DIM;
+        case DXO_OPERAND_EPS_MANDEL: return bs == gdim ? (gdim == 2 ? 4 : 6) : DXO_E_DIM;
+        case DXO_OPERAND_DEFGRAD: return bs == gdim ? gdim * gdim : DXO_E_DIM;
+    }
+    return DXO_E_OPTION;
+}
+
+extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!d || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_create: NULL argument");
+    *out = nullptr;
+    if (d->gdim != 2 && d->gdim != 3) return dxo_fail(ctx, DXO_E_DIM, "dxo_mesh_create: gdim must be 2 or 3");
+    if (d->nq < 1 || d->nq > DXO_WAVE) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: 1 <= nq <= 64 required");
+    if (d->ndofs < 1 || d->ngeom < d->gdim + 1 || d->num_cells < 0 || d->num_field_nodes < 0 || d->num_geom_nodes < 0)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: bad sizes");
+    if (!d->phi || !d->dphi || !d->dpsi || (d->num_cells > 0 && (!d->dofmap || !d->geom_dofmap || !d->x)))
+        return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_create: NULL array");
+    const int G = d->gdim;
+    for (int64_t i = 0; i < d->num_cells * d->ndofs; ++i)
+        if (d->dofmap[i] < 0 || d->dofmap[i] >= d->num_field_nodes)
+            return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: dofmap entry outside [0, num_field_nodes)");
+    for (int64_t i = 0; i < d->num_cells * d->ngeom; ++i)
+        if (d->geom_dofmap[i] < 0 || d->geom_dofmap[i] >= d->num_geom_nodes)
+            return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: geometry dofmap entry outside [0, num_geom_nodes)");
+    dxo_mesh* m = new dxo_mesh();
+    m->gdim = G;
+    m->num_cells = d->num_cells;
+    m->num_field_nodes = d->num_field_nodes;
+    m->num_geom_nodes = d->num_geom_nodes;
+    OperandDev& v = m->dev;
+    v.nq = d->nq; v.ndofs = d->ndofs; v.ngeom = d->ngeom;
+    v.cells_per_wave = DXO_WAVE / d->nq;
+    const int maxbs = G, maxD = G * G;
+    int wd = v.cells_per_wave * (d->ndofs * maxbs + d->ngeom * G);
+    if (wd < DXO_WAVE * maxD) wd = DXO_WAVE * maxD;
+    v.wave_doubles = (wd + 1) & ~1;
+    v.table_doubles = (d->nq * d->ndofs * (1 + G) + d->nq * d->ngeom * G + 1) & ~1;
+    if ((size_t)(v.table_doubles + 4 * v.wave_doubles) * sizeof(double) > 64 * 1024) {
+        delete m;
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: element too large for the 64 KiB LDS budget of the operand kernel");
+    }
+    // one blob: phi | dphi | dpsi | x | dofmap | geom_dofmap
+    const size_t n_phi = (size_t)d->nq * d->ndofs, n_dphi = n_phi * G, n_dpsi = (size_t)d->nq * d->ngeom * G;
+    const size_t n_x = (size_t)d->num_geom_nodes * G;
+    const size_t n_dm = (size_t)d->num_cells * d->ndofs, n_gm = (size_t)d->num_cells * d->ngeom;
+    const size_t bytes = (n_phi + n_dphi + n_dpsi + n_x) * sizeof(double) + (n_dm + n_gm) * sizeof(int32_t);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&m->blob, bytes ? bytes : 8);
+    if (e != hipSuccess) { delete m; return dxo_hip_fail(ctx, e, "dxo_mesh_create: hipMalloc"); }
+    std::vector<char> host(bytes);
+    char* h = host.data();
+    double* hd = reinterpret_cast<double*>(h);
+    std::memcpy(hd, d->phi, n_phi * sizeof(double));
+    std::memcpy(hd + n_phi, d->dphi, n_dphi * sizeof(double));
+    std::memcpy(hd + n_phi + n_dphi, d->dpsi, n_dpsi * sizeof(double));
+    // coordinates: x_stride doubles per node in the source (DOLFINx pads to 3), gdim kept
+    const int xs = d->x_stride > 0 ? d->x_stride : G;
+    double* hx = hd + n_phi + n_dphi + n_dpsi;
+    for (int64_t i = 0; i < d->num_geom_nodes; ++i)
+        for (int j = 0; j < G; ++j) hx[i * G + j] = d->x[i * xs + j];
+    int32_t* hi = reinterpret_cast<int32_t*>(hx + n_x);
+    if (n_dm) std::memcpy(hi, d->dofmap, n_dm * sizeof(int32_t));
+    if (n_gm) std::memcpy(hi + n_dm, d->geom_dofmap, n_gm * sizeof(int32_t));
+    e = hipMemcpy(m->blob, h, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m->blob); delete m; return dxo_hip_fail(ctx, e, "dxo_mesh_create: hipMemcpy"); }
+    double* bd = static_cast<double*>(m->blob);
+    v.phi = bd; v.dphi = bd + n_phi; v.dpsi = bd + n_phi + n_dphi; v.x = bd + n_phi + n_dphi + n_dpsi;
+    const int32_t* bi = reinterpret_cast<const int32_t*>(v.x + n_x);
+    v.dofmap = bi; v.geom_dofmap = bi + n_dm;
+    *out = m;
+    return DXO_OK;
+}
+
+extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
+    if (!ctx) return DXO_E_NULL;
+    if (!m) return DXO_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (m->blob) (void)hipFree(m->blob);
+    if (m->d_u) (void)hipFree(m->d_u);
+    if (m->d_cells) (void)hipFree(m->d_cells);
+    if (m->d_out) (void)hipFree(m->d_out);
+    delete m;
+    return DXO_OK;
+}
+
+extern "C" int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* m, int kind, int bs, int mem, const double* u,
+                                const int32_t* cells, int64_t n_cells, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!m) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_operand: mesh is NULL");
+    const int D = dxo_operand_value_size(m->gdim, bs, kind);
+    if (D == DXO_E_OPTION) return dxo_fail(ctx, DXO_E_OPTION, "dxo_eval_operand: unknown operand kind");
+    if (D < 0) return dxo_fail(ctx, DXO_E_DIM, "dxo_eval_operand: block size does not fit the operand kind / gdim");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_eval_operand: bad mem");
+    if (!cells) n_cells = n_cells < 0 ? m->num_cells : n_cells;
+    if (n_cells < 0 || (!cells && n_cells > m->num_cells)) return dxo_fail(ctx, DXO_E_SIZE, "dxo_eval_operand: bad n_cells");
+    if (n_cells == 0) return DXO_OK;
+    if (!u || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_operand: NULL array");
+    if (((uintptr_t)u | (uintptr_t)out) & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_eval_operand: arrays must be 8-byte aligned");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    const double* du = u;
+    const int32_t* dc = cells;
+    double* dout = out;
+    const size_t out_bytes = (size_t)n_cells * m->dev.nq * D * sizeof(double);
+    if (mem == DXO_MEM_HOST) {
+        if (cells)
+            for (int64_t i = 0; i < n_cells; ++i)
+                if (cells[i] < 0 || cells[i] >= m->num_cells) return dxo_fail(ctx, DXO_E_SIZE, "dxo_eval_operand: entity outside [0, num_cells)");
+        const size_t ub = (size_t)m->num_field_nodes * bs * sizeof(double);
+        int rc = ensure(ctx, (void**)&m->d_u, &m->u_cap, ub);
+        if (rc != DXO_OK) return rc;
+        DXO_HIP(ctx, hipMemcpyAsync(m->d_u, u, ub, hipMemcpyHostToDevice, s));
+        du = m->d_u;
+        if (cells) {
+            rc = ensure(ctx, (void**)&m->d_cells, &m->cells_cap, (size_t)n_cells * sizeof(int32_t));
+            if (rc != DXO_OK) return rc;
+            DXO_HIP(ctx, hipMemcpyAsync(m->d_cells, cells, (size_t)n_cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            dc = m->d_cells;
+        }
+        rc = ensure(ctx, (void**)&m->d_out, &m->out_cap, out_bytes);
+        if (rc != DXO_OK) return rc;
+        dout = m->d_out;
+    }
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    if (m->gdim == 2) rc = bs == 1 ? dispatch_kind<2, 1>(ctx, m, kind, du, dc, n_cells, dout, s) : dispatch_kind<2, 2>(ctx, m, kind, du, dc, n_cells, dout, s);
+    else              rc = bs == 1 ? dispatch_kind<3, 1>(ctx, m, kind, du, dc, n_cells, dout, s) : dispatch_kind<3, 3>(ctx, m, kind, du, dc, n_cells, dout, s);
+    if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_eval_operand: unsupported (gdim, bs, kind)");
+    rc = dxo_device_end(ctx, s);
+    if (rc != DXO_OK) return rc;
+    if (mem == DXO_MEM_HOST) {
+        DXO_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return DXO_OK;
+}

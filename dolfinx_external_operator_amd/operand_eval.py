@@ -1,0 +1,156 @@
+"""Operand evaluation on the GPU: the device counterpart of `fem.Expression(operand, points).eval(mesh, entities)`
+inside `evaluate_operands` (src/dolfinx_external_operator/external_operator.py:386-402), for operands that are
+linear in the value or gradient of one Lagrange field — eps(Du), I + grad u, T, grad T: every operand of the
+reference's demos.
+
+    mesh = DeviceMesh(gdim=2, phi=..., dphi=..., dpsi=..., dofmap=V.dofmap.list, geom_dofmap=domain.geometry.dofmap,
+                      x=domain.geometry.x, num_field_nodes=...)
+    deps = mesh.operand("eps", Du)           # an object with .eval(entities) -> (len(entities), nq, 4)
+    evaluated = evaluate_operands([sigma])   # evaluation.py mirror; or call deps.eval(cells) directly
+
+The field holder (`fem.Function`, ndarray or zero-argument callable) is re-read at every evaluation, like the
+reference's Expression re-reads the Function's vector.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import MEM_DEVICE, MEM_HOST, Context, default_context
+
+KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3}
+
+
+class MeshDesc(C.Structure):
+    """dxo_mesh_desc (include/dxo.h)."""
+    _fields_ = [("gdim", C.c_int32), ("nq", C.c_int32), ("ndofs", C.c_int32), ("ngeom", C.c_int32),
+                ("x_stride", C.c_int32), ("_pad", C.c_int32),
+                ("num_cells", C.c_int64), ("num_field_nodes", C.c_int64), ("num_geom_nodes", C.c_int64),
+                ("phi", C.c_void_p), ("dphi", C.c_void_p), ("dpsi", C.c_void_p),
+                ("dofmap", C.c_void_p), ("geom_dofmap", C.c_void_p), ("x", C.c_void_p)]
+
+
+def _state(holder):
+    if callable(holder) and not hasattr(holder, "x") and not hasattr(holder, "data_ptr"):
+        holder = holder()
+    xv = getattr(holder, "x", None)
+    if xv is not None and hasattr(xv, "array"):
+        return xv.array
+    return holder
+
+
+class DeviceMesh:
+    """Element tables, dofmaps and coordinates resident on the GPU (uploaded once)."""
+
+    def __init__(self, *, gdim: int, phi, dphi, dpsi, dofmap, geom_dofmap, x, num_field_nodes: int | None = None,
+                 ctx: Context | None = None, device: int = 0):
+        self.ctx = ctx if ctx is not None else default_context(device)
+        phi = np.ascontiguousarray(phi, dtype=np.float64)
+        dphi = np.ascontiguousarray(dphi, dtype=np.float64)
+        dpsi = np.ascontiguousarray(dpsi, dtype=np.float64)
+        dofmap = np.ascontiguousarray(dofmap, dtype=np.int32)
+        geom_dofmap = np.ascontiguousarray(geom_dofmap, dtype=np.int32)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nq, ndofs = phi.shape
+        if dphi.shape != (nq, ndofs, gdim) or dpsi.shape[0] != nq or dpsi.shape[2] != gdim:
+            raise ValueError("table shapes: phi (nq, ndofs), dphi (nq, ndofs, gdim), dpsi (nq, ngeom, gdim)")
+        if dofmap.ndim != 2 or dofmap.shape[1] != ndofs or geom_dofmap.shape != (dofmap.shape[0], dpsi.shape[1]):
+            raise ValueError("dofmap (num_cells, ndofs) and geom_dofmap (num_cells, ngeom) do not match the tables")
+        if num_field_nodes is None:
+            num_field_nodes = int(dofmap.max()) + 1 if dofmap.size else 0
+        self.gdim, self.nq, self.num_cells, self.num_field_nodes = gdim, nq, dofmap.shape[0], int(num_field_nodes)
+        d = MeshDesc(gdim, nq, ndofs, dpsi.shape[1], x.shape[1], 0, self.num_cells, self.num_field_nodes, x.shape[0],
+                     phi.ctypes.data, dphi.ctypes.data, dpsi.ctypes.data, dofmap.ctypes.data, geom_dofmap.ctypes.data,
+                     x.ctypes.data)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dxo_mesh_create(self.ctx._h, C.byref(d), C.byref(h)), "dxo_mesh_create")
+        self._h = h
+
+    @classmethod
+    def from_synthetic(cls, mesh, **kw):
+        """From `synthetic.SyntheticMesh`."""
+        return cls(gdim=mesh.gdim, phi=mesh.phi, dphi=mesh.dphi, dpsi=mesh.dpsi, dofmap=mesh.dofmap,
+                   geom_dofmap=mesh.geom_dofmap, x=mesh.x, num_field_nodes=mesh.node_x.shape[0], **kw)
+
+    @classmethod
+    def from_dolfinx(cls, V, quadrature_points, **kw):
+        """From a DOLFINx function space `V` (blocked Lagrange) and the reference quadrature points the operator's
+        quadrature element uses (`basix.make_quadrature(...)[0]`). Not exercised on the GPU box (no DOLFINx there)."""
+        mesh = V.mesh
+        gdim = mesh.geometry.dim
+        tab = V.element.basix_element.tabulate(1, quadrature_points)          # (1 + tdim, nq, ndofs, 1)
+        ctab = mesh.geometry.cmap.tabulate(1, quadrature_points)              # (1 + tdim, nq, ngeom, 1)
+        phi = tab[0, :, :, 0]
+        dphi = np.moveaxis(tab[1:, :, :, 0], 0, 2)
+        dpsi = np.moveaxis(ctab[1:, :, :, 0], 0, 2)
+        n_nodes = V.dofmap.index_map.size_local + V.dofmap.index_map.num_ghosts
+        return cls(gdim=gdim, phi=phi, dphi=dphi, dpsi=dpsi, dofmap=V.dofmap.list, geom_dofmap=mesh.geometry.dofmap,
+                   x=mesh.geometry.x, num_field_nodes=n_nodes, **kw)
+
+    def value_size(self, kind: str, bs: int) -> int:
+        r = self.ctx.lib.dxo_operand_value_size(self.gdim, int(bs), KINDS[kind])
+        if r < 0:
+            raise ValueError(f"operand '{kind}' is not defined for gdim={self.gdim}, block size {bs}")
+        return r
+
+    def evaluate(self, kind: str, bs: int, u, entities=None, out=None) -> np.ndarray:
+        """Host arrays in, host array (n_cells, nq, value_size) out."""
+        D = self.value_size(kind, bs)
+        u = np.ascontiguousarray(_state(u), dtype=np.float64).reshape(-1)
+        if u.size != self.num_field_nodes * bs:
+            raise ValueError(f"field vector has {u.size} entries, expected {self.num_field_nodes * bs}")
+        cells = None if entities is None else np.ascontiguousarray(entities, dtype=np.int32)
+        n = self.num_cells if cells is None else cells.size
+        if out is None:
+            out = np.empty((n, self.nq, D))
+        rc = self.ctx.lib.dxo_eval_operand(self.ctx._h, self._h, KINDS[kind], int(bs), MEM_HOST, u.ctypes.data,
+                                           None if cells is None else cells.ctypes.data, n, out.ctypes.data)
+        self.ctx.check(rc, "dxo_eval_operand")
+        return out
+
+    def evaluate_device(self, kind: str, bs: int, u_ptr: int, n_cells: int, out_ptr: int, cells_ptr: int | None = None) -> None:
+        """Raw device pointers, asynchronous on the context's stream."""
+        rc = self.ctx.lib.dxo_eval_operand(self.ctx._h, self._h, KINDS[kind], int(bs), MEM_DEVICE, C.c_void_p(u_ptr),
+                                           None if cells_ptr is None else C.c_void_p(cells_ptr), int(n_cells),
+                                           C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_eval_operand")
+
+    def operand(self, kind: str, field, bs: int | None = None, name: str | None = None) -> "DeviceOperand":
+        return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self.ctx._h:
+            self.ctx.lib.dxo_mesh_destroy(self.ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceOperand:
+    """Plays the role of a UFL operand in `evaluation.evaluate_operands`: `.eval(entities)` returns what
+    `Expression.eval` returns, (len(entities), nq, *shape); for "F" the trailing shape is (gdim, gdim) like the
+    tensor operand of the hyperelasticity demo, for "grad" of a vector field (bs, gdim)."""
+
+    def __init__(self, mesh: DeviceMesh, kind: str, field, bs: int, name: str):
+        self.mesh, self.kind, self.field, self.bs, self.name = mesh, kind, field, bs, name
+        self.eval_count = 0
+
+    def eval(self, entities) -> np.ndarray:
+        self.eval_count += 1
+        out = self.mesh.evaluate(self.kind, self.bs, self.field, entities)
+        g = self.mesh.gdim
+        if self.kind == "F":
+            return out.reshape(out.shape[0], out.shape[1], g, g)
+        if self.kind == "grad" and self.bs > 1:
+            return out.reshape(out.shape[0], out.shape[1], self.bs, g)
+        if out.shape[2] == 1:
+            return out.reshape(out.shape[0], out.shape[1])       # scalar operand is 2-D (heat demo, part2.py:220-228)
+        return out
+
+    def __repr__(self) -> str:
+        return f"DeviceOperand({self.name})"

@@ -1,0 +1,183 @@
+"""DOLFINx-free element tables and structured meshes for the tests and benches of the device operand evaluation.
+
+On a DOLFINx installation the tables come from basix (`element.tabulate(1, points)`) and the arrays from
+`V.dofmap.list`, `mesh.geometry.dofmap`, `mesh.geometry.x` (see `operand_eval.DeviceMesh.from_dolfinx`). The GPU
+box has neither, so this module provides what the synthetic workloads need: Lagrange bases of degree 1 and 2 on
+the reference triangle, quadrilateral, tetrahedron and hexahedron (built by inverting a Vandermonde matrix, so no
+hand-written shape functions), Gauss rules matching the reference's quadrature degree 2, and structured meshes
+with consistent field and geometry dofmaps. Node ORDER inside a cell is this module's own (lattice order), which
+is all a self-consistent (tables, dofmap) pair needs; it is not basix's.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def _lattice_nodes(cell: str, degree: int) -> np.ndarray:
+    tdim = {"triangle": 2, "quadrilateral": 2, "tetrahedron": 3, "hexahedron": 3}[cell]
+    pts = []
+    for idx in itertools.product(range(degree + 1), repeat=tdim):
+        if cell in ("triangle", "tetrahedron") and sum(idx) > degree:
+            continue
+        pts.append([i / degree for i in idx[::-1]])      # x fastest
+    return np.array(pts, dtype=np.float64)
+
+
+def _exponents(cell: str, degree: int) -> np.ndarray:
+    tdim = {"triangle": 2, "quadrilateral": 2, "tetrahedron": 3, "hexahedron": 3}[cell]
+    ex = [e for e in itertools.product(range(degree + 1), repeat=tdim)
+          if cell in ("quadrilateral", "hexahedron") or sum(e) <= degree]
+    return np.array(ex, dtype=np.int64)
+
+
+def _monomials(ex: np.ndarray, pts: np.ndarray, deriv: int | None = None) -> np.ndarray:
+    """(npts, nmono) values of the monomials x^e, or of their derivative along axis `deriv`."""
+    out = np.ones((pts.shape[0], ex.shape[0]))
+    for k in range(ex.shape[1]):
+        e = ex[:, k]
+        if deriv == k:
+            out *= e[None, :] * pts[:, k:k + 1] ** np.maximum(e - 1, 0)[None, :]
+        else:
+            out *= pts[:, k:k + 1] ** e[None, :]
+    return out
+
+
+@dataclass(frozen=True)
+class LagrangeElement:
+    cell: str
+    degree: int
+
+    @property
+    def nodes(self) -> np.ndarray:
+        return _lattice_nodes(self.cell, self.degree)
+
+    def tabulate(self, points: np.ndarray):
+        """phi (npts, ndofs), dphi (npts, ndofs, tdim) at reference `points`."""
+        ex = _exponents(self.cell, self.degree)
+        coeff = np.linalg.inv(_monomials(ex, self.nodes))          # (nmono, ndofs): phi_a = sum_m coeff[m,a] x^e_m
+        phi = _monomials(ex, points) @ coeff
+        dphi = np.stack([_monomials(ex, points, k) @ coeff for k in range(points.shape[1])], axis=2)
+        return phi, dphi
+
+
+def quadrature_degree2(cell: str):
+    """Points and weights integrating degree 2 exactly: the rules DOLFINx's default scheme gives for
+    `quadrature_degree = 2` (3-point triangle rule, demo_plasticity_von_mises.py:230-245; 4-point tetrahedron;
+    2-point Gauss per direction on quadrilaterals and hexahedra)."""
+    g = 0.5 - 0.5 / np.sqrt(3.0)
+    line = np.array([g, 1.0 - g])
+    if cell == "triangle":
+        return np.array([[1 / 6, 1 / 6], [1 / 6, 2 / 3], [2 / 3, 1 / 6]]), np.full(3, 1 / 6)
+    if cell == "tetrahedron":
+        a, b = 0.1381966011250105, 0.5854101966249685
+        return np.array([[a, a, a], [b, a, a], [a, b, a], [a, a, b]]), np.full(4, 1 / 24)
+    if cell == "quadrilateral":
+        return np.array([[x, y] for y in line for x in line]), np.full(4, 0.25)
+    if cell == "hexahedron":
+        return np.array([[x, y, z] for z in line for y in line for x in line]), np.full(8, 0.125)
+    raise ValueError(cell)
+
+
+@dataclass
+class SyntheticMesh:
+    """Arrays of a structured mesh in the layout `dxo_mesh_desc` takes."""
+    cell: str
+    gdim: int
+    degree: int
+    x: np.ndarray             # (num_geom_nodes, gdim)
+    geom_dofmap: np.ndarray   # (num_cells, ngeom) int32, degree-1 coordinate element
+    dofmap: np.ndarray        # (num_cells, ndofs) int32, field element of `degree`
+    node_x: np.ndarray        # (num_field_nodes, gdim) physical position of every field node (for interpolation)
+    points: np.ndarray        # (nq, gdim) reference quadrature points
+    phi: np.ndarray
+    dphi: np.ndarray
+    dpsi: np.ndarray
+
+    @property
+    def num_cells(self) -> int:
+        return self.dofmap.shape[0]
+
+    @property
+    def nq(self) -> int:
+        return self.points.shape[0]
+
+    def physical_points(self) -> np.ndarray:
+        """(num_cells, nq, gdim) positions of the quadrature points."""
+        geo = LagrangeElement(self.cell, 1)
+        psi, _ = geo.tabulate(self.points)
+        return np.einsum("qv,cvj->cqj", psi, self.x[self.geom_dofmap])
+
+
+def structured_mesh(cell: str, n: tuple[int, ...], degree: int = 2, distort: float = 0.0, seed: int = 0) -> SyntheticMesh:
+    """Unit square / cube split into n[0] x n[1] (x n[2]) boxes; triangles: 2 per box, tetrahedra: 6 per box.
+
+    `distort` moves the interior VERTICES by up to that fraction of the box size (seeded), so simplices stay
+    affine with different Jacobians and quadrilaterals / hexahedra become genuinely non-affine (bi/trilinear
+    geometry, J varies inside the cell). Field nodes sit at the images of the reference nodes under the cell map."""
+    gdim = len(n)
+    if {"triangle": 2, "quadrilateral": 2, "tetrahedron": 3, "hexahedron": 3}[cell] != gdim:
+        raise ValueError("len(n) must equal the cell's dimension")
+    n = tuple(int(k) for k in n)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vshape = tuple(k + 1 for k in n)                       # vertices per direction
+    grids = np.meshgrid(*[np.linspace(0.0, 1.0, k + 1) for k in n], indexing="ij")
+    vx = np.stack(grids, axis=-1)                          # (..., gdim), index order (i, j[, k])
+    if distort:
+        h = np.array([1.0 / k for k in n])
+        move = rng.uniform(-distort, distort, size=vx.shape) * h
+        interior = np.ones(vshape, dtype=bool)
+        for ax in range(gdim):
+            sl = [slice(None)] * gdim
+            sl[ax] = [0, -1]
+            interior[tuple(sl)] = False
+        vx = vx + move * interior[..., None]
+    vid = np.arange(int(np.prod(vshape))).reshape(vshape)
+    fshape = tuple(degree * k + 1 for k in n)              # field-node lattice
+    fid = np.arange(int(np.prod(fshape))).reshape(fshape)
+
+    B = np.stack(np.meshgrid(*[np.arange(k) for k in n], indexing="ij"), axis=-1).reshape(-1, gdim)   # boxes
+
+    def lattice_ids(offsets, scale, shape):
+        """ids of lattice points scale*box + offsets[l] for every box: (nboxes, len(offsets))"""
+        idx = scale * B[:, None, :] + np.asarray(offsets)[None, :, :]
+        return np.ravel_multi_index(tuple(idx.transpose(2, 0, 1)), shape).astype(np.int32)
+
+    if cell in ("quadrilateral", "hexahedron"):
+        # reference lattice order: x fastest  ->  local node (a_x, a_y[, a_z]) with x fastest
+        corner = [c[::-1] for c in itertools.product(range(2), repeat=gdim)]
+        geom = lattice_ids(corner, 1, vshape)
+        lat = [c[::-1] for c in itertools.product(range(degree + 1), repeat=gdim)]
+        dm = lattice_ids(lat, degree, fshape)
+    else:
+        # simplices of a box: one per permutation of the axes (Kuhn triangulation): vertices 0, e_p0, e_p0+e_p1, ...
+        ref_lat = _lattice_nodes(cell, degree)             # reference node positions, x fastest
+        geom_parts, dm_parts = [], []
+        for perm in itertools.permutations(range(gdim)):
+            corners = [np.zeros(gdim, dtype=int)]
+            for ax in perm:
+                nxt = corners[-1].copy()
+                nxt[ax] += 1
+                corners.append(nxt)
+            corners = np.array(corners)                    # (gdim+1, gdim) offsets inside the box
+            edges = corners[1:] - corners[0]
+            # field node for reference position r: lattice offset = degree*corners[0] + degree * sum_k r_k edges[k]
+            offs = degree * corners[0] + np.rint(degree * (ref_lat @ edges)).astype(int)
+            geom_parts.append(lattice_ids(corners, 1, vshape))
+            dm_parts.append(lattice_ids(offs, degree, fshape))
+        geom = np.stack(geom_parts, axis=1).reshape(-1, gdim + 1)        # box-major, permutation inside
+        dm = np.stack(dm_parts, axis=1).reshape(-1, ref_lat.shape[0])
+        # (half of the Kuhn simplices have det J < 0, as DOLFINx meshes may: the push-forward does not care)
+    x = vx.reshape(-1, gdim)
+    fe = LagrangeElement(cell, degree)
+    geo = LagrangeElement(cell, 1)
+    points, _ = quadrature_degree2(cell)
+    phi, dphi = fe.tabulate(points)
+    _, dpsi = geo.tabulate(points)
+    # physical position of field nodes: image of the reference nodes under each cell's map (shared nodes agree)
+    psi_nodes, _ = geo.tabulate(fe.nodes)
+    node_x = np.zeros((int(np.prod(fshape)), gdim))
+    node_x[dm.reshape(-1)] = np.einsum("av,cvj->caj", psi_nodes, x[geom]).reshape(-1, gdim)
+    return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi)

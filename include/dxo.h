@@ -219,6 +219,51 @@ typedef struct dxo_isihara_params { double c1, c2, c3, c4; } dxo_isihara_params;
 int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, int mem,
                 const double* F, double* dP, double* P);
 
+/* ---- operand evaluation on the device ----------------------------------------
+ * Device counterpart of `fem.Expression(operand, points).eval(mesh, entities)` as evaluate_operands calls it
+ * (src/dolfinx_external_operator/external_operator.py:386-402) for operands that are linear in the value or the
+ * gradient of ONE Lagrange field (every operand of the reference's demos). The mesh/element description is
+ * uploaded once (dxo_mesh_create); each call gathers the field's dofs and writes (n_cells, nq, value_size)
+ * doubles in Expression.eval's C order.
+ *   dofmap       = V.dofmap.list            [num_cells][ndofs]  node indices (unblocked); field vector u is
+ *                                            blocked: u[node*bs + i], as fem.Function.x.array
+ *   geom_dofmap  = mesh.geometry.dofmap     [num_cells][ngeom]
+ *   x            = mesh.geometry.x          [num_geom_nodes][x_stride]  (DOLFINx: x_stride = 3), first gdim used
+ *   phi, dphi    = V.element.basix_element.tabulate(1, points): values [nq][ndofs], reference gradients
+ *                  [nq][ndofs][gdim]; dpsi = the coordinate element's reference gradients [nq][ngeom][gdim]
+ * Cells are not assumed affine: J is rebuilt at every point from dpsi. */
+enum {
+    DXO_OPERAND_VALUE = 0,       /* u                       value_size = bs                         (heat: T)        */
+    DXO_OPERAND_GRAD = 1,        /* grad u, [i][j]=du_i/dx_j value_size = bs*gdim                    (heat: grad T)   */
+    DXO_OPERAND_EPS_MANDEL = 2,  /* [g00,g11,0,r(g01+g10)] (2-D, demo_plasticity_von_mises.py:225-227),
+                                    [g00,g11,g22,r(g01+g10),r(g02+g20),r(g12+g21)] (3-D), r = sqrt(2)/2; bs = gdim   */
+    DXO_OPERAND_DEFGRAD = 3      /* I + grad u, row-major   value_size = gdim*gdim (demo_hyperelasticity.py:479)      */
+};
+typedef struct dxo_mesh_desc {
+    int32_t gdim;               /* 2 or 3 (= topological dimension) */
+    int32_t nq;                 /* quadrature points per cell, <= 64 */
+    int32_t ndofs;              /* scalar basis functions per cell of the field's element */
+    int32_t ngeom;              /* basis functions per cell of the coordinate element */
+    int32_t x_stride;           /* doubles per node in x (0 = gdim) */
+    int32_t _pad;
+    int64_t num_cells, num_field_nodes, num_geom_nodes;
+    const double* phi;
+    const double* dphi;
+    const double* dpsi;
+    const int32_t* dofmap;
+    const int32_t* geom_dofmap;
+    const double* x;
+} dxo_mesh_desc;
+typedef struct dxo_mesh dxo_mesh;
+int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* desc, dxo_mesh** out);   /* host pointers; copies everything */
+int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* mesh);
+/* value_size of an operand, or a negative error code if (gdim, bs, kind) is unsupported */
+int dxo_operand_value_size(int gdim, int bs, int kind);
+/* u: field vector (num_field_nodes*bs doubles); cells: entity list or NULL for cells [0, n_cells) (n_cells < 0: all);
+ * out: n_cells*nq*value_size doubles. mem applies to u, cells and out alike. */
+int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, const double* u,
+                     const int32_t* cells, int64_t n_cells, double* out);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

@@ -1,0 +1,186 @@
+"""Operand evaluation at quadrature points: synthetic tables, the NumPy oracle against known
+answers (polynomial fields are represented exactly, so their analytic gradients are the expected output), and the
+HIP kernel (through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from dolfinx_external_operator_amd.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
+from oracle.operand_oracle import DEFGRAD, EPS_MANDEL, GRAD, VALUE, eval_operand
+
+CELLS = {"triangle": (5, 4), "quadrilateral": (4, 3), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 2)}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD}
+
+
+def poly_field(gdim, bs, degree, seed):
+    """u_i(x) = a_i + b_i.x + x^T Q_i x (Q = 0 for degree 1) and its gradient."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a, b = rng.normal(size=bs), rng.normal(size=(bs, gdim))
+    Q = rng.normal(size=(bs, gdim, gdim)) * (degree >= 2)
+    Q = 0.5 * (Q + Q.transpose(0, 2, 1))
+
+    def u(x):
+        return a + x @ b.T + np.einsum("...j,ijk,...k->...i", x, Q, x)
+
+    def grad(x):
+        return b + 2.0 * np.einsum("ijk,...k->...ij", Q, x)
+
+    return u, grad
+
+
+def expected(kind, g, val):
+    gdim = g.shape[-1]
+    r = np.sqrt(2.0) * 0.5
+    if kind == "value":
+        return val
+    if kind == "grad":
+        return g.reshape(*g.shape[:2], -1)
+    if kind == "F":
+        return (g + np.eye(gdim)).reshape(*g.shape[:2], -1)
+    if gdim == 2:
+        return np.stack([g[..., 0, 0], g[..., 1, 1], 0 * g[..., 0, 0], r * (g[..., 0, 1] + g[..., 1, 0])], axis=-1)
+    return np.stack([g[..., 0, 0], g[..., 1, 1], g[..., 2, 2], r * (g[..., 0, 1] + g[..., 1, 0]),
+                     r * (g[..., 0, 2] + g[..., 2, 0]), r * (g[..., 1, 2] + g[..., 2, 1])], axis=-1)
+
+
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_lagrange_tables(cell, degree):
+    fe = LagrangeElement(cell, degree)
+    phi, dphi = fe.tabulate(fe.nodes)
+    assert np.allclose(phi, np.eye(phi.shape[0]), atol=1e-12)            # nodal basis
+    pts, w = quadrature_degree2(cell)
+    phi, dphi = fe.tabulate(pts)
+    assert np.allclose(phi.sum(axis=1), 1.0, atol=1e-13) and np.allclose(dphi.sum(axis=1), 0.0, atol=1e-12)
+    vol = {"triangle": 0.5, "quadrilateral": 1.0, "tetrahedron": 1 / 6, "hexahedron": 1.0}[cell]
+    assert np.isclose(w.sum(), vol)
+    # the rule integrates x_0^2 exactly (degree 2)
+    exact = {"triangle": 1 / 12, "quadrilateral": 1 / 3, "tetrahedron": 1 / 60, "hexahedron": 1 / 3}[cell]
+    assert np.isclose((w * pts[:, 0] ** 2).sum(), exact)
+
+
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_oracle_known_answers_on_distorted_meshes(cell, degree):
+    m = structured_mesh(cell, CELLS[cell], degree, distort=0.25, seed=3)
+    xq = m.physical_points()
+    for bs in (1, m.gdim):
+        u, grad = poly_field(m.gdim, bs, degree, seed=bs)
+        uvec = u(m.node_x).reshape(-1)                                     # nodal interpolation is exact
+        for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+            got = eval_operand(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+            want = expected(kind, grad(xq), u(xq))
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
+    cells = np.array([m.num_cells - 1, 0, 2], dtype=np.int32)
+    sub = eval_operand(GRAD, 1, u(m.node_x)[:, 0], m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, cells)
+    full = eval_operand(GRAD, 1, u(m.node_x)[:, 0], m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+    assert np.array_equal(sub, full[cells])
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_hip_matches_oracle_and_known_answers(ctx, cell, degree):
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh(cell, CELLS[cell], degree, distort=0.25, seed=4)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    xq = m.physical_points()
+    rng = np.random.Generator(np.random.PCG64(8))
+    try:
+        for bs in (1, m.gdim):
+            u, grad = poly_field(m.gdim, bs, degree, seed=10 + bs)
+            uvec = u(m.node_x).reshape(-1)
+            rough = rng.normal(size=uvec.size)                             # not a polynomial: oracle comparison only
+            for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+                got = dm.evaluate(kind, bs, uvec)
+                want = expected(kind, grad(xq), u(xq))
+                assert got.shape == want.shape
+                assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
+                ref = eval_operand(KIND_ID[kind], bs, rough, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+                got = dm.evaluate(kind, bs, rough)
+                assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (cell, degree, bs, kind)
+        # entity subsets (evaluate_operands' `entities`, external_operator.py:365-371, :402), incl. repeats and 1 cell
+        for cells in (np.array([m.num_cells - 1, 0, 2, 2], dtype=np.int32), np.array([1], dtype=np.int32),
+                      np.arange(m.num_cells - 1, -1, -1, dtype=np.int32)):
+            got = dm.evaluate("grad", 1, rough[: m.node_x.shape[0]], cells)
+            ref = eval_operand(GRAD, 1, rough[: m.node_x.shape[0]], m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, cells)
+            assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert dm.evaluate("value", 1, rough[: m.node_x.shape[0]], np.empty(0, dtype=np.int32)).shape == (0, m.nq, 1)
+    finally:
+        dm.close()
+
+
+@pytest.mark.gpu
+def test_argument_checks(ctx):
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh("triangle", (2, 2), 2)
+    bad = m.dofmap.copy()
+    bad[1, 2] = m.node_x.shape[0]
+    with pytest.raises(ValueError):
+        DeviceMesh(gdim=2, phi=m.phi, dphi=m.dphi, dpsi=m.dpsi, dofmap=bad, geom_dofmap=m.geom_dofmap, x=m.x,
+                   num_field_nodes=m.node_x.shape[0], ctx=ctx)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        with pytest.raises(ValueError):
+            dm.evaluate("eps", 2, np.zeros(5))                       # wrong field size
+        with pytest.raises(ValueError):
+            dm.evaluate("eps", 1, np.zeros(m.node_x.shape[0]))       # eps of a scalar field
+        with pytest.raises(ValueError):
+            dm.evaluate("grad", 1, np.zeros(m.node_x.shape[0]), np.array([m.num_cells], dtype=np.int32))
+    finally:
+        dm.close()
+
+
+@pytest.mark.gpu
+def test_padded_dolfinx_style_coordinates(ctx):
+    """DOLFINx stores geometry.x with 3 columns also in 2-D: x_stride = 3."""
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh("triangle", (3, 3), 2, distort=0.2, seed=1)
+    x3 = np.zeros((m.x.shape[0], 3))
+    x3[:, :2] = m.x
+    dm = DeviceMesh(gdim=2, phi=m.phi, dphi=m.dphi, dpsi=m.dpsi, dofmap=m.dofmap, geom_dofmap=m.geom_dofmap, x=x3,
+                    num_field_nodes=m.node_x.shape[0], ctx=ctx)
+    try:
+        u, grad = poly_field(2, 2, 2, seed=0)
+        got = dm.evaluate("eps", 2, u(m.node_x).reshape(-1))
+        assert np.abs(got - expected("eps", grad(m.physical_points()), None)).max() <= 5e-12
+    finally:
+        dm.close()
+
+
+@pytest.mark.gpu
+def test_operand_feeds_the_von_mises_operator_like_the_reference_loop(ctx, oracle):
+    """The demo's sequence (demo_plasticity_von_mises.py:445-456) with the operand evaluated on the device:
+    evaluate_operands -> evaluate_external_operators, against operand oracle -> von Mises oracle."""
+    from dolfinx_external_operator_amd import (DeviceMesh, QuadratureExternalOperator, evaluate_external_operators,
+                                               evaluate_operands, make_von_mises)
+
+    m = structured_mesh("triangle", (12, 9), 2, distort=0.2, seed=5)
+    rng = np.random.Generator(np.random.PCG64(2))
+    Du = rng.normal(0.0, 1e-4, size=m.node_x.shape[0] * 2)
+    n = m.num_cells * m.nq
+    sigma_n, p = rng.normal(0.0, 50.0, (n, 4)), np.abs(rng.normal(0.0, 1e-3, n))
+    sigma_n[:, 2] = 0.3 * (sigma_n[:, 0] + sigma_n[:, 1])
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        holder = {"Du": Du}
+        deps = dm.operand("eps", lambda: holder["Du"])
+        op = QuadratureExternalOperator(deps, num_cells=m.num_cells, num_points=m.nq, value_shape=(4, 4),
+                                        external_function=make_von_mises(sigma_n, p, ctx=ctx), derivatives=(1,))
+        ev = evaluate_operands([op])
+        assert ev[deps].shape == (m.num_cells, m.nq, 4) and deps.eval_count == 1
+        ((C_tang, sigma, dp),) = evaluate_external_operators([op], ev)
+        e_ref = eval_operand(EPS_MANDEL, 2, Du, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+        C_o, s_o, dp_o = oracle.von_mises(e_ref.reshape(-1, 4), sigma_n, p)
+        assert 0.05 < (dp_o > 0).mean() < 0.95
+        assert np.abs(sigma.reshape(-1, 4) - s_o).max() <= 1e-12 * np.abs(s_o).max()
+        assert np.abs(C_tang.reshape(-1, 4, 4) - C_o).max() <= 1e-12 * np.abs(C_o).max()
+        assert np.array_equal(op.ref_coefficient.x.array, C_tang)
+        holder["Du"] = 2.0 * Du                                     # the field changed: the operand must follow
+        assert np.abs(deps.eval(None) - 2.0 * e_ref).max() <= 1e-13 * np.abs(e_ref).max() * 2
+    finally:
+        dm.close()
