@@ -85,8 +85,11 @@ typedef int (*dxo_chunk_launch)(dxo_ctx* ctx, void* user, int64_t n_chunk, void*
 
 // H2D -> kernel -> D2H, chunked over points and rotated over DXO_HOST_SLOTS streams so copies
 // of one chunk overlap the kernel of another. Blocks until every output byte is on the host.
+// `n` counts units of `points_per_unit` quadrature points (1: points; nq: cells — bytes_pp is then per cell); the
+// chunk size option host_chunk_points stays in points.
 int dxo_run_host_pipeline(dxo_ctx* ctx, int64_t n, const std::vector<dxo_span>& inputs,
-                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user);
+                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
+                          int64_t points_per_unit = 1);
 
 // Device-path bracket: optional event timing around a launch sequence.
 int dxo_device_begin(dxo_ctx* ctx, hipStream_t s);

@@ -228,12 +228,14 @@ int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {
 }
 
 int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& inputs,
-                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user) {
+                          const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
+                          int64_t points_per_unit) {
     DXO_HIP(c, hipSetDevice(c->device));
     c->last = {0, 0, 0, 0};
     c->ev_pending = false;
     if (n == 0) return DXO_OK;
-    int64_t chunk = c->host_chunk_points;
+    int64_t chunk = c->host_chunk_points / (points_per_unit > 0 ? points_per_unit : 1);
+    if (chunk < DXO_WAVE) chunk = DXO_WAVE;
     if (chunk > n) chunk = n;
     if (chunk < n) chunk = chunk / DXO_WAVE * DXO_WAVE;  // interior chunk borders on whole wave tiles
     // slot layout: every span starts on a 256-byte border

@@ -1,0 +1,134 @@
+// vm_core.h — device code of the von Mises kernels shared between translation units (von_mises.hip, vm_field.hip).
+// Reference: doc/demo/demo_plasticity_von_mises.py:185-204 (constants), :307-326 (per-point `_kernel`).
+#pragma once
+
+#include "dxo_common.h"
+
+namespace {
+
+struct VmConst {
+    double lmbda, mu2, mu3;   // lambda, 2 mu, 3 mu
+    double sigma_0, H;
+    double mu3_H;             // 3 mu + H
+    double ratio;             // 3 mu / (3 mu + H)
+};
+
+VmConst make_const(const dxo_vm_params& p) {
+    VmConst c;
+    // demo_plasticity_von_mises.py:190-191
+    c.lmbda = p.E * p.nu / (1.0 + p.nu) / (1.0 - 2.0 * p.nu);
+    const double mu = p.E / 2.0 / (1.0 + p.nu);
+    c.mu2 = 2.0 * mu;
+    c.mu3 = 3 * mu;
+    c.sigma_0 = p.sigma_0;
+    c.H = p.H;
+    c.mu3_H = 3 * mu + p.H;
+    c.ratio = 3 * mu / (3 * mu + p.H);
+    return c;
+}
+
+// Per-point radial return. Outputs: sigma[D], dp, direction n[D], and the two scalars of the
+// tangent C_tang = C_elas - a n(x)n - b dev  (a = 3mu(3mu/(3mu+H) - beta), b = 2 mu beta).
+template <int D>
+__device__ __forceinline__ void vm_return_map(const VmConst& c, const double (&deps)[D], const double (&sn)[D],
+                                              double p, double (&sig)[D], double& dp, double (&nrm)[D],
+                                              double& a, double& b) {
+    // sigma_elastic = sigma_n + C_elas @ deps  (:309); C_elas = lmbda * 1(x)1 + 2 mu I on the Mandel vector
+    const double tr_e = deps[0] + deps[1] + deps[2];
+    double se[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) se[i] = sn[i] + ((i < 3 ? c.lmbda * tr_e : 0.0) + c.mu2 * deps[i]);
+    // s = deviatoric @ sigma_elastic (:310)
+    const double mean = (se[0] + se[1] + se[2]) * (1.0 / 3.0);
+    double s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = i < 3 ? se[i] - mean : se[i];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ss += s[i] * s[i];
+    const double sigma_eq = sqrt(3.0 / 2.0 * ss);                 // :311
+    const double f_el = sigma_eq - c.sigma_0 - c.H * p;          // :313
+    const double f_plus = (f_el + sqrt(f_el * f_el)) / 2.0;      // :314
+    dp = f_plus / c.mu3_H;                                       // :316
+    // n_elas = s / sigma_eq * f_plus / f_el (:318); 0/0 -> NaN exactly as the reference
+    const double beta = c.mu3 * dp / sigma_eq;                   // :319
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        nrm[i] = s[i] / sigma_eq * f_plus / f_el;
+        sig[i] = se[i] - beta * s[i];                            // :321
+    }
+    a = c.mu3 * (c.ratio - beta);                                // :324
+    b = c.mu2 * beta;
+}
+
+// Entry (i, j) of C_elas and of `deviatoric` on the Mandel vector (:193-204).
+__device__ __forceinline__ double c_elas_ij(const VmConst& c, int i, int j) {
+    return ((i < 3 && j < 3) ? c.lmbda : 0.0) + (i == j ? c.mu2 : 0.0);
+}
+__device__ __forceinline__ double dev_ij(int i, int j) {
+    return (i == j ? 1.0 : 0.0) - ((i < 3 && j < 3) ? 1.0 / 3.0 : 0.0);
+}
+
+// ------------------------------------------------------------------ wave-tile helpers
+__device__ __forceinline__ void wave_lds_fence() {
+    // Orders this wave's LDS traffic for the compiler; the hardware already executes one wave's DS
+    // instructions in issue order, so no s_barrier and no cross-wave wait is involved.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool NT>
+__device__ __forceinline__ void store16(dxo_f64x2* ptr, dxo_f64x2 v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, ptr);
+    else
+        *ptr = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store8(double* ptr, double v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, ptr);
+    else
+        *ptr = v;
+}
+
+template <int D>
+struct VmTile {
+    static constexpr int PTS = DXO_WAVE;            // points per wave tile
+    static constexpr int CH_VEC = D / 2;            // 16-byte chunks per lane for one [PTS][D] block
+    static constexpr int CH_CT = D * D / 2;         // 16-byte chunks per point of C_tang = per lane per tile
+    static constexpr int ST = D + 2;                // LDS state doubles per point: n[D], a, b
+    static constexpr int X_DOUBLES = PTS * D;       // deps staging, later sigma staging
+    static constexpr int Y_DOUBLES = PTS * (D > ST ? D : ST);  // sigma_n staging, later state
+    static constexpr int WAVE_DOUBLES = X_DOUBLES + Y_DOUBLES;
+    static constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+};
+
+// Phase C of a wave tile: the 64 points' tangent state (n[D], a, b per point) sits in the wave's LDS slice Y;
+// lanes walk the tile's C_tang block in OUTPUT order (16-byte chunk q = it*64 + lane), so every store
+// instruction of the wave covers 1 KiB of consecutive addresses.
+template <int D, bool NT>
+__device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double* Y, dxo_f64x2* g_c, int nct, int lane) {
+    using T = VmTile<D>;
+    const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
+    // partial unroll: a full unroll lets the scheduler hoist all 3*CH_CT LDS reads and spill
+#pragma unroll T::CH_VEC
+    for (int it = 0; it < T::CH_CT; ++it) {
+        const int q = it * DXO_WAVE + lane;     // 16-byte chunk index inside the tile's C_tang block
+        const int pt = q / T::CH_CT;            // local point
+        const int k = q - pt * T::CH_CT;        // chunk inside the point's d x d block
+        const int i = k / T::CH_VEC;            // row
+        const int j0 = (k - i * T::CH_VEC) * 2; // first of two columns
+        const double n_i = Y[pt * T::ST + i];
+        const dxo_f64x2 n_j = Y2[pt * (T::ST / 2) + (j0 >> 1)];
+        const dxo_f64x2 ab = Y2[pt * (T::ST / 2) + T::CH_VEC];
+        dxo_f64x2 out;
+        out.x = c_elas_ij(c, i, j0) - ab.x * (n_i * n_j.x) - ab.y * dev_ij(i, j0);
+        out.y = c_elas_ij(c, i, j0 + 1) - ab.x * (n_i * n_j.y) - ab.y * dev_ij(i, j0 + 1);
+        if (q < nct) store16<NT>(g_c + q, out);
+    }
+}
+
+
+}  // namespace

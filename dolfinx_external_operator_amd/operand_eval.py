@@ -116,8 +116,18 @@ class DeviceMesh:
                                            C.c_void_p(out_ptr))
         self.ctx.check(rc, "dxo_eval_operand")
 
-    def operand(self, kind: str, field, bs: int | None = None, name: str | None = None) -> "DeviceOperand":
-        return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind)
+    def operand(self, kind: str, field, bs: int | None = None, name: str | None = None, lazy: bool = False) -> "DeviceOperand":
+        """lazy=True: `.eval()` over all cells returns a `LazyOperand` — an array-like that a fused consumer
+        (`make_von_mises`) evaluates inside its own launch and that turns into the ndarray on `np.asarray`."""
+        return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind, lazy)
+
+    def von_mises(self, prm, u, sigma_n, p, C_tang, sigma, dp, mem: int = MEM_HOST) -> None:
+        """dxo_von_mises_field: eps(u) + radial return + tangent in one launch (all cells of the mesh)."""
+        def ptr(a):
+            return a if isinstance(a, (int, np.integer)) or a is None else a.ctypes.data
+        rc = self.ctx.lib.dxo_von_mises_field(self.ctx._h, C.byref(prm), self._h, int(mem), *(C.c_void_p(ptr(a)) for a in
+                                              (u, sigma_n, p, C_tang, sigma, dp)))
+        self.ctx.check(rc, "dxo_von_mises_field")
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self.ctx._h:
@@ -136,12 +146,16 @@ class DeviceOperand:
     `Expression.eval` returns, (len(entities), nq, *shape); for "F" the trailing shape is (gdim, gdim) like the
     tensor operand of the hyperelasticity demo, for "grad" of a vector field (bs, gdim)."""
 
-    def __init__(self, mesh: DeviceMesh, kind: str, field, bs: int, name: str):
-        self.mesh, self.kind, self.field, self.bs, self.name = mesh, kind, field, bs, name
+    def __init__(self, mesh: DeviceMesh, kind: str, field, bs: int, name: str, lazy: bool = False):
+        self.mesh, self.kind, self.field, self.bs, self.name, self.lazy = mesh, kind, field, bs, name, lazy
         self.eval_count = 0
 
-    def eval(self, entities) -> np.ndarray:
+    def eval(self, entities):
         self.eval_count += 1
+        if self.lazy and (entities is None or (len(entities) == self.mesh.num_cells
+                                               and np.array_equal(entities, np.arange(self.mesh.num_cells)))):
+            u = np.array(_state(self.field), dtype=np.float64).reshape(-1)      # snapshot, like Expression.eval's result
+            return LazyOperand(self.mesh, self.kind, self.bs, u)
         out = self.mesh.evaluate(self.kind, self.bs, self.field, entities)
         g = self.mesh.gdim
         if self.kind == "F":
@@ -154,3 +168,31 @@ class DeviceOperand:
 
     def __repr__(self) -> str:
         return f"DeviceOperand({self.name})"
+
+
+class LazyOperand:
+    """The value of an operand over all cells, not yet computed: (mesh, kind, snapshot of the field vector).
+
+    `make_von_mises` recognises it and runs dxo_von_mises_field (operand + return map in one launch, the strain
+    never reaches memory). Anything else sees an array: `np.asarray(lazy)`, `.shape`, `.reshape` evaluate it once
+    with dxo_eval_operand."""
+
+    def __init__(self, mesh: DeviceMesh, kind: str, bs: int, u: np.ndarray):
+        self.mesh, self.kind, self.bs, self.u = mesh, kind, bs, u
+        self._value = None
+
+    @property
+    def shape(self):
+        return (self.mesh.num_cells, self.mesh.nq, self.mesh.value_size(self.kind, self.bs))
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    def __array__(self, dtype=None, copy=None):
+        if self._value is None:
+            self._value = self.mesh.evaluate(self.kind, self.bs, self.u)
+        return self._value if dtype is None else self._value.astype(dtype)
+
+    def reshape(self, *shape):
+        return np.asarray(self).reshape(*shape)

@@ -24,6 +24,7 @@ from typing import Callable
 
 import numpy as np
 
+from .operand_eval import LazyOperand
 from ._lib import MEM_DEVICE, MEM_HOST, Context, IsiharaParams, McParams, VmParams, default_context
 
 
@@ -105,6 +106,18 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         c = _ctx()
         if _is_device_tensor(deps):
             return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p))
+        if isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is c:
+            # operand still unevaluated: strain + return map + tangent in ONE launch (dxo_von_mises_field)
+            n, d = deps.shape[0] * deps.shape[1], deps.shape[2]
+            sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape(-1)
+            p_ = _as_f64_host(_state_array(p), "p").reshape(-1)
+            if sigma_n_.size != n * d or p_.size != n:
+                raise ValueError(f"state size mismatch: sigma_n {sigma_n_.size} (want {n * d}), p {p_.size} (want {n})")
+            out = holder["out"]
+            C_tang_, sigma_, dp_ = out.get("C_tang", n * d * d), out.get("sigma", n * d), out.get("dp", n)
+            deps.mesh.von_mises(prm, deps.u, sigma_n_, p_, C_tang_, sigma_, dp_)
+            return C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1)
+        deps = np.asarray(deps)
         num_cells, num_quadrature_points, d = deps.shape      # :344
         if d not in (4, 6):
             raise ValueError(f"von Mises kernel supports Mandel vectors of length 4 or 6, got {d}")

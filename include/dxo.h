@@ -264,6 +264,14 @@ int dxo_operand_value_size(int gdim, int bs, int kind);
 int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, const double* u,
                      const int32_t* cells, int64_t n_cells, double* out);
 
+/* Operand evaluation FUSED in front of the von Mises return map: one launch for the demo's
+ * evaluate_operands + evaluate_external_operators pair (demo_plasticity_von_mises.py:445-456) when the operand is
+ * eps(u) of a vector Lagrange field on `mesh` (gdim 2 -> d = 4, gdim 3 -> d = 6). u: num_field_nodes*gdim doubles;
+ * state and outputs cover ALL cells of the mesh in cell order: n = num_cells*nq points, same layout and meaning as
+ * dxo_von_mises. The strain increment is never written to memory. */
+int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
+                        const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

@@ -67,6 +67,44 @@ for cell, n, degree, kind, label in CASES:
                                "sample": f"first {nc} cells, oracle/operand_oracle.py (einsum push-forward)"}
         rec["max_abs_diff_vs_oracle_on_sample"] = float(np.abs(got - ref).max())
     print(json.dumps(rec), flush=True)
+    if kind == "eps":
+        # the demo's pair evaluate_operands + evaluate_external_operators (demo_plasticity_von_mises.py:445-456):
+        # two launches (operand, then dxo_von_mises reading it back) against the fused dxo_von_mises_field
+        from dolfinx_external_operator_amd import MEM_DEVICE, VmParams
+        E = 70e3
+        prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+        d = D
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        sig = torch.randn(npts * d, generator=g, device=dev, dtype=torch.float64) * 100
+        pp = (torch.randn(npts, generator=g, device=dev, dtype=torch.float64) * 1e-3).abs()
+        u.mul_(3.0)
+        Ct = torch.empty(npts * d * d, dtype=torch.float64, device=dev)
+        st = torch.empty(npts * d, dtype=torch.float64, device=dev)
+        dpt = torch.empty(npts, dtype=torch.float64, device=dev)
+
+        def two():
+            dm.evaluate_device(kind, bs, u.data_ptr(), m.num_cells, out.data_ptr())
+            ctx.von_mises(prm, d, npts, MEM_DEVICE, out.data_ptr(), sig.data_ptr(), pp.data_ptr(), Ct.data_ptr(), st.data_ptr(), dpt.data_ptr())
+
+        def fused():
+            dm.von_mises(prm, u.data_ptr(), sig.data_ptr(), pp.data_ptr(), Ct.data_ptr(), st.data_ptr(), dpt.data_ptr(), mem=MEM_DEVICE)
+
+        res = {}
+        for name, fn in (("two_launches", two), ("fused", fused)):
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launches)]
+            for a, b in ev:
+                a.record(stream); fn(); b.record(stream)
+            torch.cuda.synchronize()
+            res[name] = statistics.median(a.elapsed_time(b) for a, b in ev)
+        out_bytes = npts * (d * d + d + 1) * 8
+        in_bytes = npts * (d + 1) * 8 + u_h.nbytes + m.x.nbytes + m.dofmap.nbytes + m.geom_dofmap.nbytes
+        print(json.dumps({"case": "operand + von Mises: " + label, "points": npts, "d": d, "plastic_fraction": float((dpt > 0).double().mean()),
+                          "two_launches_ms": res["two_launches"], "fused_ms": res["fused"],
+                          "fused_qp_per_s": npts / res["fused"] * 1e3, "fused_bytes_per_qp": (in_bytes + out_bytes) / npts,
+                          "fused_GBps_algorithmic": (in_bytes + out_bytes) / res["fused"] / 1e6}), flush=True)
+        del sig, pp, Ct, st, dpt
     dm.close()
     del u, out
 ctx.close()

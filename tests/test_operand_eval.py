@@ -184,3 +184,92 @@ def test_operand_feeds_the_von_mises_operator_like_the_reference_loop(ctx, oracl
         assert np.abs(deps.eval(None) - 2.0 * e_ref).max() <= 1e-13 * np.abs(e_ref).max() * 2
     finally:
         dm.close()
+
+
+def _vm_state(n, d, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sigma_n, p = rng.normal(0.0, 50.0, (n, d)), np.abs(rng.normal(0.0, 1e-3, n))
+    return sigma_n, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,n,chunk", [("triangle", (7, 5), 0), ("triangle", (40, 33), 640), ("quadrilateral", (9, 4), 0),
+                                          ("tetrahedron", (3, 2, 2), 0), ("hexahedron", (5, 3, 3), 0),
+                                          ("hexahedron", (12, 10, 9), 2048)])
+def test_fused_operand_plus_von_mises(ctx, oracle, cell, n, chunk):
+    """dxo_von_mises_field == operand oracle -> von Mises oracle, host arrays (optionally through several pipeline
+    chunks whose borders fall inside wave groups) and device pointers."""
+    import torch
+
+    from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh, VmParams
+
+    E = 70e3
+    prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=9)
+    d = 4 if m.gdim == 2 else 6
+    npts = m.num_cells * m.nq
+    rng = np.random.Generator(np.random.PCG64(4))
+    u = rng.normal(size=m.node_x.shape[0] * m.gdim)
+    u *= 1.5e-3 / eval_operand(EPS_MANDEL, m.gdim, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi).std()
+    sigma_n, p = _vm_state(npts, d, seed=1)
+    e_ref = eval_operand(EPS_MANDEL, m.gdim, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+    C_o, s_o, dp_o = oracle.von_mises(e_ref.reshape(-1, d), sigma_n, p)
+    assert 0.05 < (dp_o > 0).mean() < 0.98
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    old_chunk = ctx.get_option("host_chunk_points")
+    try:
+        if chunk:
+            ctx.set_option("host_chunk_points", chunk)
+        C, s, dp = np.full(npts * d * d + 4, -7.0), np.full(npts * d + 4, -7.0), np.full(npts + 4, -7.0)
+        dm.von_mises(prm, u, sigma_n, p, C, s, dp)
+        assert np.all(C[npts * d * d:] == -7.0) and np.all(s[npts * d:] == -7.0) and np.all(dp[npts:] == -7.0)
+        tol = 1e-12
+        assert np.abs(s[: npts * d].reshape(-1, d) - s_o).max() <= tol * np.abs(s_o).max()
+        assert np.abs(dp[:npts] - dp_o).max() <= tol * max(np.abs(dp_o).max(), 1e-300)
+        assert np.abs(C[: npts * d * d].reshape(-1, d, d) - C_o).max() <= tol * np.abs(C_o).max()
+        ctx.set_option("host_chunk_points", old_chunk)
+        t = [torch.from_numpy(a).cuda() for a in (u, sigma_n.reshape(-1), p)]
+        Ct = torch.empty(npts * d * d, dtype=torch.float64, device="cuda")
+        st = torch.empty(npts * d, dtype=torch.float64, device="cuda")
+        dpt = torch.empty(npts, dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dm.von_mises(prm, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), Ct.data_ptr(), st.data_ptr(), dpt.data_ptr(),
+                     mem=MEM_DEVICE)
+        torch.cuda.synchronize()
+        assert np.array_equal(Ct.cpu().numpy(), C[: npts * d * d]) and np.array_equal(st.cpu().numpy(), s[: npts * d])
+        assert np.array_equal(dpt.cpu().numpy(), dp[:npts])
+    finally:
+        ctx.set_option("host_chunk_points", old_chunk)
+        dm.close()
+
+
+@pytest.mark.gpu
+def test_lazy_operand_takes_the_fused_path_inside_the_reference_call_sequence(ctx, oracle):
+    from dolfinx_external_operator_amd import (DeviceMesh, LazyOperand, QuadratureExternalOperator,
+                                               evaluate_external_operators, evaluate_operands, make_von_mises)
+
+    m = structured_mesh("triangle", (12, 9), 2, distort=0.2, seed=5)
+    rng = np.random.Generator(np.random.PCG64(2))
+    Du = rng.normal(0.0, 1e-4, size=m.node_x.shape[0] * 2)
+    npts = m.num_cells * m.nq
+    sigma_n, p = _vm_state(npts, 4, seed=3)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        deps = dm.operand("eps", Du, lazy=True)
+        op = QuadratureExternalOperator(deps, num_cells=m.num_cells, num_points=m.nq, value_shape=(4, 4),
+                                        external_function=make_von_mises(sigma_n, p, ctx=ctx), derivatives=(1,))
+        ev = evaluate_operands([op])
+        assert isinstance(ev[deps], LazyOperand) and ev[deps].shape == (m.num_cells, m.nq, 4)
+        ((C_tang, sigma, dp),) = evaluate_external_operators([op], ev)
+        assert ev[deps]._value is None                                   # the strain array was never materialised
+        e_ref = eval_operand(EPS_MANDEL, 2, Du, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+        C_o, s_o, dp_o = oracle.von_mises(e_ref.reshape(-1, 4), sigma_n, p)
+        assert np.abs(C_tang.reshape(-1, 4, 4) - C_o).max() <= 1e-12 * np.abs(C_o).max()
+        assert np.abs(sigma.reshape(-1, 4) - s_o).max() <= 1e-12 * np.abs(s_o).max()
+        assert np.array_equal(op.ref_coefficient.x.array, C_tang)
+        # any other consumer sees an ordinary array
+        assert np.abs(np.asarray(ev[deps]) - e_ref).max() <= 1e-13 * np.abs(e_ref).max()
+        sub = deps.eval(np.array([3, 1], dtype=np.int32))               # entity subsets are evaluated eagerly
+        assert isinstance(sub, np.ndarray) and np.abs(sub - e_ref[[3, 1]]).max() <= 1e-13 * np.abs(e_ref).max()
+    finally:
+        dm.close()
