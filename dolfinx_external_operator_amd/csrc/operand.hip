@@ -28,21 +28,21 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval(OperandDev m, const do
     constexpr int D = OperandShape<G, BS, KIND>::D;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
-    for (int i = threadIdx.x; i < m.nq * m.ndofs; i += blockDim.x) tab[i] = m.phi[i];
-    for (int i = threadIdx.x; i < m.nq * m.ndofs * G; i += blockDim.x) tab[m.nq * m.ndofs + i] = m.dphi[i];
-    for (int i = threadIdx.x; i < m.nq * m.ngeom * G; i += blockDim.x) tab[m.nq * m.ndofs * (1 + G) + i] = m.dpsi[i];
+    operand_load_tables<G>(m, tab);
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     double* W = lds + m.table_doubles + wave * m.wave_doubles;
     const int cpw = m.cells_per_wave;
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
-    const int64_t stride = (int64_t)gridDim.x * (DXO_BLOCK / DXO_WAVE);
-    for (int64_t grp = (int64_t)blockIdx.x * (DXO_BLOCK / DXO_WAVE) + wave; grp < n_groups; grp += stride) {
-        const int64_t c0 = grp * cpw;
-        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
-        double o[D];
-        const bool active = operand_point<G, BS, KIND>(m, tab, W, u, cells, c0, ncell, lane, o);
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    auto store_points = [&](int64_t c0, int ncell, bool active, const double (&o)[D]) {
         // output-ordered store: the wave's ncell*nq points are consecutive in `out`
         if (active) {
 #pragma unroll
@@ -53,6 +53,30 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval(OperandDev m, const do
         double* g_o = out + c0 * m.nq * D;
         for (int idx = lane; idx < nval; idx += DXO_WAVE) __builtin_nontemporal_store(W[idx], g_o + idx);
         op_fence();
+    };
+    int64_t grp = walk.first;
+    if (cells == nullptr && operand_can_pipe(m)) {
+        OperandPipe<G, BS> pf;
+        pipe_load_indices<G, BS>(m, pf, grp * cpw, cells_in(grp), lane);
+        pipe_load_values<G, BS>(m, pf, u);
+        pipe_load_indices<G, BS>(m, pf, (grp + stride) * cpw, cells_in(grp + stride), lane);
+        for (; grp < walk.end; grp += stride) {
+            const int ncell = cells_in(grp);
+            pipe_commit<G, BS>(m, pf, W, ncell, lane);                       // group g: registers -> LDS
+            pipe_load_values<G, BS>(m, pf, u);                               // group g+1 in flight during the compute
+            pipe_load_indices<G, BS>(m, pf, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+            double o[D];
+            const bool active = operand_compute<G, BS, KIND>(m, tab, W, ncell, lane, o);
+            store_points(grp * cpw, ncell, active, o);
+        }
+        return;
+    }
+    for (; grp < walk.end; grp += stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = cells_in(grp);
+        double o[D];
+        const bool active = operand_point<G, BS, KIND>(m, tab, W, u, cells, c0, ncell, lane, o);
+        store_points(c0, ncell, active, o);
     }
 }
 
@@ -68,6 +92,7 @@ void launch_operand(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, cons
     int64_t blocks = (n_groups + 3) / 4;
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const size_t shm = (size_t)(m->dev.table_doubles + 4 * m->dev.wave_doubles) * sizeof(double);
     hipLaunchKernelGGL((operand_eval<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, m->dev, u, cells, n_cells, out);
 }
@@ -137,10 +162,10 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     v.nq = d->nq; v.ndofs = d->ndofs; v.ngeom = d->ngeom;
     v.cells_per_wave = DXO_WAVE / d->nq;
     const int maxbs = G, maxD = G * G;
-    int wd = v.cells_per_wave * (d->ndofs * maxbs + d->ngeom * G);
+    int wd = v.cells_per_wave * (op_odd(d->ndofs * maxbs) + op_odd(d->ngeom * G));
     if (wd < DXO_WAVE * maxD) wd = DXO_WAVE * maxD;
     v.wave_doubles = (wd + 1) & ~1;
-    v.table_doubles = (d->nq * d->ndofs * (1 + G) + d->nq * d->ngeom * G + 1) & ~1;
+    v.table_doubles = (d->nq * (op_odd(d->ndofs) + op_odd(d->ndofs * G) + op_odd(d->ngeom * G)) + 1) & ~1;
     if ((size_t)(v.table_doubles + 4 * v.wave_doubles) * sizeof(double) > 64 * 1024) {
         delete m;
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_mesh_create: element too large for the 64 KiB LDS budget of the operand kernel");

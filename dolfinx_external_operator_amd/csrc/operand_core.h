@@ -86,48 +86,182 @@ __device__ __forceinline__ void shape_operand(const double (&val)[BS], const dou
     }
 }
 
-// One wave-group of cells: gather -> per-lane gradient -> `o` (D values of this lane's point). Returns false for
-// lanes without a point. Shared by the standalone kernel below and by kernels that consume the operand in place.
-template <int G, int BS, int KIND>
-__device__ __forceinline__ bool operand_point(const OperandDev& m, const double* tab, double* W,
-                                              const double* __restrict__ u, const int32_t* __restrict__ cells,
-                                              int64_t c0, int ncell, int lane,
-                                              double (&o)[OperandShape<G, BS, KIND>::D]) {
+// ---- LDS layout. Lanes of one wave read, in the same instruction, the SAME slot of up to 64/nq different cells
+// (U, X) or of nq different points (tables): a per-cell / per-point stride that is an ODD number of doubles sends
+// those addresses to different banks (an even stride such as 24 doubles = 48 dwords collides 4-way on 32 banks).
+__device__ __host__ __forceinline__ int op_odd(int n) { return n | 1; }
+
+template <int G>
+struct OperandLayout {
+    int sphi, sdphi, sdpsi;     // per-point strides of the three tables
+    int o_dphi, o_dpsi;         // table offsets
+    int sx;                     // per-cell stride of the coordinates
+    __device__ __host__ OperandLayout(const OperandDev& m)
+        : sphi(op_odd(m.ndofs)), sdphi(op_odd(m.ndofs * G)), sdpsi(op_odd(m.ngeom * G)),
+          o_dphi(m.nq * op_odd(m.ndofs)), o_dpsi(m.nq * (op_odd(m.ndofs) + op_odd(m.ndofs * G))), sx(op_odd(m.ngeom * G)) {}
+};
+
+// tables -> LDS in the padded layout (whole workgroup, followed by __syncthreads() in the caller)
+template <int G>
+__device__ __forceinline__ void operand_load_tables(const OperandDev& m, double* tab) {
+    const OperandLayout<G> L(m);
+    for (int i = threadIdx.x; i < m.nq * m.ndofs; i += blockDim.x) {
+        const int q = i / m.ndofs;
+        tab[q * L.sphi + (i - q * m.ndofs)] = m.phi[i];
+    }
+    for (int i = threadIdx.x; i < m.nq * m.ndofs * G; i += blockDim.x) {
+        const int q = i / (m.ndofs * G);
+        tab[L.o_dphi + q * L.sdphi + (i - q * m.ndofs * G)] = m.dphi[i];
+    }
+    for (int i = threadIdx.x; i < m.nq * m.ngeom * G; i += blockDim.x) {
+        const int q = i / (m.ngeom * G);
+        tab[L.o_dpsi + q * L.sdpsi + (i - q * m.ngeom * G)] = m.dpsi[i];
+    }
+}
+
+// ---- which wave-groups a wave walks. Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has
+// its own L2, while a mesh node is gathered by every cell that touches it (3.4 times on average for Q2 hexahedra). So
+// each XCD gets ONE contiguous eighth of the groups (a slab of the mesh) and its workgroups sweep that slab together:
+// the re-reads of shared nodes then hit the XCD's L2 instead of crossing to another XCD's or to HBM.
+struct GroupWalk {
+    int64_t first, end, stride;
+};
+__device__ __forceinline__ GroupWalk xcd_group_walk(int64_t n_groups, int waves_per_block, int wave) {
+    constexpr int XCDS = 8;
+    if (gridDim.x % XCDS != 0) return {(int64_t)blockIdx.x * waves_per_block + wave, n_groups, (int64_t)gridDim.x * waves_per_block};
+    const int xcd = blockIdx.x % XCDS, local = blockIdx.x / XCDS, per_xcd = gridDim.x / XCDS;
+    const int64_t begin = n_groups * xcd / XCDS, end = n_groups * (xcd + 1) / XCDS;
+    return {begin + (int64_t)local * waves_per_block + wave, end, (int64_t)per_xcd * waves_per_block};
+}
+
+// ---- gather of one wave-group's dofs and vertex coordinates into the wave's LDS buffer W
+template <int G, int BS>
+__device__ __forceinline__ void operand_gather(const OperandDev& m, double* W, const double* __restrict__ u,
+                                               const int32_t* __restrict__ cells, int64_t c0, int ncell, int lane) {
     const int nd = m.ndofs, ng = m.ngeom;
-    double* U = W;                                   // [ncell][nd][BS]
-    double* X = W + m.cells_per_wave * nd * BS;      // [ncell][ng][G]
-    // ---- cooperative gather
+    const int su = op_odd(nd * BS), sx = op_odd(ng * G);
+    double* U = W;                                   // [ncell] x su : [nd][BS]
+    double* X = W + m.cells_per_wave * su;           // [ncell] x sx : [ng][G]
     for (int idx = lane; idx < ncell * nd; idx += DXO_WAVE) {
         const int c = idx / nd, a = idx - c * nd;
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
         const int64_t node = m.dofmap[cell * nd + a];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) U[idx * BS + i] = u[node * BS + i];
+        for (int i = 0; i < BS; ++i) U[c * su + a * BS + i] = u[node * BS + i];
     }
     for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
         const int c = idx / ng, v = idx - c * ng;
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
         const int64_t node = m.geom_dofmap[cell * ng + v];
 #pragma unroll
-        for (int j = 0; j < G; ++j) X[idx * G + j] = m.x[node * G + j];
+        for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = m.x[node * G + j];
     }
+}
+
+// ---- the same gather as a two-deep register pipeline (entity list absent, at most OP_GI*64 dof slots and
+// OP_XI*64 vertex slots per wave-group). While group g is being computed from LDS, the values of group g+1 are in
+// flight into `ud/xd` and the node indices of group g+2 into `un/xn`, so neither the dofmap -> u dependency nor the
+// HBM/L2 latency of the scattered 8-byte loads is exposed inside a wave.
+constexpr int OP_GI = 4, OP_XI = 2;
+
+template <int G, int BS>
+struct OperandPipe {
+    int32_t un[OP_GI], xn[OP_XI];
+    double ud[OP_GI][BS], xd[OP_XI][G];
+};
+
+__device__ __forceinline__ bool operand_can_pipe(const OperandDev& m) {
+    return m.cells_per_wave * m.ndofs <= OP_GI * DXO_WAVE && m.cells_per_wave * m.ngeom <= OP_XI * DXO_WAVE;
+}
+
+template <int G, int BS>
+__device__ __forceinline__ void pipe_load_indices(const OperandDev& m, OperandPipe<G, BS>& pf, int64_t c0, int ncell, int lane) {
+    const int nd = m.ndofs, ng = m.ngeom;
+#pragma unroll
+    for (int it = 0; it < OP_GI; ++it) {
+        const int idx = it * DXO_WAVE + lane;
+        pf.un[it] = -1;
+        if (idx < ncell * nd) pf.un[it] = m.dofmap[c0 * nd + idx];          // cells are consecutive: one flat slice
+    }
+#pragma unroll
+    for (int it = 0; it < OP_XI; ++it) {
+        const int idx = it * DXO_WAVE + lane;
+        pf.xn[it] = -1;
+        if (idx < ncell * ng) pf.xn[it] = m.geom_dofmap[c0 * ng + idx];
+    }
+}
+
+template <int G, int BS>
+__device__ __forceinline__ void pipe_load_values(const OperandDev& m, OperandPipe<G, BS>& pf, const double* __restrict__ u) {
+#pragma unroll
+    for (int it = 0; it < OP_GI; ++it)
+        if (pf.un[it] >= 0) {
+#pragma unroll
+            for (int i = 0; i < BS; ++i) pf.ud[it][i] = u[(int64_t)pf.un[it] * BS + i];
+        }
+#pragma unroll
+    for (int it = 0; it < OP_XI; ++it)
+        if (pf.xn[it] >= 0) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) pf.xd[it][j] = m.x[(int64_t)pf.xn[it] * G + j];
+        }
+}
+
+template <int G, int BS>
+__device__ __forceinline__ void pipe_commit(const OperandDev& m, const OperandPipe<G, BS>& pf, double* W, int ncell, int lane) {
+    const int nd = m.ndofs, ng = m.ngeom;
+    const int su = op_odd(nd * BS), sx = op_odd(ng * G);
+    double* U = W;
+    double* X = W + m.cells_per_wave * su;
+#pragma unroll
+    for (int it = 0; it < OP_GI; ++it) {
+        const int idx = it * DXO_WAVE + lane;
+        if (idx < ncell * nd) {
+            const int c = idx / nd, a = idx - c * nd;
+#pragma unroll
+            for (int i = 0; i < BS; ++i) U[c * su + a * BS + i] = pf.ud[it][i];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < OP_XI; ++it) {
+        const int idx = it * DXO_WAVE + lane;
+        if (idx < ncell * ng) {
+            const int c = idx / ng, v = idx - c * ng;
+#pragma unroll
+            for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = pf.xd[it][j];
+        }
+    }
+}
+
+// ---- per-lane gradient from the gathered data -> `o` (D values of this lane's point). Returns false for lanes
+// without a point. Shared by the standalone kernel and by kernels that consume the operand in place.
+template <int G, int BS, int KIND>
+__device__ __forceinline__ bool operand_compute(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
+                                                double (&o)[OperandShape<G, BS, KIND>::D]) {
+    const int nd = m.ndofs, ng = m.ngeom;
+    const OperandLayout<G> L(m);
+    const int su = op_odd(nd * BS);
+    double* U = W;
+    double* X = W + m.cells_per_wave * su;
     op_fence();
     const int c = lane / m.nq, q = lane - c * m.nq;
     const bool active = c < ncell;
     if (active) {
-        const double* phi = tab + q * nd;
-        const double* dphi = tab + m.nq * nd + (q * nd) * G;
-        const double* dpsi = tab + m.nq * nd * (1 + G) + (q * ng) * G;
+        const double* phi = tab + q * L.sphi;
+        const double* dphi = tab + L.o_dphi + q * L.sdphi;
+        const double* dpsi = tab + L.o_dpsi + q * L.sdpsi;
+        const double* Xc = X + c * L.sx;
         double J[G][G], K[G][G];
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int k = 0; k < G; ++k) J[j][k] = 0.0;
+#pragma unroll 2
         for (int v = 0; v < ng; ++v) {
 #pragma unroll
             for (int j = 0; j < G; ++j)
 #pragma unroll
-                for (int k = 0; k < G; ++k) J[j][k] += X[(c * ng + v) * G + j] * dpsi[v * G + k];
+                for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
         }
         invert<G>(J, K);
         double val[BS], gref[BS][G];
@@ -137,7 +271,9 @@ __device__ __forceinline__ bool operand_point(const OperandDev& m, const double*
 #pragma unroll
             for (int k = 0; k < G; ++k) gref[i][k] = 0.0;
         }
-        const double* Uc = U + c * nd * BS;
+        const double* Uc = U + c * su;
+        // partial unroll: batches the LDS reads of three nodes so their latency overlaps the FMAs of the previous ones
+#pragma unroll 3
         for (int a = 0; a < nd; ++a) {
             double ua[BS];
 #pragma unroll
@@ -169,6 +305,16 @@ __device__ __forceinline__ bool operand_point(const OperandDev& m, const double*
     }
     op_fence();   // W may be reused by the caller
     return active;
+}
+
+// gather + compute for one group (no pipelining): entity lists and elements too large for the register pipeline
+template <int G, int BS, int KIND>
+__device__ __forceinline__ bool operand_point(const OperandDev& m, const double* tab, double* W,
+                                              const double* __restrict__ u, const int32_t* __restrict__ cells,
+                                              int64_t c0, int ncell, int lane,
+                                              double (&o)[OperandShape<G, BS, KIND>::D]) {
+    operand_gather<G, BS>(m, W, u, cells, c0, ncell, lane);
+    return operand_compute<G, BS, KIND>(m, tab, W, ncell, lane, o);
 }
 
 }  // namespace

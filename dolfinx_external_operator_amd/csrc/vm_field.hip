@@ -19,7 +19,7 @@
 namespace {
 
 template <int G, bool NT>
-__global__ __launch_bounds__(DXO_BLOCK, 4) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
+__global__ __launch_bounds__(DXO_BLOCK, 3) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
                                                          const double* __restrict__ p, double* __restrict__ C_tang,
@@ -28,9 +28,7 @@ __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_field(VmConst c, OperandDev m
     using T = VmTile<D>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
-    for (int i = threadIdx.x; i < m.nq * m.ndofs; i += blockDim.x) tab[i] = m.phi[i];
-    for (int i = threadIdx.x; i < m.nq * m.ndofs * G; i += blockDim.x) tab[m.nq * m.ndofs + i] = m.dphi[i];
-    for (int i = threadIdx.x; i < m.nq * m.ngeom * G; i += blockDim.x) tab[m.nq * m.ndofs * (1 + G) + i] = m.dpsi[i];
+    operand_load_tables<G>(m, tab);
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -41,17 +39,40 @@ __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_field(VmConst c, OperandDev m
     dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
     const int cpw = m.cells_per_wave;
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
-    const int64_t stride = (int64_t)gridDim.x * T::WAVES;
-    for (int64_t grp = (int64_t)blockIdx.x * T::WAVES + wave; grp < n_groups; grp += stride) {
+    const GroupWalk walk = xcd_group_walk(n_groups, T::WAVES, wave);
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    // the dof gather runs as a register pipeline two groups ahead (operand_core.h) whenever the element fits it
+    const bool piped = operand_can_pipe(m);
+    OperandPipe<G, G> pf;
+    int64_t grp = walk.first;
+    if (piped) {
+        pipe_load_indices<G, G>(m, pf, cell0 + grp * cpw, cells_in(grp), lane);
+        pipe_load_values<G, G>(m, pf, u);
+        pipe_load_indices<G, G>(m, pf, cell0 + (grp + stride) * cpw, cells_in(grp + stride), lane);
+    }
+    for (; grp < walk.end; grp += stride) {
         const int64_t c0 = grp * cpw;                 // first cell of the group, relative to cell0
-        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        const int ncell = cells_in(grp);
         const int npts = ncell * m.nq;
         const int64_t p0 = c0 * m.nq;                 // first point, relative to the state/output arrays passed in
         const int nvec = npts * T::CH_VEC;
 
         // ---- A1: strain increment of this lane's point from the displacement dofs
         double e[D];
-        const bool active = operand_point<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, e);
+        bool active;
+        if (piped) {
+            pipe_commit<G, G>(m, pf, W, ncell, lane);
+            pipe_load_values<G, G>(m, pf, u);
+            pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+            active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, ncell, lane, e);
+        } else {
+            active = operand_point<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, e);
+        }
         if (!active) {
 #pragma unroll
             for (int k = 0; k < D; ++k) e[k] = 0.0;
@@ -110,7 +131,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (n_cells == 0) return DXO_OK;
     const OperandDev& m = L.mesh->dev;
     const int D = L.mesh->gdim == 2 ? 4 : 6;
-    int wd = m.cells_per_wave * (m.ndofs * L.mesh->gdim + m.ngeom * L.mesh->gdim);
+    int wd = m.cells_per_wave * (op_odd(m.ndofs * L.mesh->gdim) + op_odd(m.ngeom * L.mesh->gdim));
     const int tile = DXO_WAVE * D + DXO_WAVE * (D + 2);
     if (wd < tile) wd = tile;
     wd = (wd + 1) & ~1;
@@ -120,6 +141,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     int64_t blocks = (n_groups + 3) / 4;
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;
     if (L.mesh->gdim == 2) {
         if (nt) hipLaunchKernelGGL((vm_field<2, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);

@@ -22,6 +22,7 @@ from dolfinx_external_operator_amd.synthetic import structured_mesh  # noqa: E40
 ap = argparse.ArgumentParser()
 ap.add_argument("--cpu", type=int, default=0, help="also time the NumPy oracle on the first 50 000 cells")
 ap.add_argument("--launches", type=int, default=10)
+ap.add_argument("--case", type=int, default=-1, help="run only this case (index into CASES); -1 = all")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -33,7 +34,7 @@ CASES = [("hexahedron", (108, 108, 108), 2, "eps", "Q2 hexahedra, 8 qp/cell, eps
          ("hexahedron", (50, 50, 50), 2, "eps", "Q2 hexahedra, 50^3 cells = 1e6 points (BASELINE config 2)"),
          ("triangle", (1000, 1000), 2, "eps", "P2 triangles, 3 qp/cell, eps(u) Mandel d=4 (the reference demos' layout)"),
          ("triangle", (1000, 1000), 2, "F", "P2 triangles, F = I + grad u (hyperelasticity demo operand)")]
-for cell, n, degree, kind, label in CASES:
+for cell, n, degree, kind, label in (CASES if args.case < 0 else [CASES[args.case]]):
     m = structured_mesh(cell, n, degree, distort=0.2, seed=0)
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     bs = m.gdim
