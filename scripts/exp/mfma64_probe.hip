@@ -29,21 +29,23 @@ __global__ void rate(double* out, int iters) {
 
 int main() {
     std::vector<double> A(64), B(64), D(256);
-    for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) A[i * 4 + k] = 1 + i + 100 * k;     // A[i][k]
-    for (int k = 0; k < 4; ++k) for (int j = 0; j < 16; ++j) B[k * 16 + j] = (k == 0) ? (j + 1) * 0.001 : 0.0;   // picks A[i][0]*(j+1)e-3
+    // D[i][j] = sum_k A[i][k] B[k][j] = (i+1) + 1000 (j+1) + 1e6 * [k=2 term] + 1e9 * [k=3 term]: unique per (i, j),
+    // and every k slot contributes, so a wrong A/B lane layout cannot go unnoticed
+    for (int i = 0; i < 16; ++i) { A[i * 4 + 0] = i + 1; A[i * 4 + 1] = 1; A[i * 4 + 2] = 1e6; A[i * 4 + 3] = 0.5; }
+    for (int j = 0; j < 16; ++j) { B[0 * 16 + j] = 1; B[1 * 16 + j] = 1000.0 * (j + 1); B[2 * 16 + j] = 1; B[3 * 16 + j] = 2e9; }
     double *dA, *dB, *dD;
     hipMalloc(&dA, 512); hipMalloc(&dB, 512); hipMalloc(&dD, 2048);
     hipMemcpy(dA, A.data(), 512, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), 512, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(layout, dim3(1), dim3(64), 0, 0, dA, dB, dD);
     hipMemcpy(D.data(), dD, 2048, hipMemcpyDeviceToHost);
-    // expected D[i][j] = (1+i) * (j+1)e-3 : decode (i, j) of each lane/reg
     int ok = 1;
     for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) {
         const double v = D[l * 4 + r];
         int fi = -1, fj = -1;
-        for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) if (fabs(v - (1 + i) * (j + 1) * 0.001) < 1e-12) { fi = i; fj = j; }
+        for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) if (fabs(v - ((i + 1) + 1000.0 * (j + 1) + 1e6 + 1e9)) < 1e-3) { fi = i; fj = j; }
         const int ei = 4 * (l / 16) + r, ej = l % 16;
-        if (fi != ei || fj != ej) { ok = 0; if (l < 20) printf("lane %d reg %d holds D[%d][%d], guess was [%d][%d]\n", l, r, fi, fj, ei, ej); }
+        if (fi != ei || fj != ej) ok = 0;
+        if (l % 16 < 2 || !ok) { if (l < 34) printf("lane %2d reg %d holds D[%2d][%2d]  (raw %.1f)\n", l, r, fi, fj, v); }
     }
     printf("layout guess D[4*(l/16)+r][l%%16], A[l%%16][l/16], B[l/16][l%%16]: %s\n", ok ? "CONFIRMED" : "WRONG");
     double* dout; hipMalloc(&dout, 256 * 1024 * 256 * 8);
