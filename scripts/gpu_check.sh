@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1 || { echo BUILD FAILED; tail -30 "$OUT/build.log"; exit 1; }
 echo "== pytest -m gpu"
-timeout 900 python3 -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -15 "$OUT/pytest_gpu.log"
+timeout 1500 python3 -m pytest tests -x -q -m gpu --durations=12 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; tail -30 "$OUT/pytest_gpu.log"
 echo "== smoke"
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 echo "== bench"
