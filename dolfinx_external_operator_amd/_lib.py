@@ -40,6 +40,12 @@ class IsiharaParams(C.Structure):
     _fields_ = [("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double), ("c4", C.c_double)]
 
 
+class AssignDesc(C.Structure):
+    """dxo_assign_desc — one subspace of a dofmap assigner (external_operator.py:286-335)."""
+    _fields_ = [("n_cells", C.c_int64), ("n_pts", C.c_int32), ("val_size", C.c_int32), ("offset", C.c_int32),
+                ("n_points_total", C.c_int32), ("comp_size", C.c_int32), ("_pad", C.c_int32)]
+
+
 class IcnnWeights(C.Structure):
     """dxo_icnn_weights — the reference's state_dict tensors (demo_hyperelasticity.py:302-315), fp32."""
     _fields_ = [(k, C.c_void_p) for k in ("layers0_weight", "layers0_bias", "layers1_weights", "skip1_weight", "skip1_bias",
@@ -90,6 +96,7 @@ _SIGNATURES = {
     "dxo_operand_value_size": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dxo_eval_operand": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_von_mises_field": (C.c_int, [_P, C.POINTER(VmParams), _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "dxo_assign": (C.c_int, [_P, C.POINTER(AssignDesc), _P, _P, _P, C.c_int64]),
     "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
@@ -331,6 +338,11 @@ class Context:
     def isihara(self, prm: "IsiharaParams", n: int, mem: int, F, dP, P) -> None:
         rc = self.lib.dxo_isihara(self._h, C.byref(prm), int(n), int(mem), _ptr(F), _ptr(dP), _ptr(P))
         self.check(rc, "dxo_isihara")
+
+    def assign(self, desc: "AssignDesc", flat_dofs, values, coeff, coeff_size: int) -> None:
+        """Device pointers (ints) or objects with .ctypes — dxo_assign works on device memory only."""
+        rc = self.lib.dxo_assign(self._h, C.byref(desc), _ptr(flat_dofs), _ptr(values), _ptr(coeff), int(coeff_size))
+        self.check(rc, "dxo_assign")
 
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))

@@ -1,0 +1,88 @@
+// assign.hip — the reference's coefficient assigners as one device scatter.
+//
+// Reference (src/dolfinx_external_operator/external_operator.py):
+//   _assign_non_mixed          :286-287   coeff.x.array[unrolled_dofmap] = values
+//   _assign_mixed_2d           :292-311   per subspace: coeff.x.array[flat_dofs] = values[:, offset:offset+n_pts]
+//   _assign_mixed_3d           :313-335   per subspace: chunk = values[:, offset:offset+n_pts, :][:, :, :val_size]
+//                                         coeff.x.array[flat_dofs] = chunk.reshape(n_cells, dofs_per_cell)
+// All three are: for cell c, point p < n_pts, component v < val_size
+//   coeff[flat_dofs[(c*n_pts + p)*val_size + v]] = values[(c*n_points_total + offset + p)*comp_size + v]
+// (non-mixed: offset 0, n_points_total = n_pts, comp_size = val_size; 2-D: comp_size = val_size = 1).
+// (_assign_non_mixed_contiguous, :289-290, is a plain copy and needs no kernel: the operator writes in place.)
+//
+// NumPy's fancy assignment is sequential, so where several entries map to the same dof (continuous spaces: dofs
+// shared between cells) the LAST one wins. A parallel scatter would leave whichever store lands last; to return the
+// same array as the reference, pass 1 records for every dof the largest source position that targets it
+// (atomicMax), pass 2 stores only from that position. HBM/atomic-bound index traffic, no arithmetic.
+#include "dxo_common.h"
+
+namespace {
+
+struct AssignDev {
+    int64_t n_cells;
+    int n_pts, val_size, offset, n_points_total, comp_size;
+};
+
+__device__ __forceinline__ int64_t assign_src(const AssignDev& a, int64_t e) {
+    const int per_cell = a.n_pts * a.val_size;
+    const int64_t c = e / per_cell;
+    const int r = (int)(e - c * per_cell);
+    const int p = r / a.val_size, v = r - p * a.val_size;
+    return (c * a.n_points_total + a.offset + p) * a.comp_size + v;
+}
+
+__global__ __launch_bounds__(DXO_BLOCK) void assign_owner(AssignDev a, const int32_t* __restrict__ dofs,
+                                                          unsigned long long* __restrict__ owner) {
+    const int64_t n = a.n_cells * a.n_pts * a.val_size;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+        atomicMax(owner + dofs[e], (unsigned long long)(e + 1));
+}
+
+__global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int32_t* __restrict__ dofs,
+                                                          const unsigned long long* __restrict__ owner,
+                                                          const double* __restrict__ values, double* __restrict__ coeff) {
+    const int64_t n = a.n_cells * a.n_pts * a.val_size;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int32_t d = dofs[e];
+        if (owner[d] == (unsigned long long)(e + 1)) coeff[d] = values[assign_src(a, e)];
+    }
+}
+
+}  // namespace
+
+extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, const double* values,
+                          double* coeff, int64_t coeff_size) {
+    if (!ctx) return DXO_E_NULL;
+    if (!d) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: descriptor is NULL");
+    if (d->n_cells < 0 || d->n_pts < 1 || d->val_size < 1 || d->offset < 0 || d->comp_size < d->val_size ||
+        d->n_points_total < d->offset + d->n_pts || coeff_size < 0)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_assign: inconsistent sizes");
+    const int64_t n = d->n_cells * d->n_pts * d->val_size;
+    if (n == 0) return DXO_OK;
+    if (!flat_dofs || !values || !coeff) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: NULL array");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    // owner table: one 8-byte word per coefficient entry, in the context's device-path scratch buffer
+    const size_t need = (size_t)coeff_size * sizeof(unsigned long long);
+    if (ctx->scratch_bytes[DXO_HOST_SLOTS] < need) {
+        DXO_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->scratch[DXO_HOST_SLOTS]) DXO_HIP(ctx, hipFree(ctx->scratch[DXO_HOST_SLOTS]));
+        ctx->scratch[DXO_HOST_SLOTS] = nullptr;
+        ctx->scratch_bytes[DXO_HOST_SLOTS] = 0;
+        DXO_HIP(ctx, hipMalloc(&ctx->scratch[DXO_HOST_SLOTS], need));
+        ctx->scratch_bytes[DXO_HOST_SLOTS] = need;
+    }
+    unsigned long long* owner = static_cast<unsigned long long*>(ctx->scratch[DXO_HOST_SLOTS]);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    DXO_HIP(ctx, hipMemsetAsync(owner, 0, need, s));
+    AssignDev a{d->n_cells, d->n_pts, d->val_size, d->offset, d->n_points_total, d->comp_size};
+    int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner);
+    hipLaunchKernelGGL(assign_store, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, values, coeff);
+    return dxo_device_end(ctx, s);
+}

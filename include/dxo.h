@@ -272,6 +272,23 @@ int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, co
 int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                         const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
 
+/* ---- coefficient assigners on the device, DEVICE memory only --------------------------
+ * One scatter for the reference's three dofmap assigners (src/dolfinx_external_operator/external_operator.py):
+ * _assign_non_mixed :286-287, _assign_mixed_2d :292-311, _assign_mixed_3d :313-335. For cell c, point p < n_pts,
+ * component v < val_size:
+ *   coeff[flat_dofs[(c*n_pts + p)*val_size + v]] = values[(c*n_points_total + offset + p)*comp_size + v]
+ * Non-mixed: offset = 0, n_points_total = n_pts, comp_size = val_size and flat_dofs = the unrolled dofmap (:18-26);
+ * mixed: one call per subspace with its offset / n_pts / val_size (:180-190) and the operator's comp_size (:161).
+ * Where several entries target the same dof the LAST one (largest source position) wins, as in NumPy's sequential
+ * fancy assignment, so the result is the reference's array, not a race. flat_dofs entries must lie in
+ * [0, coeff_size). */
+typedef struct dxo_assign_desc {
+    int64_t n_cells;
+    int32_t n_pts, val_size, offset, n_points_total, comp_size, _pad;
+} dxo_assign_desc;
+int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, const double* values,
+               double* coeff, int64_t coeff_size);
+
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte
  * accesses: n_tiles tiles, each 64 lanes x read_chunks 16-byte loads and 64 x write_chunks 16-byte

@@ -67,6 +67,24 @@ def vm_case(n, d, label, expand=False):
 
 vm_case(1_000_000, 6, "von Mises d=6, config 2 size (448 MB working set, inputs fit the 256 MB Infinity Cache)")
 vm_case(10_000_000, 6, "von Mises d=6, 1e7 points", expand=True)
+# the kernel is branch-free, so all-elastic and all-plastic batches must time like the mixed one
+def vm_branch_case(n, d, scale, label):
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    deps = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 3e-3 * scale
+    sig = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 100 * scale
+    p = (torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 1e-3).abs()
+    C = torch.empty(n * d * d, dtype=torch.float64, device=dev)
+    s = torch.empty(n * d, dtype=torch.float64, device=dev)
+    dp = torch.empty(n, dtype=torch.float64, device=dev)
+    ms = ev_time(lambda: ctx.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sig.data_ptr(), p.data_ptr(),
+                                       C.data_ptr(), s.data_ptr(), dp.data_ptr()))
+    print(json.dumps({"case": label, "n": n, "d": d, "plastic_fraction": float((dp > 0).double().mean()), "kernel_ms": ms,
+                      "GBps": BPP[d] * n / ms / 1e6}), flush=True)
+
+
+vm_branch_case(10_000_000, 6, 0.05, "von Mises d=6, all-elastic batch")
+vm_branch_case(10_000_000, 6, 10.0, "von Mises d=6, all-plastic batch")
 vm_case(10_000_000, 4, "von Mises d=4 (reference demo layout), 1e7 points")
 vm_case(30_000_000, 4, "von Mises d=4, 3e7 points")
 
