@@ -18,7 +18,11 @@ d = 6 golden : the reference's nested `_kernel` body (dimension agnostic apart
                with the 3-D Mandel 6x6 `C_elas` / `deviatoric` built the same
                way the reference builds the 4x4 ones (:193-204).
 
-Outputs: tests/golden/von_mises_d4.npz, tests/golden/von_mises_d6.npz
+history golden : the reference `return_mapping` driven through six load steps (loading, further loading, elastic
+               unloading, reverse loading) with the demo's own state update between steps, `p += dp` and
+               `sigma_n = sigma` (:564-565); every step's inputs and outputs are stored.
+
+Outputs: tests/golden/von_mises_d4.npz, tests/golden/von_mises_d6.npz, tests/golden/von_mises_history_d4.npz
 """
 import ast
 import pathlib
@@ -129,6 +133,26 @@ def main():
     )
     plastic = np.count_nonzero(dp.reshape(-1) > 0)
     print(f"d=4: N={nc * nq} plastic={plastic} nan_points={np.count_nonzero(np.isnan(sigma).any(-1))}")
+
+    # ---------------- d = 4 load history: return_mapping + the demo's state update (:564-565) --------------
+    nc_h = 100
+    rng = np.random.Generator(np.random.PCG64(777))
+    base = rng.normal(0.0, 1.2e-3, size=(nc_h, nq, d))
+    base[..., 3] *= np.sqrt(2.0)
+    factors = [0.6, 1.0, 1.8, -0.4, -1.5, 0.9]          # per-step multiples of the base increment
+    sig_hist = np.zeros((nc_h, nq, d))
+    p_hist = np.zeros((nc_h, nq))
+    steps = {}
+    for k, fac in enumerate(factors):
+        deps_k = base * fac
+        with np.errstate(all="ignore"):
+            C_k, s_k, dp_k = ns["return_mapping"](deps_k, sig_hist, p_hist)
+        steps[f"deps_{k}"], steps[f"C_tang_{k}"], steps[f"sigma_{k}"], steps[f"dp_{k}"] = deps_k, C_k, s_k, dp_k
+        p_hist = p_hist + dp_k.reshape(p_hist.shape)                    # p.x.petsc_vec.axpy(1.0, dp.x.petsc_vec), :564
+        sig_hist = s_k.reshape(sig_hist.shape).copy()                   # sigma_n.x.array[:] = sigma...x.array, :565
+        steps[f"p_after_{k}"], steps[f"sigma_n_after_{k}"] = p_hist.copy(), sig_hist.copy()
+        print(f"history step {k}: factor {fac:+.1f} plastic {np.count_nonzero(dp_k > 0)}/{dp_k.size}")
+    np.savez(OUT / "von_mises_history_d4.npz", params=params, n_steps=len(factors), **steps)
 
     # ---------------- d = 6: the reference _kernel body, 6x6 constants -----
     ns6 = _namespace()

@@ -69,3 +69,23 @@ def test_heat_oracle_matches_reference_golden_bitwise(oracle, golden):
     assert np.array_equal(dqds.reshape(-1), g["dqdsigma"])
     # -k * 0 is a negative zero in the reference (part2.py:260); the oracle keeps the sign
     assert np.array_equal(np.signbit(dqds.reshape(-1)), np.signbit(g["dqdsigma"]))
+
+
+def test_von_mises_load_history_golden(oracle, golden):
+    """Six load steps of the reference's return_mapping with the demo's state update (p += dp, sigma_n = sigma,
+    demo_plasticity_von_mises.py:564-565) in between: the oracle, driven by its OWN accumulated state, has to stay
+    on the reference's trajectory (errors would compound across steps)."""
+    g = golden("von_mises_history_d4.npz")
+    n_steps = int(g["n_steps"])
+    d = 4
+    sigma_n = np.zeros_like(g["sigma_0"]).reshape(-1, d)
+    p = np.zeros(sigma_n.shape[0])
+    for k in range(n_steps):
+        C, s, dp = oracle.von_mises(g[f"deps_{k}"].reshape(-1, d), sigma_n, p)
+        assert_close_scaled(C, g[f"C_tang_{k}"], 1e-13, f"C_tang step {k}")
+        assert_close_scaled(s, g[f"sigma_{k}"], 1e-13, f"sigma step {k}")
+        assert_close_scaled(dp, g[f"dp_{k}"], 1e-13, f"dp step {k}")
+        p = p + dp.reshape(-1)
+        sigma_n = s.reshape(-1, d).copy()
+        assert_close_scaled(p, g[f"p_after_{k}"], 1e-13, f"p after step {k}")
+    assert (g["dp_2"] > 0).mean() > 0.5 and (g["dp_3"] > 0).sum() == 0       # loading, then elastic unloading

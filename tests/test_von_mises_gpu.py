@@ -371,3 +371,68 @@ def test_expand_tangent_device_pointers_and_errors(ctx):
     with pytest.raises(ValueError):
         ctx.vm_expand_tangent(PRM, d, n, MEM_DEVICE, None, dp_t.data_ptr(), C_t.data_ptr())
     ctx.vm_expand_tangent(PRM, d, 0, MEM_DEVICE, None, None, None)
+
+
+def test_reference_load_history_golden(ctx, golden):
+    """The reference's own six-step load history (tests/golden/von_mises_history_d4.npz): the drop-in callback with the
+    state update done as in the demo (:564-565), and the device-resident variant with dxo_vm_commit_state, both
+    carried on their own accumulated state."""
+    import torch
+
+    g = golden("von_mises_history_d4.npz")
+    n_steps, d = int(g["n_steps"]), 4
+    n = g["dp_0"].size
+    sigma_n, p = np.zeros(n * d), np.zeros(n)                     # the closure state the callback re-reads (:347-348)
+    fn = make_von_mises(lambda: sigma_n, lambda: p, ctx=ctx)
+    dev = [torch.zeros(n * d, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")]
+    out = [torch.empty(n * d * d, dtype=torch.float64, device="cuda"), torch.empty(n * d, dtype=torch.float64, device="cuda"),
+           torch.empty(n, dtype=torch.float64, device="cuda")]
+    for k in range(n_steps):
+        deps = g[f"deps_{k}"]
+        C, s, dp = fn((1,))(deps)
+        assert_close_scaled(C, g[f"C_tang_{k}"], RTOL, f"C_tang step {k}")
+        assert_close_scaled(s, g[f"sigma_{k}"], RTOL, f"sigma step {k}")
+        assert_close_scaled(dp, g[f"dp_{k}"], RTOL, f"dp step {k}")
+        p += dp                                                    # :564
+        sigma_n[:] = s                                             # :565
+        e = torch.from_numpy(np.ascontiguousarray(deps).reshape(-1)).cuda()
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.von_mises(PRM, d, n, MEM_DEVICE, e.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), out[0].data_ptr(),
+                      out[1].data_ptr(), out[2].data_ptr())
+        ctx.vm_commit_state(d, n, dev[1].data_ptr(), out[2].data_ptr(), dev[0].data_ptr(), out[1].data_ptr())
+        torch.cuda.synchronize()
+        assert_close_scaled(dev[1].cpu().numpy(), g[f"p_after_{k}"], RTOL, f"device p after step {k}")
+        assert_close_scaled(dev[0].cpu().numpy(), g[f"sigma_n_after_{k}"], RTOL, f"device sigma_n after step {k}")
+
+
+def test_two_contexts_from_two_threads(oracle):
+    """SURVEY.md 8b threading row: entry points are blocking and re-entrant per ctx; ctypes releases the GIL, so two
+    Python threads with their own contexts really run concurrently. Each checks its own results."""
+    import threading
+
+    from dolfinx_external_operator_amd import Context
+
+    errors = []
+
+    def worker(seed, d):
+        try:
+            c = Context(0)
+            try:
+                deps, sigma_n, p = vm_inputs(200_000, d, seed=seed)
+                Co, so, dpo = oracle.von_mises(deps, sigma_n, p, nthreads=2)
+                for _ in range(4):
+                    C, s, dp = run_host(c, deps, sigma_n, p)
+                    assert_close_scaled(C, Co, RTOL, "C_tang")
+                    assert_close_scaled(s, so, RTOL, "sigma")
+                    assert_close_scaled(dp, dpo, RTOL, "dp")
+            finally:
+                c.close()
+        except Exception as exc:   # noqa: BLE001 - reported to the main thread
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(31, 4)), threading.Thread(target=worker, args=(32, 6))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
