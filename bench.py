@@ -199,18 +199,29 @@ def main():
         C_f, s_f, dp_f = carve(slab)
         return (C_f.data_ptr() + own * n * d * d * 8, s_f.data_ptr() + own * n * d * 8, dp_f.data_ptr() + own * n * 8)
 
+    free_bytes = torch.cuda.mem_get_info(device)[0]
+    n_cand = max(1, min(n_cand, int(0.7 * free_bytes // (blocks * n * per_pt * 8))))   # all candidates coexist
+    placement["candidates"] = n_cand
     cands = [torch.empty(blocks * n * per_pt, dtype=torch.float64, device=device) for _ in range(n_cand)]
-    for cnd in cands:
+
+    def time_candidate(cnd, launches):
         pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), *own_ptrs(cnd))
         ctx.von_mises(prm, d, n, MEM_DEVICE, *pp)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(6):   # back to back: a single isolated launch reads ~7 % faster than the sustained rate
+        for _ in range(launches):   # back to back: a single isolated launch reads ~7 % faster than the sustained rate
             ctx.von_mises(prm, d, n, MEM_DEVICE, *pp)
         e1.record(stream)
         torch.cuda.synchronize(device)
-        placement["kernel_GBps"].append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 6 * 1e-3) / 1e9)
-    placement["chosen"] = max(range(len(cands)), key=lambda k: placement["kernel_GBps"][k])
+        return BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / launches * 1e-3) / 1e9
+
+    placement["kernel_GBps"] = [time_candidate(cnd, 6) for cnd in cands]
+    ranked = sorted(range(len(cands)), key=lambda k: -placement["kernel_GBps"][k])
+    # the two best are timed again over more launches: one 6-launch reading is noisy by a few per cent
+    finals = {k: time_candidate(cands[k], 12) for k in ranked[:2]}
+    placement["finalists_GBps"] = {str(k): v for k, v in finals.items()}
+    placement["chosen"] = max(finals, key=finals.get)
+    cnd = None
     out_slab = cands[placement["chosen"]]
     del cands, cnd
     torch.cuda.empty_cache()
