@@ -112,10 +112,11 @@ def main():
     ap.add_argument("--d", type=int, default=6, choices=(4, 6))
     ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
     ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
-    ap.add_argument("--gather-mode", choices=("compact", "full"), default="compact",
+    ap.add_argument("--gather-mode", choices=("compact", "compact_pipelined", "full"), default="compact",
                     help="compact: RCCL all-gather of (sigma, dp) + local rebuild of the remote tangents "
-                         "(dxo_vm_expand_tangent); full: RCCL all-gather of (C_tang, sigma, dp). The other mode is "
-                         "timed too and reported under config.gather_modes.")
+                         "(dxo_vm_expand_tangent); compact_pipelined: the same in 4 pieces, rebuild overlapped with the "
+                         "link traffic; full: RCCL all-gather of (C_tang, sigma, dp). The other modes are timed too "
+                         "and reported under config.gather_modes.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the stream-ceiling probe")
     ap.add_argument("--variant", type=int, default=1)
@@ -125,6 +126,13 @@ def main():
                     help="HBM placement calibration: allocate this many candidate output slabs, time the kernel once on "
                          "each, keep the fastest (0/1 = plain first allocation). See DESIGN.md 3.1.")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the result. Libraries that write to fd 1 on their own (RCCL prints a version
+    # banner when its first communicator comes up) are sent to stderr: fd 1 is pointed at fd 2 for the whole run and
+    # the JSON line is written to a saved copy of the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -149,7 +157,8 @@ def main():
 
     from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
     from dolfinx_external_operator_amd._build import build_library
-    from dolfinx_external_operator_amd.sharding import WAVE_TILE, all_gather_in_place, gather_von_mises_compact
+    from dolfinx_external_operator_amd.sharding import (WAVE_TILE, all_gather_in_place, gather_von_mises_compact,
+                                                        gather_von_mises_compact_pipelined)
 
     if rank == 0:
         build_library()
@@ -246,6 +255,8 @@ def main():
                 return
             if mode == "compact":
                 gather_von_mises_compact(C_full, sigma_full, dp_full, rank, d, expand)
+            elif mode == "compact_pipelined":
+                gather_von_mises_compact_pipelined(C_full, sigma_full, dp_full, rank, d, expand, chunks=4)
             else:
                 for buf in (C_full, sigma_full, dp_full):
                     all_gather_in_place(buf, rank)
@@ -269,35 +280,38 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # the other gather mode, same protocol, reported beside the headline (never as `value`)
-    other_mode, other_elapsed = ("full" if args.gather_mode == "compact" else "compact"), None
+    # the other gather modes, same protocol, reported beside the headline (never as `value`)
+    other_elapsed = {}
     if gather_on:
         if world > 1:   # remote tangents rebuilt from (sigma, dp) must be usable: finite and symmetric
             nb = (rank + 1) % world
             chk = C_full[nb * n * d * d: nb * n * d * d + 4096 * d * d].view(-1, d, d)
             if not bool(torch.isfinite(chk).all()) or float((chk - chk.transpose(1, 2)).abs().max()) > 1e-9 * E:
                 raise SystemExit("bench: gathered/rebuilt remote C_tang block is not a finite symmetric tangent")
-        try:    # a comparison figure only: it must never cost the headline line
-            step2 = make_step(other_mode)
-            for _ in range(min(W, 2)):
-                step2()
-            fence()
-            t0 = time.perf_counter()
-            for k in range(K):
-                step2()
-            fence()
-            other_elapsed = time.perf_counter() - t0
-        except Exception as exc:   # noqa: BLE001
-            log(f"bench: gather mode '{other_mode}' failed and is left out: {exc!r}")
-            other_elapsed = None
+        for mode in ("compact", "compact_pipelined", "full"):
+            if mode == args.gather_mode:
+                continue
+            try:    # comparison figures only: they must never cost the headline line
+                step2 = make_step(mode)
+                for _ in range(min(W, 2)):
+                    step2()
+                fence()
+                t0 = time.perf_counter()
+                for k in range(K):
+                    step2()
+                fence()
+                other_elapsed[mode] = time.perf_counter() - t0
+            except Exception as exc:   # noqa: BLE001
+                log(f"bench: gather mode '{mode}' failed and is left out: {exc!r}")
 
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     if dist_on:
-        t = torch.tensor([elapsed, kernel_ms_avg, other_elapsed or 0.0], dtype=torch.float64, device=device)
+        names = ("compact", "compact_pipelined", "full")
+        t = torch.tensor([elapsed, kernel_ms_avg] + [other_elapsed.get(m, 0.0) for m in names], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
-        other_elapsed = float(t[2]) if other_elapsed is not None else None
+        other_elapsed = {m: float(t[2 + i]) for i, m in enumerate(names) if m in other_elapsed}
     else:
         kernel_ms_avg_max = kernel_ms_avg
 
@@ -352,17 +366,15 @@ def main():
                 "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
                             f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
                             + ((", cell-block sharded, RCCL all-gather of (sigma, dp) + on-device rebuild of the remote "
-                                "tangents every step" if args.gather_mode == "compact" else
+                                "tangents every step" if args.gather_mode.startswith("compact") else
                                 ", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step") if gather_on
                                else (", cell-block sharded, no gather" if world > 1 else "")),
                 "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
                 "sharding": "cell-block" if world > 1 else "none",
                 "gather": f"rccl_all_gather_{args.gather_mode}" if gather_on else "none",
-                "gather_modes": ({args.gather_mode: {"value": value, "ms_per_step": elapsed / K * 1e3,
-                                                     "link_bytes_per_qp": 8 * (d + 1) if args.gather_mode == "compact" else 8 * per_pt},
-                                  other_mode: {"value": total_points * K / other_elapsed, "ms_per_step": other_elapsed / K * 1e3,
-                                               "link_bytes_per_qp": 8 * (d + 1) if other_mode == "compact" else 8 * per_pt}}
-                                 if gather_on and other_elapsed else None),
+                "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
+                                      "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
+                                  for m, t_m in {args.gather_mode: elapsed, **other_elapsed}.items()} if gather_on else None),
                 "kernel": "vm_tile" if args.variant else "vm_point",
                 "arch": info["arch"], "compute_units": info["compute_units"],
             },
@@ -382,7 +394,7 @@ def main():
         if world == 1 and not args.no_cpu:
             del out_slab, C_tang, sigma, dp, C_full, sigma_full, dp_full
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
