@@ -39,6 +39,11 @@ struct dxo_ctx {
     int64_t mc_blocks_per_cu = 2;       // persistent Newton workgroups per CU
     int64_t icnn_variant = 1;           // fp32 network: 0 VALU lane-per-point kernel, 1 MFMA wave-per-64-points kernel
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
+    // small-batch path of the host pipeline: one pinned staging buffer, one H2D, one D2H, events made once
+    void* small_pinned = nullptr;
+    size_t small_pinned_bytes = 0;
+    hipEvent_t small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t host_small_bytes = 1 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     dxo_timing last = {0, 0, 0, 0};

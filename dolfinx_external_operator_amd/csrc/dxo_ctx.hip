@@ -67,6 +67,11 @@ int dxo_ctx_destroy(dxo_ctx* c) {
     for (int i = 0; i < DXO_HOST_SLOTS; ++i) {
         if (c->slot_buf[i]) (void)hipFree(c->slot_buf[i]);
         if (c->slot_stream[i]) (void)hipStreamDestroy(c->slot_stream[i]);
+        if (i == 0) {
+            if (c->small_pinned) (void)hipHostFree(c->small_pinned);
+            for (auto& e : c->small_ev)
+                if (e) (void)hipEventDestroy(e);
+        }
     }
     for (int i = 0; i <= DXO_HOST_SLOTS; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
@@ -117,6 +122,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "mc_blocks_per_cu")) return &c->mc_blocks_per_cu;
     if (!std::strcmp(key, "mc_waves_per_simd")) return &c->mc_waves_per_simd;
     if (!std::strcmp(key, "icnn_variant")) return &c->icnn_variant;
+    if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;
     return nullptr;
 }
 
@@ -234,6 +240,81 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
     c->last = {0, 0, 0, 0};
     c->ev_pending = false;
     if (n == 0) return DXO_OK;
+    {
+        // ---- small batches (the reference's demo meshes: hundreds to thousands of points): the fixed cost of a call is
+        // the number of driver calls, not bytes. Inputs are packed into ONE pinned staging buffer and go up in one copy,
+        // the outputs come back in one copy; events are created once per context.
+        size_t in_bytes = 0, out_bytes = 0;
+        for (const auto& s : inputs) in_bytes += round_up(s.bytes_pp * (size_t)n, 256);
+        for (const auto& s : outputs) out_bytes += round_up(s.bytes_pp * (size_t)n, 256);
+        if ((int64_t)(in_bytes + out_bytes) <= c->host_small_bytes) {
+            const size_t need = in_bytes + out_bytes;
+            if (need > c->small_pinned_bytes) {
+                if (c->small_pinned) DXO_HIP(c, hipHostFree(c->small_pinned));
+                c->small_pinned = nullptr;
+                c->small_pinned_bytes = 0;
+                const size_t want = need > (size_t)c->host_small_bytes ? need : (size_t)c->host_small_bytes;
+                DXO_HIP(c, hipHostMalloc(&c->small_pinned, want, hipHostMallocDefault));
+                c->small_pinned_bytes = want;
+            }
+            // device side: slot 0's buffer (grown like the chunked path grows it)
+            if (need > c->slot_bytes) {
+                for (int i = 0; i < DXO_HOST_SLOTS; ++i) {
+                    DXO_HIP(c, hipStreamSynchronize(c->slot_stream[i]));
+                    if (c->slot_buf[i]) DXO_HIP(c, hipFree(c->slot_buf[i]));
+                    c->slot_buf[i] = nullptr;
+                }
+                c->slot_bytes = 0;
+                const size_t want = need > (size_t)c->host_small_bytes ? need : (size_t)c->host_small_bytes;
+                for (int i = 0; i < DXO_HOST_SLOTS; ++i) DXO_HIP(c, hipMalloc(&c->slot_buf[i], want));
+                c->slot_bytes = want;
+            }
+            const bool timed = c->timing != 0;
+            if (timed)
+                for (auto& e : c->small_ev)
+                    if (!e) DXO_HIP(c, hipEventCreate(&e));
+            const auto t0s = std::chrono::steady_clock::now();
+            hipStream_t s = c->slot_stream[0];
+            char* hbase = static_cast<char*>(c->small_pinned);
+            char* dbase = static_cast<char*>(c->slot_buf[0]);
+            std::vector<void*> d_in(inputs.size()), d_out(outputs.size());
+            size_t off = 0;
+            for (size_t k = 0; k < inputs.size(); ++k) {
+                std::memcpy(hbase + off, inputs[k].in, inputs[k].bytes_pp * (size_t)n);
+                d_in[k] = dbase + off;
+                off += round_up(inputs[k].bytes_pp * (size_t)n, 256);
+            }
+            if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[0], s));
+            DXO_HIP(c, hipMemcpyAsync(dbase, hbase, in_bytes, hipMemcpyHostToDevice, s));
+            if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[1], s));
+            const size_t out_base = off;
+            for (size_t k = 0; k < outputs.size(); ++k) {
+                d_out[k] = dbase + off;
+                off += round_up(outputs[k].bytes_pp * (size_t)n, 256);
+            }
+            int rc = launch(c, user, n, d_in.data(), d_out.data(), s);
+            if (rc != DXO_OK) return rc;
+            DXO_HIP(c, hipGetLastError());
+            if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[2], s));
+            DXO_HIP(c, hipMemcpyAsync(hbase + out_base, dbase + out_base, out_bytes, hipMemcpyDeviceToHost, s));
+            if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[3], s));
+            DXO_HIP(c, hipStreamSynchronize(s));
+            off = out_base;
+            for (size_t k = 0; k < outputs.size(); ++k) {
+                if (outputs[k].out) std::memcpy(outputs[k].out, hbase + off, outputs[k].bytes_pp * (size_t)n);
+                off += round_up(outputs[k].bytes_pp * (size_t)n, 256);
+            }
+            if (timed) {
+                float a = 0, b = 0, d = 0;
+                DXO_HIP(c, hipEventElapsedTime(&a, c->small_ev[0], c->small_ev[1]));
+                DXO_HIP(c, hipEventElapsedTime(&b, c->small_ev[1], c->small_ev[2]));
+                DXO_HIP(c, hipEventElapsedTime(&d, c->small_ev[2], c->small_ev[3]));
+                c->last.h2d_ms = a; c->last.kernel_ms = b; c->last.d2h_ms = d;
+            }
+            c->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0s).count();
+            return DXO_OK;
+        }
+    }
     int64_t chunk = c->host_chunk_points / (points_per_unit > 0 ? points_per_unit : 1);
     if (chunk < DXO_WAVE) chunk = DXO_WAVE;
     if (chunk > n) chunk = n;

@@ -436,3 +436,39 @@ def test_two_contexts_from_two_threads(oracle):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n", [1, 600, 6144])
+def test_small_batch_path_equals_chunked_pipeline(ctx, oracle, n):
+    """Host batches below host_small_bytes take the single-copy staging path; it must return exactly what the chunked
+    pipeline returns (same kernel, same data), with guard words intact, for every kernel that uses the pipeline."""
+    from dolfinx_external_operator_amd import MEM_HOST as HOST
+
+    deps, sigma_n, p = vm_inputs(n, 4, seed=n)
+    old = ctx.get_option("host_small_bytes")
+    res = {}
+    try:
+        for small in (0, 1 << 20):
+            ctx.set_option("host_small_bytes", small)
+            C, s, dp = np.full(n * 16 + 2, -5.0), np.full(n * 4 + 2, -5.0), np.full(n + 2, -5.0)
+            ctx.von_mises(PRM, 4, n, HOST, deps, sigma_n, p, C, s, dp)
+            assert C[-1] == -5.0 and s[-2] == -5.0 and dp[-1] == -5.0
+            res[small] = (C.copy(), s.copy(), dp.copy())
+            T = np.random.default_rng(n).random(n) + 0.5
+            sg = np.random.default_rng(n + 1).normal(size=(n, 2))
+            q, dT, ds = np.empty(n * 2), np.empty(n * 2), np.empty(n * 4)
+            ctx.heat(1.0, 1.0, 2, n, HOST, T, sg, q, dT, ds)
+            res[("heat", small)] = (q, dT, ds)
+        ctx.set_option("timing", 1)
+        ctx.von_mises(PRM, 4, n, HOST, deps, sigma_n, p, C, s, dp)
+        t = ctx.last_timing()
+        assert t["total_ms"] > 0 and t["kernel_ms"] > 0
+    finally:
+        ctx.set_option("timing", 0)
+        ctx.set_option("host_small_bytes", old)
+    for a, b in zip(res[0], res[1 << 20]):
+        assert np.array_equal(a, b, equal_nan=True)
+    for a, b in zip(res[("heat", 0)], res[("heat", 1 << 20)]):
+        assert np.array_equal(a, b)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(res[1 << 20][0][: n * 16], Co, RTOL, "C_tang small path")
