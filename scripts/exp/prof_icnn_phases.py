@@ -1,3 +1,6 @@
+"""Experiment driver (not part of the product): prints per-phase cycle counts of icnn_mfma. It needs an INSTRUMENTED
+build of csrc/icnn.hip that accumulates __builtin_readcyclecounter() deltas around the four phases into a device array
+and exports `dxo_icnn_prof_dump`; the shipped library has neither. Results of the round-1 run are in DESIGN.md 8."""
 import sys, ctypes
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
