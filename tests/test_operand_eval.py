@@ -273,3 +273,19 @@ def test_lazy_operand_takes_the_fused_path_inside_the_reference_call_sequence(ct
         assert isinstance(sub, np.ndarray) and np.abs(sub - e_ref[[3, 1]]).max() <= 1e-13 * np.abs(e_ref).max()
     finally:
         dm.close()
+
+
+@pytest.mark.gpu
+def test_load_stepping_example_runs():
+    """examples/von_mises_load_stepping.py: the reference's calling sequence with the lazy operand + fused kernel."""
+    import importlib.util
+    import pathlib
+
+    path = pathlib.Path(__file__).resolve().parents[1] / "examples" / "von_mises_load_stepping.py"
+    spec = importlib.util.spec_from_file_location("vm_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.main(24)
+    fr = [s["plastic_fraction"] for s in rep["steps"]]
+    assert fr[0] < fr[2] and fr[3] == 0.0                     # yielding spreads under loading, unloading is elastic
+    assert rep["steps"][2]["max_p"] > 0
