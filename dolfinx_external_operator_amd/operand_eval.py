@@ -77,10 +77,18 @@ class DeviceMesh:
     def from_dolfinx(cls, V, quadrature_points, **kw):
         """From a DOLFINx function space `V` (blocked Lagrange) and the reference quadrature points the operator's
         quadrature element uses (`basix.make_quadrature(...)[0]`). Not exercised on the GPU box (no DOLFINx there)."""
+        import basix
+
         mesh = V.mesh
         gdim = mesh.geometry.dim
-        tab = V.element.basix_element.tabulate(1, quadrature_points)          # (1 + tdim, nq, ndofs, 1)
-        ctab = mesh.geometry.cmap.tabulate(1, quadrature_points)              # (1 + tdim, nq, ngeom, 1)
+        quadrature_points = np.asarray(quadrature_points, dtype=np.float64)
+        # scalar sub-element of the (blocked) Lagrange space: values (1 + tdim, nq, ndofs, 1)
+        tab = V.element.basix_element.tabulate(1, quadrature_points)
+        # the coordinate element as a basix element of the same family / degree / variant as mesh.geometry.cmap
+        cmap = mesh.geometry.cmap
+        cell = getattr(basix.CellType, mesh.topology.cell_name())
+        cel = basix.create_element(basix.ElementFamily.P, cell, cmap.degree, basix.LagrangeVariant(int(cmap.variant)))
+        ctab = cel.tabulate(1, quadrature_points)
         phi = tab[0, :, :, 0]
         dphi = np.moveaxis(tab[1:, :, :, 0], 0, 2)
         dpsi = np.moveaxis(ctab[1:, :, :, 0], 0, 2)
