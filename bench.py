@@ -315,15 +315,19 @@ def main():
     else:
         kernel_ms_avg_max = kernel_ms_avg
 
-    # correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface
-    s_chk = sigma.view(n, d)[:4096]
-    dev_chk = s_chk.clone()
-    dev_chk[:, :3] -= s_chk[:, :3].mean(dim=1, keepdim=True)
-    f_chk = (1.5 * (dev_chk * dev_chk).sum(1)).sqrt() - sigma_0 - H * (p[:4096] + dp[:4096])
-    plastic = dp[:4096] > 0
-    if plastic.any() and float(f_chk[plastic].abs().max()) > 1e-8 * sigma_0:
-        raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
-
+    # correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface — checked on
+    # the first and on the LAST 4096 points (the tail exercises the 64-bit index arithmetic of very large batches)
+    for lo in sorted({0, max(n - 4096, 0)}):
+        sl = slice(lo, lo + 4096)
+        s_chk = sigma.view(n, d)[sl]
+        dev_chk = s_chk.clone()
+        dev_chk[:, :3] -= s_chk[:, :3].mean(dim=1, keepdim=True)
+        f_chk = (1.5 * (dev_chk * dev_chk).sum(1)).sqrt() - sigma_0 - H * (p[sl] + dp[sl])
+        plastic = dp[sl] > 0
+        if plastic.any() and float(f_chk[plastic].abs().max()) > 1e-8 * sigma_0:
+            raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
+        if not bool(torch.isfinite(C_tang[lo * d * d:(lo + 4096) * d * d]).all()):
+            raise SystemExit("bench: non-finite tangent in the kernel output — refusing to report a number")
     total_points = n * world
     value = total_points * K / elapsed
     bytes_per_launch = BYTES_PER_QP[d] * n
