@@ -300,7 +300,10 @@ int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, co
         return DXO_OK;
     }
     // int32 list entries: split gigantic batches
-    const int64_t max_part = (int64_t)1 << 30;
+    int64_t max_part = ctx->mc_part_points;
+    if (max_part < DXO_WAVE) max_part = DXO_WAVE;
+    if (max_part > ((int64_t)1 << 30)) max_part = (int64_t)1 << 30;
+    max_part = max_part / DXO_WAVE * DXO_WAVE;      // parts start on 16-byte aligned rows
     for (int64_t off = 0; off < n; off += max_part) {
         const int64_t m = (n - off < max_part) ? (n - off) : max_part;
         void* scratch = mc_scratch(ctx, s, sizeof(McScratchHeader) + (size_t)m * sizeof(int32_t));

@@ -219,3 +219,21 @@ def test_device_side_newton_summary(ctx, oracle):
     assert summ["nan_norm_res"] == int(np.isnan(nr_h).sum())
     with pytest.raises(ValueError, match="SIZE"):
         ctx.mc_summary(n, it, y, nr, nbins=5000)
+
+
+def test_batches_larger_than_one_list_part(ctx, oracle):
+    """The compacted-Newton schedule keeps int32 list entries, so batches beyond 2^30 points are processed in parts;
+    `mc_part_points` shrinks the part size so that path runs here: same bits as the single-part run, including the
+    ragged last part and parts without any plastic point."""
+    deps, sn = mc_tracing_inputs(oracle, 30_011, seed=12, shear=0.1)
+    deps[:5000] *= 1e-3                                      # a stretch that stays elastic: parts with an empty list
+    whole = run_device(ctx, deps, sn)
+    old = ctx.get_option("mc_part_points")
+    try:
+        for part in (4096, 64, 1000):                        # 1000 is rounded down to 960 (whole wave tiles)
+            ctx.set_option("mc_part_points", part)
+            split = run_device(ctx, deps, sn)
+            for a, b in zip(whole, split):
+                assert np.array_equal(a, b, equal_nan=True), part
+    finally:
+        ctx.set_option("mc_part_points", old)
