@@ -472,3 +472,26 @@ def test_small_batch_path_equals_chunked_pipeline(ctx, oracle, n):
         assert np.array_equal(a, b)
     Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
     assert_close_scaled(res[1 << 20][0][: n * 16], Co, RTOL, "C_tang small path")
+
+
+@pytest.mark.parametrize("E_,nu_,s0_,H_", [(210e3, 0.25, 400.0, 2000.0), (10.0, 0.45, 0.05, 0.0), (70e3, 0.0, 250.0, 70e3)])
+def test_other_material_parameters(ctx, oracle, E_, nu_, s0_, H_):
+    """Nothing in the kernels is specialised to the demo's constants (:185-188): steel-like values, a soft nearly
+    incompressible material with perfect plasticity (H = 0), and nu = 0 with very stiff hardening."""
+    prm = VmParams(E_, nu_, s0_, H_)
+    for d in (4, 6):
+        n = 5000
+        rng = np.random.Generator(np.random.PCG64(d))
+        deps = rng.normal(0.0, 0.35 * s0_ / E_, size=(n, d))
+        sigma_n = rng.normal(0.0, 0.25 * s0_, size=(n, d))
+        p = np.abs(rng.normal(0.0, 1e-3, size=n))
+        Co, so, dpo = oracle.von_mises(deps, sigma_n, p, E=E_, nu=nu_, sigma_0=s0_, H=H_)
+        assert 0.1 < (dpo > 0).mean() < 0.99
+        C, s, dp = np.empty(n * d * d), np.empty(n * d), np.empty(n)
+        ctx.von_mises(prm, d, n, MEM_HOST, deps, sigma_n, p, C, s, dp)
+        assert_close_scaled(C, Co, RTOL, "C_tang")
+        assert_close_scaled(s, so, RTOL, "sigma")
+        assert_close_scaled(dp, dpo, RTOL, "dp")
+        Cx = np.empty(n * d * d)
+        ctx.vm_expand_tangent(prm, d, n, MEM_HOST, s, dp, Cx)
+        assert_close_scaled(Cx, Co, RTOL, "tangent from state")
