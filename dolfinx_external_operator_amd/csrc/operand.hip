@@ -103,6 +103,7 @@ int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double*
     switch (kind) {
         case DXO_OPERAND_VALUE: launch_operand<G, BS, DXO_OPERAND_VALUE>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
         case DXO_OPERAND_GRAD: launch_operand<G, BS, DXO_OPERAND_GRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_VALUE_GRAD: launch_operand<G, BS, DXO_OPERAND_VALUE_GRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
         case DXO_OPERAND_EPS_MANDEL:
             if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
             return DXO_E_DIM;
@@ -130,6 +131,7 @@ extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
     switch (kind) {
         case DXO_OPERAND_VALUE: return bs == 1 || bs == gdim ? bs : DXO_E_DIM;
         case DXO_OPERAND_GRAD: return bs == 1 || bs == gdim ? bs * gdim : DXO_E_DIM;
+        case DXO_OPERAND_VALUE_GRAD: return bs == 1 || bs == gdim ? bs * (1 + gdim) : DXO_E_DIM;
         case DXO_OPERAND_EPS_MANDEL: return bs == gdim ? (gdim == 2 ? 4 : 6) : DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD: return bs == gdim ? gdim * gdim : DXO_E_DIM;
     }
@@ -161,7 +163,7 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     OperandDev& v = m->dev;
     v.nq = d->nq; v.ndofs = d->ndofs; v.ngeom = d->ngeom;
     v.cells_per_wave = DXO_WAVE / d->nq;
-    const int maxbs = G, maxD = G * G;
+    const int maxbs = G, maxD = G * (1 + G);
     int wd = v.cells_per_wave * (op_odd(d->ndofs * maxbs) + op_odd(d->ngeom * G));
     if (wd < DXO_WAVE * maxD) wd = DXO_WAVE * maxD;
     v.wave_doubles = (wd + 1) & ~1;

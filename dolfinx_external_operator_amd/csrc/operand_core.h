@@ -53,6 +53,7 @@ __device__ __forceinline__ void invert(const double (&J)[G][G], double (&K)[G][G
 template <int G, int BS, int KIND>
 struct OperandShape {
     static constexpr int D = KIND == DXO_OPERAND_VALUE ? BS
+                           : KIND == DXO_OPERAND_VALUE_GRAD ? BS * (1 + G)
                            : KIND == DXO_OPERAND_GRAD ? BS * G
                            : KIND == DXO_OPERAND_EPS_MANDEL ? (G == 2 ? 4 : 6)
                            : G * G;   // DXO_OPERAND_DEFGRAD
@@ -71,6 +72,13 @@ __device__ __forceinline__ void shape_operand(const double (&val)[BS], const dou
         for (int i = 0; i < BS; ++i)
 #pragma unroll
             for (int j = 0; j < G; ++j) o[i * G + j] = g[i][j];
+    } else if constexpr (KIND == DXO_OPERAND_VALUE_GRAD) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            o[i] = val[i];
+#pragma unroll
+            for (int j = 0; j < G; ++j) o[BS + i * G + j] = g[i][j];
+        }
     } else if constexpr (KIND == DXO_OPERAND_EPS_MANDEL) {
         if constexpr (G == 2) {
             o[0] = g[0][0]; o[1] = g[1][1]; o[2] = 0.0; o[3] = r2 * (g[0][1] + g[1][0]);
@@ -278,11 +286,12 @@ __device__ __forceinline__ bool operand_compute(const OperandDev& m, const doubl
             double ua[BS];
 #pragma unroll
             for (int i = 0; i < BS; ++i) ua[i] = Uc[a * BS + i];
-            if constexpr (KIND == DXO_OPERAND_VALUE) {
+            if constexpr (KIND == DXO_OPERAND_VALUE || KIND == DXO_OPERAND_VALUE_GRAD) {
                 const double ph = phi[a];
 #pragma unroll
                 for (int i = 0; i < BS; ++i) val[i] += ua[i] * ph;
-            } else {
+            }
+            if constexpr (KIND != DXO_OPERAND_VALUE) {
 #pragma unroll
                 for (int k = 0; k < G; ++k) {
                     const double dk = dphi[a * G + k];

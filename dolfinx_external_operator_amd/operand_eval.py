@@ -19,7 +19,7 @@ import numpy as np
 
 from ._lib import MEM_DEVICE, MEM_HOST, Context, default_context
 
-KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3}
+KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3, "value_grad": 4}
 
 
 class MeshDesc(C.Structure):
@@ -136,6 +136,14 @@ class DeviceMesh:
         rc = self.ctx.lib.dxo_von_mises_field(self.ctx._h, C.byref(prm), self._h, int(mem), *(C.c_void_p(ptr(a)) for a in
                                               (u, sigma_n, p, C_tang, sigma, dp)))
         self.ctx.check(rc, "dxo_von_mises_field")
+
+    def heat(self, A: float, B: float, T_dofs, q=None, dqdT=None, dqdsigma=None, mem: int = MEM_HOST) -> None:
+        """dxo_heat_field: T and grad T of a scalar field + the heat-flux kernels in one launch (all cells)."""
+        def ptr(a):
+            return a if isinstance(a, (int, np.integer)) or a is None else a.ctypes.data
+        rc = self.ctx.lib.dxo_heat_field(self.ctx._h, float(A), float(B), self._h, int(mem),
+                                         *(None if a is None else C.c_void_p(ptr(a)) for a in (T_dofs, q, dqdT, dqdsigma)))
+        self.ctx.check(rc, "dxo_heat_field")
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self.ctx._h:

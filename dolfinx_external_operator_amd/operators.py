@@ -208,6 +208,15 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
         c = holder["ctx"]
         if fuse_by_identity and holder["keep"] is not None and holder["keep"][0] is T and holder["keep"][1] is sigma:
             return holder["val"][which]
+        if (isinstance(T, LazyOperand) and isinstance(sigma, LazyOperand) and T.kind == "value" and sigma.kind == "grad"
+                and T.bs == 1 and sigma.bs == 1 and T.mesh is sigma.mesh and T.mesh.ctx is c and np.array_equal(T.u, sigma.u)):
+            # both operands are still unevaluated views of the SAME scalar field: T, grad T and the requested output
+            # in one launch (dxo_heat_field)
+            n, gdim = T.shape[0] * T.shape[1], T.mesh.gdim
+            sizes = (n * gdim, n * gdim, n * gdim * gdim)
+            outs = [np.empty(sz) if k == which else None for k, sz in enumerate(sizes)]
+            T.mesh.heat(A, B, T.u, outs[0], outs[1], outs[2])
+            return outs[which]
         T_ = _as_f64_host(T, "T").reshape(-1)
         n = T_.size
         sig_ = _as_f64_host(sigma, "sigma").reshape(-1)

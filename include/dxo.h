@@ -242,7 +242,8 @@ enum {
     DXO_OPERAND_GRAD = 1,        /* grad u, [i][j]=du_i/dx_j value_size = bs*gdim                    (heat: grad T)   */
     DXO_OPERAND_EPS_MANDEL = 2,  /* [g00,g11,0,r(g01+g10)] (2-D, demo_plasticity_von_mises.py:225-227),
                                     [g00,g11,g22,r(g01+g10),r(g02+g20),r(g12+g21)] (3-D), r = sqrt(2)/2; bs = gdim   */
-    DXO_OPERAND_DEFGRAD = 3      /* I + grad u, row-major   value_size = gdim*gdim (demo_hyperelasticity.py:479)      */
+    DXO_OPERAND_DEFGRAD = 3,     /* I + grad u, row-major   value_size = gdim*gdim (demo_hyperelasticity.py:479)      */
+    DXO_OPERAND_VALUE_GRAD = 4   /* [u (bs), grad u (bs*gdim)] in one pass, value_size = bs*(1+gdim) (heat: T and grad T)   */
 };
 typedef struct dxo_mesh_desc {
     int32_t gdim;               /* 2 or 3 (= topological dimension) */
@@ -293,6 +294,13 @@ typedef struct dxo_assign_desc {
 } dxo_assign_desc;
 int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, const double* values,
                double* coeff, int64_t coeff_size);
+
+/* Operand evaluation FUSED in front of the heat-flux kernel: T and sigma = grad T of a scalar Lagrange field on
+ * `mesh` are formed per quadrature point and fed to q_impl / dqdT_impl / dqdsigma_impl
+ * (demo_nonlinear_heat_equation_part2.py:219-261) in the same launch. T_dofs: num_field_nodes doubles; outputs cover
+ * all cells: q[n][gdim], dqdT[n][gdim], dqdsigma[n][gdim][gdim], n = num_cells*nq; any output may be NULL. */
+int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, const double* T_dofs,
+                   double* q, double* dqdT, double* dqdsigma);
 
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte

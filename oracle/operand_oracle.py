@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
-VALUE, GRAD, EPS_MANDEL, DEFGRAD = 0, 1, 2, 3
+VALUE, GRAD, EPS_MANDEL, DEFGRAD, VALUE_GRAD = 0, 1, 2, 3, 4
 
 
 def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=None):
@@ -36,6 +36,8 @@ def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=Non
     nc, nq = g.shape[:2]
     if kind == GRAD:
         return g.reshape(nc, nq, bs * gdim)
+    if kind == VALUE_GRAD:
+        return np.concatenate([np.einsum("cai,qa->cqi", U, phi), g.reshape(nc, nq, bs * gdim)], axis=2)
     if bs != gdim:
         raise ValueError("eps / F need a vector field with bs = gdim")
     r = np.sqrt(2.0) * 0.5

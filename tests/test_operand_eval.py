@@ -289,3 +289,50 @@ def test_load_stepping_example_runs():
     fr = [s["plastic_fraction"] for s in rep["steps"]]
     assert fr[0] < fr[2] and fr[3] == 0.0                     # yielding spreads under loading, unloading is elastic
     assert rep["steps"][2]["max_p"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,n", [("triangle", (9, 7)), ("hexahedron", (3, 3, 2)), ("quadrilateral", (5, 5))])
+def test_value_and_gradient_in_one_pass_and_fused_heat(ctx, oracle, cell, n):
+    """Operand kind "value_grad" against the oracle, and dxo_heat_field (T, grad T and the heat-flux kernels of
+    demo_nonlinear_heat_equation_part2.py:219-261 in one launch) against operand oracle -> heat oracle; then the same
+    through make_heat with two lazy operands of one field, as the demo's three operators would call it."""
+    from dolfinx_external_operator_amd import DeviceMesh, make_heat
+    from oracle.operand_oracle import VALUE_GRAD
+
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=2)
+    G = m.gdim
+    x = m.node_x
+    Tn = 1.0 + x[:, 0] ** 2 + x[:, 1] + (0.3 * x[:, 2] * x[:, 0] if G == 3 else 0.0)     # T = x^2 + y (:148) is in the space
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        vg = dm.evaluate("value_grad", 1, Tn)
+        ref = eval_operand(VALUE_GRAD, 1, Tn, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+        assert vg.shape == (m.num_cells, m.nq, 1 + G)
+        assert np.abs(vg - ref).max() <= 1e-13 * np.abs(ref).max()
+        xq = m.physical_points()
+        assert np.abs(vg[..., 0] - (1.0 + xq[..., 0] ** 2 + xq[..., 1] + (0.3 * xq[..., 2] * xq[..., 0] if G == 3 else 0.0))).max() <= 1e-12
+        npts = m.num_cells * m.nq
+        q, dT, ds = np.full(npts * G + 2, -3.0), np.full(npts * G + 2, -3.0), np.full(npts * G * G + 2, -3.0)
+        dm.heat(1.0, 1.0, Tn, q, dT, ds)
+        assert q[-1] == -3.0 and dT[-2] == -3.0 and ds[-1] == -3.0
+        if G == 2:
+            qo, dTo, dso = oracle.heat(ref[..., 0].reshape(-1), ref[..., 1:].reshape(-1, 2))
+        else:   # the C oracle is the 2-D reference kernel; 3-D: the same three formulas in NumPy
+            k = 1.0 / (1.0 + ref[..., 0].reshape(-1))
+            sg = ref[..., 1:].reshape(-1, 3)
+            qo, dTo, dso = -k[:, None] * sg, (k * k)[:, None] * sg, -k[:, None, None] * np.eye(3)[None]
+        for got, want in ((q[:-2], qo), (dT[:-2], dTo), (ds[:-2], dso)):
+            assert np.abs(got - np.asarray(want).reshape(-1)).max() <= 1e-13 * np.abs(want).max()
+        only = np.empty(npts * G)
+        dm.heat(1.0, 1.0, Tn, None, only, None)                      # a single requested output
+        assert np.array_equal(only, dT[:-2])
+        # the demo's call pattern: q((0,0)), dq/dT((1,0)), dq/dsigma((0,1)) on (T, sigma) operands of the same field
+        T_op, s_op = dm.operand("value", Tn, bs=1, lazy=True), dm.operand("grad", Tn, bs=1, lazy=True)
+        ext = make_heat(A=1.0, B=1.0, ctx=ctx)
+        Tv, sv = T_op.eval(None), s_op.eval(None)
+        for deriv, want in (((0, 0), q[:-2]), ((1, 0), dT[:-2]), ((0, 1), ds[:-2])):
+            assert np.array_equal(ext(deriv)(Tv, sv), want)
+        assert Tv._value is None and sv._value is None               # neither operand array was ever materialised
+    finally:
+        dm.close()
