@@ -1,0 +1,330 @@
+// adjoint.hip — the consumer side of the path on the device: virtual work of a quadrature field and
+// the matrix-free action of the tangent.
+//
+// In the reference the coefficient the operator wrote is consumed by DOLFINx assembly: the residual form
+// inner(sigma, eps(v)) dx and the Jacobian form inner(C_tang : eps(du), eps(v)) dx that `_apply_derivative_tensor`
+// produces (src/dolfinx_external_operator/external_operator.py:463-486; demo_plasticity_von_mises.py:378-391). That
+// step is what forces the 16/36-double tangents across PCIe. Its arithmetic is the ADJOINT of the operand evaluation:
+//   operand      e_q   = B_q u          (gather dofs, contract with grad phi, push forward, shape)      operand.hip
+//   virtual work f     = sum_q w_q |det J_q| B_q^T s_q                                                  dxo_operand_adjoint
+//   tangent      K v   = sum_q w_q |det J_q| B_q^T C_q B_q v   (never forming K)                        dxo_tangent_apply
+// so with these two entry points a Newton-Krylov solver can keep sigma and C_tang in HBM and move only dof vectors.
+//
+// Kernel shape (both): a wave owns floor(64/nq) consecutive cells. Phase 1, lane = (cell, point): J^-1 and det J from
+// the gathered vertices, the point's dual tensor pulled back to reference gradients T_q[i][k] = w|detJ| sum_j G_ij K[k][j]
+// (G = the stress-like quantity unpacked from Mandel / row-major form), parked in the wave's LDS slice. Phase 2, lane =
+// (cell, node): f_a,i = sum_q sum_k T_q[i][k] dphi_a,k(xi_q) (+ the value part), one fp64 atomic add per dof into the
+// global vector (global_atomic_add_f64; nodes are shared between cells, the order of the additions is not fixed, so
+// results are reproducible to rounding, not bit for bit).
+#include "dxo_common.h"
+#include "operand_core.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+// Mandel / row-major operand value -> dual tensor Ghat[i][j] = d(pairing)/d(grad u)_ij, and the value part
+template <int G, int BS, int KIND>
+__device__ __forceinline__ void dual_tensor(const double (&s)[OperandShape<G, BS, KIND>::D], double (&vh)[BS],
+                                            double (&gh)[BS][G]) {
+    constexpr double r2 = 0.70710678118654752440;
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+        vh[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) gh[i][j] = 0.0;
+    }
+    if constexpr (KIND == DXO_OPERAND_VALUE) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) vh[i] = s[i];
+    } else if constexpr (KIND == DXO_OPERAND_GRAD || KIND == DXO_OPERAND_DEFGRAD) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) gh[i][j] = s[i * G + j];
+    } else if constexpr (KIND == DXO_OPERAND_VALUE_GRAD) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            vh[i] = s[i];
+#pragma unroll
+            for (int j = 0; j < G; ++j) gh[i][j] = s[BS + i * G + j];
+        }
+    } else {   // EPS_MANDEL: e = [g00, g11, (g22 | 0), r(g01+g10), r(g02+g20), r(g12+g21)]
+        if constexpr (G == 2) {
+            gh[0][0] = s[0]; gh[1][1] = s[1]; gh[0][1] = gh[1][0] = r2 * s[3];
+        } else {
+            gh[0][0] = s[0]; gh[1][1] = s[1]; gh[2][2] = s[2];
+            gh[0][1] = gh[1][0] = r2 * s[3]; gh[0][2] = gh[2][0] = r2 * s[4]; gh[1][2] = gh[2][1] = r2 * s[5];
+        }
+    }
+}
+
+// Phase 1 tail + phase 2: park (vh, T) of this lane's point, then scatter the cell-node sums. W layout behind the
+// gathered data: Tm[point][BS*(G+1)].
+template <int G, int BS>
+__device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const double* tab, double* Tm, bool active, int lane,
+                                                const double (&vh)[BS], const double (&gh)[BS][G], const double (&K)[G][G],
+                                                double scale, int64_t c0, int ncell, const int32_t* __restrict__ cells,
+                                                double* __restrict__ out) {
+    const OperandLayout<G> L(m);
+    constexpr int PT = BS * (G + 1);
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            Tm[lane * PT + i] = scale * vh[i];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < G; ++j) t += gh[i][j] * K[k][j];
+                Tm[lane * PT + BS + i * G + k] = scale * t;
+            }
+        }
+    }
+    op_fence();
+    const int nd = m.ndofs, nq = m.nq;
+    for (int idx = lane; idx < ncell * nd; idx += DXO_WAVE) {
+        const int c = idx / nd, a = idx - c * nd;
+        double acc[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) acc[i] = 0.0;
+        for (int q = 0; q < nq; ++q) {
+            const double* T = Tm + (c * nq + q) * PT;
+            const double ph = tab[q * L.sphi + a];
+            const double* dp = tab + L.o_dphi + q * L.sdphi + a * G;
+#pragma unroll
+            for (int i = 0; i < BS; ++i) {
+                double t = T[i] * ph;
+#pragma unroll
+                for (int k = 0; k < G; ++k) t += T[BS + i * G + k] * dp[k];
+                acc[i] += t;
+            }
+        }
+        const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
+        const int64_t node = m.dofmap[cell * nd + a];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) unsafeAtomicAdd(out + node * BS + i, acc[i]);
+    }
+    op_fence();
+}
+
+template <int G, int BS, int KIND>
+__global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const double* __restrict__ wq, int lds_wave,
+                                                             const double* __restrict__ S, const int32_t* __restrict__ cells,
+                                                             int64_t n_cells, double* __restrict__ out) {
+    constexpr int D = OperandShape<G, BS, KIND>::D;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tab = lds;
+    operand_load_tables<G>(m, tab);
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + m.table_doubles + wave * lds_wave;
+    const int cpw = m.cells_per_wave;
+    double* Tm = W + cpw * (op_odd(m.ndofs * BS) + op_odd(m.ngeom * G));
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        // only the geometry is needed
+        {
+            const int ng = m.ngeom, sx = op_odd(ng * G);
+            double* X = W + cpw * op_odd(m.ndofs * BS);
+            for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
+                const int c = idx / ng, v = idx - c * ng;
+                const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
+                const int64_t node = m.geom_dofmap[cell * ng + v];
+#pragma unroll
+                for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = m.x[node * G + j];
+            }
+        }
+        op_fence();
+        const int c = lane / m.nq, q = lane - c * m.nq;
+        const bool active = c < ncell;
+        double K[G][G], vh[BS], gh[BS][G], scale = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) K[i][j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < BS; ++i) {
+            vh[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) gh[i][j] = 0.0;
+        }
+        if (active) {
+            const OperandLayout<G> L(m);
+            const double* dpsi = tab + L.o_dpsi + q * L.sdpsi;
+            const double* Xc = W + cpw * op_odd(m.ndofs * BS) + c * L.sx;
+            double J[G][G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int k = 0; k < G; ++k) J[j][k] = 0.0;
+            for (int v = 0; v < m.ngeom; ++v)
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
+            const double det = invert<G>(J, K);
+            scale = wq[q] * fabs(det);
+            double s[D];
+            const double* Sp = S + ((c0 + c) * m.nq + q) * D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s[k] = Sp[k];
+            dual_tensor<G, BS, KIND>(s, vh, gh);
+        }
+        adjoint_scatter<G, BS>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, cells, out);
+    }
+}
+
+// K v without K: gather v, eps(v) per point, t = C_tang e, scatter B^T t (bs = gdim, Mandel pairing)
+template <int G>
+__global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
+                                                              const double* __restrict__ C_tang, const double* __restrict__ v,
+                                                              int64_t n_cells, double* __restrict__ out) {
+    constexpr int D = G == 2 ? 4 : 6;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tab = lds;
+    operand_load_tables<G>(m, tab);
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + m.table_doubles + wave * lds_wave;
+    const int cpw = m.cells_per_wave;
+    double* Tm = W + cpw * (op_odd(m.ndofs * G) + op_odd(m.ngeom * G));
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        operand_gather<G, G>(m, W, v, nullptr, c0, ncell, lane);
+        double e[D], K[G][G], det = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) K[i][j] = 0.0;
+        const bool active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, ncell, lane, e, K, det);
+        double vh[G], gh[G][G], scale = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            vh[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) gh[i][j] = 0.0;
+        }
+        if (active) {
+            const int q = lane - (lane / m.nq) * m.nq;
+            scale = wq[q] * fabs(det);
+            const double* Cp = C_tang + (c0 * m.nq + lane) * (D * D);     // lane = local point index
+            double t[D];
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < D; ++cc) acc += Cp[r * D + cc] * e[cc];
+                t[r] = acc;
+            }
+            dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
+        }
+        adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out);
+    }
+}
+
+int adjoint_lds_wave(const dxo_mesh* m) {
+    const OperandDev& v = m->dev;
+    const int G = m->gdim;
+    int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G)) + DXO_WAVE * G * (G + 1);
+    return (wd + 1) & ~1;
+}
+
+template <int G, int BS, int KIND>
+void launch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, const double* S, const int32_t* cells, int64_t n_cells,
+                    double* out, hipStream_t s) {
+    const int wd = adjoint_lds_wave(m);
+    const int64_t n_groups = (n_cells + m->dev.cells_per_wave - 1) / m->dev.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;
+    const size_t shm = (size_t)(m->dev.table_doubles + 4 * wd) * sizeof(double);
+    hipLaunchKernelGGL((operand_adjoint<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, m->dev, m->d_wq, wd, S,
+                       cells, n_cells, out);
+}
+
+template <int G, int BS>
+int dispatch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double* S, const int32_t* cells,
+                     int64_t n_cells, double* out, hipStream_t s) {
+    switch (kind) {
+        case DXO_OPERAND_VALUE: launch_adjoint<G, BS, DXO_OPERAND_VALUE>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_GRAD: launch_adjoint<G, BS, DXO_OPERAND_GRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_VALUE_GRAD: launch_adjoint<G, BS, DXO_OPERAND_VALUE_GRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_EPS_MANDEL:
+            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, S, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_DEFGRAD:
+            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+    }
+    return DXO_E_OPTION;
+}
+
+}  // namespace
+
+extern "C" int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights) {
+    if (!ctx) return DXO_E_NULL;
+    if (!mesh || !weights) return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_set_weights: NULL argument");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    if (!mesh->d_wq) DXO_HIP(ctx, hipMalloc((void**)&mesh->d_wq, (size_t)mesh->dev.nq * sizeof(double)));
+    DXO_HIP(ctx, hipMemcpy(mesh->d_wq, weights, (size_t)mesh->dev.nq * sizeof(double), hipMemcpyHostToDevice));
+    return DXO_OK;
+}
+
+extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
+                                   int64_t n_cells, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_operand_adjoint: mesh is NULL");
+    if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: quadrature weights not set (dxo_mesh_set_weights)");
+    const int D = dxo_operand_value_size(mesh->gdim, bs, kind);
+    if (D == DXO_E_OPTION) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: unknown operand kind");
+    if (D < 0) return dxo_fail(ctx, DXO_E_DIM, "dxo_operand_adjoint: block size does not fit the operand kind / gdim");
+    if (!cells) n_cells = n_cells < 0 ? mesh->num_cells : n_cells;
+    if (n_cells < 0 || (!cells && n_cells > mesh->num_cells)) return dxo_fail(ctx, DXO_E_SIZE, "dxo_operand_adjoint: bad n_cells");
+    if (n_cells == 0) return DXO_OK;
+    if (!S || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_operand_adjoint: NULL array");
+    if ((size_t)(mesh->dev.table_doubles + 4 * adjoint_lds_wave(mesh)) * sizeof(double) > 64 * 1024)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_operand_adjoint: element too large for the LDS budget");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    if (mesh->gdim == 2) rc = bs == 1 ? dispatch_adjoint<2, 1>(ctx, mesh, kind, S, cells, n_cells, out, s) : dispatch_adjoint<2, 2>(ctx, mesh, kind, S, cells, n_cells, out, s);
+    else                 rc = bs == 1 ? dispatch_adjoint<3, 1>(ctx, mesh, kind, S, cells, n_cells, out, s) : dispatch_adjoint<3, 3>(ctx, mesh, kind, S, cells, n_cells, out, s);
+    if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_operand_adjoint: unsupported (gdim, bs, kind)");
+    return dxo_device_end(ctx, s);
+}
+
+extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: mesh is NULL");
+    if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_apply: quadrature weights not set (dxo_mesh_set_weights)");
+    if (mesh->num_cells == 0) return DXO_OK;
+    if (!C_tang || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
+    const int wd = adjoint_lds_wave(mesh);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
+    if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;
+    if (mesh->gdim == 2)
+        hipLaunchKernelGGL(tangent_apply<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out);
+    else
+        hipLaunchKernelGGL(tangent_apply<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out);
+    return dxo_device_end(ctx, s);
+}

@@ -213,6 +213,7 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_u) (void)hipFree(m->d_u);
     if (m->d_cells) (void)hipFree(m->d_cells);
     if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_wq) (void)hipFree(m->d_wq);
     delete m;
     return DXO_OK;
 }

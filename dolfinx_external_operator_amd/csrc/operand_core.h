@@ -29,16 +29,19 @@ __device__ __forceinline__ void op_fence() {
 }
 
 template <int G>
-__device__ __forceinline__ void invert(const double (&J)[G][G], double (&K)[G][G]) {
+__device__ __forceinline__ double invert(const double (&J)[G][G], double (&K)[G][G]) {   // returns det J
     if constexpr (G == 2) {
-        const double idet = 1.0 / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+        const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        const double idet = 1.0 / det;
         K[0][0] = J[1][1] * idet; K[0][1] = -J[0][1] * idet;
         K[1][0] = -J[1][0] * idet; K[1][1] = J[0][0] * idet;
+        return det;
     } else {
         const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
         const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
         const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-        const double idet = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double idet = 1.0 / det;
         K[0][0] = c00 * idet; K[1][0] = c01 * idet; K[2][0] = c02 * idet;
         K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * idet;
         K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * idet;
@@ -46,6 +49,7 @@ __device__ __forceinline__ void invert(const double (&J)[G][G], double (&K)[G][G
         K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * idet;
         K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * idet;
         K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * idet;
+        return det;
     }
 }
 
@@ -244,8 +248,9 @@ __device__ __forceinline__ void pipe_commit(const OperandDev& m, const OperandPi
 // ---- per-lane gradient from the gathered data -> `o` (D values of this lane's point). Returns false for lanes
 // without a point. Shared by the standalone kernel and by kernels that consume the operand in place.
 template <int G, int BS, int KIND>
-__device__ __forceinline__ bool operand_compute(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
-                                                double (&o)[OperandShape<G, BS, KIND>::D]) {
+__device__ __forceinline__ bool operand_compute_geo(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
+                                                    double (&o)[OperandShape<G, BS, KIND>::D], double (&K)[G][G],
+                                                    double& detJ) {
     const int nd = m.ndofs, ng = m.ngeom;
     const OperandLayout<G> L(m);
     const int su = op_odd(nd * BS);
@@ -259,7 +264,7 @@ __device__ __forceinline__ bool operand_compute(const OperandDev& m, const doubl
         const double* dphi = tab + L.o_dphi + q * L.sdphi;
         const double* dpsi = tab + L.o_dpsi + q * L.sdpsi;
         const double* Xc = X + c * L.sx;
-        double J[G][G], K[G][G];
+        double J[G][G];
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
@@ -271,7 +276,7 @@ __device__ __forceinline__ bool operand_compute(const OperandDev& m, const doubl
 #pragma unroll
                 for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
         }
-        invert<G>(J, K);
+        detJ = invert<G>(J, K);
         double val[BS], gref[BS][G];
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
@@ -316,6 +321,13 @@ __device__ __forceinline__ bool operand_compute(const OperandDev& m, const doubl
     return active;
 }
 
+template <int G, int BS, int KIND>
+__device__ __forceinline__ bool operand_compute(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
+                                                double (&o)[OperandShape<G, BS, KIND>::D]) {
+    double K[G][G], detJ;
+    return operand_compute_geo<G, BS, KIND>(m, tab, W, ncell, lane, o, K, detJ);
+}
+
 // gather + compute for one group (no pipelining): entity lists and elements too large for the register pipeline
 template <int G, int BS, int KIND>
 __device__ __forceinline__ bool operand_point(const OperandDev& m, const double* tab, double* W,
@@ -339,4 +351,5 @@ struct dxo_mesh {
     size_t cells_cap = 0;
     double* d_out = nullptr;    // staging for host-resident outputs
     size_t out_cap = 0;
+    double* d_wq = nullptr;     // quadrature weights (dxo_mesh_set_weights), needed by the adjoint kernels only
 };

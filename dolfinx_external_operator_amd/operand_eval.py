@@ -70,8 +70,11 @@ class DeviceMesh:
     @classmethod
     def from_synthetic(cls, mesh, **kw):
         """From `synthetic.SyntheticMesh`."""
-        return cls(gdim=mesh.gdim, phi=mesh.phi, dphi=mesh.dphi, dpsi=mesh.dpsi, dofmap=mesh.dofmap,
-                   geom_dofmap=mesh.geom_dofmap, x=mesh.x, num_field_nodes=mesh.node_x.shape[0], **kw)
+        dm = cls(gdim=mesh.gdim, phi=mesh.phi, dphi=mesh.dphi, dpsi=mesh.dpsi, dofmap=mesh.dofmap,
+                 geom_dofmap=mesh.geom_dofmap, x=mesh.x, num_field_nodes=mesh.node_x.shape[0], **kw)
+        if getattr(mesh, "weights", None) is not None:
+            dm.set_weights(mesh.weights)
+        return dm
 
     @classmethod
     def from_dolfinx(cls, V, quadrature_points, **kw):
@@ -136,6 +139,25 @@ class DeviceMesh:
         rc = self.ctx.lib.dxo_von_mises_field(self.ctx._h, C.byref(prm), self._h, int(mem), *(C.c_void_p(ptr(a)) for a in
                                               (u, sigma_n, p, C_tang, sigma, dp)))
         self.ctx.check(rc, "dxo_von_mises_field")
+
+    def set_weights(self, weights) -> None:
+        """Reference quadrature weights (nq values, `basix.make_quadrature(...)[1]`): needed by adjoint / tangent_apply."""
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != self.nq:
+            raise ValueError(f"{w.size} weights for {self.nq} quadrature points")
+        self.ctx.check(self.ctx.lib.dxo_mesh_set_weights(self.ctx._h, self._h, w.ctypes.data), "dxo_mesh_set_weights")
+
+    def adjoint(self, kind: str, bs: int, S_ptr: int, out_ptr: int, n_cells: int | None = None, cells_ptr: int | None = None) -> None:
+        """out += sum_q w |det J| B^T S (DEVICE pointers): the assembled vector of inner(S, operand(v)) dx."""
+        rc = self.ctx.lib.dxo_operand_adjoint(self.ctx._h, self._h, KINDS[kind], int(bs), C.c_void_p(S_ptr),
+                                              None if cells_ptr is None else C.c_void_p(cells_ptr),
+                                              self.num_cells if n_cells is None else int(n_cells), C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_operand_adjoint")
+
+    def tangent_apply(self, C_tang_ptr: int, v_ptr: int, out_ptr: int) -> None:
+        """out += K v with K = sum_q w |det J| B^T C_tang B never formed (DEVICE pointers, eps / Mandel, bs = gdim)."""
+        rc = self.ctx.lib.dxo_tangent_apply(self.ctx._h, self._h, C.c_void_p(C_tang_ptr), C.c_void_p(v_ptr), C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_tangent_apply")
 
     def heat(self, A: float, B: float, T_dofs, q=None, dqdT=None, dqdsigma=None, mem: int = MEM_HOST) -> None:
         """dxo_heat_field: T and grad T of a scalar field + the heat-flux kernels in one launch (all cells)."""

@@ -95,6 +95,7 @@ class SyntheticMesh:
     phi: np.ndarray
     dphi: np.ndarray
     dpsi: np.ndarray
+    weights: np.ndarray | None = None   # (nq,) reference quadrature weights
 
     @property
     def num_cells(self) -> int:
@@ -173,11 +174,11 @@ def structured_mesh(cell: str, n: tuple[int, ...], degree: int = 2, distort: flo
     x = vx.reshape(-1, gdim)
     fe = LagrangeElement(cell, degree)
     geo = LagrangeElement(cell, 1)
-    points, _ = quadrature_degree2(cell)
+    points, weights = quadrature_degree2(cell)
     phi, dphi = fe.tabulate(points)
     _, dpsi = geo.tabulate(points)
     # physical position of field nodes: image of the reference nodes under each cell's map (shared nodes agree)
     psi_nodes, _ = geo.tabulate(fe.nodes)
     node_x = np.zeros((int(np.prod(fshape)), gdim))
     node_x[dm.reshape(-1)] = np.einsum("av,cvj->caj", psi_nodes, x[geom]).reshape(-1, gdim)
-    return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi)
+    return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi, weights)

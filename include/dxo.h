@@ -278,6 +278,22 @@ int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, co
 int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                         const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
 
+/* ---- the consumer side on the device, DEVICE memory only ---------------------------------
+ * In the reference the coefficient is consumed by DOLFINx assembly of inner(sigma, eps(v)) dx and of the Jacobian
+ * form `_apply_derivative_tensor` builds (src/dolfinx_external_operator/external_operator.py:463-486;
+ * demo_plasticity_von_mises.py:378-391). These two entry points are the ADJOINT of dxo_eval_operand, so a
+ * matrix-free Newton-Krylov solver can leave sigma and C_tang in HBM and move only dof vectors:
+ *   dxo_operand_adjoint : out[dof] += sum_q w_q |det J_q| B_q^T s_q   for a quadrature field s of the operand's shape
+ *                         (kind EPS_MANDEL with s = sigma: the internal force; GRAD with s = q: the heat residual)
+ *   dxo_tangent_apply   : out[dof] += sum_q w_q |det J_q| B_q^T C_tang_q B_q v   (eps / Mandel, bs = gdim), K never formed
+ * `out` is ACCUMULATED into (zero it first); S / C_tang are laid out like the operator outputs, (n_cells, nq, ...).
+ * Additions into shared dofs are fp64 hardware atomics: reproducible to rounding, not bit for bit.
+ * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
+int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
+int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
+                        int64_t n_cells, double* out);
+int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out);
+
 /* ---- coefficient assigners on the device, DEVICE memory only --------------------------
  * One scatter for the reference's three dofmap assigners (src/dolfinx_external_operator/external_operator.py):
  * _assign_non_mixed :286-287, _assign_mixed_2d :292-311, _assign_mixed_3d :313-335. For cell c, point p < n_pts,

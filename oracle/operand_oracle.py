@@ -49,3 +49,58 @@ def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=Non
     if kind == DEFGRAD:
         return (g + np.eye(gdim)).reshape(nc, nq, gdim * gdim)
     raise ValueError(kind)
+
+
+def _geometry(dofmap, geom_dofmap, x, dphi, dpsi, cells):
+    gdim = dphi.shape[2]
+    X = np.asarray(x)[:, :gdim][geom_dofmap[cells]]
+    J = np.einsum("cvj,qvk->cqjk", X, dpsi)
+    return np.linalg.inv(J), np.linalg.det(J)
+
+
+def operand_adjoint(kind, bs, S, weights, dofmap, geom_dofmap, x, phi, dphi, dpsi, n_nodes, cells=None):
+    """Adjoint of eval_operand weighted by the quadrature rule: out[node, i] = sum over cells and points of
+    w_q |det J_q| B_q^T S_q — the assembled vector of the form inner(S, operand(v)) dx (internal force for
+    kind EPS_MANDEL with S = sigma). S has the operand's shape (n_cells, nq, value_size). Returns (n_nodes*bs,)."""
+    gdim = dphi.shape[2]
+    if cells is None:
+        cells = np.arange(dofmap.shape[0])
+    cells = np.asarray(cells, dtype=np.int64)
+    K, det = _geometry(dofmap, geom_dofmap, x, dphi, dpsi, cells)
+    scale = np.asarray(weights)[None, :] * np.abs(det)                          # (nc, nq)
+    gphys = np.einsum("qak,cqkj->cqaj", dphi, K)                                 # d phi_a / d x_j
+    S = np.asarray(S, dtype=np.float64).reshape(len(cells), phi.shape[0], -1)
+    nc, nq = S.shape[:2]
+    vh = np.zeros((nc, nq, bs))
+    gh = np.zeros((nc, nq, bs, gdim))
+    r = np.sqrt(2.0) * 0.5
+    if kind == VALUE:
+        vh = S
+    elif kind in (GRAD, DEFGRAD):
+        gh = S.reshape(nc, nq, bs, gdim)
+    elif kind == VALUE_GRAD:
+        vh, gh = S[..., :bs], S[..., bs:].reshape(nc, nq, bs, gdim)
+    elif kind == EPS_MANDEL:
+        if gdim == 2:
+            gh[..., 0, 0], gh[..., 1, 1] = S[..., 0], S[..., 1]
+            gh[..., 0, 1] = gh[..., 1, 0] = r * S[..., 3]
+        else:
+            gh[..., 0, 0], gh[..., 1, 1], gh[..., 2, 2] = S[..., 0], S[..., 1], S[..., 2]
+            gh[..., 0, 1] = gh[..., 1, 0] = r * S[..., 3]
+            gh[..., 0, 2] = gh[..., 2, 0] = r * S[..., 4]
+            gh[..., 1, 2] = gh[..., 2, 1] = r * S[..., 5]
+    else:
+        raise ValueError(kind)
+    contrib = np.einsum("cq,cqi,qa->cai", scale, vh, phi) + np.einsum("cq,cqij,cqaj->cai", scale, gh, gphys)
+    out = np.zeros((n_nodes, bs))
+    np.add.at(out, dofmap[cells], contrib)
+    return out.reshape(-1)
+
+
+def tangent_apply(C_tang, v, weights, dofmap, geom_dofmap, x, phi, dphi, dpsi, n_nodes):
+    """K v = sum_q w |det J| B^T C_tang B v for the eps / Mandel operand (bs = gdim), without forming K."""
+    gdim = dphi.shape[2]
+    e = eval_operand(EPS_MANDEL, gdim, v, dofmap, geom_dofmap, x, phi, dphi, dpsi)
+    d = e.shape[2]
+    t = np.einsum("cqrs,cqs->cqr", np.asarray(C_tang).reshape(e.shape[0], e.shape[1], d, d), e)
+    return operand_adjoint(EPS_MANDEL, gdim, t, weights, dofmap, geom_dofmap, x, phi, dphi, dpsi, n_nodes)

@@ -105,7 +105,26 @@ for cell, n, degree, kind, label in (CASES if args.case < 0 else [CASES[args.cas
                           "two_launches_ms": res["two_launches"], "fused_ms": res["fused"],
                           "fused_qp_per_s": npts / res["fused"] * 1e3, "fused_bytes_per_qp": (in_bytes + out_bytes) / npts,
                           "fused_GBps_algorithmic": (in_bytes + out_bytes) / res["fused"] / 1e6}), flush=True)
-        del sig, pp, Ct, st, dpt
+        # consumer side: internal force f = sum w|detJ| B^T sigma and the matrix-free tangent action K v
+        fv = torch.zeros(m.node_x.shape[0] * bs, dtype=torch.float64, device=dev)
+        vv = torch.randn(m.node_x.shape[0] * bs, dtype=torch.float64, device=dev)
+        cons = {}
+        for name, fn in (("internal_force", lambda: dm.adjoint("eps", bs, st.data_ptr(), fv.data_ptr())),
+                         ("tangent_apply", lambda: dm.tangent_apply(Ct.data_ptr(), vv.data_ptr(), fv.data_ptr()))):
+            for _ in range(3):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launches)]
+            for a, b in ev:
+                a.record(stream); fn(); b.record(stream)
+            torch.cuda.synchronize()
+            cons[name] = statistics.median(a.elapsed_time(b) for a, b in ev)
+        geo = m.x.nbytes + m.dofmap.nbytes + m.geom_dofmap.nbytes
+        print(json.dumps({"case": "consumer side: " + label, "points": npts, "d": d,
+                          "internal_force_ms": cons["internal_force"], "internal_force_qp_per_s": npts / cons["internal_force"] * 1e3,
+                          "internal_force_GBps_algorithmic": (npts * d * 8 + geo + 2 * u_h.nbytes) / cons["internal_force"] / 1e6,
+                          "tangent_apply_ms": cons["tangent_apply"], "tangent_apply_qp_per_s": npts / cons["tangent_apply"] * 1e3,
+                          "tangent_apply_GBps_algorithmic": (npts * d * d * 8 + geo + 3 * u_h.nbytes) / cons["tangent_apply"] / 1e6}), flush=True)
+        del sig, pp, Ct, st, dpt, fv, vv
     dm.close()
     del u, out
 ctx.close()

@@ -1,0 +1,152 @@
+"""The consumer side on the device: dxo_operand_adjoint (assembled vector of inner(S, operand(v)) dx)
+and dxo_tangent_apply (matrix-free K v). No reference code exists for these on the GPU box (DOLFINx assembly), so the
+pins are mathematical identities that do not depend on any oracle — adjointness <B u, S>_w = <u, B^T S>, the patch test,
+symmetry of v -> K v — plus agreement with the NumPy oracle."""
+import numpy as np
+import pytest
+
+from dolfinx_external_operator_amd.synthetic import structured_mesh
+from oracle.operand_oracle import (DEFGRAD, EPS_MANDEL, GRAD, VALUE, VALUE_GRAD, _geometry, eval_operand, operand_adjoint,
+                                   tangent_apply)
+
+pytestmark = pytest.mark.gpu
+CELLS = {"triangle": (6, 5), "quadrilateral": (4, 4), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 3)}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "value_grad": VALUE_GRAD}
+
+
+def device_adjoint(ctx, dm, kind, bs, S, n_nodes, cells=None):
+    import torch
+
+    St = torch.from_numpy(np.ascontiguousarray(S).reshape(-1)).cuda()
+    out = torch.zeros(n_nodes * bs, dtype=torch.float64, device="cuda")
+    ct = None if cells is None else torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int32)).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dm.adjoint(kind, bs, St.data_ptr(), out.data_ptr(), n_cells=None if cells is None else len(cells),
+               cells_ptr=None if ct is None else ct.data_ptr())
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_adjoint_identity_patch_test_and_oracle(ctx, cell, degree):
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh(cell, CELLS[cell], degree, distort=0.2, seed=6)
+    G, nn = m.gdim, m.node_x.shape[0]
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    rng = np.random.Generator(np.random.PCG64(3))
+    _, det = _geometry(m.dofmap, m.geom_dofmap, m.x, m.dphi, m.dpsi, np.arange(m.num_cells))
+    wdet = m.weights[None, :] * np.abs(det)
+    try:
+        for bs in (1, G):
+            for kind in ("value", "grad", "value_grad") + (("eps", "F") if bs == G else ()):
+                u = rng.normal(size=nn * bs)
+                e = dm.evaluate(kind, bs, u)                               # B u on the device
+                if kind == "F":
+                    e = e - np.eye(G).reshape(-1)                          # the adjoint is that of the linear part
+                S = rng.normal(size=e.shape)
+                f = device_adjoint(ctx, dm, kind, bs, S, nn)
+                lhs, rhs = np.sum(wdet[:, :, None] * e * S), u @ f          # <B u, S>_w  vs  <u, B^T S>
+                assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), np.abs(wdet).sum()), (kind, bs, lhs, rhs)
+                ref = operand_adjoint(KIND_ID[kind], bs, S, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
+                assert np.abs(f - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-30), (kind, bs)
+        # patch test: a constant stress field does no work on interior nodes
+        Sc = np.broadcast_to(rng.normal(size=dm.value_size("eps", G)), (m.num_cells, m.nq, dm.value_size("eps", G)))
+        fc = device_adjoint(ctx, dm, "eps", G, Sc, nn).reshape(-1, G)
+        interior = np.all((m.node_x > 1e-9) & (m.node_x < 1 - 1e-9), axis=1)
+        if interior.any():
+            assert np.abs(fc[interior]).max() <= 1e-13 * np.abs(fc).max()
+        # an entity subset: S is indexed by position in the entity list, like Expression.eval's output
+        cells = np.array([m.num_cells - 1, 0, 2], dtype=np.int32)
+        Ss = rng.normal(size=(3, m.nq, G))
+        fs = device_adjoint(ctx, dm, "grad", 1, Ss, nn, cells)
+        ref = operand_adjoint(GRAD, 1, Ss, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn, cells)
+        assert np.abs(fs - ref).max() <= 1e-12 * np.abs(ref).max()
+    finally:
+        dm.close()
+
+
+@pytest.mark.parametrize("cell,n", [("triangle", (9, 8)), ("hexahedron", (4, 3, 3)), ("tetrahedron", (2, 2, 3))])
+def test_matrix_free_tangent(ctx, oracle, cell, n):
+    """K v from dxo_tangent_apply with the tangents the von Mises kernel wrote: equals the oracle's B^T C B v, is
+    symmetric (w.Kv = v.Kw), and with C = C_elas a linear displacement field loads only the boundary."""
+    import torch
+
+    from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh, VmParams
+
+    m = structured_mesh(cell, n, 2, distort=0.15, seed=8)
+    G, nn = m.gdim, m.node_x.shape[0]
+    d = 4 if G == 2 else 6
+    npts = m.num_cells * m.nq
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    rng = np.random.Generator(np.random.PCG64(5))
+    E = 70e3
+    prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+    try:
+        u = rng.normal(size=nn * G)
+        u *= 1.5e-3 / eval_operand(EPS_MANDEL, G, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi).std()
+        sig_n, p = rng.normal(0.0, 50.0, npts * d), np.abs(rng.normal(0.0, 1e-3, npts))
+        t = {k: torch.from_numpy(v).cuda() for k, v in (("u", u), ("sn", sig_n), ("p", p))}
+        C = torch.empty(npts * d * d, dtype=torch.float64, device="cuda")
+        s = torch.empty(npts * d, dtype=torch.float64, device="cuda")
+        dp = torch.empty(npts, dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dm.von_mises(prm, t["u"].data_ptr(), t["sn"].data_ptr(), t["p"].data_ptr(), C.data_ptr(), s.data_ptr(), dp.data_ptr(), mem=MEM_DEVICE)
+        torch.cuda.synchronize()
+        assert 0.1 < float((dp > 0).double().mean()) < 0.99
+        Ch = C.cpu().numpy()
+
+        def K_times(vec):
+            vt = torch.from_numpy(np.ascontiguousarray(vec)).cuda()
+            out = torch.zeros(nn * G, dtype=torch.float64, device="cuda")
+            dm.tangent_apply(C.data_ptr(), vt.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            return out.cpu().numpy()
+
+        v, w = rng.normal(size=nn * G), rng.normal(size=nn * G)
+        Kv, Kw = K_times(v), K_times(w)
+        ref = tangent_apply(Ch, v, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
+        assert np.abs(Kv - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert abs(w @ Kv - v @ Kw) <= 1e-11 * abs(w @ Kv)                  # the consistent tangent is symmetric
+        assert v @ Kv > 0                                                   # and positive here (hardening material)
+        # internal force from the stresses of the same launch, against the oracle
+        f = torch.zeros(nn * G, dtype=torch.float64, device="cuda")
+        dm.adjoint("eps", G, s.data_ptr(), f.data_ptr())
+        torch.cuda.synchronize()
+        fref = operand_adjoint(EPS_MANDEL, G, s.cpu().numpy(), m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
+        assert np.abs(f.cpu().numpy() - fref).max() <= 1e-12 * np.abs(fref).max()
+        # elastic patch test: C = C_elas everywhere, v linear in x -> constant stress -> interior rows of K v vanish
+        lm, mu = E * 0.3 / (1.3 * 0.4), E / 2.6
+        one = np.zeros(d)
+        one[:3] = 1.0
+        C_el = lm * np.outer(one, one) + 2 * mu * np.eye(d)
+        C.copy_(torch.from_numpy(np.tile(C_el.reshape(-1), npts)).cuda())
+        A = rng.normal(size=(G, G))
+        v_lin = (m.node_x @ A.T).reshape(-1)
+        Kl = K_times(v_lin).reshape(-1, G)
+        interior = np.all((m.node_x > 1e-9) & (m.node_x < 1 - 1e-9), axis=1)
+        assert np.abs(Kl[interior]).max() <= 1e-12 * np.abs(Kl).max()
+    finally:
+        dm.close()
+
+
+def test_weights_are_required(ctx):
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh("triangle", (2, 2), 1)
+    dm = DeviceMesh(gdim=2, phi=m.phi, dphi=m.dphi, dpsi=m.dpsi, dofmap=m.dofmap, geom_dofmap=m.geom_dofmap, x=m.x,
+                    num_field_nodes=m.node_x.shape[0], ctx=ctx)
+    try:
+        S = torch.zeros(m.num_cells * m.nq * 2, dtype=torch.float64, device="cuda")
+        out = torch.zeros(m.node_x.shape[0], dtype=torch.float64, device="cuda")
+        with pytest.raises(ValueError):
+            dm.adjoint("grad", 1, S.data_ptr(), out.data_ptr())
+        with pytest.raises(ValueError):
+            dm.set_weights(np.ones(m.nq + 1))
+        dm.set_weights(m.weights)
+        dm.adjoint("grad", 1, S.data_ptr(), out.data_ptr())
+    finally:
+        dm.close()
