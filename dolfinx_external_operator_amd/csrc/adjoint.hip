@@ -65,7 +65,7 @@ template <int G, int BS>
 __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const double* tab, double* Tm, bool active, int lane,
                                                 const double (&vh)[BS], const double (&gh)[BS][G], const double (&K)[G][G],
                                                 double scale, int64_t c0, int ncell, const int32_t* __restrict__ cells,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out, double* __restrict__ fe) {
     const OperandLayout<G> L(m);
     constexpr int PT = BS * (G + 1);
     if (active) {
@@ -101,9 +101,14 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
             }
         }
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
-        const int64_t node = m.dofmap[cell * nd + a];
+        if (fe) {        // two-pass form: the element vector entry, summed per node afterwards (node_sum)
 #pragma unroll
-        for (int i = 0; i < BS; ++i) unsafeAtomicAdd(out + node * BS + i, acc[i]);
+            for (int i = 0; i < BS; ++i) fe[(cell * nd + a) * BS + i] = acc[i];
+        } else {
+            const int64_t node = m.dofmap[cell * nd + a];
+#pragma unroll
+            for (int i = 0; i < BS; ++i) unsafeAtomicAdd(out + node * BS + i, acc[i]);
+        }
     }
     op_fence();
 }
@@ -111,7 +116,8 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
 template <int G, int BS, int KIND>
 __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                              const double* __restrict__ S, const int32_t* __restrict__ cells,
-                                                             int64_t n_cells, double* __restrict__ out) {
+                                                             int64_t n_cells, double* __restrict__ out,
+                                                             double* __restrict__ fe) {
     constexpr int D = OperandShape<G, BS, KIND>::D;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
@@ -175,7 +181,28 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
             for (int k = 0; k < D; ++k) s[k] = Sp[k];
             dual_tensor<G, BS, KIND>(s, vh, gh);
         }
-        adjoint_scatter<G, BS>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, cells, out);
+        adjoint_scatter<G, BS>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, cells, out, fe);
+    }
+}
+
+// second pass of the two-pass form: out[node] += sum of the node's element-vector entries, in the fixed order of the
+// transposed dofmap — no atomics, bit-reproducible
+template <int BS>
+__global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int64_t* __restrict__ ptr,
+                                                      const uint32_t* __restrict__ ent, const double* __restrict__ fe,
+                                                      double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += stride) {
+        double acc[BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) acc[i] = 0.0;
+        for (int64_t e = ptr[n]; e < ptr[n + 1]; ++e) {
+            const double* f = fe + (int64_t)ent[e] * BS;
+#pragma unroll
+            for (int i = 0; i < BS; ++i) acc[i] += f[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BS; ++i) out[n * BS + i] += acc[i];
     }
 }
 
@@ -183,7 +210,8 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
 template <int G>
 __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                               const double* __restrict__ C_tang, const double* __restrict__ v,
-                                                              int64_t n_cells, double* __restrict__ out) {
+                                                              int64_t n_cells, double* __restrict__ out,
+                                                              double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
@@ -227,7 +255,7 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, cons
             }
             dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
         }
-        adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out);
+        adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
     }
 }
 
@@ -238,9 +266,52 @@ int adjoint_lds_wave(const dxo_mesh* m) {
     return (wd + 1) & ~1;
 }
 
+// transposed dofmap on the device, built once per mesh from the host copy of the dofmap
+int ensure_transpose(dxo_ctx* ctx, dxo_mesh* m) {
+    if (m->d_node_ptr) return DXO_OK;
+    const int64_t nc = m->num_cells, nd = m->dev.ndofs, nn = m->num_field_nodes;
+    if (nc * nd >= ((int64_t)1 << 32)) return DXO_E_SIZE;      // uint32 entries; the caller falls back to atomics
+    std::vector<int64_t> ptr((size_t)nn + 1, 0);
+    for (int64_t e = 0; e < nc * nd; ++e) ++ptr[(size_t)m->h_dofmap[(size_t)e] + 1];
+    for (int64_t n = 0; n < nn; ++n) ptr[(size_t)n + 1] += ptr[(size_t)n];
+    std::vector<uint32_t> ent((size_t)(nc * nd));
+    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t e = 0; e < nc * nd; ++e) ent[(size_t)fill[(size_t)m->h_dofmap[(size_t)e]]++] = (uint32_t)e;   // ascending per node
+    DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ptr, ptr.size() * sizeof(int64_t)));
+    DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ent, (ent.size() ? ent.size() : 1) * sizeof(uint32_t)));
+    DXO_HIP(ctx, hipMemcpy(m->d_node_ptr, ptr.data(), ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!ent.empty()) DXO_HIP(ctx, hipMemcpy(m->d_node_ent, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return DXO_OK;
+}
+
+// element-vector buffer for `bs` components, or nullptr when the call has to use atomics
+double* two_pass_buffer(dxo_ctx* ctx, dxo_mesh* m, int bs, const int32_t* cells, int64_t n_cells) {
+    if (ctx->adjoint_atomics || cells || n_cells != m->num_cells) return nullptr;
+    if (ensure_transpose(ctx, m) != DXO_OK) return nullptr;
+    const size_t need = (size_t)m->num_cells * m->dev.ndofs * bs * sizeof(double);
+    if (m->fe_cap < need) {
+        if (m->d_fe) (void)hipFree(m->d_fe);
+        m->d_fe = nullptr;
+        m->fe_cap = 0;
+        if (hipMalloc((void**)&m->d_fe, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        m->fe_cap = need;
+    }
+    return m->d_fe;
+}
+
+void launch_node_sum(const dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out, hipStream_t s) {
+    int64_t blocks = (m->num_field_nodes + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (bs == 1) hipLaunchKernelGGL(node_sum<1>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
+    else if (bs == 2) hipLaunchKernelGGL(node_sum<2>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
+    else hipLaunchKernelGGL(node_sum<3>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
+}
+
 template <int G, int BS, int KIND>
 void launch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, const double* S, const int32_t* cells, int64_t n_cells,
-                    double* out, hipStream_t s) {
+                    double* out, double* fe, hipStream_t s) {
     const int wd = adjoint_lds_wave(m);
     const int64_t n_groups = (n_cells + m->dev.cells_per_wave - 1) / m->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
@@ -249,21 +320,21 @@ void launch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, const double* S, cons
     blocks = (blocks + 7) / 8 * 8;
     const size_t shm = (size_t)(m->dev.table_doubles + 4 * wd) * sizeof(double);
     hipLaunchKernelGGL((operand_adjoint<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, m->dev, m->d_wq, wd, S,
-                       cells, n_cells, out);
+                       cells, n_cells, out, fe);
 }
 
 template <int G, int BS>
 int dispatch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double* S, const int32_t* cells,
-                     int64_t n_cells, double* out, hipStream_t s) {
+                     int64_t n_cells, double* out, double* fe, hipStream_t s) {
     switch (kind) {
-        case DXO_OPERAND_VALUE: launch_adjoint<G, BS, DXO_OPERAND_VALUE>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
-        case DXO_OPERAND_GRAD: launch_adjoint<G, BS, DXO_OPERAND_GRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
-        case DXO_OPERAND_VALUE_GRAD: launch_adjoint<G, BS, DXO_OPERAND_VALUE_GRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK;
+        case DXO_OPERAND_VALUE: launch_adjoint<G, BS, DXO_OPERAND_VALUE>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK;
+        case DXO_OPERAND_GRAD: launch_adjoint<G, BS, DXO_OPERAND_GRAD>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK;
+        case DXO_OPERAND_VALUE_GRAD: launch_adjoint<G, BS, DXO_OPERAND_VALUE_GRAD>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK;
         case DXO_OPERAND_EPS_MANDEL:
-            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, S, cells, n_cells, out, s); return DXO_OK; }
+            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK; }
             return DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD:
-            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, S, cells, n_cells, out, s); return DXO_OK; }
+            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK; }
             return DXO_E_DIM;
     }
     return DXO_E_OPTION;
@@ -296,11 +367,13 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_operand_adjoint: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
+    double* fe = two_pass_buffer(ctx, mesh, bs, cells, n_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
-    if (mesh->gdim == 2) rc = bs == 1 ? dispatch_adjoint<2, 1>(ctx, mesh, kind, S, cells, n_cells, out, s) : dispatch_adjoint<2, 2>(ctx, mesh, kind, S, cells, n_cells, out, s);
-    else                 rc = bs == 1 ? dispatch_adjoint<3, 1>(ctx, mesh, kind, S, cells, n_cells, out, s) : dispatch_adjoint<3, 3>(ctx, mesh, kind, S, cells, n_cells, out, s);
+    if (mesh->gdim == 2) rc = bs == 1 ? dispatch_adjoint<2, 1>(ctx, mesh, kind, S, cells, n_cells, out, fe, s) : dispatch_adjoint<2, 2>(ctx, mesh, kind, S, cells, n_cells, out, fe, s);
+    else                 rc = bs == 1 ? dispatch_adjoint<3, 1>(ctx, mesh, kind, S, cells, n_cells, out, fe, s) : dispatch_adjoint<3, 3>(ctx, mesh, kind, S, cells, n_cells, out, fe, s);
     if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_operand_adjoint: unsupported (gdim, bs, kind)");
+    if (fe) launch_node_sum(ctx, mesh, bs, out, s);
     return dxo_device_end(ctx, s);
 }
 
@@ -315,6 +388,7 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
+    double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
@@ -323,8 +397,9 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     if (mesh->gdim == 2)
-        hipLaunchKernelGGL(tangent_apply<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out);
+        hipLaunchKernelGGL(tangent_apply<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
     else
-        hipLaunchKernelGGL(tangent_apply<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out);
+        hipLaunchKernelGGL(tangent_apply<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
+    if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
 }

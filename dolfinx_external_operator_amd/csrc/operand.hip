@@ -200,6 +200,7 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     v.phi = bd; v.dphi = bd + n_phi; v.dpsi = bd + n_phi + n_dphi; v.x = bd + n_phi + n_dphi + n_dpsi;
     const int32_t* bi = reinterpret_cast<const int32_t*>(v.x + n_x);
     v.dofmap = bi; v.geom_dofmap = bi + n_dm;
+    if (n_dm) m->h_dofmap.assign(d->dofmap, d->dofmap + n_dm);
     *out = m;
     return DXO_OK;
 }
@@ -214,6 +215,9 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_cells) (void)hipFree(m->d_cells);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_node_ptr) (void)hipFree(m->d_node_ptr);
+    if (m->d_node_ent) (void)hipFree(m->d_node_ent);
+    if (m->d_fe) (void)hipFree(m->d_fe);
     delete m;
     return DXO_OK;
 }

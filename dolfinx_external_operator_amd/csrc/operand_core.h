@@ -352,4 +352,10 @@ struct dxo_mesh {
     double* d_out = nullptr;    // staging for host-resident outputs
     size_t out_cap = 0;
     double* d_wq = nullptr;     // quadrature weights (dxo_mesh_set_weights), needed by the adjoint kernels only
+    // adjoint kernels, two-pass form: element vectors + the transposed dofmap (node -> its (cell, local node) entries)
+    std::vector<int32_t> h_dofmap;     // host copy kept for building the transpose on first use
+    int64_t* d_node_ptr = nullptr;     // [num_field_nodes + 1]
+    uint32_t* d_node_ent = nullptr;    // [num_cells * ndofs], values cell * ndofs + a, ascending per node
+    double* d_fe = nullptr;            // [num_cells * ndofs * bs] element vectors of the last adjoint call
+    size_t fe_cap = 0;
 };

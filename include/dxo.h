@@ -287,7 +287,9 @@ int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, 
  *                         (kind EPS_MANDEL with s = sigma: the internal force; GRAD with s = q: the heat residual)
  *   dxo_tangent_apply   : out[dof] += sum_q w_q |det J_q| B_q^T C_tang_q B_q v   (eps / Mandel, bs = gdim), K never formed
  * `out` is ACCUMULATED into (zero it first); S / C_tang are laid out like the operator outputs, (n_cells, nq, ...).
- * Additions into shared dofs are fp64 hardware atomics: reproducible to rounding, not bit for bit.
+ * Full-mesh calls write element vectors and add them per node in the fixed order of the transposed dofmap (no atomics,
+ * bit-reproducible); entity subsets, or option "adjoint_atomics" = 1, add with fp64 hardware atomics instead
+ * (reproducible to rounding only).
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,

@@ -51,6 +51,17 @@ def test_adjoint_identity_patch_test_and_oracle(ctx, cell, degree):
                 assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), np.abs(wdet).sum()), (kind, bs, lhs, rhs)
                 ref = operand_adjoint(KIND_ID[kind], bs, S, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
                 assert np.abs(f - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-30), (kind, bs)
+        # the two forms of the scatter: element vectors + node sums (default, no atomics: bit-reproducible) and fp64
+        # atomics into the dof vector (entity subsets always use it)
+        S = rng.normal(size=(m.num_cells, m.nq, dm.value_size("eps", G)))
+        two_a, two_b = device_adjoint(ctx, dm, "eps", G, S, nn), device_adjoint(ctx, dm, "eps", G, S, nn)
+        assert np.array_equal(two_a, two_b)
+        ctx.set_option("adjoint_atomics", 1)
+        try:
+            atom = device_adjoint(ctx, dm, "eps", G, S, nn)
+        finally:
+            ctx.set_option("adjoint_atomics", 0)
+        assert np.abs(atom - two_a).max() <= 1e-13 * np.abs(two_a).max()
         # patch test: a constant stress field does no work on interior nodes
         Sc = np.broadcast_to(rng.normal(size=dm.value_size("eps", G)), (m.num_cells, m.nq, dm.value_size("eps", G)))
         fc = device_adjoint(ctx, dm, "eps", G, Sc, nn).reshape(-1, G)
