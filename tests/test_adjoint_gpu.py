@@ -161,3 +161,26 @@ def test_weights_are_required(ctx):
         dm.adjoint("grad", 1, S.data_ptr(), out.data_ptr())
     finally:
         dm.close()
+
+
+def test_device_newton_krylov_converges_quadratically():
+    """examples/device_newton_krylov.py: load stepping with the fused constitutive kernel, the internal force and the
+    matrix-free tangent, all on the device. Newton only converges quadratically if the tangent IS the derivative of the
+    stress that the residual is built from — the kernel-level version of the reference's Taylor test
+    (demo_plasticity_mohr_coulomb.py:1149-1235)."""
+    import importlib.util
+    import pathlib
+
+    path = pathlib.Path(__file__).resolve().parents[1] / "examples" / "device_newton_krylov.py"
+    spec = importlib.util.spec_from_file_location("nk_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.main(20, verbose=False)
+    assert rep["steps"][0]["newton_residuals"][-1] <= 1e-8 * rep["steps"][0]["newton_residuals"][0]
+    assert len(rep["steps"][0]["newton_residuals"]) == 2                       # elastic step: one linear solve
+    last = rep["steps"][-1]
+    r = last["newton_residuals"]
+    assert last["plastic_fraction"] > 0.2 and r[-1] <= 1e-8 * r[0] and len(r) <= 12
+    # quadratic tail (before the round-off / CG-tolerance floor of the very last iterate): rho_{k+1} <= c rho_k^2
+    rho = [v / r[0] for v in r]
+    assert rho[-2] <= 50.0 * rho[-3] ** 2
