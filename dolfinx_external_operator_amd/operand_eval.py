@@ -69,7 +69,7 @@ class DeviceMesh:
 
     @classmethod
     def from_synthetic(cls, mesh, **kw):
-        """From `synthetic.SyntheticMesh`."""
+        """From a `tools.synthetic.SyntheticMesh` (tests, benches, examples): any object with these attributes."""
         dm = cls(gdim=mesh.gdim, phi=mesh.phi, dphi=mesh.dphi, dpsi=mesh.dpsi, dofmap=mesh.dofmap,
                  geom_dofmap=mesh.geom_dofmap, x=mesh.x, num_field_nodes=mesh.node_x.shape[0], **kw)
         if getattr(mesh, "weights", None) is not None:

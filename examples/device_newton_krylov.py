@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from dolfinx_external_operator_amd import MEM_DEVICE, Context, DeviceMesh, VmParams  # noqa: E402
-from dolfinx_external_operator_amd.synthetic import structured_mesh  # noqa: E402
+from tools.synthetic import structured_mesh  # noqa: E402
 
 
 def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool = True) -> dict:

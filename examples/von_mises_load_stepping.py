@@ -24,7 +24,7 @@ import numpy as np  # noqa: E402
 
 from dolfinx_external_operator_amd import (DeviceMesh, QuadratureExternalOperator, evaluate_external_operators,  # noqa: E402
                                            evaluate_operands, make_von_mises)
-from dolfinx_external_operator_amd.synthetic import structured_mesh  # noqa: E402
+from tools.synthetic import structured_mesh  # noqa: E402
 
 
 def main(n_side: int = 100) -> dict:

@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from dolfinx_external_operator_amd import Context, DeviceMesh  # noqa: E402
-from dolfinx_external_operator_amd.synthetic import structured_mesh  # noqa: E402
+from tools.synthetic import structured_mesh  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cpu", type=int, default=0, help="also time the NumPy oracle on the first 50 000 cells")

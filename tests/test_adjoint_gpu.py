@@ -5,7 +5,7 @@ symmetry of v -> K v — plus agreement with the NumPy oracle."""
 import numpy as np
 import pytest
 
-from dolfinx_external_operator_amd.synthetic import structured_mesh
+from tools.synthetic import structured_mesh
 from oracle.operand_oracle import (DEFGRAD, EPS_MANDEL, GRAD, VALUE, VALUE_GRAD, _geometry, eval_operand, operand_adjoint,
                                    tangent_apply)
 

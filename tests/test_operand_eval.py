@@ -4,7 +4,7 @@ HIP kernel (through the C ABI) against the oracle."""
 import numpy as np
 import pytest
 
-from dolfinx_external_operator_amd.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
+from tools.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
 from oracle.operand_oracle import DEFGRAD, EPS_MANDEL, GRAD, VALUE, eval_operand
 
 CELLS = {"triangle": (5, 4), "quadrilateral": (4, 3), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 2)}

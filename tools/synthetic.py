@@ -1,7 +1,7 @@
 """DOLFINx-free element tables and structured meshes for the tests and benches of the device operand evaluation.
 
 On a DOLFINx installation the tables come from basix (`element.tabulate(1, points)`) and the arrays from
-`V.dofmap.list`, `mesh.geometry.dofmap`, `mesh.geometry.x` (see `operand_eval.DeviceMesh.from_dolfinx`). The GPU
+`V.dofmap.list`, `mesh.geometry.dofmap`, `mesh.geometry.x` (see `dolfinx_external_operator_amd.operand_eval.DeviceMesh.from_dolfinx`). The GPU
 box has neither, so this module provides what the synthetic workloads need: Lagrange bases of degree 1 and 2 on
 the reference triangle, quadrilateral, tetrahedron and hexahedron (built by inverting a Vandermonde matrix, so no
 hand-written shape functions), Gauss rules matching the reference's quadrature degree 2, and structured meshes
