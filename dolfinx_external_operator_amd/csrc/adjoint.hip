@@ -101,9 +101,12 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
             }
         }
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
-        if (fe) {        // two-pass form: the element vector entry, summed per node afterwards (node_sum)
+        if (fe) {        // two-pass form: the element vector entry, summed per node afterwards (node_sum).
+            // Layout fe[a][cell][i]: the cells of a wave group are consecutive, so each local node's entries leave as one
+            // contiguous run per group, and in node_sum neighbouring nodes (same local role in neighbouring cells) read
+            // neighbouring addresses.
 #pragma unroll
-            for (int i = 0; i < BS; ++i) fe[(cell * nd + a) * BS + i] = acc[i];
+            for (int i = 0; i < BS; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * BS + i] = acc[i];
         } else {
             const int64_t node = m.dofmap[cell * nd + a];
 #pragma unroll
@@ -276,7 +279,8 @@ int ensure_transpose(dxo_ctx* ctx, dxo_mesh* m) {
     for (int64_t n = 0; n < nn; ++n) ptr[(size_t)n + 1] += ptr[(size_t)n];
     std::vector<uint32_t> ent((size_t)(nc * nd));
     std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-    for (int64_t e = 0; e < nc * nd; ++e) ent[(size_t)fill[(size_t)m->h_dofmap[(size_t)e]]++] = (uint32_t)e;   // ascending per node
+    for (int64_t e = 0; e < nc * nd; ++e)      // visited in ascending (cell, a): a fixed order per node; stored as the fe index a*nc + cell
+        ent[(size_t)fill[(size_t)m->h_dofmap[(size_t)e]]++] = (uint32_t)((e % nd) * nc + e / nd);
     DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ptr, ptr.size() * sizeof(int64_t)));
     DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ent, (ent.size() ? ent.size() : 1) * sizeof(uint32_t)));
     DXO_HIP(ctx, hipMemcpy(m->d_node_ptr, ptr.data(), ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));

@@ -162,6 +162,7 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     m->num_geom_nodes = d->num_geom_nodes;
     OperandDev& v = m->dev;
     v.nq = d->nq; v.ndofs = d->ndofs; v.ngeom = d->ngeom;
+    v.num_cells_fe = d->num_cells;
     v.cells_per_wave = DXO_WAVE / d->nq;
     const int maxbs = G, maxD = G * (1 + G);
     int wd = v.cells_per_wave * (op_odd(d->ndofs * maxbs) + op_odd(d->ngeom * G));

@@ -11,6 +11,7 @@ struct OperandDev {
     int cells_per_wave;            // floor(64 / nq)
     int wave_doubles;              // LDS doubles per wave
     int table_doubles;             // LDS doubles for the tables
+    int64_t num_cells_fe;          // cells of the mesh: stride of the element-vector layout fe[a][cell][i] (adjoint kernels)
     const double* phi;             // [nq][ndofs]
     const double* dphi;            // [nq][ndofs][G]
     const double* dpsi;            // [nq][ngeom][G]
@@ -355,7 +356,7 @@ struct dxo_mesh {
     // adjoint kernels, two-pass form: element vectors + the transposed dofmap (node -> its (cell, local node) entries)
     std::vector<int32_t> h_dofmap;     // host copy kept for building the transpose on first use
     int64_t* d_node_ptr = nullptr;     // [num_field_nodes + 1]
-    uint32_t* d_node_ent = nullptr;    // [num_cells * ndofs], values cell * ndofs + a, ascending per node
-    double* d_fe = nullptr;            // [num_cells * ndofs * bs] element vectors of the last adjoint call
+    uint32_t* d_node_ent = nullptr;    // [num_cells * ndofs], values a * num_cells + cell (index into d_fe), fixed order per node
+    double* d_fe = nullptr;            // [ndofs][num_cells][bs] element vectors of the last adjoint call
     size_t fe_cap = 0;
 };
