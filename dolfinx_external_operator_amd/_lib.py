@@ -100,6 +100,7 @@ _SIGNATURES = {
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),
     "dxo_operand_adjoint": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
+    "dxo_tangent_diagonal": (C.c_int, [_P, _P, _P, _P]),
     "dxo_heat_field": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),

@@ -262,6 +262,120 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, cons
     }
 }
 
+// diag(K) without K, for a Jacobi preconditioner: K_(a,i),(a,i) = sum_q w|detJ| e_(a,i)^T C_q e_(a,i) with e_(a,i) the Mandel
+// strain of the unit dof (local node a, component i). Phase 1 parks (J^-1, w|detJ|) per point; phase 2, lane = (cell, node).
+// Runs once per Newton iteration, not per Krylov iteration: C_tang is read through the caches, not staged.
+template <int G>
+__global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
+                                                         const double* __restrict__ C_tang, int64_t n_cells,
+                                                         double* __restrict__ out, double* __restrict__ fe) {
+    constexpr int D = G == 2 ? 4 : 6;
+    constexpr int PT = G * G + 1;
+    constexpr double r2 = 0.70710678118654752440;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tab = lds;
+    operand_load_tables<G>(m, tab);
+    __syncthreads();
+    const OperandLayout<G> L(m);
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + m.table_doubles + wave * lds_wave;
+    const int cpw = m.cells_per_wave, nd = m.ndofs, nq = m.nq, ng = m.ngeom;
+    double* X = W + cpw * op_odd(nd * G);
+    double* Pm = X + cpw * op_odd(ng * G);           // [point][K (G*G), scale]
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        const int sx = op_odd(ng * G);
+        for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
+            const int c = idx / ng, v = idx - c * ng;
+            const int64_t node = m.geom_dofmap[(c0 + c) * ng + v];
+#pragma unroll
+            for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = m.x[node * G + j];
+        }
+        op_fence();
+        {
+            const int c = lane / nq, q = lane - c * nq;
+            if (c < ncell) {
+                const double* dpsi = tab + L.o_dpsi + q * L.sdpsi;
+                const double* Xc = X + c * sx;
+                double J[G][G], K[G][G];
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int k = 0; k < G; ++k) J[j][k] = 0.0;
+                for (int v = 0; v < ng; ++v)
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+#pragma unroll
+                        for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
+                const double det = invert<G>(J, K);
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+#pragma unroll
+                    for (int j = 0; j < G; ++j) Pm[lane * PT + k * G + j] = K[k][j];
+                Pm[lane * PT + G * G] = wq[q] * fabs(det);
+            }
+        }
+        op_fence();
+        for (int idx = lane; idx < ncell * nd; idx += DXO_WAVE) {
+            const int c = idx / nd, a = idx - c * nd;
+            double acc[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) acc[i] = 0.0;
+            for (int q = 0; q < nq; ++q) {
+                const double* P = Pm + (c * nq + q) * PT;
+                const double* dp = tab + L.o_dphi + q * L.sdphi + a * G;
+                double g[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) t += dp[k] * P[k * G + j];
+                    g[j] = t;                                   // d phi_a / d x_j
+                }
+                const double* Cq = C_tang + ((c0 + c) * nq + q) * (D * D);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    double e[D];
+#pragma unroll
+                    for (int r = 0; r < D; ++r) e[r] = 0.0;
+                    if constexpr (G == 2) {
+                        e[i] = g[i];
+                        e[3] = r2 * g[1 - i];
+                    } else {
+                        e[i] = g[i];
+                        if (i == 0) { e[3] = r2 * g[1]; e[4] = r2 * g[2]; }
+                        else if (i == 1) { e[3] = r2 * g[0]; e[5] = r2 * g[2]; }
+                        else { e[4] = r2 * g[0]; e[5] = r2 * g[1]; }
+                    }
+                    double s = 0.0;
+#pragma unroll
+                    for (int r = 0; r < D; ++r) {
+                        double row = 0.0;
+#pragma unroll
+                        for (int cc = 0; cc < D; ++cc) row += Cq[r * D + cc] * e[cc];
+                        s += e[r] * row;
+                    }
+                    acc[i] += P[G * G] * s;
+                }
+            }
+            const int64_t cell = c0 + c;
+            if (fe) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * G + i] = acc[i];
+            } else {
+                const int64_t node = m.dofmap[cell * nd + a];
+#pragma unroll
+                for (int i = 0; i < G; ++i) unsafeAtomicAdd(out + node * G + i, acc[i]);
+            }
+        }
+        op_fence();
+    }
+}
+
 int adjoint_lds_wave(const dxo_mesh* m) {
     const OperandDev& v = m->dev;
     const int G = m->gdim;
@@ -378,6 +492,33 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     else                 rc = bs == 1 ? dispatch_adjoint<3, 1>(ctx, mesh, kind, S, cells, n_cells, out, fe, s) : dispatch_adjoint<3, 3>(ctx, mesh, kind, S, cells, n_cells, out, fe, s);
     if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_operand_adjoint: unsupported (gdim, bs, kind)");
     if (fe) launch_node_sum(ctx, mesh, bs, out, s);
+    return dxo_device_end(ctx, s);
+}
+
+extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: mesh is NULL");
+    if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_diagonal: quadrature weights not set (dxo_mesh_set_weights)");
+    if (mesh->num_cells == 0) return DXO_OK;
+    if (!C_tang || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: NULL array");
+    const int wd = adjoint_lds_wave(mesh);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
+    if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;
+    if (mesh->gdim == 2)
+        hipLaunchKernelGGL(tangent_diag<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+    else
+        hipLaunchKernelGGL(tangent_diag<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+    if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
 }
 

@@ -159,6 +159,11 @@ class DeviceMesh:
         rc = self.ctx.lib.dxo_tangent_apply(self.ctx._h, self._h, C.c_void_p(C_tang_ptr), C.c_void_p(v_ptr), C.c_void_p(out_ptr))
         self.ctx.check(rc, "dxo_tangent_apply")
 
+    def tangent_diagonal(self, C_tang_ptr: int, out_ptr: int) -> None:
+        """out += diag(K) for the same K as tangent_apply (DEVICE pointers): Jacobi preconditioner."""
+        rc = self.ctx.lib.dxo_tangent_diagonal(self.ctx._h, self._h, C.c_void_p(C_tang_ptr), C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_tangent_diagonal")
+
     def heat(self, A: float, B: float, T_dofs, q=None, dqdT=None, dqdsigma=None, mem: int = MEM_HOST) -> None:
         """dxo_heat_field: T and grad T of a scalar field + the heat-flux kernels in one launch (all cells)."""
         def ptr(a):

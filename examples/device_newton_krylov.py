@@ -7,7 +7,7 @@ and assembles a sparse Jacobian from it. Here, per Newton iteration:
 
     sigma, C_tang, dp = von Mises(eps(Du), sigma_n, p)      dxo_von_mises_field   (strain + return map + tangent, one launch)
     R = sum w|J| B^T sigma  on the free dofs                dxo_operand_adjoint   (internal force; no external load here)
-    solve K d = -R with conjugate gradients, K v by         dxo_tangent_apply     (K is never formed)
+    solve K d = -R with Jacobi-preconditioned CG, K v by    dxo_tangent_apply, diag(K) by dxo_tangent_diagonal   (K is never formed)
     Du += d
 and at the end of a load step  p += dp, sigma_n <- sigma    dxo_vm_commit_state.
 Only dof vectors (and a few scalars of the CG) are touched outside the kernels; they are torch CUDA tensors.
@@ -67,21 +67,29 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
         dm.tangent_apply(C_tang.data_ptr(), v.data_ptr(), Kv.data_ptr())
         return torch.where(free, Kv, torch.zeros_like(Kv))
 
-    def cg(b, tol=1e-10, maxit=2000):
+    diag = torch.zeros(nn * G, **f64)
+
+    def cg(b, tol=1e-10, maxit=4000):
+        """Jacobi-preconditioned conjugate gradients; diag(K) comes from dxo_tangent_diagonal, also matrix-free."""
+        diag.zero_()
+        dm.tangent_diagonal(C_tang.data_ptr(), diag.data_ptr())
+        minv = torch.where(free, 1.0 / diag, torch.zeros_like(diag))
         xk = torch.zeros_like(b)
         r = b.clone()
-        pk = r.clone()
-        rs = torch.dot(r, r)
-        b2 = float(rs)
+        z = minv * r
+        pk = z.clone()
+        rz = torch.dot(r, z)
+        b2 = float(torch.dot(b, b))
         its = 0
-        while its < maxit and float(rs) > tol * tol * b2:
+        while its < maxit and float(torch.dot(r, r)) > tol * tol * b2:
             Ap = K_times(pk)
-            alpha = rs / torch.dot(pk, Ap)
+            alpha = rz / torch.dot(pk, Ap)
             xk += alpha * pk
             r -= alpha * Ap
-            rs_new = torch.dot(r, r)
-            pk = r + (rs_new / rs) * pk
-            rs = rs_new
+            z = minv * r
+            rz_new = torch.dot(r, z)
+            pk = z + (rz_new / rz) * pk
+            rz = rz_new
             its += 1
         return xk, its
 

@@ -295,6 +295,8 @@ int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
                         int64_t n_cells, double* out);
 int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out);
+/* out[dof] += K_(dof,dof): the diagonal of the same operator (Jacobi preconditioner of a matrix-free Krylov solve). */
+int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out);
 
 /* ---- coefficient assigners on the device, DEVICE memory only --------------------------
  * One scatter for the reference's three dofmap assigners (src/dolfinx_external_operator/external_operator.py):

@@ -184,3 +184,37 @@ def test_device_newton_krylov_converges_quadratically():
     # quadratic tail (before the round-off / CG-tolerance floor of the very last iterate): rho_{k+1} <= c rho_k^2
     rho = [v / r[0] for v in r]
     assert rho[-2] <= 50.0 * rho[-3] ** 2
+
+
+@pytest.mark.parametrize("cell,n", [("triangle", (4, 3)), ("hexahedron", (2, 1, 2)), ("quadrilateral", (3, 2))])
+def test_matrix_free_diagonal(ctx, cell, n):
+    """diag(K) from dxo_tangent_diagonal equals e_k . K e_k with K v from the oracle, for every dof of a small mesh, with
+    non-constant symmetric positive tangents."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=4)
+    G, nn = m.gdim, m.node_x.shape[0]
+    d = 4 if G == 2 else 6
+    npts = m.num_cells * m.nq
+    rng = np.random.Generator(np.random.PCG64(9))
+    A = rng.normal(size=(npts, d, d))
+    Cn = np.einsum("nij,nkj->nik", A, A) + 3.0 * np.eye(d)              # SPD, different at every point
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        Ct = torch.from_numpy(Cn.reshape(-1)).cuda()
+        out = torch.zeros(nn * G, dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dm.tangent_diagonal(Ct.data_ptr(), out.data_ptr())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want = np.empty(nn * G)
+        for k in range(nn * G):
+            e = np.zeros(nn * G)
+            e[k] = 1.0
+            want[k] = tangent_apply(Cn, e, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)[k]
+        assert np.all(got > 0)
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    finally:
+        dm.close()
