@@ -18,6 +18,7 @@
 // results are reproducible to rounding, not bit for bit).
 #include "dxo_common.h"
 #include "operand_core.h"
+#include "adjoint_cell.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -488,6 +489,10 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     double* fe = two_pass_buffer(ctx, mesh, bs, cells, n_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
+    if (fe && kind == DXO_OPERAND_EPS_MANDEL && ctx->adjoint_cell && launch_adjoint_cell_eps(ctx, mesh, S, fe, s)) {
+        launch_node_sum(ctx, mesh, bs, out, s);      // lane = cell form (adjoint_cell.h) for the standard elements
+        return dxo_device_end(ctx, s);
+    }
     if (mesh->gdim == 2) rc = bs == 1 ? dispatch_adjoint<2, 1>(ctx, mesh, kind, S, cells, n_cells, out, fe, s) : dispatch_adjoint<2, 2>(ctx, mesh, kind, S, cells, n_cells, out, fe, s);
     else                 rc = bs == 1 ? dispatch_adjoint<3, 1>(ctx, mesh, kind, S, cells, n_cells, out, fe, s) : dispatch_adjoint<3, 3>(ctx, mesh, kind, S, cells, n_cells, out, fe, s);
     if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_operand_adjoint: unsupported (gdim, bs, kind)");

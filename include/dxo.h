@@ -289,7 +289,8 @@ int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, 
  * `out` is ACCUMULATED into (zero it first); S / C_tang are laid out like the operator outputs, (n_cells, nq, ...).
  * Full-mesh calls write element vectors and add them per node in the fixed order of the transposed dofmap (no atomics,
  * bit-reproducible); entity subsets, or option "adjoint_atomics" = 1, add with fp64 hardware atomics instead
- * (reproducible to rounding only).
+ * (reproducible to rounding only). Option "adjoint_cell" = 0 switches off the lane-per-cell kernel that the internal
+ * force (kind EPS_MANDEL) uses on the standard elements.
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,

@@ -218,3 +218,29 @@ def test_matrix_free_diagonal(ctx, cell, n):
         assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     finally:
         dm.close()
+
+
+@pytest.mark.parametrize("cell,n,degree", [("hexahedron", (3, 2, 2), 2), ("hexahedron", (3, 2, 2), 1), ("tetrahedron", (2, 2, 2), 2),
+                                           ("triangle", (5, 4), 2), ("quadrilateral", (4, 3), 2)])
+def test_lane_per_cell_kernel_equals_wave_group_kernel(ctx, cell, n, degree):
+    """The standard elements take the lane = cell kernel for the virtual work of eps (adjoint_cell.h); switching it off
+    (option adjoint_cell = 0) must give the same vector to rounding."""
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh(cell, n, degree, distort=0.2, seed=12)
+    G, nn = m.gdim, m.node_x.shape[0]
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    rng = np.random.Generator(np.random.PCG64(1))
+    S = rng.normal(size=(m.num_cells, m.nq, dm.value_size("eps", G)))
+    try:
+        a = device_adjoint(ctx, dm, "eps", G, S, nn)
+        ctx.set_option("adjoint_cell", 0)
+        try:
+            b = device_adjoint(ctx, dm, "eps", G, S, nn)
+        finally:
+            ctx.set_option("adjoint_cell", 1)
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+        ref = operand_adjoint(EPS_MANDEL, G, S, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
+        assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max()
+    finally:
+        dm.close()
