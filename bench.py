@@ -9,11 +9,16 @@ the RCCL all-gather that reassembles the flat coefficient vectors (BASELINE nort
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent
+process spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before importing torch or
+touching the GPU, relays rank 0's single JSON line and exits with the child's code (never an exec, never a restart of a
+process that has initialised HIP).
+
 Workload (named in config.workload): 3-D hex mesh, 8 quadrature points per cell (degree-2 rule), Mandel
 d = 6, fp64; 1 250 000 cells = 10^7 quadrature points per GPU — the size BASELINE.json's north_star quotes
 the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, of which the 104 MB of inputs stay
-in the 256 MB Infinity Cache between steps; scripts/bench_extra.py reports it). Scaling is weak: every rank
-owns its own cell block of 10^7 points (config 3 is 1.25*10^7 per GPU).
+in the 256 MB Infinity Cache between steps; scripts/bench_extra.py reports it). Scaling is weak: with N > 1 every
+rank owns its own cell block of 1.25*10^7 points (BASELINE config 3: 10^8 points over 8 GPUs).
 
 Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (contract: task statement).
 """
@@ -103,12 +108,43 @@ def cpu_baseline(d, n_sample, budget_s=10.0):
     }
 
 
+def launch_ranks(n_gpus: int, argv: list[str]) -> int:
+    """Parent side of `python bench.py --gpus N` (N > 1): one rank per GPU under torch.distributed.run, started as a
+    child process. This function runs BEFORE torch is imported and makes no HIP / torch.cuda call, so the parent never
+    initialises the GPU; the ranks check the device count themselves and fail loudly if the node has fewer GPUs."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:   # a free rendezvous port on the loopback
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only form this pool's host driver supports
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(pathlib.Path(__file__).resolve()), *argv]
+    log("bench: launching", " ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)   # stderr passes through
+    lines = [ln for ln in res.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            log(ln)
+    if res.returncode != 0 or not json_lines:
+        log(f"bench: the {n_gpus}-rank run failed (exit code {res.returncode}, {len(json_lines)} result lines)")
+        return res.returncode or 1
+    print(json_lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nqp", type=int, default=10_000_000, help="quadrature points per GPU")
+    ap.add_argument("--nqp", type=int, default=0,
+                    help="quadrature points per GPU; default 10^7 at --gpus 1 (north_star's target size) and 1.25*10^7 at "
+                         "--gpus N > 1 (BASELINE config 3: 10^8 points over 8 GPUs)")
     ap.add_argument("--d", type=int, default=6, choices=(4, 6))
     ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
     ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
@@ -126,6 +162,10 @@ def main():
                     help="HBM placement calibration: allocate this many candidate output slabs, time the kernel once on "
                          "each, keep the fastest (0/1 = plain first allocation). See DESIGN.md 3.1.")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the result. Libraries that write to fd 1 on their own (RCCL prints a version
     # banner when its first communicator comes up) are sent to stderr: fd 1 is pointed at fd 2 for the whole run and
@@ -141,11 +181,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU path to benchmark (only the cpu_baseline leg uses the oracle)")
+    n_dev = torch.cuda.device_count()   # counting devices does not initialise HIP
+    if n_dev < max(world, 1) or local_rank >= n_dev:
+        raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} needs {world} MI355X on this node, {n_dev} visible. "
+                         "There is no CPU path to benchmark (only the cpu_baseline leg uses the oracle).")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # under torch.distributed.run the process group is always brought up (also for a single rank, which
@@ -166,7 +206,8 @@ def main():
         dist.barrier()
 
     d, K, W = args.d, args.steps, args.warmup
-    n = (args.nqp + 2 * WAVE_TILE - 1) // (2 * WAVE_TILE) * (2 * WAVE_TILE)  # shard borders on wave tiles
+    nqp = args.nqp if args.nqp > 0 else (10_000_000 if world == 1 else 12_500_000)
+    n = (nqp + 2 * WAVE_TILE - 1) // (2 * WAVE_TILE) * (2 * WAVE_TILE)  # shard borders on wave tiles
     gather = (world > 1) if args.gather < 0 else bool(args.gather)
     E, nu, sigma_0 = 70e3, 0.3, 250.0
     H = E * (E / 100.0) / (E - E / 100.0)

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import pathlib
 import threading
+import weakref
 
 import numpy as np
 
@@ -180,6 +181,59 @@ def _ptr(a) -> int | None:
     return a.ctypes.data
 
 
+class _PinnedPool:
+    """Size-keyed free lists of hipHostMalloc blocks. A block handed out as an ndarray comes back through a
+    weakref finalizer on the ctypes object that every NumPy view of it keeps alive (ndarray.base chain), i.e.
+    only when no view can observe a later overwrite. After close() returning blocks are freed instead."""
+
+    KEEP_PER_SIZE = 4
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.free: dict[int, list[int]] = {}
+        self.closed = False
+        self.lock = threading.Lock()
+
+    def empty(self, n: int, dtype: np.dtype) -> np.ndarray:
+        cap = max(n * dtype.itemsize, 1)
+        with self.lock:
+            if self.closed:
+                raise DxoError("pinned pool used after Context.close()")
+            lst = self.free.get(cap)
+            addr = lst.pop() if lst else None
+            if addr is None:
+                # the batch size changed (or first call): drop idle blocks of other sizes before growing
+                for other in [k for k in self.free if k != cap]:
+                    for a in self.free.pop(other):
+                        self.lib.dxo_host_free(None, _P(a))
+        if addr is None:
+            p = _P()
+            rc = self.lib.dxo_host_alloc(None, cap, C.byref(p))
+            if rc != 0:
+                raise DxoError(f"hipHostMalloc({cap}) failed: {ERRORS.get(rc, rc)}")
+            addr = p.value
+        buf = (C.c_char * cap).from_address(addr)
+        fin = weakref.finalize(buf, self._give_back, addr, cap)
+        fin.atexit = False   # at interpreter exit the OS reclaims the mapping
+        return np.frombuffer(buf, dtype=dtype, count=n)
+
+    def _give_back(self, addr: int, cap: int) -> None:
+        with self.lock:
+            lst = self.free.setdefault(cap, [])
+            if not self.closed and len(lst) < self.KEEP_PER_SIZE:
+                lst.append(addr)
+                return
+        self.lib.dxo_host_free(None, _P(addr))
+
+    def close(self) -> None:
+        with self.lock:
+            self.closed = True
+            blocks = [a for lst in self.free.values() for a in lst]
+            self.free.clear()
+        for a in blocks:
+            self.lib.dxo_host_free(None, _P(a))
+
+
 class Context:
     """One dxo_ctx: a (process, GPU) pair owning streams and device scratch."""
 
@@ -195,6 +249,8 @@ class Context:
         self._h = h
         self.device = int(device)
         self._pinned: list[tuple[int, np.ndarray]] = []
+        self._pool = _PinnedPool(self.lib)
+        self._lock = threading.RLock()   # dxo_ctx itself also serialises its entry points (include/dxo.h)
 
     # -- plumbing ----------------------------------------------------------------------------
     def check(self, rc: int, what: str) -> None:
@@ -211,6 +267,7 @@ class Context:
             for addr, _ in self._pinned:
                 self.lib.dxo_host_free(self._h, _P(addr))
             self._pinned.clear()
+            self._pool.close()
             self.lib.dxo_ctx_destroy(self._h)
             self._h = None
 
@@ -252,7 +309,8 @@ class Context:
         return {"h2d_ms": t.h2d_ms, "kernel_ms": t.kernel_ms, "d2h_ms": t.d2h_ms, "total_ms": t.total_ms}
 
     def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
-        """NumPy array backed by hipHostMalloc memory owned by this context."""
+        """NumPy array backed by hipHostMalloc memory owned by this context (freed by pinned_free or close():
+        the caller manages the lifetime; for buffers that are handed to users see pinned_recycled)."""
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
         p = _P()
@@ -270,6 +328,14 @@ class Context:
                 self._pinned.pop(k)
                 self.check(self.lib.dxo_host_free(self._h, _P(addr)), "host_free")
                 return
+
+    def pinned_recycled(self, n: int, dtype=np.float64) -> np.ndarray:
+        """A flat pinned (hipHostMalloc) array whose memory returns to this context's pool only once the array
+        AND every view of it have been garbage-collected — so it can be handed to a user like a fresh ndarray
+        (the reference's kernels return fresh arrays, demo_plasticity_von_mises.py:352) while D2H copies still
+        land in page-locked memory that has been touched before (a first-touched pageable 344 MB array costs
+        ~30 ms of page faults inside the copy). No buffer is ever freed or reused while a view of it is alive."""
+        return self._pool.empty(int(n), np.dtype(dtype))
 
     # -- kernels -------------------------------------------------------------------------------
     def von_mises(self, prm: VmParams, d: int, n: int, mem: int, deps, sigma_n, p, C_tang, sigma, dp) -> None:

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,8 +20,15 @@ constexpr int DXO_WAVE = 64;          // gfx950 wavefront
 constexpr int DXO_BLOCK = 256;        // 4 waves per workgroup
 constexpr int DXO_HOST_SLOTS = 3;     // H2D / kernel / D2H pipeline depth
 
+// Host worker threads of a context (dxo_ctx.hip): the host half of the DXO_MEM_HOST pipeline (tangent rebuild from
+// the returned state while later chunks are still on the PCIe link). Created on first use, joined by dxo_ctx_destroy.
+struct dxo_host_pool;
+void dxo_host_pool_destroy(dxo_host_pool* pool);
+
 struct dxo_ctx {
     int device = 0;
+    std::recursive_mutex mu;            // every public entry point holds it: calls on one ctx are serialised
+    dxo_host_pool* pool = nullptr;
     hipStream_t stream = nullptr;       // library-owned compute stream
     hipStream_t user_stream = nullptr;  // borrowed (dxo_ctx_set_stream)
     bool use_user_stream = false;
@@ -42,6 +51,8 @@ struct dxo_ctx {
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
+    int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
+    int64_t host_threads = 16;          // worker threads of the host half of the pipeline
     // small-batch path of the host pipeline: one pinned staging buffer, one H2D, one D2H, events made once
     void* small_pinned = nullptr;
     size_t small_pinned_bytes = 0;
@@ -91,13 +102,23 @@ struct dxo_span {
 typedef int (*dxo_chunk_launch)(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const* d_in,
                                 void* const* d_out, hipStream_t stream);
 
+// Optional host-side completion hook of the pipeline: called on the calling thread once the D2H copies of points
+// [first, first + m) have landed, while later chunks are still in flight.
+typedef int (*dxo_chunk_post)(dxo_ctx* ctx, void* user, int64_t first, int64_t m);
+
+// Run fn(begin, end) over [0, n) split into contiguous ranges on the context's host threads; returns when all are done.
+void dxo_host_parallel_for(dxo_ctx* ctx, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& fn);
+
+// Every extern "C" entry point that takes a ctx starts with this (ctx may be NULL: the guard is then a no-op).
+#define DXO_LOCK(ctx) std::unique_lock<std::recursive_mutex> dxo_lock_guard_ = (ctx) ? std::unique_lock<std::recursive_mutex>((ctx)->mu) : std::unique_lock<std::recursive_mutex>()
+
 // H2D -> kernel -> D2H, chunked over points and rotated over DXO_HOST_SLOTS streams so copies
 // of one chunk overlap the kernel of another. Blocks until every output byte is on the host.
 // `n` counts units of `points_per_unit` quadrature points (1: points; nq: cells — bytes_pp is then per cell); the
 // chunk size option host_chunk_points stays in points.
 int dxo_run_host_pipeline(dxo_ctx* ctx, int64_t n, const std::vector<dxo_span>& inputs,
                           const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
-                          int64_t points_per_unit = 1);
+                          int64_t points_per_unit = 1, dxo_chunk_post post = nullptr);
 
 // Device-path bracket: optional event timing around a launch sequence.
 int dxo_device_begin(dxo_ctx* ctx, hipStream_t s);

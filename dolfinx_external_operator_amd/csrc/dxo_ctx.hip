@@ -1,8 +1,91 @@
 // dxo_ctx.hip — context, options, pinned host memory, the chunked host pipeline.
 // Host-side runtime of libdxo_hip.so; the kernels live in von_mises.hip / heat.hip / ...
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 
 #include "dxo_common.h"
+
+// ---------------------------------------------------------------------------------------------- host worker threads
+struct dxo_host_pool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int64_t, int64_t)>* fn = nullptr;
+    int64_t n = 0, grain = 1, next = 0;
+    int active = 0;          // workers inside the current job
+    uint64_t generation = 0;
+    bool stop = false;
+
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            ++active;
+            while (next < n) {
+                const int64_t b = next, e = b + grain < n ? b + grain : n;
+                next = e;
+                lk.unlock();
+                (*fn)(b, e);
+                lk.lock();
+            }
+            if (--active == 0) cv_done.notify_all();
+        }
+    }
+};
+
+void dxo_host_pool_destroy(dxo_host_pool* pool) {
+    if (!pool) return;
+    {
+        std::lock_guard<std::mutex> lk(pool->m);
+        pool->stop = true;
+    }
+    pool->cv_work.notify_all();
+    for (auto& t : pool->threads) t.join();
+    delete pool;
+}
+
+void dxo_host_parallel_for(dxo_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& fn) {
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    int want = (int)c->host_threads;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && want > hw) want = hw;
+    if (want <= 1 || n <= grain) {
+        fn(0, n);
+        return;
+    }
+    if (c->pool && (int)c->pool->threads.size() != want - 1) {   // host_threads changed
+        dxo_host_pool_destroy(c->pool);
+        c->pool = nullptr;
+    }
+    if (!c->pool) {
+        c->pool = new dxo_host_pool();
+        for (int i = 0; i < want - 1; ++i) c->pool->threads.emplace_back([p = c->pool] { p->worker(); });
+    }
+    dxo_host_pool* p = c->pool;
+    std::unique_lock<std::mutex> lk(p->m);
+    p->fn = &fn;
+    p->n = n;
+    p->grain = grain;
+    p->next = 0;
+    ++p->generation;
+    p->cv_work.notify_all();
+    // the calling thread works too
+    while (p->next < p->n) {
+        const int64_t b = p->next, e = b + grain < n ? b + grain : n;
+        p->next = e;
+        lk.unlock();
+        fn(b, e);
+        lk.lock();
+    }
+    p->cv_done.wait(lk, [&] { return p->active == 0; });
+    // a worker that has not woken up yet will find next == n and leave at once; make sure none is still inside fn
+    p->fn = nullptr;
+}
 
 namespace {
 
@@ -78,6 +161,7 @@ int dxo_ctx_destroy(dxo_ctx* c) {
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    dxo_host_pool_destroy(c->pool);
     delete c;
     return DXO_OK;
 }
@@ -126,6 +210,8 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
     if (!std::strcmp(key, "mc_part_points")) return &c->mc_part_points;
     if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;
+    if (!std::strcmp(key, "vm_host_tangent")) return &c->vm_host_tangent;
+    if (!std::strcmp(key, "host_threads")) return &c->host_threads;
     return nullptr;
 }
 
@@ -161,17 +247,18 @@ int dxo_last_timing(dxo_ctx* c, dxo_timing* t) {
     return DXO_OK;
 }
 
+// ctx may be NULL for both (page-locked host memory belongs to the process, not to a device context): a buffer can
+// then outlive the context it was first used with, which is what the Python binding's recycling pool needs.
 int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
-    if (!c || !ptr) return DXO_E_NULL;
+    if (!ptr) return DXO_E_NULL;
     if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
     *ptr = nullptr;
-    DXO_HIP(c, hipSetDevice(c->device));
+    if (c) DXO_HIP(c, hipSetDevice(c->device));
     DXO_HIP(c, hipHostMalloc(ptr, bytes > 0 ? (size_t)bytes : 1, hipHostMallocDefault));
     return DXO_OK;
 }
 
 int dxo_host_free(dxo_ctx* c, void* ptr) {
-    if (!c) return DXO_E_NULL;
     if (!ptr) return DXO_OK;
     DXO_HIP(c, hipHostFree(ptr));
     return DXO_OK;
@@ -238,7 +325,7 @@ int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {
 
 int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& inputs,
                           const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
-                          int64_t points_per_unit) {
+                          int64_t points_per_unit, dxo_chunk_post post) {
     DXO_HIP(c, hipSetDevice(c->device));
     c->last = {0, 0, 0, 0};
     c->ev_pending = false;
@@ -307,6 +394,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                 if (outputs[k].out) std::memcpy(outputs[k].out, hbase + off, outputs[k].bytes_pp * (size_t)n);
                 off += round_up(outputs[k].bytes_pp * (size_t)n, 256);
             }
+            if (post) {
+                rc = post(c, user, 0, n);
+                if (rc != DXO_OK) return rc;
+            }
             if (timed) {
                 float a = 0, b = 0, d = 0;
                 DXO_HIP(c, hipEventElapsedTime(&a, c->small_ev[0], c->small_ev[1]));
@@ -337,6 +428,7 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         c->slot_bytes = need;
     }
     SlotEvents ev[DXO_HOST_SLOTS];
+    int64_t slot_first[DXO_HOST_SLOTS] = {0, 0, 0}, slot_m[DXO_HOST_SLOTS] = {0, 0, 0};
     int rc = DXO_OK;
     auto destroy_events = [&]() {
         for (auto& s : ev)
@@ -362,6 +454,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         c->last.kernel_ms += b;
         c->last.d2h_ms += d;
         ev[slot].used = false;
+        // host half of the chunk (e.g. tangent rebuild) while the other slots' copies and kernels keep running
+        if (post) return post(c, user, slot_first[slot], slot_m[slot]);
         return DXO_OK;
     };
     const auto t0 = std::chrono::steady_clock::now();
@@ -399,6 +493,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         if (e == hipSuccess) e = hipEventRecord(ev[slot].e[3], s);
         if (e != hipSuccess) { rc = dxo_hip_fail(c, e, "host pipeline D2H"); break; }
         ev[slot].used = true;
+        slot_first[slot] = done;
+        slot_m[slot] = m;
         done += m;
     }
     for (int slot = 0; slot < DXO_HOST_SLOTS; ++slot) {

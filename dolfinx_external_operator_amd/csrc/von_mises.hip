@@ -25,6 +25,8 @@
 //        per CU, and every C_tang store instruction writes 1 KiB of consecutive bytes.
 //   No cross-wave communication, hence no __syncthreads(): LDS slices are wave-private and DS
 //   operations of one wave execute in order; only the compiler must be kept from reordering.
+#include <emmintrin.h>
+
 #include "dxo_common.h"
 #include "vm_core.h"
 
@@ -136,6 +138,10 @@ __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, co
 struct VmLaunch {
     VmConst c;
     int d;
+    // host half of the DXO_MEM_HOST pipeline with option "vm_host_tangent" = 1 (see vm_host_rebuild)
+    const double* h_sigma = nullptr;
+    const double* h_dp = nullptr;
+    double* h_C_tang = nullptr;
 };
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -287,6 +293,58 @@ int vm_expand_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void
     return vm_expand_launch(ctx, L, m, (const double*)d_in[0], (const double*)d_in[1], (double*)d_out[0], s);
 }
 
+// ------------------------------------------------------------------ host half: tangent from (sigma, dp) on the CPU
+// DXO_MEM_HOST with option "vm_host_tangent" = 1: of the 344 B/point (d = 6) the kernel produces, 288 are the
+// tangent, and the tangent is a function of the returned state (vm_tangent_state above). PCIe, not HBM, bounds a
+// host call, so only (sigma, dp) cross the link (56 B/point) and the caller's C_tang array is filled by the
+// context's host threads from the chunk that has just landed while the next chunks are still in flight. Same
+// formulas and operation order as vm_tangent_state / vm_store_tangent; streaming (non-temporal) stores because the
+// array is write-only here and larger than any cache. Product code of the host pipeline, not a CPU fallback: the
+// return map itself always runs on the GPU.
+template <int D>
+void vm_host_rebuild_range(const VmConst& c, const double* __restrict__ sigma, const double* __restrict__ dp,
+                           double* __restrict__ C_tang, int64_t b, int64_t e) {
+    const bool stream = (((uintptr_t)C_tang) & 15u) == 0;   // D*D*8 is a multiple of 16: every point block is aligned
+    for (int64_t i = b; i < e; ++i) {
+        const double* sg = sigma + i * D;
+        const double mean = (sg[0] + sg[1] + sg[2]) * (1.0 / 3.0);
+        double s[D], nrm[D];
+        for (int k = 0; k < D; ++k) s[k] = k < 3 ? sg[k] - mean : sg[k];
+        double ss = 0.0;
+        for (int k = 0; k < D; ++k) ss += s[k] * s[k];
+        const double sigma_eq = std::sqrt(3.0 / 2.0 * ss);
+        const double dpi = dp[i];
+        const double beta = c.mu3 * dpi / (sigma_eq + c.mu3 * dpi);
+        const double ind = dpi > 0.0 ? 1.0 : 0.0;
+        for (int k = 0; k < D; ++k) nrm[k] = s[k] / sigma_eq * ind;
+        const double a = c.mu3 * (c.ratio - beta), bb = c.mu2 * beta;
+        double* Ct = C_tang + i * (D * D);
+        for (int r = 0; r < D; ++r)
+            for (int q = 0; q < D; q += 2) {
+                const double v0 = ((r < 3 && q < 3) ? c.lmbda : 0.0) + (r == q ? c.mu2 : 0.0) - a * (nrm[r] * nrm[q]) -
+                                  bb * ((r == q ? 1.0 : 0.0) - ((r < 3 && q < 3) ? 1.0 / 3.0 : 0.0));
+                const double v1 = ((r < 3 && q + 1 < 3) ? c.lmbda : 0.0) + (r == q + 1 ? c.mu2 : 0.0) - a * (nrm[r] * nrm[q + 1]) -
+                                  bb * ((r == q + 1 ? 1.0 : 0.0) - ((r < 3 && q + 1 < 3) ? 1.0 / 3.0 : 0.0));
+                if (stream) _mm_stream_pd(Ct + r * D + q, _mm_set_pd(v1, v0));
+                else { Ct[r * D + q] = v0; Ct[r * D + q + 1] = v1; }
+            }
+    }
+    if (stream) _mm_sfence();
+}
+
+int vm_host_rebuild(dxo_ctx* ctx, void* user, int64_t first, int64_t m) {
+    const VmLaunch& L = *static_cast<const VmLaunch*>(user);
+    const int d = L.d;
+    const double* sg = L.h_sigma + first * d;
+    const double* dp = L.h_dp + first;
+    double* Ct = L.h_C_tang + first * d * d;
+    dxo_host_parallel_for(ctx, m, 4096, [&](int64_t b, int64_t e) {
+        if (d == 4) vm_host_rebuild_range<4>(L.c, sg, dp, Ct, b, e);
+        else vm_host_rebuild_range<6>(L.c, sg, dp, Ct, b, e);
+    });
+    return DXO_OK;
+}
+
 }  // namespace
 
 extern "C" int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
@@ -338,6 +396,14 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     }
     const size_t sd = sizeof(double);
     std::vector<dxo_span> in = {{deps, nullptr, d * sd}, {sigma_n, nullptr, d * sd}, {p, nullptr, sd}};
+    if (ctx->vm_host_tangent) {
+        // (sigma, dp) over PCIe, C_tang rebuilt by the host threads from each chunk as it lands (vm_host_rebuild)
+        L.h_sigma = sigma;
+        L.h_dp = dp;
+        L.h_C_tang = C_tang;
+        std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
+        return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+    }
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
     return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
 }

@@ -52,33 +52,61 @@ def _as_f64_host(a, what: str) -> np.ndarray:
 class _Outputs:
     """Output buffers for host calls.
 
-    reuse=True (default of the factories): the returned flat arrays are views of pinned (hipHostMalloc) buffers
-    owned by the operator and are OVERWRITTEN BY ITS NEXT CALL. That matches how the reference consumes them —
-    `evaluate_external_operators` copies element 0 into the coefficient at once (external_operator.py:441) and
-    the demos copy the extras right after the call (demo_plasticity_von_mises.py:451-456) — and it is what makes
-    the boundary PCIe-bound instead of page-fault-bound: 7.5 ms vs 38 ms per call at 10^6 points (d = 6), because
-    a fresh 344 MB ndarray is first touched inside the D2H copy. reuse=False returns fresh pageable arrays."""
+    Default (reuse=False): every call returns arrays nobody else can overwrite, like the reference's kernels, which
+    return fresh ndarrays (demo_plasticity_von_mises.py:352). They are page-locked blocks from the context's recycling
+    pool (Context.pinned_recycled): a block goes back to the pool only after the array and all its views have been
+    garbage-collected, so `a = f(x0); b = f(x1); b - a` is what it is in the reference, while a caller that drops the
+    results between calls (evaluate_external_operators copies element 0 into the coefficient at once,
+    external_operator.py:441; the demos copy the extras right after, demo_plasticity_von_mises.py:451-456) gets the
+    same page-locked, already-touched memory back at the next call: 7.5 ms vs 38 ms per call at 10^6 points (d = 6)
+    against first-touched pageable arrays.
+    reuse=True (opt-in): ONE set of buffers owned by the operator, overwritten by its next call and released by
+    Context.close() — only for callers that copy the results out before calling again."""
 
     def __init__(self, ctx: Context, reuse: bool):
         self.ctx = ctx
         self.reuse = reuse
         self._cache: dict[tuple[str, int], np.ndarray] = {}
+        self._retired: list[np.ndarray] = []   # reuse=True buffers of an earlier batch size: never freed under a live view
 
-    def get(self, key: str, size: int) -> np.ndarray:
+    def get(self, key: str, size: int, dtype=np.float64) -> np.ndarray:
         if not self.reuse:
-            return np.empty(size, dtype=np.float64)
+            return self.ctx.pinned_recycled(size, dtype)
         buf = self._cache.get((key, size))
         if buf is None:
-            for k in [k for k in self._cache if k[0] == key]:   # the batch size changed: release the old buffer
-                self.ctx.pinned_free(self._cache.pop(k))
-            buf = self.ctx.pinned_empty(size)
+            for k in [k for k in self._cache if k[0] == key]:   # the batch size changed
+                self._retired.append(self._cache.pop(k))        # kept until Context.close(); views stay valid
+            buf = self.ctx.pinned_empty(size, dtype)
             self._cache[(key, size)] = buf
         return buf
 
 
+def _torch_stream(c: Context, t):
+    """Launch on torch's current stream of the tensor's device; refuse tensors of another GPU."""
+    import torch
+
+    if t.device.index != c.device:
+        raise ValueError(f"tensor lives on cuda:{t.device.index}, the context on device {c.device}")
+    c.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+    return torch
+
+
+def _dev_f64(t, what: str, numel: int | None = None):
+    import torch
+
+    if not _is_device_tensor(t):
+        raise TypeError(f"{what}: with a CUDA operand every state array must be a CUDA tensor too, got {type(t).__name__}")
+    if t.dtype != torch.float64:
+        raise TypeError(f"{what}: the HIP kernels are fp64 (reference default PETSc.ScalarType); got {t.dtype}")
+    t = t.contiguous()
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"state size mismatch: {what} has {t.numel()} entries, want {numel}")
+    return t
+
+
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = True) -> Callable:
+                   reuse_outputs: bool = False) -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -86,8 +114,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     `deps` has shape (num_cells, nq, d), d = 4 (reference) or 6 (3-D Mandel). Default constants: :185-188.
     Host ndarrays go through the chunked H2D/kernel/D2H pipeline; torch CUDA tensors stay on the device
     (outputs are then CUDA tensors on the same device, launched on torch's current stream).
-    With reuse_outputs=True (default) the returned arrays live in pinned buffers that the NEXT call of this
-    callable overwrites (see _Outputs); pass reuse_outputs=False for fresh arrays at ~5x the call time.
+    Results are arrays of their own, as in the reference (page-locked blocks recycled only after the caller has
+    dropped them, see _Outputs); reuse_outputs=True opts into ONE set of buffers that the next call overwrites.
+    `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors carved from the context's
+    placement-calibrated output arena (Context.output_arena); pass them as `out=` to the device call.
     """
     if H is None:
         E_tangent = E / 100.0                      # :186
@@ -102,10 +132,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
             holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
         return holder["ctx"]
 
-    def C_tang_impl(deps):
+    def C_tang_impl(deps, out=None):
         c = _ctx()
         if _is_device_tensor(deps):
-            return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p))
+            return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p), out)
         if isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is c:
             # operand still unevaluated: strain + return map + tangent in ONE launch (dxo_von_mises_field)
             n, d = deps.shape[0] * deps.shape[1], deps.shape[2]
@@ -140,27 +170,37 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
             return C_tang_impl
         raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
 
+    def arena(n_points: int, d: int):
+        """(C_tang, sigma, dp) as flat CUDA tensors inside the context's output arena (placement-calibrated device
+        memory owned by the dxo_ctx, dxo_output_arena): the persistent coefficient buffers of a solver."""
+        return _ctx().output_tensors((n_points * d * d, n_points * d, n_points))
+
     sigma_external.params = prm
     sigma_external.context = _ctx
+    sigma_external.arena = arena
     return sigma_external
 
 
-def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p):
-    import torch
-
+def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p, out=None):
+    """Zero-copy path: torch CUDA tensors in, CUDA tensors out, launched on torch's current stream. `out` =
+    (C_tang, sigma, dp) preallocated flat fp64 CUDA tensors (e.g. views of Context.output_arena)."""
+    torch = _torch_stream(c, deps)
     if deps.dtype != torch.float64:
         raise TypeError(f"deps: the HIP kernels are fp64, got {deps.dtype}")
     num_cells, nq, d = deps.shape
+    if d not in (4, 6):
+        raise ValueError(f"von Mises kernel supports Mandel vectors of length 4 or 6, got {d}")
     n = num_cells * nq
     deps = deps.contiguous()
-    sigma_n = sigma_n.contiguous()
-    p = p.contiguous()
-    if sigma_n.numel() != n * d or p.numel() != n:
-        raise ValueError("state size mismatch")
-    C_tang = torch.empty(n * d * d, dtype=torch.float64, device=deps.device)
-    sigma = torch.empty(n * d, dtype=torch.float64, device=deps.device)
-    dp = torch.empty(n, dtype=torch.float64, device=deps.device)
-    c.set_stream(torch.cuda.current_stream(deps.device).cuda_stream)
+    sigma_n = _dev_f64(sigma_n, "sigma_n", n * d)
+    p = _dev_f64(p, "p", n)
+    if out is None:
+        C_tang = torch.empty(n * d * d, dtype=torch.float64, device=deps.device)
+        sigma = torch.empty(n * d, dtype=torch.float64, device=deps.device)
+        dp = torch.empty(n, dtype=torch.float64, device=deps.device)
+    else:
+        C_tang, sigma, dp = (_dev_f64(t, name, size) for t, name, size in
+                             zip(out, ("out C_tang", "out sigma", "out dp"), (n * d * d, n * d, n)))
     c.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(),
                 sigma.data_ptr(), dp.data_ptr())
     return C_tang, sigma, dp
@@ -180,7 +220,7 @@ def von_mises_commit_state(p, dp, sigma_n, sigma, *, ctx: Context | None = None,
         raise ValueError("state size mismatch")
     d = sigma.numel() // n if n else 4
     c = ctx if ctx is not None else default_context(device)
-    c.set_stream(torch.cuda.current_stream(p.device).cuda_stream)
+    _torch_stream(c, p)
     c.vm_commit_state(d, n, p.data_ptr(), dp.data_ptr(), sigma_n.data_ptr(), sigma.data_ptr())
 
 
@@ -216,6 +256,29 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
             sizes = (n * gdim, n * gdim, n * gdim * gdim)
             outs = [np.empty(sz) if k == which else None for k, sz in enumerate(sizes)]
             T.mesh.heat(A, B, T.u, outs[0], outs[1], outs[2])
+            return outs[which]
+        if _is_device_tensor(T) or _is_device_tensor(sigma):
+            # zero-copy: CUDA tensors in, a CUDA tensor out, on torch's current stream
+            torch = _torch_stream(c, T if _is_device_tensor(T) else sigma)
+            T_d = _dev_f64(T, "T").reshape(-1)
+            n = T_d.numel()
+            sig_d = _dev_f64(sigma, "sigma").reshape(-1)
+            if n == 0:
+                gdim = sigma.shape[-1] if sigma.dim() == 3 and sigma.shape[-1] in (1, 2, 3) else 2
+            else:
+                if sig_d.numel() % n:
+                    raise ValueError(f"sigma size {sig_d.numel()} is not a multiple of the number of points {n}")
+                gdim = sig_d.numel() // n
+            if gdim not in (1, 2, 3):
+                raise ValueError(f"heat kernel supports gdim 1, 2, 3; got {gdim}")
+            sizes = (n * gdim, n * gdim, n * gdim * gdim)
+            outs = [torch.empty(sz, dtype=torch.float64, device=T_d.device) if (fuse_by_identity or k == which) else None
+                    for k, sz in enumerate(sizes)]
+            c.heat(A, B, gdim, n, MEM_DEVICE, T_d.data_ptr(), sig_d.data_ptr(),
+                   *(o.data_ptr() if o is not None else None for o in outs))
+            if fuse_by_identity:
+                holder["keep"] = (T, sigma)
+                holder["val"] = outs
             return outs[which]
         T_ = _as_f64_host(T, "T").reshape(-1)
         n = T_.size
@@ -259,7 +322,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
                       phi: float = 30 * np.pi / 180, psi: float = 30 * np.pi / 180, theta_T: float = 26 * np.pi / 180,
                       a: float | None = None, tol: float = 1e-8, Nitermax: int = 200, diagnostics: bool = True,
                       on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0,
-                      reuse_outputs: bool = True) -> Callable:
+                      reuse_outputs: bool = False) -> Callable:
     """`sigma_external` of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:604-608) on the GPU.
 
     `external_function((1,))(deps) -> (C_tang, sigma)`, flat arrays, the reference's order (:593); any other
@@ -284,6 +347,8 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
         cx = holder["ctx"]
         if holder["out"] is None:
             holder["out"] = _Outputs(cx, reuse_outputs)
+        if _is_device_tensor(deps):
+            return _mohr_coulomb_device(cx, prm, deps, _state_array(sigma_n), diagnostics, on_summary, sigma_external)
         deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
         sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape((-1, 4))   # :579
         n = deps_.shape[0]
@@ -314,8 +379,51 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
     return sigma_external
 
 
+def _mohr_coulomb_device(cx: Context, prm: McParams, deps, sigma_n, diagnostics: bool, on_summary, fn):
+    """Zero-copy Mohr-Coulomb: CUDA tensors in/out; the per-point diagnostics stay on the device
+    (`external_function.last_state` holds CUDA tensors) and the summary the reference prints at every call
+    (demo_plasticity_mohr_coulomb.py:584-591) is reduced on the GPU by dxo_mc_summary."""
+    torch = _torch_stream(cx, deps)
+    if deps.dtype != torch.float64:
+        raise TypeError(f"deps: the HIP kernels are fp64, got {deps.dtype}")
+    deps = deps.contiguous().reshape(-1, 4)                          # :578
+    n = deps.shape[0]
+    sigma_n = _dev_f64(sigma_n, "sigma_n", n * 4)                   # :579
+    dev = deps.device
+    C_tang = torch.empty(n * 16, dtype=torch.float64, device=dev)
+    sigma = torch.empty(n * 4, dtype=torch.float64, device=dev)
+    if diagnostics or on_summary is not None:
+        niter = torch.empty(n, dtype=torch.int32, device=dev)
+        yielding, norm_res, dlambda = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+        aux = (niter.data_ptr(), yielding.data_ptr(), norm_res.data_ptr(), dlambda.data_ptr())
+    else:
+        niter = yielding = norm_res = dlambda = None
+        aux = (None, None, None, None)
+    cx.mohr_coulomb(prm, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), *aux)
+    fn.last_state = (niter, yielding, norm_res, dlambda)
+    if on_summary is not None and n > 0:
+        smry = cx.mc_summary(n, niter, yielding, norm_res, nbins=int(prm.nitermax) + 1)
+        on_summary({"unique_iters": smry["unique_iters"], "counts": smry["counts"],
+                    "max_yielding": smry["max_yielding"] if smry["nan_yielding"] == 0 else float("nan"),
+                    "max_norm_res": smry["max_norm_res"] if np.isfinite(smry["max_norm_res"]) else float("nan")})
+    return C_tang, sigma                                             # :593
+
+
+def _P_device(cx: Context, Fvals, launch):
+    """Shared zero-copy wrapper of the two hyperelastic operators: F (.., 2, 2) CUDA tensor -> (dP, P) CUDA tensors."""
+    torch = _torch_stream(cx, Fvals)
+    if Fvals.dtype != torch.float64:
+        raise TypeError(f"Fvals: operand arrays are fp64 (the network itself runs in fp32 or fp64), got {Fvals.dtype}")
+    F = Fvals.contiguous().reshape(-1, 4)                            # :452
+    n = F.shape[0]
+    dP = torch.empty(n * 16, dtype=torch.float64, device=F.device)
+    P = torch.empty(n * 4, dtype=torch.float64, device=F.device)
+    launch(n, F.data_ptr(), dP.data_ptr(), P.data_ptr())
+    return dP, P                                                     # :456
+
+
 def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None, device: int = 0,
-              reuse_outputs: bool = True) -> Callable:
+              reuse_outputs: bool = False) -> Callable:
     """`P_external` of the hyperelasticity demo (demo_hyperelasticity.py:459-466) on the GPU.
 
     `external_function((1,))(Fvals) -> (dP, P)`, flat arrays in the reference's order (:456); other
@@ -338,6 +446,8 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
 
     def dP_dF_impl(Fvals):
         cx, model = _model()
+        if _is_device_tensor(Fvals):
+            return _P_device(cx, Fvals, lambda n, F, dP, P: cx.icnn_eval(model, prec, n, MEM_DEVICE, F, dP, P))
         F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)      # :452
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
@@ -353,11 +463,8 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
     return P_external
 
 
-__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn"]
-
-
 def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float = 1.5, ctx: Context | None = None,
-                 device: int = 0, reuse_outputs: bool = True) -> Callable:
+                 device: int = 0, reuse_outputs: bool = False) -> Callable:
     """The analytic Isihara model behind the same `P_external` contract as `make_icnn`.
 
     The reference states it in UFL only (demo_hyperelasticity.py:686-703, `P = ufl.diff(W_Isihara, F_)`) and
@@ -372,6 +479,9 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
             holder["ctx"] = default_context(device)
         if holder["out"] is None:
             holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+        if _is_device_tensor(Fvals):
+            cx = holder["ctx"]
+            return _P_device(cx, Fvals, lambda n, F, dP, P: cx.isihara(prm, n, MEM_DEVICE, F, dP, P))
         F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
@@ -385,3 +495,6 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
 
     P_external.params = prm
     return P_external
+
+
+__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn", "make_isihara", "von_mises_commit_state"]

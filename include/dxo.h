@@ -111,7 +111,8 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
 int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);
-/* Pinned host buffers (hipHostMalloc) so DXO_MEM_HOST calls DMA without staging. */
+/* Pinned host buffers (hipHostMalloc) so DXO_MEM_HOST calls DMA without staging. ctx may be NULL for both
+ * (the memory belongs to the process; a buffer may outlive the context it was first used with). */
 int dxo_host_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_host_free(dxo_ctx* ctx, void* ptr);
 
