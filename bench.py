@@ -108,6 +108,55 @@ def cpu_baseline(d, n_sample, budget_s=10.0):
     }
 
 
+def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
+    """The drop-in boundary as the reference uses it — NumPy in, NumPy out (external_operator.py:432-446,
+    demo_plasticity_von_mises.py:343-352): dxo_von_mises with DXO_MEM_HOST on page-locked host arrays, i.e.
+    H2D + kernel + D2H through the chunked three-stream pipeline. Two forms of the D2H leg:
+      copy     (C_tang, sigma, dp) come back over PCIe: 344 B/point at d = 6, bit-identical to a device call
+      rebuild  only (sigma, dp) cross PCIe (56 B/point); the caller's C_tang array is rebuilt from them by the
+               context's host threads while later chunks are in flight (option vm_host_tangent = 1)
+    Reported beside the headline, never as `value`. Times are medians over `calls` calls; h2d/kernel/d2h are sums
+    of the per-chunk event times (they overlap, so they do not add up to total_ms)."""
+    import numpy as np
+
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    out = {"memory": "hipHostMalloc (page-locked) host arrays", "host_threads": ctx.get_option("host_threads"), "sizes": []}
+    rng = np.random.Generator(np.random.PCG64(7))
+    for n in sizes:
+        bufs = [ctx.pinned_empty(m) for m in (n * d, n * d, n, n * d * d, n * d, n)]
+        deps, sigma_n, p, C_tang, sigma, dp = bufs
+        deps[:] = rng.normal(0.0, 3e-3, size=n * d)
+        sigma_n[:] = rng.normal(0.0, 100.0, size=n * d)
+        p[:] = np.abs(rng.normal(0.0, 1e-3, size=n))
+        entry = {"points": n}
+        ref_C = None
+        for mode, name in ((0, "copy"), (1, "rebuild")):
+            ctx.set_option("vm_host_tangent", mode)
+            rows = []
+            for _ in range(calls + 1):
+                t0 = time.perf_counter()
+                ctx.von_mises(prm, d, n, MEM_HOST, deps, sigma_n, p, C_tang, sigma, dp)
+                wall = time.perf_counter() - t0
+                rows.append((wall, ctx.last_timing()))
+            rows = sorted(rows[1:], key=lambda r: r[0])
+            wall, t = rows[len(rows) // 2]
+            entry[name] = {"qp_per_s": n / wall, "total_ms": wall * 1e3, "h2d_ms": t["h2d_ms"], "kernel_ms": t["kernel_ms"],
+                           "d2h_ms": t["d2h_ms"], "pcie_bytes_per_qp": 8 * (2 * d + 1) + (8 * (d * d + d + 1) if mode == 0 else 8 * (d + 1))}
+            if mode == 0:
+                ref_C = C_tang[: 4096 * d * d].copy()
+            else:   # the host-rebuilt tangent must agree with the one the device wrote
+                err = float(np.max(np.abs(C_tang[: 4096 * d * d] - ref_C)) / np.max(np.abs(ref_C)))
+                entry["rebuild_vs_copy_max_rel_err"] = err
+                if not err < 1e-12:
+                    raise SystemExit(f"bench: host-rebuilt tangent differs from the device tangent ({err:.2e})")
+        ctx.set_option("vm_host_tangent", 0)
+        for b in bufs:
+            ctx.pinned_free(b)
+        out["sizes"].append(entry)
+    return out
+
+
 def launch_ranks(n_gpus: int, argv: list[str]) -> int:
     """Parent side of `python bench.py --gpus N` (N > 1): one rank per GPU under torch.distributed.run, started as a
     child process. This function runs BEFORE torch is imported and makes no HIP / torch.cuda call, so the parent never
@@ -154,13 +203,14 @@ def main():
                          "link traffic; full: RCCL all-gather of (C_tang, sigma, dp). The other modes are timed too "
                          "and reported under config.gather_modes.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-probe", action="store_true", help="skip the stream-ceiling probe")
+    ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
-    ap.add_argument("--placement", type=int, default=8,
-                    help="HBM placement calibration: allocate this many candidate output slabs, time the kernel once on "
-                         "each, keep the fastest (0/1 = plain first allocation). See DESIGN.md 3.1.")
+    ap.add_argument("--placement", type=int, default=16,
+                    help="candidates of the LIBRARY's output-arena calibration (ctx option placement_candidates; "
+                         "0/1 = plain hipMalloc). The bench itself selects nothing. See DESIGN.md 3.1.")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -225,37 +275,32 @@ def main():
 
     seed = 1 if world == 1 else 100 + rank
     in_slab, deps, sigma_n, p = synth_inputs(torch, n, d, seed, device)
-    # outputs carved from one slab too (C_tang | sigma | dp), 43 doubles per point at d = 6
-    # HBM placement calibration. Streaming-WRITE bandwidth on this chip is bimodal in the physical region an
-    # allocation lands in (5.9 vs 6.85 TB/s pure write, runs of 6-36 GB; scripts/exp/map_exp.hip),
-    # and this kernel's traffic is 77 % writes. Like a solver that sizes its persistent coefficient buffers once,
-    # the bench allocates a few candidate output slabs, runs the kernel once on each and keeps the fastest. The
-    # first candidate is what a plain allocation would have returned; its figure is reported as
-    # roofline.achieved_first_allocation.
+    # Outputs live in the library's OUTPUT ARENA (dxo_output_alloc, csrc/arena.hip): on this chip the rate of a multi-GB
+    # streaming-write sweep is bimodal and the class belongs to the buffer's VIRTUAL address range, so
+    # the library creates the physical memory once and searches an address reservation for a fast range. This is what
+    # any user of `Context.output_tensors` / `make_von_mises(...).arena(n, d)` gets; the bench does no selection of
+    # its own any more. `roofline.achieved_plain_hipMalloc` is the same kernel writing into a plain torch.empty slab.
     # With the gather on, every rank holds the FULL-length outputs and its kernel writes its cell block straight
-    # into them at [rank*n, (rank+1)*n): the all-gather is RCCL's in-place form and nothing is copied locally.
+    # into them at [rank*n, (rank+1)*n): the all-gather is RCCL's in-place form and nothing is copied locally; those
+    # buffers must be IPC-shareable by RCCL, so the arena then uses ordinary hipMalloc candidates (placement_mode 2).
     gather_on = gather and dist_on
     blocks = world if gather_on else 1
     own = rank if gather_on else 0
-    n_cand = max(args.placement, 1) if blocks == 1 else max(1, min(args.placement, 3, int(120e9 // (blocks * n * 344))))
-    placement = {"candidates": n_cand, "kernel_GBps": []}
     per_pt = d * d + d + 1
+    N_full = blocks * n
+    if args.placement <= 1:
+        ctx.set_option("placement_mode", 0)
+    else:
+        ctx.set_option("placement_candidates", min(args.placement, 3) if gather_on else args.placement)
+        ctx.set_option("placement_mode", 2 if gather_on else 1)
+    C_full, sigma_full, dp_full = ctx.output_tensors((N_full * d * d, N_full * d, N_full))
+    placement = dict(C_full.dxo_block.info)
+    C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]
+    sigma = sigma_full[own * n * d:(own + 1) * n * d]
+    dp = dp_full[own * n:(own + 1) * n]
 
-    def carve(slab):
-        N = blocks * n
-        return slab[: N * d * d], slab[N * d * d: N * (d * d + d)], slab[N * (d * d + d):]
-
-    def own_ptrs(slab):
-        C_f, s_f, dp_f = carve(slab)
-        return (C_f.data_ptr() + own * n * d * d * 8, s_f.data_ptr() + own * n * d * 8, dp_f.data_ptr() + own * n * 8)
-
-    free_bytes = torch.cuda.mem_get_info(device)[0]
-    n_cand = max(1, min(n_cand, int(0.7 * free_bytes // (blocks * n * per_pt * 8))))   # all candidates coexist
-    placement["candidates"] = n_cand
-    cands = [torch.empty(blocks * n * per_pt, dtype=torch.float64, device=device) for _ in range(n_cand)]
-
-    def time_candidate(cnd, launches):
-        pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), *own_ptrs(cnd))
+    def time_kernel(out_ptrs, launches):
+        pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), *out_ptrs)
         ctx.von_mises(prm, d, n, MEM_DEVICE, *pp)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -265,20 +310,12 @@ def main():
         torch.cuda.synchronize(device)
         return BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / launches * 1e-3) / 1e9
 
-    placement["kernel_GBps"] = [time_candidate(cnd, 6) for cnd in cands]
-    ranked = sorted(range(len(cands)), key=lambda k: -placement["kernel_GBps"][k])
-    # the two best are timed again over more launches: one 6-launch reading is noisy by a few per cent
-    finals = {k: time_candidate(cands[k], 12) for k in ranked[:2]}
-    placement["finalists_GBps"] = {str(k): v for k, v in finals.items()}
-    placement["chosen"] = max(finals, key=finals.get)
-    cnd = None
-    out_slab = cands[placement["chosen"]]
-    del cands, cnd
-    torch.cuda.empty_cache()
-    C_full, sigma_full, dp_full = carve(out_slab)
-    C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]
-    sigma = sigma_full[own * n * d:(own + 1) * n * d]
-    dp = dp_full[own * n:(own + 1) * n]
+    plain_GBps = None
+    if rank == 0 and not gather_on:
+        plain = torch.empty(n * per_pt, dtype=torch.float64, device=device)   # what an un-placed allocation gives
+        plain_GBps = time_kernel((plain.data_ptr(), plain.data_ptr() + n * d * d * 8, plain.data_ptr() + n * (d * d + d) * 8), 12)
+        del plain
+        torch.cuda.empty_cache()
 
     ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
 
@@ -374,34 +411,42 @@ def main():
     bytes_per_launch = BYTES_PER_QP[d] * n
     achieved = bytes_per_launch / (kernel_ms_avg_max * 1e-3) / 1e9
 
-    # stream ceiling: a no-arithmetic kernel moving the same read:write mix over the SAME two slabs
-    ceiling = None
+    # stream probe: a no-arithmetic kernel moving the same read:write mix (13 : 43 sixteen-byte rows per tile) from the
+    # input slab into the SAME output block, persistent grid of 16 workgroups per CU. A reference point beside the
+    # 8 TB/s spec peak — NOT a ceiling: its access pattern differs from the kernel's (one output stream, not three).
+    probe_GBps = None
     if rank == 0 and not args.no_probe:
         R, Wc = PROBE_MIX[d]
         tiles = n // (2 * WAVE_TILE)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        saved_bpc = ctx.get_option("blocks_per_cu")
+        ctx.set_option("blocks_per_cu", 16)
         for _ in range(W):
-            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), out_slab.data_ptr())
-        for a, b in ev:
-            a.record(stream)
-            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), out_slab.data_ptr())
-            b.record(stream)
+            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), C_full.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(K):
+            ctx.stream_probe(R, Wc, tiles, in_slab.data_ptr(), C_full.data_ptr())
+        e1.record(stream)
         torch.cuda.synchronize(device)
-        ms = statistics.mean(a.elapsed_time(b) for a, b in ev)
-        ceiling = tiles * (R + Wc) * 1024 / (ms * 1e-3) / 1e9
+        ctx.set_option("blocks_per_cu", saved_bpc)
+        probe_GBps = tiles * (R + Wc) * 1024 / (e0.elapsed_time(e1) / K * 1e-3) / 1e9
 
     result = None
     if rank == 0:
-        traffic = None
+        # HBM traffic of this kernel is NOT measured in this run (PMC counters need rocprofv3 around the process): the
+        # stored result of the last counter pass over the same launch shape is quoted with its source, `traffic` is null.
+        traffic_from_profile = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
                 # the counter pass records the launch's grid size in threads = points rounded up to whole workgroups
                 if 0 <= tj.get("grid_threads", -1) - n < 256 and tj.get("d") == d:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_from_profile = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"), "file": "profiles/traffic.json",
+                                            "measured": tj.get("measured", "earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                                           "(scripts/gpu_check.sh), not this run")}
             except Exception:
-                traffic = None
+                traffic_from_profile = None
         result = {
             "metric": "quadrature-points/sec (von Mises return-map + tangent)",
             "value": value, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -420,24 +465,33 @@ def main():
                 "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
                                       "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
                                   for m, t_m in {args.gather_mode: elapsed, **other_elapsed}.items()} if gather_on else None),
+                "gather_modes_meaning": ({"full": "north_star's plain RCCL all-gather of all three output arrays",
+                                          "compact": "all-gather of (sigma, dp) + local rebuild of the remote tangents (to rounding; C_elas at "
+                                                     "the reference's 0/0 point f_el == 0)",
+                                          "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic"}
+                                         if gather_on else None),
+                "rccl_ranks": world if dist_on else 0,
                 "kernel": "vm_tile" if args.variant else "vm_point",
                 "arch": info["arch"], "compute_units": info["compute_units"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profile": traffic_from_profile,
                 "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
                 "kernel_ms_avg": kernel_ms_avg_max, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "bytes_per_qp": BYTES_PER_QP[d],
-                "achieved_first_allocation": placement["kernel_GBps"][0],
+                "output_memory": "dxo_output_alloc (library output arena, " + placement["mode"] + ")",
                 "placement": placement,
-                "stream_ceiling_GBps": ceiling,
-                "frac_of_stream_ceiling": (achieved / ceiling) if ceiling else None,
+                "achieved_plain_hipMalloc": plain_GBps,
+                "stream_probe_GBps": probe_GBps,
             },
             "kernel_only_value": total_points / (kernel_ms_avg_max * 1e-3),
         }
+        if world == 1 and not args.no_e2e:
+            del C_tang, sigma, dp, C_full, sigma_full, dp_full, in_slab, deps, sigma_n, p
+            torch.cuda.empty_cache()
+            result["end_to_end"] = end_to_end(ctx, prm, d)
         if world == 1 and not args.no_cpu:
-            del out_slab, C_tang, sigma, dp, C_full, sigma_full, dp_full
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist_on:

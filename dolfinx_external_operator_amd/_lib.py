@@ -59,6 +59,15 @@ class Timing(C.Structure):
                 ("total_ms", C.c_double)]
 
 
+PLACEMENT_MAX = 32
+
+
+class PlacementInfo(C.Structure):
+    """dxo_placement_info — what dxo_output_alloc's calibration saw."""
+    _fields_ = [("mode", C.c_int32), ("candidates", C.c_int32), ("chosen", C.c_int32), ("_pad", C.c_int32),
+                ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
                 ("wavefront_size", C.c_int32), ("total_mem_bytes", C.c_int64)]
@@ -79,6 +88,9 @@ _SIGNATURES = {
     "dxo_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "dxo_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_host_free": (C.c_int, [_P, _P]),
+    "dxo_output_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "dxo_output_free": (C.c_int, [_P, _P]),
+    "dxo_output_info": (C.c_int, [_P, _P, C.POINTER(PlacementInfo)]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
@@ -428,6 +440,47 @@ class Context:
         self.check(self.lib.dxo_vm_commit_state(self._h, int(d), int(n), _ptr(p), _ptr(dp), _ptr(sigma_n), _ptr(sigma)),
                    "dxo_vm_commit_state")
 
+    # -- output arena (placement-calibrated device memory, include/dxo.h "output arena") --------------
+    def output_alloc(self, nbytes: int) -> int:
+        """Device pointer of a block whose virtual range was chosen for streaming-write speed (dxo_output_alloc)."""
+        p = _P()
+        self.check(self.lib.dxo_output_alloc(self._h, int(nbytes), C.byref(p)), "dxo_output_alloc")
+        return p.value
+
+    def output_free(self, ptr: int) -> None:
+        if self._h and ptr:
+            self.check(self.lib.dxo_output_free(self._h, _P(ptr)), "dxo_output_free")
+
+    def output_info(self, ptr: int) -> dict:
+        info = PlacementInfo()
+        self.check(self.lib.dxo_output_info(self._h, _P(ptr), C.byref(info)), "dxo_output_info")
+        return {"mode": {0: "hipMalloc", 1: "virtual_range_search", 2: "hipMalloc_candidates"}[info.mode],
+                "candidates": info.candidates, "chosen": info.chosen,
+                "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
+                "calibration_ms": info.calibration_ms}
+
+    def output_tensors(self, sizes, dtype=None):
+        """Flat torch CUDA tensors of `sizes` elements each (fp64 unless dtype is given), carved from ONE
+        dxo_output_alloc block (each on a 256-byte border). The block stays alive as long as any of the tensors
+        (or the context) does; `tensors[0].dxo_block.info` holds the calibration record."""
+        import torch
+
+        dtype = dtype or torch.float64
+        item = torch.empty((), dtype=dtype).element_size()
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (int(n) * item + 255) // 256 * 256
+        block = _ArenaBlock(self, max(total, 256))
+        typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+        out = []
+        for n, off in zip(sizes, offs):
+            view = _CudaArrayView(block, block.ptr + off, int(n), typestr)
+            t = torch.as_tensor(view, device=torch.device("cuda", self.device)) if n else torch.empty(0, dtype=dtype, device=torch.device("cuda", self.device))
+            t.dxo_block = block   # keeps the arena block alive with the tensor
+            out.append(t)
+        return out
+
     def device_alloc(self, nbytes: int) -> int:
         p = _P()
         self.check(self.lib.dxo_device_alloc(self._h, int(nbytes), C.byref(p)), "dxo_device_alloc")
@@ -444,6 +497,35 @@ class Context:
         rc = self.lib.dxo_heat(self._h, float(A), float(B), int(gdim), int(n), int(mem), _ptr(T), _ptr(sigma),
                                _ptr(q), _ptr(dqdT), _ptr(dqdsigma))
         self.check(rc, "dxo_heat")
+
+
+class _ArenaBlock:
+    """Owner object of one dxo_output_alloc block; freed when the last tensor view and this object are gone."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        self.ptr = ctx.output_alloc(nbytes)
+        self.info = ctx.output_info(self.ptr)
+        self._fin = weakref.finalize(self, _ArenaBlock._release, weakref.ref(ctx), self.ptr)
+        self._fin.atexit = False
+
+    @staticmethod
+    def _release(ctx_ref, ptr):
+        ctx = ctx_ref()
+        if ctx is not None and ctx._h:
+            try:
+                ctx.output_free(ptr)
+            except Exception:
+                pass   # the context (and with it every arena block) is already gone
+
+
+class _CudaArrayView:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned device memory without a copy."""
+
+    def __init__(self, owner, ptr: int, n: int, typestr: str):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
 
 
 _default_ctx: dict[int, Context] = {}

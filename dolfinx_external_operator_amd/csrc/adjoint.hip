@@ -463,6 +463,7 @@ int dispatch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const doub
 
 extern "C" int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!mesh || !weights) return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_set_weights: NULL argument");
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     if (!mesh->d_wq) DXO_HIP(ctx, hipMalloc((void**)&mesh->d_wq, (size_t)mesh->dev.nq * sizeof(double)));
@@ -473,6 +474,7 @@ extern "C" int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
 extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
                                    int64_t n_cells, double* out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_operand_adjoint: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: quadrature weights not set (dxo_mesh_set_weights)");
     const int D = dxo_operand_value_size(mesh->gdim, bs, kind);
@@ -502,6 +504,7 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
 
 extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_diagonal: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;
@@ -529,6 +532,7 @@ extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
 
 extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_apply: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;

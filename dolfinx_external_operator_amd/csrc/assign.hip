@@ -31,21 +31,29 @@ __device__ __forceinline__ int64_t assign_src(const AssignDev& a, int64_t e) {
     return (c * a.n_points_total + a.offset + p) * a.comp_size + v;
 }
 
+// owner[coeff_size] is the error word: number of flat_dofs entries outside [0, coeff_size). Such entries are skipped by
+// both passes (the NumPy assigner the kernel mirrors raises IndexError, external_operator.py:287; here the call
+// returns DXO_E_SIZE and coeff holds the in-range part).
 __global__ __launch_bounds__(DXO_BLOCK) void assign_owner(AssignDev a, const int32_t* __restrict__ dofs,
-                                                          unsigned long long* __restrict__ owner) {
+                                                          unsigned long long* __restrict__ owner, int64_t coeff_size) {
     const int64_t n = a.n_cells * a.n_pts * a.val_size;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
-        atomicMax(owner + dofs[e], (unsigned long long)(e + 1));
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t d = dofs[e];
+        if (d < 0 || d >= coeff_size) atomicAdd(owner + coeff_size, 1ull);
+        else atomicMax(owner + d, (unsigned long long)(e + 1));
+    }
 }
 
 __global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int32_t* __restrict__ dofs,
                                                           const unsigned long long* __restrict__ owner,
-                                                          const double* __restrict__ values, double* __restrict__ coeff) {
+                                                          const double* __restrict__ values, double* __restrict__ coeff,
+                                                          int64_t coeff_size) {
     const int64_t n = a.n_cells * a.n_pts * a.val_size;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int32_t d = dofs[e];
+        const int64_t d = dofs[e];
+        if (d < 0 || d >= coeff_size) continue;
         if (owner[d] == (unsigned long long)(e + 1)) coeff[d] = values[assign_src(a, e)];
     }
 }
@@ -55,6 +63,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int
 extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, const double* values,
                           double* coeff, int64_t coeff_size) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!d) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: descriptor is NULL");
     if (d->n_cells < 0 || d->n_pts < 1 || d->val_size < 1 || d->offset < 0 || d->comp_size < d->val_size ||
         d->n_points_total < d->offset + d->n_pts || coeff_size < 0)
@@ -64,17 +73,10 @@ extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t*
     if (!flat_dofs || !values || !coeff) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: NULL array");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
-    // owner table: one 8-byte word per coefficient entry, in the context's device-path scratch buffer
-    const size_t need = (size_t)coeff_size * sizeof(unsigned long long);
-    if (ctx->scratch_bytes[DXO_HOST_SLOTS] < need) {
-        DXO_HIP(ctx, hipStreamSynchronize(s));
-        if (ctx->scratch[DXO_HOST_SLOTS]) DXO_HIP(ctx, hipFree(ctx->scratch[DXO_HOST_SLOTS]));
-        ctx->scratch[DXO_HOST_SLOTS] = nullptr;
-        ctx->scratch_bytes[DXO_HOST_SLOTS] = 0;
-        DXO_HIP(ctx, hipMalloc(&ctx->scratch[DXO_HOST_SLOTS], need));
-        ctx->scratch_bytes[DXO_HOST_SLOTS] = need;
-    }
-    unsigned long long* owner = static_cast<unsigned long long*>(ctx->scratch[DXO_HOST_SLOTS]);
+    // owner table: one 8-byte word per coefficient entry + the error word, in the context's device-path scratch
+    const size_t need = ((size_t)coeff_size + 1) * sizeof(unsigned long long);
+    unsigned long long* owner = static_cast<unsigned long long*>(dxo_scratch(ctx, s, need));
+    if (!owner) return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign: scratch allocation");
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
     DXO_HIP(ctx, hipMemsetAsync(owner, 0, need, s));
@@ -82,7 +84,17 @@ extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t*
     int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner);
-    hipLaunchKernelGGL(assign_store, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, values, coeff);
-    return dxo_device_end(ctx, s);
+    hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, coeff_size);
+    hipLaunchKernelGGL(assign_store, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, values, coeff, coeff_size);
+    rc = dxo_device_end(ctx, s);
+    if (rc != DXO_OK || !ctx->assign_validate) return rc;
+    unsigned long long bad = 0;
+    DXO_HIP(ctx, hipMemcpyAsync(&bad, owner + coeff_size, sizeof bad, hipMemcpyDeviceToHost, s));
+    DXO_HIP(ctx, hipStreamSynchronize(s));
+    if (bad) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "dxo_assign: %llu flat_dofs entries outside [0, coeff_size = %lld)", bad, (long long)coeff_size);
+        return dxo_fail(ctx, DXO_E_SIZE, msg);
+    }
+    return DXO_OK;
 }

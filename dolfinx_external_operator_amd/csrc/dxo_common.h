@@ -20,6 +20,18 @@ constexpr int DXO_WAVE = 64;          // gfx950 wavefront
 constexpr int DXO_BLOCK = 256;        // 4 waves per workgroup
 constexpr int DXO_HOST_SLOTS = 3;     // H2D / kernel / D2H pipeline depth
 
+// One block handed out by dxo_output_alloc (arena.hip)
+struct dxo_arena_block {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    char* va_base = nullptr;            // mode 1: the address reservation the block is mapped into
+    size_t va_bytes = 0;
+    hipMemGenericAllocationHandle_t handle{};
+    dxo_placement_info info;
+};
+struct dxo_ctx;
+void dxo_arena_release_all(dxo_ctx* ctx);
+
 // Host worker threads of a context (dxo_ctx.hip): the host half of the DXO_MEM_HOST pipeline (tangent rebuild from
 // the returned state while later chunks are still on the PCIe link). Created on first use, joined by dxo_ctx_destroy.
 struct dxo_host_pool;
@@ -51,8 +63,15 @@ struct dxo_ctx {
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
+    // output arena (arena.hip)
+    int64_t placement_mode = 1;         // 0 plain hipMalloc, 1 virtual-range search, 2 hipMalloc candidates
+    int64_t placement_candidates = 16;  // ranges / allocations tried at most (<= DXO_PLACEMENT_MAX)
+    int64_t placement_min_bytes = (int64_t)1 << 30;
+    int64_t placement_good_GBps = 6500; // stop searching at the first candidate whose write sweep reaches this
+    std::vector<dxo_arena_block> arena;
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
-    int64_t host_threads = 16;          // worker threads of the host half of the pipeline
+    int64_t host_threads = 32;          // worker threads of the host half of the pipeline (capped by the hardware's)
+    int64_t vm_rebuild_chunk_points = 1 << 16;   // pipeline chunk of the vm_host_tangent = 1 mode
     // small-batch path of the host pipeline: one pinned staging buffer, one H2D, one D2H, events made once
     void* small_pinned = nullptr;
     size_t small_pinned_bytes = 0;
@@ -60,6 +79,9 @@ struct dxo_ctx {
     int64_t host_small_bytes = 1 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
+    hipStream_t scratch_stream = nullptr;   // stream of the last DEVICE-path launch that used scratch[DXO_HOST_SLOTS]
+    bool scratch_stream_set = false;
+    int64_t assign_validate = 1;        // dxo_assign: check flat_dofs against coeff_size on the device (one sync per call)
     dxo_timing last = {0, 0, 0, 0};
     std::string err;
 };
@@ -125,3 +147,8 @@ int dxo_device_begin(dxo_ctx* ctx, hipStream_t s);
 int dxo_device_end(dxo_ctx* ctx, hipStream_t s);
 
 int dxo_grid_for_tiles(const dxo_ctx* ctx, int64_t n_tiles, int tiles_per_block);
+
+// ctx-owned device scratch of at least `bytes`: one buffer per host-pipeline slot stream plus ONE for device-path
+// launches. The device-path buffer is shared by every caller stream, so when the launch stream changes the previous
+// stream is drained first (two user streams must not race on it). nullptr on allocation failure.
+void* dxo_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes);

@@ -158,6 +158,7 @@ int dxo_ctx_destroy(dxo_ctx* c) {
     }
     for (int i = 0; i <= DXO_HOST_SLOTS; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    dxo_arena_release_all(c);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -170,6 +171,7 @@ const char* dxo_last_error(const dxo_ctx* c) { return c ? c->err.c_str() : "null
 
 int dxo_ctx_device_info(dxo_ctx* c, dxo_device_info* info) {
     if (!c || !info) return DXO_E_NULL;
+    DXO_LOCK(c);
     hipDeviceProp_t prop;
     DXO_HIP(c, hipGetDeviceProperties(&prop, c->device));
     std::memset(info, 0, sizeof *info);
@@ -183,6 +185,7 @@ int dxo_ctx_device_info(dxo_ctx* c, dxo_device_info* info) {
 
 int dxo_ctx_set_stream(dxo_ctx* c, void* hip_stream) {
     if (!c) return DXO_E_NULL;
+    DXO_LOCK(c);
     c->user_stream = (hipStream_t)hip_stream;
     c->use_user_stream = true;  // NULL selects the legacy default stream explicitly
     return DXO_OK;
@@ -190,6 +193,7 @@ int dxo_ctx_set_stream(dxo_ctx* c, void* hip_stream) {
 
 int dxo_ctx_synchronize(dxo_ctx* c) {
     if (!c) return DXO_E_NULL;
+    DXO_LOCK(c);
     DXO_HIP(c, hipSetDevice(c->device));
     DXO_HIP(c, hipStreamSynchronize(dxo_launch_stream(c)));
     for (int i = 0; i < DXO_HOST_SLOTS; ++i) DXO_HIP(c, hipStreamSynchronize(c->slot_stream[i]));
@@ -211,16 +215,24 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "mc_part_points")) return &c->mc_part_points;
     if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;
     if (!std::strcmp(key, "vm_host_tangent")) return &c->vm_host_tangent;
+    if (!std::strcmp(key, "assign_validate")) return &c->assign_validate;
+    if (!std::strcmp(key, "placement_mode")) return &c->placement_mode;
+    if (!std::strcmp(key, "placement_candidates")) return &c->placement_candidates;
+    if (!std::strcmp(key, "placement_min_bytes")) return &c->placement_min_bytes;
+    if (!std::strcmp(key, "placement_good_GBps")) return &c->placement_good_GBps;
     if (!std::strcmp(key, "host_threads")) return &c->host_threads;
+    if (!std::strcmp(key, "vm_rebuild_chunk_points")) return &c->vm_rebuild_chunk_points;
     return nullptr;
 }
 
 int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return DXO_E_NULL;
+    DXO_LOCK(c);
     int64_t* slot = option_slot(c, key);
     if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
     if (value < 0) return dxo_fail(c, DXO_E_OPTION, "option value must be >= 0");
     if (slot == &c->mc_blocks_per_cu && value < 1) return dxo_fail(c, DXO_E_OPTION, "mc_blocks_per_cu < 1");
+    if (slot == &c->vm_rebuild_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "vm_rebuild_chunk_points < 64");
     if (slot == &c->host_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "host_chunk_points < 64");
     *slot = value;
     return DXO_OK;
@@ -228,6 +240,7 @@ int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
 
 int dxo_ctx_get_option(dxo_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return DXO_E_NULL;
+    DXO_LOCK(c);
     int64_t* slot = option_slot(c, key);
     if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
     *value = *slot;
@@ -236,6 +249,7 @@ int dxo_ctx_get_option(dxo_ctx* c, const char* key, int64_t* value) {
 
 int dxo_last_timing(dxo_ctx* c, dxo_timing* t) {
     if (!c || !t) return DXO_E_NULL;
+    DXO_LOCK(c);
     if (c->ev_pending) {
         DXO_HIP(c, hipEventSynchronize(c->ev_stop));
         float ms = 0.f;
@@ -250,6 +264,7 @@ int dxo_last_timing(dxo_ctx* c, dxo_timing* t) {
 // ctx may be NULL for both (page-locked host memory belongs to the process, not to a device context): a buffer can
 // then outlive the context it was first used with, which is what the Python binding's recycling pool needs.
 int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
+    DXO_LOCK(c);
     if (!ptr) return DXO_E_NULL;
     if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
     *ptr = nullptr;
@@ -259,6 +274,7 @@ int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
 }
 
 int dxo_host_free(dxo_ctx* c, void* ptr) {
+    DXO_LOCK(c);
     if (!ptr) return DXO_OK;
     DXO_HIP(c, hipHostFree(ptr));
     return DXO_OK;
@@ -266,6 +282,7 @@ int dxo_host_free(dxo_ctx* c, void* ptr) {
 
 int dxo_device_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     if (!c || !ptr) return DXO_E_NULL;
+    DXO_LOCK(c);
     if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
     *ptr = nullptr;
     DXO_HIP(c, hipSetDevice(c->device));
@@ -275,6 +292,7 @@ int dxo_device_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
 
 int dxo_device_free(dxo_ctx* c, void* ptr) {
     if (!c) return DXO_E_NULL;
+    DXO_LOCK(c);
     if (!ptr) return DXO_OK;
     DXO_HIP(c, hipSetDevice(c->device));
     DXO_HIP(c, hipFree(ptr));
@@ -283,6 +301,7 @@ int dxo_device_free(dxo_ctx* c, void* ptr) {
 
 int dxo_copy(dxo_ctx* c, void* dst, const void* src, int64_t bytes, int kind) {
     if (!c) return DXO_E_NULL;
+    DXO_LOCK(c);
     if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
     if (kind < 0 || kind > 2) return dxo_fail(c, DXO_E_MEM, "dxo_copy: kind must be 0 (H2D), 1 (D2H) or 2 (D2D)");
     if (bytes == 0) return DXO_OK;
@@ -310,6 +329,31 @@ int dxo_device_end(dxo_ctx* c, hipStream_t s) {
         c->ev_pending = true;
     }
     return DXO_OK;
+}
+
+void* dxo_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes) {
+    int slot = DXO_HOST_SLOTS;
+    for (int i = 0; i < DXO_HOST_SLOTS; ++i)
+        if (ctx->slot_stream[i] == s) slot = i;
+    if (slot == DXO_HOST_SLOTS) {
+        if (ctx->scratch_stream_set && ctx->scratch_stream != s && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) {
+            (void)hipGetLastError();   // the earlier stream may have been destroyed by its owner: nothing left to wait for
+        }
+        ctx->scratch_stream = s;
+        ctx->scratch_stream_set = true;
+    }
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+            (void)hipFree(ctx->scratch[slot]);
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) return nullptr;
+        ctx->scratch_bytes[slot] = want;
+    }
+    return ctx->scratch[slot];
 }
 
 int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {

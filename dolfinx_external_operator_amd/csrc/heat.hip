@@ -103,6 +103,7 @@ int heat_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* con
 extern "C" int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, int mem, const double* T,
                         const double* sigma, double* q, double* dqdT, double* dqdsigma) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (gdim < 1 || gdim > 3) return dxo_fail(ctx, DXO_E_DIM, "dxo_heat: gdim must be 1, 2 or 3");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_heat: n < 0");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_heat: bad mem");

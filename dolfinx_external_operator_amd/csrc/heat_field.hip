@@ -104,6 +104,7 @@ int heat_field_chunk(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const*, vo
 extern "C" int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, const double* T_dofs, double* q,
                               double* dqdT, double* dqdsigma) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_heat_field: mesh is NULL");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_heat_field: bad mem");
     const int64_t nc = mesh->num_cells;

@@ -560,6 +560,7 @@ int isihara_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* 
 extern "C" int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, int mem, const double* F, double* dP,
                            double* P) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_isihara: params is NULL");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_isihara: n < 0");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_isihara: bad mem");
@@ -586,6 +587,7 @@ struct dxo_icnn : dxo_icnn_impl {};
 
 extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn** out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!w || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_create: NULL argument");
     *out = nullptr;
     if (w->n_hidden != NH) return dxo_fail(ctx, DXO_E_DIM, "dxo_icnn_create: n_hidden must be 64 (the reference's [64, 64, 64])");
@@ -674,6 +676,7 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
 
 extern "C" int dxo_icnn_destroy(dxo_ctx* ctx, dxo_icnn* m) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!m) return DXO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -684,6 +687,7 @@ extern "C" int dxo_icnn_destroy(dxo_ctx* ctx, dxo_icnn* m) {
 
 extern "C" int dxo_icnn_correction(dxo_ctx* ctx, const dxo_icnn* m, double* H_flat) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!m || !H_flat) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_correction: NULL argument");
     for (int k = 0; k < 4; ++k) H_flat[k] = m->f32.H[k];
     return DXO_OK;
@@ -692,6 +696,7 @@ extern "C" int dxo_icnn_correction(dxo_ctx* ctx, const dxo_icnn* m, double* H_fl
 extern "C" int dxo_icnn_eval(dxo_ctx* ctx, const dxo_icnn* m, int precision, int64_t n, int mem, const double* F,
                              double* dP, double* P) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!m) return dxo_fail(ctx, DXO_E_NULL, "dxo_icnn_eval: model is NULL");
     if (precision != 0 && precision != 1) return dxo_fail(ctx, DXO_E_OPTION, "dxo_icnn_eval: precision must be 0 (fp32 network) or 1 (fp64)");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_icnn_eval: n < 0");

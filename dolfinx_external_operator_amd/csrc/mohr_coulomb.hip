@@ -270,24 +270,7 @@ struct McLaunch {
     bool d_niter, d_yield, d_res, d_dl;
 };
 
-// ctx-owned scratch, one buffer per stream slot (3 host-pipeline slots + the device path)
-void* mc_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes) {
-    int slot = DXO_HOST_SLOTS;
-    for (int i = 0; i < DXO_HOST_SLOTS; ++i)
-        if (ctx->slot_stream[i] == s) slot = i;
-    if (ctx->scratch_bytes[slot] < bytes) {
-        if (ctx->scratch[slot]) {
-            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-            (void)hipFree(ctx->scratch[slot]);
-            ctx->scratch[slot] = nullptr;
-            ctx->scratch_bytes[slot] = 0;
-        }
-        const size_t want = bytes + bytes / 4 + 4096;
-        if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) return nullptr;
-        ctx->scratch_bytes[slot] = want;
-    }
-    return ctx->scratch[slot];
-}
+void* mc_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes) { return dxo_scratch(ctx, s, bytes); }
 
 int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, const double* sigma_n, double* C_tang,
               double* sigma, int32_t* niter, double* yielding, double* norm_res, double* dlambda, hipStream_t s) {
@@ -404,6 +387,7 @@ extern "C" int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t 
                                 const double* sigma_n, double* C_tang, double* sigma, int32_t* niter, double* yielding,
                                 double* norm_res, double* dlambda) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_mohr_coulomb: params is NULL");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mohr_coulomb: n < 0");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_mohr_coulomb: bad mem");
@@ -436,6 +420,7 @@ extern "C" int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t 
 extern "C" int dxo_mc_summary(dxo_ctx* ctx, int64_t n, const int32_t* niter, const double* yielding, const double* norm_res,
                               int nbins, int64_t* hist, double* max_yielding, double* max_norm_res, int64_t* nan_counts) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_summary: n < 0");
     if (nbins < 1 || nbins > MC_HIST_BINS) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_summary: nbins must be in [1, 1024]");
     if (!hist || (n > 0 && !niter)) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_summary: NULL array");

@@ -140,6 +140,7 @@ extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
 
 extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!d || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_create: NULL argument");
     *out = nullptr;
     if (d->gdim != 2 && d->gdim != 3) return dxo_fail(ctx, DXO_E_DIM, "dxo_mesh_create: gdim must be 2 or 3");
@@ -208,6 +209,7 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
 
 extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!m) return DXO_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -226,6 +228,7 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
 extern "C" int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* m, int kind, int bs, int mem, const double* u,
                                 const int32_t* cells, int64_t n_cells, double* out) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!m) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_operand: mesh is NULL");
     const int D = dxo_operand_value_size(m->gdim, bs, kind);
     if (D == DXO_E_OPTION) return dxo_fail(ctx, DXO_E_OPTION, "dxo_eval_operand: unknown operand kind");

@@ -50,6 +50,7 @@ void launch(dxo_ctx* ctx, int64_t n_tiles, const void* src, void* dst, hipStream
 extern "C" int dxo_stream_probe(dxo_ctx* ctx, int read_chunks, int write_chunks, int64_t n_tiles, const void* src,
                                 void* dst) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (n_tiles < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_stream_probe: n_tiles < 0");
     if (n_tiles > 0 && (!src || !dst)) return dxo_fail(ctx, DXO_E_NULL, "dxo_stream_probe: NULL buffer");
     if (((uintptr_t)src | (uintptr_t)dst) & 15u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_stream_probe: 16-byte alignment");

@@ -166,6 +166,7 @@ int field_chunk(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const* d_in, vo
 extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                                    const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!prm || !mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field: NULL params or mesh");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises_field: bad mem");
     const int64_t nc = mesh->num_cells;

@@ -350,6 +350,7 @@ int vm_host_rebuild(dxo_ctx* ctx, void* user, int64_t first, int64_t m) {
 extern "C" int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
                                      const double* sigma, const double* dp, double* C_tang) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_expand_tangent: params is NULL");
     if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_expand_tangent: d must be 4 or 6");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_expand_tangent: n < 0");
@@ -376,6 +377,7 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
                              const double* deps, const double* sigma_n, const double* p, double* C_tang,
                              double* sigma, double* dp) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (!prm) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises: params is NULL");
     if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_von_mises: d must be 4 or 6");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises: n < 0");
@@ -402,7 +404,13 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
         L.h_dp = dp;
         L.h_C_tang = C_tang;
         std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
-        return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+        // smaller chunks than the copy mode: the host half of a chunk runs on the calling thread between two enqueues,
+        // so the un-overlapped tail of the call is the rebuild of the last DXO_HOST_SLOTS chunks
+        const int64_t saved_chunk = ctx->host_chunk_points;
+        if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
+        const int rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+        ctx->host_chunk_points = saved_chunk;
+        return rc;
     }
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
     return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void vm_commit(int64_t n_p, int64_t n_s,
 extern "C" int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, const double* dp, double* sigma_n,
                                    const double* sigma) {
     if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
     if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_commit_state: d must be 4 or 6");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_commit_state: n < 0");
     if (n > 0 && (!p || !dp || !sigma_n || !sigma)) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_commit_state: NULL array");

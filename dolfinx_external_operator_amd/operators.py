@@ -106,7 +106,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = False) -> Callable:
+                   reuse_outputs: bool = False, host_tangent: str = "copy") -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -116,6 +116,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     (outputs are then CUDA tensors on the same device, launched on torch's current stream).
     Results are arrays of their own, as in the reference (page-locked blocks recycled only after the caller has
     dropped them, see _Outputs); reuse_outputs=True opts into ONE set of buffers that the next call overwrites.
+    host_tangent (NumPy operands only): "copy" brings C_tang back over PCIe (344 B/point at d = 6, bit-identical to a
+    device call); "rebuild" moves only (sigma, dp) (56 B/point) and fills the C_tang array on the host from them
+    while later chunks are in flight (ctx option vm_host_tangent, include/dxo.h) — the tangent then agrees with the
+    device tangent to rounding and the reference's 0/0 point at f_el == 0 exactly comes out as C_elas.
     `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors carved from the context's
     placement-calibrated output arena (Context.output_arena); pass them as `out=` to the device call.
     """
@@ -123,6 +127,8 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         E_tangent = E / 100.0                      # :186
         H = E * E_tangent / (E - E_tangent)        # :187
     prm = VmParams(float(E), float(nu), float(sigma_0), float(H))
+    if host_tangent not in ("copy", "rebuild"):
+        raise ValueError('host_tangent must be "copy" or "rebuild"')
     holder = {"ctx": ctx, "out": None}
 
     def _ctx() -> Context:
@@ -162,7 +168,15 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         C_tang_ = out.get("C_tang", n * d * d)
         sigma_ = out.get("sigma", n * d)
         dp_ = out.get("dp", n)
-        c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
+        if host_tangent == "rebuild":
+            with c._lock:   # the option is per context: set, call, restore without another thread's call in between
+                c.set_option("vm_host_tangent", 1)
+                try:
+                    c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
+                finally:
+                    c.set_option("vm_host_tangent", 0)
+        else:
+            c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
         return C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1)   # :352
 
     def sigma_external(derivatives):

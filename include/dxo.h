@@ -18,9 +18,10 @@
  *   - the library never frees or keeps caller memory. Scratch is owned by the ctx.
  *   - non-convergence of a local Newton solve is NOT an error (the reference only reports
  *     niter / norm_res, demo_plasticity_mohr_coulomb.py:584-591).
- *   - one ctx per (process, device). Calls on one ctx are serialised by the caller
- *     (the reference calls from a single Python thread inside the SNES callback,
- *     petsc/petsc.py:60).
+ *   - one ctx per (process, device). Every entry point takes the ctx's mutex, so calls on one ctx
+ *     from several host threads are serialised by the library (the reference calls from a single
+ *     Python thread inside the SNES callback, petsc/petsc.py:60); use one ctx per thread for
+ *     concurrency.
  */
 #ifndef DXO_H
 #define DXO_H
@@ -107,7 +108,12 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * (0 VALU, 1 MFMA 8 waves per workgroup, 2 MFMA 4 waves), "host_small_bytes" (host batches whose inputs + outputs
  * fit this many bytes, default 1 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
  * the chunked pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase
- * dxo_timing is recorded on it only with "timing" = 1). */
+ * dxo_timing is recorded on it only with "timing" = 1), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
+ * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
+ * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
+ * dxo_vm_expand_tangent, agrees with the device tangent to rounding, the reference's 0/0 point at f_el == 0 exactly
+ * comes out as C_elas), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^16), and the "placement_*" options
+ * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
 int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);
@@ -115,6 +121,31 @@ int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);
  * (the memory belongs to the process; a buffer may outlive the context it was first used with). */
 int dxo_host_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_host_free(dxo_ctx* ctx, void* ptr);
+
+/* ---- output arena: device memory for OUTPUT arrays, placed by calibration -------------------------------------
+ * The kernels are HBM-bound and mostly stores (von Mises d = 6: 344 of 448 B per point). On MI355X the rate of a
+ * multi-GB streaming-write sweep is bimodal (about 5.9 vs 6.9 TB/s pure stores) and the class belongs to the
+ * buffer's VIRTUAL address range (profiles/r02_place_exp*.txt). dxo_output_alloc creates the
+ * physical memory once and searches an address reservation for a fast range (hipMemMap at candidate ranges, one
+ * timed write sweep each, keep the first above option "placement_good_GBps" = 6500, else the best); the block is
+ * owned by the ctx (freed by dxo_output_free or dxo_ctx_destroy). Meant for the persistent coefficient buffers a
+ * solver allocates once. Options: "placement_mode" 1 = virtual-range search (default), 2 = several ordinary
+ * hipMalloc allocations of which the fastest is kept (use where a collective library must IPC-share the buffer),
+ * 0 = plain hipMalloc; "placement_candidates" (default 16, at most 32); "placement_min_bytes" (default 1 GiB:
+ * smaller blocks are plain hipMalloc, a working set that small lives in the caches). The calibration WRITES the
+ * block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
+#define DXO_PLACEMENT_MAX 32
+typedef struct dxo_placement_info {
+    int32_t mode;                           /* how the block was obtained: 0, 1 or 2 as above                      */
+    int32_t candidates;                     /* ranges / allocations timed                                          */
+    int32_t chosen;                         /* index of the one kept (-1: no calibration)                          */
+    int32_t _pad;
+    double probe_GBps[DXO_PLACEMENT_MAX];   /* streaming-write rate of each candidate                              */
+    double calibration_ms;                  /* wall time of the whole call                                         */
+} dxo_placement_info;
+int dxo_output_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
+int dxo_output_free(dxo_ctx* ctx, void* ptr);
+int dxo_output_info(dxo_ctx* ctx, const void* ptr, dxo_placement_info* info);
 
 /* ---- von Mises radial return + consistent tangent ---------------------------------------
  * Replaces return_mapping/_kernel + C_tang_impl, demo_plasticity_von_mises.py:298-352.
@@ -309,7 +340,9 @@ int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, dou
  * mixed: one call per subspace with its offset / n_pts / val_size (:180-190) and the operator's comp_size (:161).
  * Where several entries target the same dof the LAST one (largest source position) wins, as in NumPy's sequential
  * fancy assignment, so the result is the reference's array, not a race. flat_dofs entries must lie in
- * [0, coeff_size). */
+ * [0, coeff_size): out-of-range entries are skipped on the device and the call returns DXO_E_SIZE (the NumPy
+ * assigner raises IndexError, :287); the check costs one stream synchronisation per call, option
+ * "assign_validate" = 0 skips it (entries are still never written out of bounds). */
 typedef struct dxo_assign_desc {
     int64_t n_cells;
     int32_t n_pts, val_size, offset, n_points_total, comp_size, _pad;

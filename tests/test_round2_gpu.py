@@ -1,0 +1,285 @@
+"""Round-2 additions on the GPU: output arena, host tangent rebuild, fresh-output semantics, zero-copy (device tensor)
+paths of every factory, dofmap validation in dxo_assign, serialised entry points."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, mc_compare, mc_tracing_inputs, vm_inputs
+from dolfinx_external_operator_amd import (
+    MEM_DEVICE,
+    MEM_HOST,
+    AssignDesc,
+    VmParams,
+    make_heat,
+    make_icnn,
+    make_isihara,
+    make_mohr_coulomb,
+    make_von_mises,
+)
+
+pytestmark = pytest.mark.gpu
+
+E, NU, SIGMA_0 = 70e3, 0.3, 250.0
+H = E * (E / 100.0) / (E - E / 100.0)
+PRM = VmParams(E, NU, SIGMA_0, H)
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------- output arena
+def test_output_arena_small_block_is_plain_and_usable(ctx):
+    import torch
+
+    C, s, dp = ctx.output_tensors((4096 * 36, 4096 * 6, 4096))
+    info = C.dxo_block.info
+    assert info["mode"] == "hipMalloc" and info["chosen"] == -1            # below placement_min_bytes: no calibration
+    assert C.is_cuda and C.dtype == torch.float64 and C.numel() == 4096 * 36
+    assert C.data_ptr() % 256 == 0 and s.data_ptr() % 256 == 0 and dp.data_ptr() % 256 == 0
+    assert s.data_ptr() >= C.data_ptr() + C.numel() * 8 and dp.data_ptr() >= s.data_ptr() + s.numel() * 8
+    C.fill_(1.5)
+    s.fill_(2.5)
+    assert float(C.sum()) == 1.5 * C.numel() and float(s[-1]) == 2.5
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_output_arena_calibrates_and_kernel_results_are_unchanged(ctx, oracle, mode):
+    """A 1.1 GB block goes through the calibration (virtual-range search, or hipMalloc candidates); the kernel writing
+    into it gives the oracle's numbers; the record names the chosen candidate."""
+    import torch
+
+    n, d = 3_200_000, 6          # 344 B/point -> 1.10 GB
+    old = {k: ctx.get_option(k) for k in ("placement_mode", "placement_candidates")}
+    ctx.set_option("placement_mode", mode)
+    ctx.set_option("placement_candidates", 4)
+    try:
+        C, s, dp = ctx.output_tensors((n * d * d, n * d, n))
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+    info = C.dxo_block.info
+    assert info["mode"] == ("virtual_range_search" if mode == 1 else "hipMalloc_candidates"), info
+    assert 1 <= info["candidates"] <= 4 and 0 <= info["chosen"] < info["candidates"]
+    assert all(b > 1000.0 for b in info["probe_GBps"]), info             # every candidate was really timed (GB/s)
+    assert info["probe_GBps"][info["chosen"]] == max(info["probe_GBps"]) or info["probe_GBps"][info["chosen"]] >= 6500
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    deps = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 3e-3, generator=g)
+    sigma_n = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 100.0, generator=g)
+    p = torch.empty(n, dtype=torch.float64, device="cuda:0").normal_(0, 1e-3, generator=g).abs_()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C.data_ptr(), s.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    idx = torch.arange(0, n, 997, device="cuda:0")                          # strided sample incl. point 0
+    idx = torch.cat([idx, torch.tensor([n - 1], device="cuda:0")])
+    Co, so, dpo = oracle.von_mises(deps[idx].cpu().numpy(), sigma_n[idx].cpu().numpy(), p[idx].cpu().numpy())
+    assert_close_scaled(C.view(n, d * d)[idx].cpu().numpy(), Co, 1e-13, "C_tang in the arena")
+    assert_close_scaled(s.view(n, d)[idx].cpu().numpy(), so, 1e-13, "sigma in the arena")
+    assert_close_scaled(dp[idx].cpu().numpy(), dpo, 1e-13, "dp in the arena")
+    ptr = C.dxo_block.ptr
+    del C, s, dp
+    import gc
+
+    gc.collect()
+    with pytest.raises(ValueError):       # the block was returned to the library when its last tensor went away
+        ctx.output_info(ptr)
+
+
+def test_factory_arena_outputs(ctx, oracle):
+    import torch
+
+    nc, nq, d = 500, 8, 6
+    deps, sigma_n, p = vm_inputs(nc * nq, d, seed=71)
+    ext = make_von_mises(_dev(sigma_n), _dev(p), ctx=ctx)
+    out = ext.arena(nc * nq, d)
+    C, s, dp = ext((1,))(_dev(deps.reshape(nc, nq, d)), out=out)
+    assert C.data_ptr() == out[0].data_ptr() and dp.data_ptr() == out[2].data_ptr()
+    torch.cuda.synchronize()
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C.cpu().numpy(), Co, 1e-13, "C_tang")
+    assert_close_scaled(dp.cpu().numpy(), dpo, 1e-13, "dp")
+
+
+# ------------------------------------------------------------------------------------------------- host tangent rebuild
+@pytest.mark.parametrize("d", [4, 6])
+@pytest.mark.parametrize("n", [1, 63, 1000, 300_001])
+def test_host_tangent_rebuild_matches_the_device_tangent(ctx, d, n):
+    """vm_host_tangent = 1: only (sigma, dp) cross PCIe and C_tang is rebuilt by the host threads. sigma and dp are
+    bit-identical to the copy mode; the tangent agrees to rounding (1e-13 of its scale), elastic points exactly."""
+    deps, sigma_n, p = vm_inputs(n, d, seed=100 + n % 97 + d)
+    outs = {}
+    old_chunk = ctx.get_option("host_chunk_points")
+    ctx.set_option("host_chunk_points", 65536)     # several chunks at the largest size: the hook runs per chunk
+    try:
+        for mode in (0, 1):
+            ctx.set_option("vm_host_tangent", mode)
+            C, s, dp = np.full(n * d * d + 8, -7.0), np.empty(n * d), np.empty(n)
+            ctx.von_mises(PRM, d, n, MEM_HOST, deps, sigma_n, p, C, s, dp)
+            assert np.all(C[n * d * d:] == -7.0)                              # guard words behind the array
+            outs[mode] = (C[: n * d * d].copy(), s, dp)
+    finally:
+        ctx.set_option("vm_host_tangent", 0)
+        ctx.set_option("host_chunk_points", old_chunk)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert_close_scaled(outs[1][0], outs[0][0], 1e-13, "host-rebuilt C_tang")
+    el = outs[0][2] == 0.0
+    C0, C1 = outs[0][0].reshape(n, -1), outs[1][0].reshape(n, -1)
+    assert np.array_equal(C0[el], C1[el])                                      # elastic points: C_elas, bit for bit
+
+
+def test_host_tangent_rebuild_through_the_factory(ctx, oracle):
+    nc, nq, d = 400, 8, 6
+    deps, sigma_n, p = vm_inputs(nc * nq, d, seed=9)
+    ext = make_von_mises(sigma_n, p, ctx=ctx, host_tangent="rebuild")
+    C, s, dp = ext((1,))(deps.reshape(nc, nq, d))
+    assert ctx.get_option("vm_host_tangent") == 0                              # the option does not leak out of the call
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(C, Co, 1e-13, "C_tang")
+    assert_close_scaled(s, so, 1e-13, "sigma")
+    assert_close_scaled(dp, dpo, 1e-13, "dp")
+
+
+# ------------------------------------------------------------------------------------------------- fresh outputs
+def test_results_of_successive_calls_do_not_alias(ctx):
+    """Reference semantics (demo_plasticity_von_mises.py:352: fresh arrays): a = f(x0); b = f(x1); b - a is the
+    difference, not zero. Memory is recycled only after the caller has dropped every view."""
+    nc, nq, d = 100, 4, 4
+    deps, sigma_n, p = vm_inputs(nc * nq, d, seed=3)
+    ext = make_von_mises(sigma_n, p, ctx=ctx)
+    f = ext((1,))
+    a = f(deps.reshape(nc, nq, d))
+    keep = a[1].copy()
+    b = f(2.0 * deps.reshape(nc, nq, d))
+    assert a[1].ctypes.data != b[1].ctypes.data
+    assert np.array_equal(a[1], keep) and not np.array_equal(a[1], b[1])
+    addr = b[1].ctypes.data
+    view = b[1].reshape(-1, d)[5:7]            # a view keeps the block alive
+    del a, b
+    c1 = f(deps.reshape(nc, nq, d))
+    assert addr not in (x.ctypes.data for x in c1)
+    del view, c1
+    import gc
+
+    gc.collect()
+    c2 = f(deps.reshape(nc, nq, d))            # now the pool may hand the same page-locked blocks out again
+    assert np.array_equal(c2[1], keep)
+
+
+def test_reuse_outputs_opt_in_never_frees_under_a_view(ctx):
+    d = 4
+    deps, sigma_n, p = vm_inputs(256, d, seed=4)
+    state = {"s": sigma_n, "p": p}
+    ext = make_von_mises(lambda: state["s"], lambda: state["p"], ctx=ctx, reuse_outputs=True)
+    a = ext((1,))(deps.reshape(32, 8, d))
+    keep = a[0].copy()
+    b = ext((1,))(deps.reshape(32, 8, d))
+    assert a[0].ctypes.data == b[0].ctypes.data                # opt-in: the same buffers, overwritten
+    deps2, state["s"], state["p"] = vm_inputs(512, d, seed=5)
+    c = ext((1,))(deps2.reshape(64, 8, d))                      # batch size changed: old buffers are retired, not freed
+    assert np.array_equal(a[0], keep) and c[0].size == 512 * d * d
+
+
+# ------------------------------------------------------------------------------------------------- zero-copy factories
+def test_heat_device_tensors(ctx, golden):
+    import torch
+
+    g = golden("heat_c1.npz")
+    T, sig = g["T"], g["sigma"]
+    q_ext = make_heat(ctx=ctx)
+    for multi, key in (((0, 0), "q"), ((1, 0), "dqdT"), ((0, 1), "dqdsigma")):
+        out = q_ext(multi)(_dev(T), _dev(sig))
+        assert out.is_cuda and out.dtype == torch.float64
+        assert_close_scaled(out.cpu().numpy(), g[key], 1e-15, key)
+    with pytest.raises(TypeError):
+        q_ext((0, 0))(_dev(T), sig)        # mixed host / device operands
+
+
+def test_mohr_coulomb_device_tensors(ctx, oracle):
+    n = 6000
+    deps, sigma_n = mc_tracing_inputs(oracle, n, seed=21)
+    seen = {}
+    ext = make_mohr_coulomb(_dev(sigma_n), ctx=ctx, on_summary=seen.update)
+    C, s = ext((1,))(_dev(deps))
+    niter, yielding, norm_res, dlambda = ext.last_state
+    assert C.is_cuda and niter.is_cuda and niter.dtype.is_floating_point is False
+    ref = oracle.mohr_coulomb(deps, sigma_n, nthreads=8)
+    got = (C.cpu().numpy().reshape(n, 4, 4), s.cpu().numpy().reshape(n, 4), niter.cpu().numpy(), yielding.cpu().numpy(),
+           norm_res.cpu().numpy(), dlambda.cpu().numpy())
+    mc_compare(got, ref, "device tensors", sigma_n)
+    it_u, it_c = np.unique(ref[2], return_counts=True)          # the summary the reference prints (:584-591), reduced on the GPU
+    assert np.array_equal(seen["unique_iters"], it_u) and np.array_equal(seen["counts"], it_c)
+    assert abs(seen["max_yielding"] - np.max(ref[3])) <= 1e-12 * max(1.0, abs(np.max(ref[3])))
+    # without diagnostics nothing but (C_tang, sigma) is allocated
+    ext2 = make_mohr_coulomb(_dev(sigma_n), ctx=ctx, diagnostics=False)
+    C2, s2 = ext2((1,))(_dev(deps))
+    assert ext2.last_state == (None, None, None, None)
+    assert np.array_equal(C2.cpu().numpy(), C.cpu().numpy())
+
+
+def test_icnn_and_isihara_device_tensors(ctx, golden):
+    g = golden("icnn_isihara.npz")
+    w = golden("icnn_isihara_weights.npz")
+    F = np.asarray(g["F"], dtype=np.float64).reshape(-1, 2, 2)
+    ext = make_icnn({k: w[k] for k in w.files}, ctx=ctx)
+    dP_h, P_h = ext((1,))(F)
+    dP_d, P_d = ext((1,))(_dev(F))
+    assert dP_d.is_cuda
+    assert np.array_equal(dP_d.cpu().numpy(), dP_h) and np.array_equal(P_d.cpu().numpy(), P_h)   # same kernel, same bits
+    isi = make_isihara(ctx=ctx)
+    a_h = isi((1,))(F)
+    a_d = isi((1,))(_dev(F))
+    assert np.array_equal(a_d[0].cpu().numpy(), a_h[0]) and np.array_equal(a_d[1].cpu().numpy(), a_h[1])
+
+
+# ------------------------------------------------------------------------------------------------- dxo_assign validation
+def test_assign_rejects_out_of_range_dofs(ctx):
+    import torch
+
+    n_cells, n_pts, vs, coeff_size = 40, 3, 2, 100
+    rng = np.random.default_rng(0)
+    dofs = rng.integers(0, coeff_size, n_cells * n_pts * vs).astype(np.int32)
+    vals = rng.normal(size=n_cells * n_pts * vs)
+    desc = AssignDesc(n_cells, n_pts, vs, 0, n_pts, vs, 0)
+    coeff = torch.zeros(coeff_size + 16, dtype=torch.float64, device="cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_dofs, d_vals = _dev(dofs), _dev(vals)       # keep the tensors alive: only raw pointers cross the C ABI
+    ctx.assign(desc, d_dofs.data_ptr(), d_vals.data_ptr(), coeff.data_ptr(), coeff_size)   # in range: fine
+    bad = dofs.copy()
+    bad[7], bad[100] = coeff_size + 3, -2
+    d_bad = _dev(bad)
+    coeff2 = torch.zeros(coeff_size + 16, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ValueError, match="2 flat_dofs entries outside"):
+        ctx.assign(desc, d_bad.data_ptr(), d_vals.data_ptr(), coeff2.data_ptr(), coeff_size)
+    torch.cuda.synchronize()
+    assert float(coeff2[coeff_size:].abs().sum()) == 0.0        # nothing was written past the coefficient
+    expect = np.zeros(coeff_size)
+    ok = (bad >= 0) & (bad < coeff_size)
+    expect[bad[ok]] = vals[ok]                                   # NumPy: last writer wins
+    assert np.array_equal(coeff2[:coeff_size].cpu().numpy(), expect)
+
+
+# ------------------------------------------------------------------------------------------------- serialised entry points
+def test_two_threads_on_one_context(ctx, oracle):
+    """ctypes releases the GIL; every C entry point takes the context's mutex, so two Python threads sharing the
+    default context get correct (serialised) results instead of racing on slot buffers and scratch."""
+    d = 4
+    jobs = []
+    for seed in (1, 2):
+        deps, sigma_n, p = vm_inputs(40_000, d, seed=seed)
+        jobs.append((deps, sigma_n, p, make_von_mises(sigma_n, p, ctx=ctx)))
+    res = [None, None]
+
+    def work(k):
+        for _ in range(5):
+            res[k] = jobs[k][3]((1,))(jobs[k][0].reshape(-1, 8, d))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        Co, so, dpo = oracle.von_mises(*jobs[k][:3])
+        assert_close_scaled(res[k][0], Co, 1e-13, f"thread {k} C_tang")
+        assert_close_scaled(res[k][2], dpo, 1e-13, f"thread {k} dp")
