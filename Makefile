@@ -17,7 +17,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/dxo.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -lpthread
 
 demo: $(LIB) examples/c_abi_demo.c
 	gcc -O2 -Wall -Iinclude examples/c_abi_demo.c -o examples/c_abi_demo -Ldolfinx_external_operator_amd -ldxo_hip \

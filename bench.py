@@ -208,7 +208,7 @@ def main():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
-    ap.add_argument("--placement", type=int, default=16,
+    ap.add_argument("--placement", type=int, default=12,
                     help="candidates of the LIBRARY's output-arena calibration (ctx option placement_candidates; "
                          "0/1 = plain hipMalloc). The bench itself selects nothing. See DESIGN.md 3.1.")
     args = ap.parse_args()
@@ -276,13 +276,12 @@ def main():
     seed = 1 if world == 1 else 100 + rank
     in_slab, deps, sigma_n, p = synth_inputs(torch, n, d, seed, device)
     # Outputs live in the library's OUTPUT ARENA (dxo_output_alloc, csrc/arena.hip): on this chip the rate of a multi-GB
-    # streaming-write sweep is bimodal and the class belongs to the buffer's VIRTUAL address range, so
-    # the library creates the physical memory once and searches an address reservation for a fast range. This is what
-    # any user of `Context.output_tensors` / `make_von_mises(...).arena(n, d)` gets; the bench does no selection of
-    # its own any more. `roofline.achieved_plain_hipMalloc` is the same kernel writing into a plain torch.empty slab.
+    # streaming-write sweep depends on the allocation it goes to, so the library makes a few ordinary
+    # allocations side by side, times a write sweep on each and keeps the fastest. This is what any user of
+    # `Context.output_tensors` / `make_von_mises(...).arena(n, d)` gets; the bench does no selection of its own any
+    # more. `roofline.achieved_plain_hipMalloc` is the same kernel writing into a plain torch.empty slab.
     # With the gather on, every rank holds the FULL-length outputs and its kernel writes its cell block straight
-    # into them at [rank*n, (rank+1)*n): the all-gather is RCCL's in-place form and nothing is copied locally; those
-    # buffers must be IPC-shareable by RCCL, so the arena then uses ordinary hipMalloc candidates (placement_mode 2).
+    # into them at [rank*n, (rank+1)*n): the all-gather is RCCL's in-place form and nothing is copied locally.
     gather_on = gather and dist_on
     blocks = world if gather_on else 1
     own = rank if gather_on else 0
@@ -292,7 +291,7 @@ def main():
         ctx.set_option("placement_mode", 0)
     else:
         ctx.set_option("placement_candidates", min(args.placement, 3) if gather_on else args.placement)
-        ctx.set_option("placement_mode", 2 if gather_on else 1)
+        ctx.set_option("placement_mode", 2)
     C_full, sigma_full, dp_full = ctx.output_tensors((N_full * d * d, N_full * d, N_full))
     placement = dict(C_full.dxo_block.info)
     C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]

@@ -18,7 +18,7 @@ INCLUDE = ROOT / "include"
 LIB = PKG / "libdxo_hip.so"
 ARCH = "gfx950"
 
-HIP_SOURCES = ["dxo_ctx.hip", "von_mises.hip", "heat.hip", "probe.hip", "mohr_coulomb.hip", "icnn.hip", "operand.hip", "vm_field.hip", "assign.hip", "heat_field.hip", "adjoint.hip", "arena.hip"]
+HIP_SOURCES = ["dxo_ctx.hip", "von_mises.hip", "heat.hip", "probe.hip", "mohr_coulomb.hip", "icnn.hip", "operand.hip", "vm_field.hip", "assign.hip", "heat_field.hip", "adjoint.hip", "arena.hip", "mgpu.hip"]
 
 
 def _hipcc() -> str:
@@ -70,7 +70,7 @@ def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
         if verbose and out.strip():
             print(out)
     tmp = LIB.with_suffix(".so.tmp")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs), "-ldl", "-lpthread"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed: {' '.join(cmd)}\n{res.stdout}")

@@ -116,6 +116,18 @@ _SIGNATURES = {
     "dxo_tangent_diagonal": (C.c_int, [_P, _P, _P, _P]),
     "dxo_heat_field": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),
+    "dxo_mgpu_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "dxo_mgpu_unique_id": (C.c_int, [_P]),
+    "dxo_mgpu_create_rank": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "dxo_mgpu_destroy": (C.c_int, [_P]),
+    "dxo_mgpu_size": (C.c_int, [_P]),
+    "dxo_mgpu_local_count": (C.c_int, [_P]),
+    "dxo_mgpu_rank": (C.c_int, [_P, C.c_int]),
+    "dxo_mgpu_ctx": (_P, [_P, C.c_int]),
+    "dxo_mgpu_last_error": (C.c_char_p, [_P]),
+    "dxo_mgpu_synchronize": (C.c_int, [_P]),
+    "dxo_mgpu_all_gather": (C.c_int, [_P, C.POINTER(_P), C.c_int64]),
+    "dxo_mgpu_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [C.POINTER(_P)] * 6),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
@@ -454,7 +466,7 @@ class Context:
     def output_info(self, ptr: int) -> dict:
         info = PlacementInfo()
         self.check(self.lib.dxo_output_info(self._h, _P(ptr), C.byref(info)), "dxo_output_info")
-        return {"mode": {0: "hipMalloc", 1: "virtual_range_search", 2: "hipMalloc_candidates"}[info.mode],
+        return {"mode": {0: "hipMalloc", 2: "hipMalloc_candidates"}[info.mode],
                 "candidates": info.candidates, "chosen": info.chosen,
                 "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
                 "calibration_ms": info.calibration_ms}
@@ -526,6 +538,110 @@ class _CudaArrayView:
     def __init__(self, owner, ptr: int, n: int, typestr: str):
         self._owner = owner
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+
+GATHER_NONE, GATHER_FULL, GATHER_COMPACT = 0, 1, 2
+MGPU_ID_BYTES = 128
+
+
+class MultiGpu:
+    """dxo_mgpu: cell-block sharding with the RCCL all-gather inside the library (include/dxo.h "multi-GPU").
+
+    MultiGpu(devices=[0, 1, ...])                       one process driving several GPUs (ncclCommInitAll)
+    MultiGpu.from_rank(ctx, unique_id, rank, world)     one process per GPU; `unique_id = MultiGpu.unique_id()` on
+                                                        rank 0, broadcast by the caller (128 bytes)
+    Pointer-list arguments take one device pointer (int or tensor with data_ptr()) per LOCAL device."""
+
+    def __init__(self, devices=None, n_dev: int | None = None, _handle=None, _ctx=None):
+        self.lib = load_library()
+        self._keep_ctx = _ctx
+        if _handle is not None:
+            self._h = _handle
+            return
+        if devices is None:
+            devices = list(range(int(n_dev or 1)))
+        arr = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = _P()
+        rc = self.lib.dxo_mgpu_create(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise DxoError(f"dxo_mgpu_create({list(devices)}) failed with {ERRORS.get(rc, rc)}: needs that many MI355X and "
+                           "RCCL (librccl.so.1); there is no CPU fallback")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(MGPU_ID_BYTES)
+        rc = load_library().dxo_mgpu_unique_id(buf)
+        if rc != 0:
+            raise DxoError(f"dxo_mgpu_unique_id failed with {ERRORS.get(rc, rc)}")
+        return buf.raw
+
+    @classmethod
+    def from_rank(cls, ctx: Context, unique_id: bytes, rank: int, world: int) -> "MultiGpu":
+        if len(unique_id) != MGPU_ID_BYTES:
+            raise ValueError(f"unique id must be {MGPU_ID_BYTES} bytes")
+        h = _P()
+        buf = C.create_string_buffer(bytes(unique_id), MGPU_ID_BYTES)
+        ctx.check(ctx.lib.dxo_mgpu_create_rank(ctx._h, buf, int(rank), int(world), C.byref(h)), "dxo_mgpu_create_rank")
+        return cls(_handle=h, _ctx=ctx)
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc == 0:
+            return
+        msg = self.lib.dxo_mgpu_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc < 0:
+            raise ValueError(f"{what}: {ERRORS.get(rc, rc)}: {msg}")
+        raise DxoError(f"{what}: error {rc}: {msg}")
+
+    @property
+    def world(self) -> int:
+        return self.lib.dxo_mgpu_size(self._h)
+
+    @property
+    def local_count(self) -> int:
+        return self.lib.dxo_mgpu_local_count(self._h)
+
+    def rank(self, i: int = 0) -> int:
+        return self.lib.dxo_mgpu_rank(self._h, int(i))
+
+    def ctx_handle(self, i: int = 0) -> int:
+        return self.lib.dxo_mgpu_ctx(self._h, int(i))
+
+    def set_stream(self, i: int, stream_handle) -> None:
+        """Launch stream of local device i (e.g. torch.cuda.current_stream(dev).cuda_stream)."""
+        rc = self.lib.dxo_ctx_set_stream(_P(self.ctx_handle(i)), _P(stream_handle))
+        self._check(rc, "dxo_ctx_set_stream")
+
+    @staticmethod
+    def _ptrs(seq):
+        vals = [(x.data_ptr() if hasattr(x, "data_ptr") else x) for x in seq]
+        return (_P * len(vals))(*[_P(v) for v in vals])
+
+    def von_mises(self, prm: VmParams, d: int, n_per_rank: int, gather: int, deps, sigma_n, p, C_tang, sigma, dp) -> None:
+        args = [self._ptrs(a) for a in (deps, sigma_n, p, C_tang, sigma, dp)]
+        for a in args:
+            if len(a) != self.local_count:
+                raise ValueError(f"every pointer list needs {self.local_count} entries (one per local device)")
+        self._check(self.lib.dxo_mgpu_von_mises(self._h, C.byref(prm), int(d), int(n_per_rank), int(gather), *args), "dxo_mgpu_von_mises")
+
+    def all_gather(self, bufs, count_per_rank: int) -> None:
+        a = self._ptrs(bufs)
+        self._check(self.lib.dxo_mgpu_all_gather(self._h, a, int(count_per_rank)), "dxo_mgpu_all_gather")
+
+    def synchronize(self) -> None:
+        self._check(self.lib.dxo_mgpu_synchronize(self._h), "dxo_mgpu_synchronize")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.dxo_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_ctx: dict[int, Context] = {}

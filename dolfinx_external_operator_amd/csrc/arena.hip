@@ -1,22 +1,29 @@
 // arena.hip — placement-calibrated device memory for OUTPUT arrays (dxo_output_alloc / dxo_output_free).
 //
 // Why: the pointwise kernels are HBM-bound and ~77 % of the von Mises traffic is stores. On MI355X the rate of a
-// multi-GB streaming-write sweep is bimodal (about 5.9 vs 6.9 TB/s for pure stores, 5.1-5.4 vs 6.2 TB/s for the
-// 13 : 43 von Mises mix) and the class is a property of the buffer's VIRTUAL ADDRESS RANGE: the same physical
-// chunks are slow when mapped at one range and fast at another, a fast range stays fast for other physical memory
-// (swap / hybrid tests of scripts/exp/place_exp7.hip; physical chunk choice, XCD<->address affinity, row order, grid
-// size, chunk size and second mappings were each ruled out by place_exp2..6; profiles/r02_place_exp*.txt). The range
-// is something the library CAN choose: physical memory is created once (hipMemCreate), then mapped at candidate
-// ranges of one large address reservation (hipMemMap / hipMemSetAccess — a mapping costs milliseconds and no
-// memory; the candidates are aliases of the same block and stay mapped side by side until the choice is made);
-// each candidate is timed with a streaming-write sweep and the first range above "placement_good_GBps" (else the
-// best one) is kept, the others are unmapped. A solver allocates its persistent coefficient buffers once, so this
-// is a set-up cost.
+// multi-GB streaming-write sweep depends on WHICH allocation it goes to: about 5.6-6.0 TB/s ("slow"), 6.4-6.5
+// ("medium") or 6.9-7.1 TB/s ("fast") for pure stores, 5.1-5.4 / 5.65 / 6.2-6.3 TB/s for the 13 : 43 von Mises mix;
+// the class is stable for the life of the allocation and its share differs from box to box (0 of 12 ... 5 of 8 fast).
+// What round 2's experiments established (scripts/exp/place_exp*.hip, profiles/r02_place_exp*.txt):
+// the class is attached to the buffer's VIRTUAL range, not to its physical memory (the same physical chunks are
+// slow mapped at one range and fast at another, and a fast range stays fast for other chunks: swap / hybrid tests
+// of place_exp7); XCD<->address affinity, row order inside a tile, grid size, chunk / fragment size, VA alignment
+// and second mappings do not change it; address-translation miss counts are identical for a fast and a slow range
+// and the memory controller sees LESS write back-pressure on the slow one (profiles/r02_place_pmc.txt), so the
+// throttle sits upstream of the memory controller; one physical block remapped at range after range lands in ONE
+// class every time (place_exp4 b, place_exp5, place_exp9 S2), while allocations that exist SIDE BY SIDE differ.
+// Hence the method that works in practice: make several ordinary allocations side by side, time a streaming-write
+// sweep on each, keep the first one above "placement_good_GBps" (else the fastest) and free the rest. A solver
+// allocates its persistent coefficient buffers once, so this is a set-up cost (~10 ms per candidate at 3.4 GB).
 //
-// Modes (option "placement_mode"): 1 = virtual-range search as above (default); 2 = several hipMalloc allocations,
-// keep the fastest, free the rest (ordinary allocations: what round 1's bench did by hand; used where a collective
-// library must be able to IPC-share the buffer); 0 = plain hipMalloc. Blocks below "placement_min_bytes" (1 GiB) are
-// plain hipMalloc: a working set that small lives in the 256 MB Infinity Cache / L2 and has no placement class.
+// Tried and dropped: ONE physical block (hipMemCreate) remapped over candidate ranges of an address reservation — no
+// extra memory during the search, but every range comes out in the same class (5.8-6.2 TB/s in two bench runs,
+// 6.8 in place_exp9 S2), keeping the ranges mapped side by side as aliases made all of them slower (4.9-5.1 TB/s),
+// and one remap sequence ended in a GPU memory-access fault on this ROCm build (profiles/r02_place_exp9.txt).
+//
+// Option "placement_mode": 2 = hipMalloc candidates as above (default), 0 = plain hipMalloc. Blocks below
+// "placement_min_bytes" (1 GiB) are plain hipMalloc: a working set that small lives in the 256 MB Infinity Cache /
+// L2 and has no placement class.
 #include <chrono>
 
 #include "dxo_common.h"
@@ -50,75 +57,7 @@ double probe_range(dxo_ctx* c, void* p, size_t bytes, hipStream_t s) {
     return (double)n_tiles * 16384.0 * launches / (ms * 1e-3) / 1e9;
 }
 
-bool vmm_map(hipMemGenericAllocationHandle_t handle, char* va, size_t span, int device) {
-    if (hipMemMap(va, span, 0, handle, 0) != hipSuccess) return false;
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = device;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(va, span, &acc, 1) != hipSuccess) {
-        (void)hipMemUnmap(va, span);
-        return false;
-    }
-    return true;
-}
-
-// mode 1. Returns true and fills blk on success; false (everything released) if the virtual-memory API is unusable.
-// Every candidate range STAYS MAPPED (aliases of the one physical block: no memory, only page-table pages) until the
-// choice is made: a range that is unmapped gives its page-table pages back and the next range mapped is built from
-// the same pages — and comes out in the same class (place_exp4 b, place_exp5: one slab moved over 14 / 48 ranges one
-// at a time was slow / fast at every one of them, while ranges that exist side by side differ, place_exp7).
-bool alloc_by_range_search(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStream_t s) {
-    const size_t MB2 = 2u << 20, GB = 1ull << 30;
-    const size_t span = round_up(bytes, MB2);
-    const size_t stride = round_up(span, GB);
-    int K = (int)c->placement_candidates;
-    if (K < 1) K = 1;
-    if (K > DXO_PLACEMENT_MAX) K = DXO_PLACEMENT_MAX;
-    hipMemGenericAllocationHandle_t handle{};
-    char* va = nullptr;
-    const size_t va_bytes = stride * (size_t)K;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = c->device;
-    if (hipMemCreate(&handle, span, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemAddressReserve((void**)&va, va_bytes, MB2, nullptr, 0) != hipSuccess) {
-        (void)hipMemRelease(handle);
-        (void)hipGetLastError();
-        return false;
-    }
-    int mapped = 0, best = -1;
-    double best_bw = -1.0;
-    for (int k = 0; k < K; ++k) {
-        if (!vmm_map(handle, va + stride * (size_t)k, span, c->device)) break;
-        mapped = k + 1;
-        const double bw = probe_range(c, va + stride * (size_t)k, span, s);
-        blk.info.probe_GBps[k] = bw;
-        blk.info.candidates = k + 1;
-        if (bw > best_bw) { best_bw = bw; best = k; }
-        if (bw >= (double)c->placement_good_GBps) break;
-    }
-    (void)hipStreamSynchronize(s);
-    for (int k = 0; k < mapped; ++k)
-        if (k != best) (void)hipMemUnmap(va + stride * (size_t)k, span);
-    if (best < 0) {
-        (void)hipMemAddressFree(va, va_bytes);
-        (void)hipMemRelease(handle);
-        (void)hipGetLastError();
-        return false;
-    }
-    blk.ptr = va + stride * (size_t)best;
-    blk.bytes = span;
-    blk.va_base = va;
-    blk.va_bytes = va_bytes;
-    blk.handle = handle;
-    blk.info.mode = 1;
-    blk.info.chosen = best;
-    return true;
-}
-
-// mode 2: ordinary allocations, all candidates alive until the choice is made (a freed block would be handed out again)
+// ordinary allocations, all candidates alive until the choice is made (a freed block would be handed out again)
 bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStream_t s) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
@@ -154,13 +93,7 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStre
 
 void dxo_arena_release_all(dxo_ctx* c) {
     for (auto& b : c->arena) {
-        if (b.info.mode == 1) {
-            (void)hipMemUnmap(b.ptr, b.bytes);
-            (void)hipMemAddressFree(b.va_base, b.va_bytes);
-            (void)hipMemRelease(b.handle);
-        } else if (b.ptr) {
-            (void)hipFree(b.ptr);
-        }
+        if (b.ptr) (void)hipFree(b.ptr);
     }
     c->arena.clear();
 }
@@ -179,8 +112,7 @@ extern "C" int dxo_output_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     hipStream_t s = c->stream;   // calibration runs on the library's own stream and is synchronous
     bool done = false;
     if ((int64_t)need >= c->placement_min_bytes && c->placement_candidates > 1) {
-        if (c->placement_mode == 1) done = alloc_by_range_search(c, need, blk, s);
-        if (!done && c->placement_mode >= 1) done = alloc_by_candidates(c, need, blk, s);
+        if (c->placement_mode >= 1) done = alloc_by_candidates(c, need, blk, s);
     }
     if (!done) {
         std::memset(&blk.info, 0, sizeof blk.info);
@@ -205,13 +137,7 @@ extern "C" int dxo_output_free(dxo_ctx* c, void* ptr) {
         c->arena.erase(c->arena.begin() + (long)i);
         DXO_HIP(c, hipSetDevice(c->device));
         DXO_HIP(c, hipDeviceSynchronize());
-        if (b.info.mode == 1) {
-            DXO_HIP(c, hipMemUnmap(b.ptr, b.bytes));
-            DXO_HIP(c, hipMemAddressFree(b.va_base, b.va_bytes));
-            DXO_HIP(c, hipMemRelease(b.handle));
-        } else {
-            DXO_HIP(c, hipFree(b.ptr));
-        }
+        DXO_HIP(c, hipFree(b.ptr));
         return DXO_OK;
     }
     return dxo_fail(c, DXO_E_NULL, "dxo_output_free: pointer was not returned by dxo_output_alloc on this context");

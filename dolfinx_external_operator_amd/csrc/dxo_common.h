@@ -24,9 +24,6 @@ constexpr int DXO_HOST_SLOTS = 3;     // H2D / kernel / D2H pipeline depth
 struct dxo_arena_block {
     void* ptr = nullptr;
     size_t bytes = 0;
-    char* va_base = nullptr;            // mode 1: the address reservation the block is mapped into
-    size_t va_bytes = 0;
-    hipMemGenericAllocationHandle_t handle{};
     dxo_placement_info info;
 };
 struct dxo_ctx;
@@ -64,10 +61,10 @@ struct dxo_ctx {
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
     // output arena (arena.hip)
-    int64_t placement_mode = 1;         // 0 plain hipMalloc, 1 virtual-range search, 2 hipMalloc candidates
-    int64_t placement_candidates = 16;  // ranges / allocations tried at most (<= DXO_PLACEMENT_MAX)
+    int64_t placement_mode = 2;         // 0 plain hipMalloc, 2 (or any value >= 1) hipMalloc candidates
+    int64_t placement_candidates = 12;  // allocations / ranges tried at most (<= DXO_PLACEMENT_MAX)
     int64_t placement_min_bytes = (int64_t)1 << 30;
-    int64_t placement_good_GBps = 6500; // stop searching at the first candidate whose write sweep reaches this
+    int64_t placement_good_GBps = 6800; // stop searching at the first candidate whose write sweep reaches this
     std::vector<dxo_arena_block> arena;
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
     int64_t host_threads = 32;          // worker threads of the host half of the pipeline (capped by the hardware's)

@@ -1,0 +1,302 @@
+// mgpu.hip — dxo_mgpu_*: cell-block sharding over the GPUs of one node with the RCCL all-gather INSIDE the library
+// (BASELINE north_star; SURVEY.md 8b "dxo_mgpu_* variants taking a device list + doing the all-gather", 8e).
+//
+// The reference never gathers quadrature data: every MPI rank evaluates its own mesh partition
+// (src/dolfinx_external_operator/external_operator.py:365-371) and halo-updates the coefficient (:445). Here the
+// quadrature points of ONE coefficient vector are split into contiguous cell blocks (arrays are cell-major, so a
+// block is a contiguous slice of every array), each GPU runs the pointwise kernel on its block and writes the result
+// straight into its slice of a FULL-length output array; RCCL's in-place all-gather (sendbuff == recvbuff +
+// rank * count) then gives every GPU the whole vector — nothing is copied locally.
+//
+// Two forms of one object:
+//   dxo_mgpu_create       single process, n_dev devices: one dxo_ctx + one communicator per device (ncclCommInitAll),
+//                         collectives issued for all local devices inside one ncclGroupStart/End.
+//   dxo_mgpu_create_rank  one process per GPU (MPI ranks of a DOLFINx run, torch.distributed workers): the caller
+//                         broadcasts the 128-byte id of dxo_mgpu_unique_id, every rank joins with ncclCommInitRank.
+// Gather modes: FULL = all-gather of (C_tang, sigma, dp), (d*d+d+1) doubles per point over xGMI; COMPACT = all-gather
+// of (sigma, dp) only ((d+1) doubles, 6.1x fewer link bytes at d = 6) + rebuild of the REMOTE tangents from the
+// returned state on the device (dxo_vm_expand_tangent, HBM-bound) — xGMI (7 links x ~153 GB/s per GPU), not HBM, is
+// the roof of the reassembly.
+//
+// RCCL is resolved lazily (dlopen "librccl.so.1" at the first dxo_mgpu_* call): libdxo_hip.so has no link-time
+// dependency on it, single-GPU users never load it, and inside a PyTorch process the copy PyTorch has already
+// loaded is the one that is used (same SONAME), so there is ONE RCCL per process.
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>
+
+#include "dxo_common.h"
+
+struct dxo_mgpu {
+    int world = 0;                 // ranks in the communicator
+    std::vector<int> rank;         // global rank of each LOCAL device
+    std::vector<dxo_ctx*> ctx;     // one per local device
+    std::vector<bool> own_ctx;
+    std::vector<ncclComm_t> comm;
+    std::string err;
+};
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            const char* e = dlerror();
+            r.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (e ? e : "");
+            return;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(r.handle, n);
+            if (!p && r.why.empty()) r.why = std::string("RCCL lacks symbol ") + n;
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return r.why.empty() ? &r : nullptr;
+}
+
+int mg_fail(dxo_mgpu* g, int code, const std::string& what) {
+    if (g) g->err = what;
+    return code;
+}
+
+// RCCL errors are reported as positive codes above the HIP range so they cannot be mistaken for a hipError_t
+int nccl_fail(dxo_mgpu* g, ncclResult_t r, const char* where) {
+    Rccl* R = rccl();
+    if (g) g->err = std::string(where) + ": " + (R && R->GetErrorString ? R->GetErrorString(r) : "RCCL error") + " (ncclResult " + std::to_string((int)r) + ")";
+    return 10000 + (int)r;
+}
+
+#define DXO_NCCL(g, call)                                             \
+    do {                                                              \
+        ncclResult_t r_ = (call);                                     \
+        if (r_ != ncclSuccess) return nccl_fail((g), r_, #call);      \
+    } while (0)
+
+int need_rccl(dxo_mgpu* g) {
+    if (rccl()) return DXO_OK;
+    static Rccl* dummy = nullptr;
+    (void)dummy;
+    // re-read the reason
+    for (const char* name : {"librccl.so.1"}) (void)name;
+    return mg_fail(g, DXO_E_NODEVICE, "RCCL is not available in this process (librccl.so.1 could not be loaded)");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dxo_mgpu_last_error(const dxo_mgpu* g) { return g ? g->err.c_str() : "null dxo_mgpu"; }
+
+int dxo_mgpu_size(const dxo_mgpu* g) { return g ? g->world : DXO_E_NULL; }
+
+int dxo_mgpu_local_count(const dxo_mgpu* g) { return g ? (int)g->ctx.size() : DXO_E_NULL; }
+
+int dxo_mgpu_rank(const dxo_mgpu* g, int i) {
+    if (!g) return DXO_E_NULL;
+    if (i < 0 || i >= (int)g->rank.size()) return DXO_E_SIZE;
+    return g->rank[(size_t)i];
+}
+
+dxo_ctx* dxo_mgpu_ctx(dxo_mgpu* g, int i) {
+    if (!g || i < 0 || i >= (int)g->ctx.size()) return nullptr;
+    return g->ctx[(size_t)i];
+}
+
+int dxo_mgpu_destroy(dxo_mgpu* g) {
+    if (!g) return DXO_E_NULL;
+    Rccl* R = rccl();
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        if (g->ctx[i]) {
+            (void)hipSetDevice(g->ctx[i]->device);
+            (void)hipStreamSynchronize(dxo_launch_stream(g->ctx[i]));
+        }
+        if (R && i < g->comm.size() && g->comm[i]) (void)R->CommDestroy(g->comm[i]);
+    }
+    for (size_t i = 0; i < g->ctx.size(); ++i)
+        if (g->own_ctx[i] && g->ctx[i]) (void)dxo_ctx_destroy(g->ctx[i]);
+    delete g;
+    return DXO_OK;
+}
+
+int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out) {
+    if (!out) return DXO_E_NULL;
+    *out = nullptr;
+    if (n_dev < 1) return DXO_E_SIZE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return DXO_E_NODEVICE;
+    }
+    std::vector<int> devs((size_t)n_dev);
+    for (int i = 0; i < n_dev; ++i) {
+        devs[(size_t)i] = devices ? devices[i] : i;
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= count) return DXO_E_NODEVICE;
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i]) return DXO_E_SIZE;   // one rank per physical device
+    }
+    if (!rccl()) return DXO_E_NODEVICE;
+    dxo_mgpu* g = new dxo_mgpu();
+    g->world = n_dev;
+    g->comm.assign((size_t)n_dev, nullptr);
+    for (int i = 0; i < n_dev; ++i) {
+        dxo_ctx* c = nullptr;
+        const int rc = dxo_ctx_create(devs[(size_t)i], &c);
+        if (rc != DXO_OK) {
+            dxo_mgpu_destroy(g);
+            return rc;
+        }
+        g->ctx.push_back(c);
+        g->own_ctx.push_back(true);
+        g->rank.push_back(i);
+    }
+    const ncclResult_t r = rccl()->CommInitAll(g->comm.data(), n_dev, devs.data());
+    if (r != ncclSuccess) {
+        const int code = nccl_fail(g, r, "ncclCommInitAll");
+        std::fprintf(stderr, "dxo_mgpu_create: %s\n", g->err.c_str());
+        for (auto& cm : g->comm) cm = nullptr;
+        dxo_mgpu_destroy(g);
+        return code;
+    }
+    *out = g;
+    return DXO_OK;
+}
+
+int dxo_mgpu_unique_id(void* id128) {
+    if (!id128) return DXO_E_NULL;
+    if (!rccl()) return DXO_E_NODEVICE;
+    static_assert(sizeof(ncclUniqueId) == DXO_MGPU_ID_BYTES, "dxo.h promises a 128-byte id");
+    ncclUniqueId id;
+    const ncclResult_t r = rccl()->GetUniqueId(&id);
+    if (r != ncclSuccess) return 10000 + (int)r;
+    std::memcpy(id128, &id, sizeof id);
+    return DXO_OK;
+}
+
+int dxo_mgpu_create_rank(dxo_ctx* ctx, const void* id128, int rank, int world, dxo_mgpu** out) {
+    if (!ctx || !id128 || !out) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mgpu_create_rank: need 0 <= rank < world");
+    if (!rccl()) return dxo_fail(ctx, DXO_E_NODEVICE, "dxo_mgpu_create_rank: RCCL (librccl.so.1) could not be loaded");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    dxo_mgpu* g = new dxo_mgpu();
+    g->world = world;
+    g->ctx.push_back(ctx);
+    g->own_ctx.push_back(false);
+    g->rank.push_back(rank);
+    g->comm.assign(1, nullptr);
+    const ncclResult_t r = rccl()->CommInitRank(&g->comm[0], world, id, rank);
+    if (r != ncclSuccess) {
+        const int code = nccl_fail(g, r, "ncclCommInitRank");
+        dxo_fail(ctx, code, g->err.c_str());
+        g->comm[0] = nullptr;
+        dxo_mgpu_destroy(g);
+        return code;
+    }
+    *out = g;
+    return DXO_OK;
+}
+
+int dxo_mgpu_synchronize(dxo_mgpu* g) {
+    if (!g) return DXO_E_NULL;
+    for (auto* c : g->ctx) {
+        const int rc = dxo_ctx_synchronize(c);
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(c));
+    }
+    return DXO_OK;
+}
+
+// In-place all-gather of `count_per_rank` doubles per rank on every local device: buf[i] is the FULL-length array of
+// local device i, whose own block already sits at offset rank * count_per_rank.
+int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank) {
+    if (!g || !buf) return DXO_E_NULL;
+    if (count_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_all_gather: negative count");
+    const int rc0 = need_rccl(g);
+    if (rc0 != DXO_OK) return rc0;
+    if (count_per_rank == 0) return DXO_OK;
+    Rccl* R = rccl();
+    DXO_NCCL(g, R->GroupStart());
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        if (!buf[i]) {
+            (void)R->GroupEnd();
+            return mg_fail(g, DXO_E_NULL, "dxo_mgpu_all_gather: NULL buffer");
+        }
+        const ncclResult_t r = R->AllGather(buf[i] + (size_t)g->rank[i] * (size_t)count_per_rank, buf[i], (size_t)count_per_rank, ncclDouble,
+                                            g->comm[i], dxo_launch_stream(g->ctx[i]));
+        if (r != ncclSuccess) {
+            (void)R->GroupEnd();
+            return nccl_fail(g, r, "ncclAllGather");
+        }
+    }
+    DXO_NCCL(g, R->GroupEnd());
+    return DXO_OK;
+}
+
+int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_per_rank, int gather,
+                       const double* const* deps, const double* const* sigma_n, const double* const* p,
+                       double* const* C_tang, double* const* sigma, double* const* dp) {
+    if (!g) return DXO_E_NULL;
+    if (!prm || !deps || !sigma_n || !p || !C_tang || !sigma || !dp) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL argument");
+    if (d != 4 && d != 6) return mg_fail(g, DXO_E_DIM, "dxo_mgpu_von_mises: d must be 4 or 6");
+    if (n_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_von_mises: n_per_rank < 0");
+    if (gather < DXO_GATHER_NONE || gather > DXO_GATHER_COMPACT) return mg_fail(g, DXO_E_MEM, "dxo_mgpu_von_mises: bad gather mode");
+    if (gather != DXO_GATHER_NONE && (n_per_rank % 2)) return mg_fail(g, DXO_E_ALIGN, "dxo_mgpu_von_mises: with a gather n_per_rank must be even (16-byte aligned blocks)");
+    const size_t n = (size_t)n_per_rank, L = g->ctx.size();
+    // 1. every local device: return map of its own cell block, written into its slice of the full-length outputs
+    for (size_t i = 0; i < L; ++i) {
+        const size_t off = gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n;
+        const int rc = dxo_von_mises(g->ctx[i], prm, d, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], p[i],
+                                     C_tang[i] ? C_tang[i] + off * d * d : nullptr, sigma[i] ? sigma[i] + off * d : nullptr,
+                                     dp[i] ? dp[i] + off : nullptr);
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+    }
+    if (gather == DXO_GATHER_NONE || g->world == 1 || n == 0) return DXO_OK;
+    // 2. the exchange step
+    int rc = dxo_mgpu_all_gather(g, sigma, n_per_rank * d);
+    if (rc == DXO_OK) rc = dxo_mgpu_all_gather(g, dp, n_per_rank);
+    if (rc != DXO_OK) return rc;
+    if (gather == DXO_GATHER_FULL) return dxo_mgpu_all_gather(g, C_tang, n_per_rank * d * d);
+    // 3. COMPACT: tangents of the remote blocks from the gathered state, on each device's stream behind its gathers
+    for (size_t i = 0; i < L; ++i) {
+        const size_t r = (size_t)g->rank[i], W = (size_t)g->world;
+        const size_t runs[2][2] = {{0, r * n}, {(r + 1) * n, W * n}};
+        for (const auto& run : runs) {
+            if (run[1] <= run[0]) continue;
+            rc = dxo_vm_expand_tangent(g->ctx[i], prm, d, (int64_t)(run[1] - run[0]), DXO_MEM_DEVICE, sigma[i] + run[0] * d, dp[i] + run[0],
+                                       C_tang[i] + run[0] * d * d);
+            if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+        }
+    }
+    return DXO_OK;
+}
+
+}  // extern "C"

@@ -124,19 +124,19 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
 
 /* ---- output arena: device memory for OUTPUT arrays, placed by calibration -------------------------------------
  * The kernels are HBM-bound and mostly stores (von Mises d = 6: 344 of 448 B per point). On MI355X the rate of a
- * multi-GB streaming-write sweep is bimodal (about 5.9 vs 6.9 TB/s pure stores) and the class belongs to the
- * buffer's VIRTUAL address range (profiles/r02_place_exp*.txt). dxo_output_alloc creates the
- * physical memory once and searches an address reservation for a fast range (hipMemMap at candidate ranges, one
- * timed write sweep each, keep the first above option "placement_good_GBps" = 6500, else the best); the block is
- * owned by the ctx (freed by dxo_output_free or dxo_ctx_destroy). Meant for the persistent coefficient buffers a
- * solver allocates once. Options: "placement_mode" 1 = virtual-range search (default), 2 = several ordinary
- * hipMalloc allocations of which the fastest is kept (use where a collective library must IPC-share the buffer),
- * 0 = plain hipMalloc; "placement_candidates" (default 16, at most 32); "placement_min_bytes" (default 1 GiB:
- * smaller blocks are plain hipMalloc, a working set that small lives in the caches). The calibration WRITES the
- * block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
+ * multi-GB streaming-write sweep depends on the allocation it goes to (pure stores about 5.6-6.0, 6.4-6.5 or 6.9-7.1
+ * TB/s; the class is stable for the life of the allocation and belongs to its virtual range, DESIGN.md 3.1,
+ * profiles/r02_place_exp*.txt). dxo_output_alloc makes several ordinary allocations side by side, times one
+ * streaming-write sweep on each, keeps the first above option "placement_good_GBps" (6800), else the fastest, and
+ * frees the rest; the block is owned by the ctx (freed by dxo_output_free or dxo_ctx_destroy). Meant for the
+ * persistent coefficient buffers a solver allocates once. Options: "placement_mode" 2 = hipMalloc candidates
+ * (default), 0 = plain hipMalloc; "placement_candidates"
+ * (default 12, at most 32, and never more than fit 60 % of the free memory together); "placement_min_bytes"
+ * (default 1 GiB: smaller blocks are plain hipMalloc, a working set that small lives in the caches). The
+ * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
 #define DXO_PLACEMENT_MAX 32
 typedef struct dxo_placement_info {
-    int32_t mode;                           /* how the block was obtained: 0, 1 or 2 as above                      */
+    int32_t mode;                           /* how the block was obtained: 0 plain hipMalloc, 2 candidates         */
     int32_t candidates;                     /* ranges / allocations timed                                          */
     int32_t chosen;                         /* index of the one kept (-1: no calibration)                          */
     int32_t _pad;
@@ -356,6 +356,49 @@ int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_do
  * all cells: q[n][gdim], dqdT[n][gdim], dqdsigma[n][gdim][gdim], n = num_cells*nq; any output may be NULL. */
 int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, const double* T_dofs,
                    double* q, double* dqdT, double* dqdsigma);
+
+/* ---- multi-GPU: cell-block sharding + RCCL all-gather inside the library (BASELINE north_star) ----
+ * The reference splits only by MPI mesh partition and never gathers quadrature data
+ * (src/dolfinx_external_operator/external_operator.py:365-371, 445). Here ONE coefficient vector's quadrature points
+ * are split into `world` contiguous, equally sized cell blocks; rank r owns points [r*n_per_rank, (r+1)*n_per_rank).
+ * Each GPU evaluates its block and writes straight into its slice of FULL-length output arrays
+ * (world*n_per_rank points, device memory on that GPU); RCCL's in-place all-gather over xGMI then gives every GPU the
+ * whole vector. All calls are asynchronous on the contexts' streams (dxo_mgpu_synchronize waits).
+ *   dxo_mgpu_create       one process, n_dev GPUs (devices == NULL: 0..n_dev-1): a dxo_ctx and a communicator per
+ *                         device (ncclCommInitAll); the pointer arrays of the calls below have n_dev entries.
+ *   dxo_mgpu_create_rank  one process per GPU: rank 0 calls dxo_mgpu_unique_id, the caller broadcasts the
+ *                         DXO_MGPU_ID_BYTES bytes (MPI_Bcast, torch.distributed, a file ...), every rank joins with
+ *                         its own ctx; pointer arrays have ONE entry. Collective: all ranks must call.
+ * RCCL is loaded at the first dxo_mgpu_* call (dlopen librccl.so.1): DXO_E_NODEVICE if it is absent; RCCL errors are
+ * returned as 10000 + ncclResult_t with the text in dxo_mgpu_last_error.
+ * gather: DXO_GATHER_NONE (outputs are block-length arrays, no exchange), DXO_GATHER_FULL (all-gather of C_tang,
+ * sigma, dp: (d*d+d+1) doubles per point per peer), DXO_GATHER_COMPACT (all-gather of sigma and dp only, then the
+ * tangents of the REMOTE blocks are rebuilt on each GPU with dxo_vm_expand_tangent: 6.1x fewer link bytes at d = 6;
+ * remote tangents agree with the owner's to rounding, see dxo_vm_expand_tangent). n_per_rank must be even with a
+ * gather (16-byte aligned blocks); pad the last block as sharding.CellBlockPartition does. */
+#define DXO_MGPU_ID_BYTES 128
+#define DXO_GATHER_NONE 0
+#define DXO_GATHER_FULL 1
+#define DXO_GATHER_COMPACT 2
+typedef struct dxo_mgpu dxo_mgpu;
+int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out);
+int dxo_mgpu_unique_id(void* id128);
+int dxo_mgpu_create_rank(dxo_ctx* ctx, const void* id128, int rank, int world, dxo_mgpu** out);
+int dxo_mgpu_destroy(dxo_mgpu* g);
+int dxo_mgpu_size(const dxo_mgpu* g);                 /* ranks in the communicator                      */
+int dxo_mgpu_local_count(const dxo_mgpu* g);          /* devices driven by this process                 */
+int dxo_mgpu_rank(const dxo_mgpu* g, int i);          /* global rank of local device i                  */
+dxo_ctx* dxo_mgpu_ctx(dxo_mgpu* g, int i);            /* its context (options, dxo_output_alloc, ...)   */
+const char* dxo_mgpu_last_error(const dxo_mgpu* g);
+int dxo_mgpu_synchronize(dxo_mgpu* g);
+/* In-place all-gather of count_per_rank doubles per rank: buf[i] = full-length array on local device i whose own
+ * block already sits at offset rank*count_per_rank. */
+int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank);
+/* dxo_von_mises on every local device + the exchange. deps/sigma_n/p[i]: block of local device i (n_per_rank points);
+ * C_tang/sigma/dp[i]: full-length arrays on that device (block-length with DXO_GATHER_NONE). */
+int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_per_rank, int gather,
+                       const double* const* deps, const double* const* sigma_n, const double* const* p,
+                       double* const* C_tang, double* const* sigma, double* const* dp);
 
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte

@@ -60,6 +60,32 @@ def test_argument_errors_without_a_device(hip_library):
     assert rc in (0, -7) and n.value >= 0
 
 
+def test_mgpu_entry_points_reject_bad_arguments_without_a_device(hip_library):
+    """dxo_mgpu_*: exported, typed, and argument errors come back before RCCL or a GPU is touched."""
+    lib = hip_library
+    h = C.c_void_p()
+    assert lib.dxo_mgpu_create(None, 1, None) == -1                # DXO_E_NULL
+    assert lib.dxo_mgpu_create(None, 0, C.byref(h)) == -3          # DXO_E_SIZE
+    assert lib.dxo_mgpu_destroy(None) == -1
+    assert lib.dxo_mgpu_size(None) == -1
+    assert lib.dxo_mgpu_unique_id(None) == -1
+    assert lib.dxo_mgpu_create_rank(None, None, 0, 1, C.byref(h)) == -1
+    assert lib.dxo_mgpu_ctx(None, 0) is None
+    n = C.c_int(0)
+    if lib.dxo_device_count(C.byref(n)) != 0 or n.value == 0:
+        assert lib.dxo_mgpu_create(None, 2, C.byref(h)) == -7      # DXO_E_NODEVICE: no silent CPU path
+        assert not h.value
+
+
+def test_libdxo_does_not_link_rccl():
+    """RCCL is resolved lazily (dlopen at the first dxo_mgpu_* call): single-GPU users never load the 570 MB library."""
+    from dolfinx_external_operator_amd._lib import LIB_PATH
+
+    res = subprocess.run(["readelf", "-d", str(LIB_PATH)], capture_output=True, text=True)
+    assert res.returncode == 0
+    assert "librccl" not in res.stdout and "libamdhip64" in res.stdout
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = ROOT / "dolfinx_external_operator_amd"
     for f in pkg.rglob("*.py"):

@@ -4,7 +4,7 @@ import pathlib
 import numpy as np
 import pytest
 
-from conftest import mc_compare, mc_elastic_matrices, mc_tracing_inputs
+from conftest import mc_compare_all, mc_compare, mc_elastic_matrices, mc_tracing_inputs
 from dolfinx_external_operator_amd import (
     MEM_DEVICE,
     MEM_HOST,
@@ -89,11 +89,10 @@ def test_shear_and_non_associated_flow(ctx, oracle):
     for kw in ({}, {"psi": 20 * np.pi / 180}, {"phi": 25 * np.pi / 180, "psi": 10 * np.pi / 180, "theta_T": 20 * np.pi / 180}):
         ref = oracle.mohr_coulomb(deps, sn, nthreads=8, **kw)
         got = run_device(ctx, deps, sn, **kw)
-        conv = ref[2] < 30
-        assert conv.mean() > 0.95
-        mc_compare(tuple(a[conv] for a in got), tuple(a[conv] for a in ref), f"HIP vs oracle {kw}", sn[conv])
-        # non-converged points are reported, not failed: same flag as the reference (niter == Nitermax)
-        assert np.array_equal(got[2] == 200, ref[2] == 200) or (got[2] == 200).sum() >= 0
+        assert (ref[2] < 30).mean() > 0.95
+        # every point is compared: fast ones to the tight bounds, slowly converging ones on sigma / norm_res, and the
+        # set of non-converged points (reported through niter == Nitermax, never raised) must be the oracle's
+        mc_compare_all(got, ref, f"HIP vs oracle {kw}", sn)
 
 
 def test_outputs_without_diagnostics_and_guards(ctx, oracle):
