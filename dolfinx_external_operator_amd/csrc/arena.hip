@@ -42,22 +42,26 @@ __global__ __launch_bounds__(DXO_BLOCK) void arena_write_sweep(int64_t n_tiles, 
 
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// GB/s of the sweep over [p, p + bytes); 0 on error
-double probe_range(dxo_ctx* c, void* p, size_t bytes, hipStream_t s) {
+void launch_sweep(dxo_ctx* c, void* p, size_t bytes, hipStream_t s) {
     const int64_t n_tiles = (int64_t)(bytes / 16384);
-    if (n_tiles <= 0) return 0.0;
-    const int grid = c->compute_units * 16;
-    hipLaunchKernelGGL(arena_write_sweep, dim3(grid), dim3(DXO_BLOCK), 0, s, n_tiles, (dxo_f64x2*)p);
+    if (n_tiles > 0) hipLaunchKernelGGL(arena_write_sweep, dim3(c->compute_units * 16), dim3(DXO_BLOCK), 0, s, n_tiles, (dxo_f64x2*)p);
+}
+
+// GB/s of `launches` back-to-back sweeps over [p, p + bytes); 0 on error. The block must have been swept before
+// (launch_sweep): the first passes over a fresh allocation run ~20 % slower than its steady state (measured: every
+// candidate of a 12-candidate search read 4.8-5.2 TB/s when timed right after hipMalloc, gpurun_out r02c).
+double probe_range(dxo_ctx* c, void* p, size_t bytes, hipStream_t s, int launches = 4) {
+    if (bytes < 16384) return 0.0;
     if (hipEventRecord(c->ev_start, s) != hipSuccess) return 0.0;
-    const int launches = 3;
-    for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(arena_write_sweep, dim3(grid), dim3(DXO_BLOCK), 0, s, n_tiles, (dxo_f64x2*)p);
+    for (int l = 0; l < launches; ++l) launch_sweep(c, p, bytes, s);
     if (hipEventRecord(c->ev_stop, s) != hipSuccess || hipEventSynchronize(c->ev_stop) != hipSuccess) return 0.0;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess || ms <= 0.f) return 0.0;
-    return (double)n_tiles * 16384.0 * launches / (ms * 1e-3) / 1e9;
+    return (double)(bytes / 16384) * 16384.0 * launches / (ms * 1e-3) / 1e9;
 }
 
-// ordinary allocations, all candidates alive until the choice is made (a freed block would be handed out again)
+// ordinary allocations, all candidates alive until the choice is made (a freed block would be handed out again).
+// Groups of four: allocate, sweep each twice untimed, then time each — so no block is timed in its first passes.
 bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStream_t s) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
@@ -69,17 +73,29 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStre
     std::vector<void*> cand;
     int best = -1;
     double best_bw = -1.0;
-    for (int k = 0; k < K; ++k) {
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        cand.push_back(p);
-        const double bw = probe_range(c, p, bytes, s);
-        blk.info.probe_GBps[k] = bw;
-        blk.info.candidates = k + 1;
-        if (bw > best_bw) { best_bw = bw; best = k; }
-        if (bw >= (double)c->placement_good_GBps) break;
+    bool good = false, oom = false;
+    while ((int)cand.size() < K && !good && !oom) {
+        const int first = (int)cand.size();
+        for (int k = first; k < K && k < first + 4; ++k) {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); oom = true; break; }
+            cand.push_back(p);
+        }
+        for (int rep = 0; rep < 2; ++rep)
+            for (int k = first; k < (int)cand.size(); ++k) launch_sweep(c, cand[k], bytes, s);
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        for (int k = first; k < (int)cand.size(); ++k) {
+            const double bw = probe_range(c, cand[k], bytes, s);
+            blk.info.probe_GBps[k] = bw;
+            blk.info.candidates = k + 1;
+            if (bw > best_bw) { best_bw = bw; best = k; }
+            if (bw >= (double)c->placement_good_GBps) { good = true; break; }
+        }
     }
-    if (best < 0) return false;
+    if (best < 0) {
+        for (void* p : cand) (void)hipFree(p);
+        return false;
+    }
     for (int k = 0; k < (int)cand.size(); ++k)
         if (k != best) (void)hipFree(cand[k]);
     blk.ptr = cand[best];

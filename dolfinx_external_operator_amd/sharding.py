@@ -94,6 +94,32 @@ def all_gather_flat(local, group=None):
     return out
 
 
+_INTO_TENSOR_OK: dict[str, bool] = {}
+
+
+def _backend_has_into_tensor(group=None) -> bool:
+    """Does the group's backend implement all_gather_into_tensor? Decided ONCE per backend with a one-element
+    collective (every rank runs it at its first gather, so the ranks stay in step); after that a RuntimeError
+    out of a gather is a real failure and propagates instead of being retried through another code path."""
+    import torch
+    import torch.distributed as dist
+
+    backend = str(dist.get_backend(group))
+    ok = _INTO_TENSOR_OK.get(backend)
+    if ok is None:
+        world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        probe_in = torch.zeros(1, dtype=torch.float64, device=dev)
+        probe_out = torch.zeros(world, dtype=torch.float64, device=dev)
+        try:
+            dist.all_gather_into_tensor(probe_out, probe_in, group=group)
+            ok = True
+        except (RuntimeError, NotImplementedError):
+            ok = False
+        _INTO_TENSOR_OK[backend] = ok
+    return ok
+
+
 def all_gather_flat_into(out, local, group=None, async_op: bool = False):
     """All-gather into a caller-owned flat buffer (no allocation inside the timed region)."""
     import torch.distributed as dist
@@ -101,13 +127,10 @@ def all_gather_flat_into(out, local, group=None, async_op: bool = False):
     world = dist.get_world_size(group)
     if out.numel() != world * local.numel():
         raise ValueError(f"gather buffer has {out.numel()} elements, need {world * local.numel()}")
-    try:
+    if _backend_has_into_tensor(group):
         return dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
-    except (RuntimeError, NotImplementedError):
-        if async_op:
-            raise
-        chunks = list(out.view(world, local.numel()).unbind(0))
-        return dist.all_gather(chunks, local, group=group)
+    chunks = list(out.view(world, local.numel()).unbind(0))
+    return dist.all_gather(chunks, local, group=group, async_op=async_op)
 
 
 def all_gather_in_place(full, rank: int, group=None):

@@ -322,6 +322,6 @@ def test_mgpu_world_of_one_matches_the_single_gpu_call(ctx, oracle, form):
         with pytest.raises(ValueError):
             g.von_mises(PRM, 5, n, GATHER_NONE, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s], [dp])   # bad d
         with pytest.raises(ValueError):
-            g.von_mises(PRM, d, n, GATHER_FULL, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s])          # missing pointer list entry
+            g.von_mises(PRM, d, n, GATHER_FULL, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s], [])      # a pointer list without an entry for the device
     finally:
         g.close()
