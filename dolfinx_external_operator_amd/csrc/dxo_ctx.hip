@@ -2,6 +2,7 @@
 // Host-side runtime of libdxo_hip.so; the kernels live in von_mises.hip / heat.hip / ...
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <thread>
 
 #include "dxo_common.h"
@@ -212,6 +213,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "icnn_variant")) return &c->icnn_variant;
     if (!std::strcmp(key, "adjoint_atomics")) return &c->adjoint_atomics;
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
+    if (!std::strcmp(key, "operand_cell")) return &c->operand_cell;
     if (!std::strcmp(key, "mc_part_points")) return &c->mc_part_points;
     if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;
     if (!std::strcmp(key, "vm_host_tangent")) return &c->vm_host_tangent;
@@ -472,17 +474,76 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         c->slot_bytes = need;
     }
     SlotEvents ev[DXO_HOST_SLOTS];
-    int64_t slot_first[DXO_HOST_SLOTS] = {0, 0, 0}, slot_m[DXO_HOST_SLOTS] = {0, 0, 0};
     int rc = DXO_OK;
+    // Host stage (only with a `post` hook): its own thread waits for a chunk's D2H copies and runs the hook (which
+    // fans out over the context's worker threads) while the calling thread keeps enqueueing the next chunks — the host
+    // half of chunk i overlaps the PCIe traffic of chunks i+1.. instead of sitting between two enqueues.
+    struct StageItem { int slot; int64_t first, m; };
+    hipEvent_t post_ev[DXO_HOST_SLOTS] = {nullptr, nullptr, nullptr};
+    bool post_pending[DXO_HOST_SLOTS] = {false, false, false};
+    std::mutex st_m;
+    std::condition_variable st_cv;
+    std::deque<StageItem> st_q;
+    bool st_done = false;
+    int st_rc = DXO_OK;
+    std::thread stage;
     auto destroy_events = [&]() {
         for (auto& s : ev)
             for (auto& e : s.e)
                 if (e) (void)hipEventDestroy(e);
+        for (auto& e : post_ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+    if (post) {
+        for (auto& e : post_ev) {
+            hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err != hipSuccess) {
+                destroy_events();
+                return dxo_hip_fail(c, err, "hipEventCreate");
+            }
+        }
+        stage = std::thread([&]() {
+            (void)hipSetDevice(c->device);
+            for (;;) {
+                StageItem it;
+                {
+                    std::unique_lock<std::mutex> lk(st_m);
+                    st_cv.wait(lk, [&] { return st_done || !st_q.empty(); });
+                    if (st_q.empty()) return;
+                    it = st_q.front();
+                    st_q.pop_front();
+                }
+                const hipError_t e = hipEventSynchronize(post_ev[it.slot]);
+                {
+                    std::lock_guard<std::mutex> lk(st_m);
+                    post_pending[it.slot] = false;   // the slot's event may be recorded again
+                    if (e != hipSuccess && st_rc == DXO_OK) st_rc = (int)e > 0 ? (int)e : 999;
+                }
+                st_cv.notify_all();
+                if (e == hipSuccess) {
+                    const int r = post(c, user, it.first, it.m);
+                    if (r != DXO_OK) {
+                        std::lock_guard<std::mutex> lk(st_m);
+                        if (st_rc == DXO_OK) st_rc = r;
+                    }
+                }
+            }
+        });
+    }
+    auto stop_stage = [&]() {
+        if (!stage.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(st_m);
+            st_done = true;
+        }
+        st_cv.notify_all();
+        stage.join();
     };
     for (auto& s : ev)
         for (auto& e : s.e) {
             hipError_t err = hipEventCreate(&e);
             if (err != hipSuccess) {
+                stop_stage();
                 destroy_events();
                 return dxo_hip_fail(c, err, "hipEventCreate");
             }
@@ -498,8 +559,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         c->last.kernel_ms += b;
         c->last.d2h_ms += d;
         ev[slot].used = false;
-        // host half of the chunk (e.g. tangent rebuild) while the other slots' copies and kernels keep running
-        if (post) return post(c, user, slot_first[slot], slot_m[slot]);
+        if (post) {   // the stage must have seen this slot's completion event before the event is recorded again
+            std::unique_lock<std::mutex> lk(st_m);
+            st_cv.wait(lk, [&] { return !post_pending[slot]; });
+        }
         return DXO_OK;
     };
     const auto t0 = std::chrono::steady_clock::now();
@@ -535,10 +598,17 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                                outputs[k].bytes_pp * (size_t)m, hipMemcpyDeviceToHost, s);
         }
         if (e == hipSuccess) e = hipEventRecord(ev[slot].e[3], s);
+        if (e == hipSuccess && post) e = hipEventRecord(post_ev[slot], s);
         if (e != hipSuccess) { rc = dxo_hip_fail(c, e, "host pipeline D2H"); break; }
         ev[slot].used = true;
-        slot_first[slot] = done;
-        slot_m[slot] = m;
+        if (post) {
+            {
+                std::lock_guard<std::mutex> lk(st_m);
+                post_pending[slot] = true;
+                st_q.push_back({slot, done, m});
+            }
+            st_cv.notify_all();
+        }
         done += m;
     }
     for (int slot = 0; slot < DXO_HOST_SLOTS; ++slot) {
@@ -547,6 +617,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         hipError_t e = hipStreamSynchronize(c->slot_stream[slot]);
         if (rc == DXO_OK && e != hipSuccess) rc = dxo_hip_fail(c, e, "host pipeline sync");
     }
+    stop_stage();   // drains the queue: every chunk's host half has run when this returns
+    if (rc == DXO_OK && st_rc != DXO_OK) rc = st_rc;
     destroy_events();
     c->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;

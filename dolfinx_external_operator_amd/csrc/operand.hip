@@ -18,6 +18,7 @@
 // order through LDS (consecutive 8-byte words per store instruction). No __syncthreads inside the cell loop.
 #include "dxo_common.h"
 #include "operand_core.h"
+#include "operand_cell.h"
 
 namespace {
 
@@ -105,7 +106,12 @@ int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double*
         case DXO_OPERAND_GRAD: launch_operand<G, BS, DXO_OPERAND_GRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
         case DXO_OPERAND_VALUE_GRAD: launch_operand<G, BS, DXO_OPERAND_VALUE_GRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK;
         case DXO_OPERAND_EPS_MANDEL:
-            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            if constexpr (BS == G) {
+                // standard elements, all cells: lane = cell kernel (registers + scalar tables, no LDS in the contraction)
+                if (!cells && ctx->operand_cell && launch_operand_cell_eps(ctx, m, u, n_cells, out, s)) return DXO_OK;
+                launch_operand<G, BS, DXO_OPERAND_EPS_MANDEL>(ctx, m, u, cells, n_cells, out, s);
+                return DXO_OK;
+            }
             return DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD:
             if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
