@@ -57,7 +57,7 @@ struct dxo_ctx {
     int64_t mc_blocks_per_cu = 2;       // persistent Newton workgroups per CU
     int64_t icnn_variant = 1;           // fp32 network: 0 VALU lane-per-point kernel, 1 MFMA wave-per-64-points kernel
     int64_t adjoint_cell = 1;           // virtual work of eps on the standard elements: lane = cell kernel (0: wave-group kernel)
-    int64_t operand_cell = 1;           // strain evaluation on the standard elements: lane = cell kernels (operand_cell.h); 0: wave-group kernels
+    int64_t operand_cell = 1;           // dxo_eval_operand, eps on the 2-D standard elements: lane = cell kernel (operand_cell.h); 0: wave-group kernel
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)

@@ -15,7 +15,6 @@
 #include "dxo_common.h"
 #include "operand_core.h"
 #include "vm_core.h"
-#include "operand_cell.h"
 
 namespace {
 
@@ -130,8 +129,6 @@ struct FieldLaunch {
 int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_cells, const double* sigma_n,
                  const double* p, double* C_tang, double* sigma, double* dp, hipStream_t s) {
     if (n_cells == 0) return DXO_OK;
-    if (ctx->operand_cell && launch_vm_field_cell(ctx, L.c, L.mesh, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, s))
-        return DXO_OK;
     const OperandDev& m = L.mesh->dev;
     const int D = L.mesh->gdim == 2 ? 4 : 6;
     int wd = m.cells_per_wave * (op_odd(m.ndofs * L.mesh->gdim) + op_odd(m.ngeom * L.mesh->gdim));

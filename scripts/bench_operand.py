@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cpu", type=int, default=0, help="also time the NumPy oracle on the first 50 000 cells")
 ap.add_argument("--launches", type=int, default=10)
 ap.add_argument("--case", type=int, default=-1, help="run only this case (index into CASES); -1 = all")
+ap.add_argument("--operand-cell", type=int, default=-1, help="ctx option operand_cell: 1 lane = cell kernels, 0 wave-group kernels; -1 = both")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -35,7 +36,10 @@ CASES = [("hexahedron", (108, 108, 108), 2, "eps", "Q2 hexahedra, 8 qp/cell, eps
          ("triangle", (1000, 1000), 2, "eps", "P2 triangles, 3 qp/cell, eps(u) Mandel d=4 (the reference demos' layout)"),
          ("triangle", (1000, 1000), 2, "F", "P2 triangles, F = I + grad u (hyperelasticity demo operand)")]
 for cell, n, degree, kind, label in (CASES if args.case < 0 else [CASES[args.case]]):
-    m = structured_mesh(cell, n, degree, distort=0.2, seed=0)
+  m = structured_mesh(cell, n, degree, distort=0.2, seed=0)
+  for oc in ((1, 0) if args.operand_cell < 0 else (args.operand_cell,)):
+    ctx.set_option("operand_cell", oc)
+    label = label.split(" [")[0] + (" [lane = cell kernels]" if oc else " [wave-group kernels]")
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     bs = m.gdim
     D = dm.value_size(kind, bs)

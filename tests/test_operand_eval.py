@@ -80,8 +80,8 @@ def test_oracle_known_answers_on_distorted_meshes(cell, degree):
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(params=[1, 0], ids=["lane=cell", "wave-group"])
 def strain_kernels(request, ctx):
-    """Both kernel families of the strain evaluation: operand_cell.h (lane = cell, default on the standard elements)
-    and the wave-group kernels of operand_core.h (every other element / kind, and ctx option operand_cell = 0)."""
+    """Both kernel families of dxo_eval_operand's strain evaluation: operand_cell.h (lane = cell, default on the 2-D
+    standard elements) and the wave-group kernel of operand_core.h (every other element / kind, ctx option operand_cell = 0)."""
     old = ctx.get_option("operand_cell")
     ctx.set_option("operand_cell", request.param)
     yield request.param
@@ -206,7 +206,7 @@ def _vm_state(n, d, seed):
 @pytest.mark.parametrize("cell,n,chunk", [("triangle", (7, 5), 0), ("triangle", (40, 33), 640), ("quadrilateral", (9, 4), 0),
                                           ("tetrahedron", (3, 2, 2), 0), ("hexahedron", (5, 3, 3), 0),
                                           ("hexahedron", (12, 10, 9), 2048)])
-def test_fused_operand_plus_von_mises(ctx, oracle, cell, n, chunk, strain_kernels):
+def test_fused_operand_plus_von_mises(ctx, oracle, cell, n, chunk):
     """dxo_von_mises_field == operand oracle -> von Mises oracle, host arrays (optionally through several pipeline
     chunks whose borders fall inside wave groups) and device pointers."""
     import torch
