@@ -65,7 +65,7 @@ PLACEMENT_MAX = 32
 class PlacementInfo(C.Structure):
     """dxo_placement_info — what dxo_output_alloc's calibration saw."""
     _fields_ = [("mode", C.c_int32), ("candidates", C.c_int32), ("chosen", C.c_int32), ("_pad", C.c_int32),
-                ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double)]
+                ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double), ("chosen_GBps", C.c_double)]
 
 
 class DeviceInfo(C.Structure):
@@ -469,7 +469,7 @@ class Context:
         return {"mode": {0: "hipMalloc", 2: "hipMalloc_candidates"}[info.mode],
                 "candidates": info.candidates, "chosen": info.chosen,
                 "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
-                "calibration_ms": info.calibration_ms}
+                "chosen_GBps": round(info.chosen_GBps, 1), "calibration_ms": info.calibration_ms}
 
     def output_tensors(self, sizes, dtype=None):
         """Flat torch CUDA tensors of `sizes` elements each (fp64 unless dtype is given), carved from ONE

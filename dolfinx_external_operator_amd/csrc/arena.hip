@@ -24,6 +24,7 @@
 // Option "placement_mode": 2 = hipMalloc candidates as above (default), 0 = plain hipMalloc. Blocks below
 // "placement_min_bytes" (1 GiB) are plain hipMalloc: a working set that small lives in the 256 MB Infinity Cache /
 // L2 and has no placement class.
+#include <algorithm>
 #include <chrono>
 
 #include "dxo_common.h"
@@ -96,10 +97,49 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStre
         for (void* p : cand) (void)hipFree(p);
         return false;
     }
-    for (int k = 0; k < (int)cand.size(); ++k)
-        if (k != best) (void)hipFree(cand[k]);
-    blk.ptr = cand[best];
+    // second look: while many candidates coexist every rate reads low (fast ones ~6.0 instead of ~6.9 TB/s) and on a
+    // box whose candidates all look alike (4.9-5.1) the first ranking is noise. Keep the three best, free the rest,
+    // and time those three again; the winner of THAT round is kept.
+    std::vector<int> order(cand.size());
+    for (size_t k = 0; k < cand.size(); ++k) order[k] = (int)k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return blk.info.probe_GBps[a] > blk.info.probe_GBps[b]; });
+    size_t keep = order.size() < 3 ? order.size() : 3;
+    (void)hipStreamSynchronize(s);
+    for (size_t r = keep; r < order.size(); ++r) {
+        (void)hipFree(cand[(size_t)order[r]]);
+        cand[(size_t)order[r]] = nullptr;
+    }
+    double final_bw = blk.info.probe_GBps[best];
+    if (!good && order.size() > 1) {
+        // one more allocation made now that the others are gone joins the final round: on boxes whose candidates all
+        // read alike, a block allocated on its own was 3-10 % faster than the pick of the crowd (three runs)
+        void* late = nullptr;
+        if ((int)cand.size() < DXO_PLACEMENT_MAX && hipMalloc(&late, bytes) == hipSuccess) {
+            launch_sweep(c, late, bytes, s);
+            launch_sweep(c, late, bytes, s);
+            (void)hipStreamSynchronize(s);
+            order.insert(order.begin() + (long)keep, (int)cand.size());
+            cand.push_back(late);
+            blk.info.probe_GBps[cand.size() - 1] = 0.0;
+            ++keep;
+        } else {
+            (void)hipGetLastError();
+        }
+        best = -1;
+        final_bw = -1.0;
+        for (size_t r = 0; r < keep; ++r) {
+            const int k = order[r];
+            const double bw = probe_range(c, cand[(size_t)k], bytes, s, 6);
+            if (k == (int)cand.size() - 1 && late) { blk.info.probe_GBps[k] = bw; blk.info.candidates = (int)cand.size(); }
+            if (bw > final_bw) { final_bw = bw; best = k; }
+        }
+        if (best < 0) best = order[0];
+    }
+    for (size_t k = 0; k < cand.size(); ++k)
+        if ((int)k != best && cand[k]) (void)hipFree(cand[k]);
+    blk.ptr = cand[(size_t)best];
     blk.bytes = bytes;
+    blk.info.chosen_GBps = final_bw;
     blk.info.mode = 2;
     blk.info.chosen = best;
     return true;

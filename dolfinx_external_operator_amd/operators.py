@@ -43,10 +43,24 @@ def _is_device_tensor(a) -> bool:
 
 
 def _as_f64_host(a, what: str) -> np.ndarray:
+    """Host operand / state as contiguous fp64. The kernels compute in fp64 (the reference's default
+    PETSc.ScalarType); float32 arrays — the reference's dispatcher is dtype-generic and its tests also run float32,
+    test/test_multiaction.py:15-23 — are widened here and the results narrowed back by `_like` (at least the
+    reference's precision). Complex and integer operands have no meaning for these constitutive kernels: TypeError."""
     arr = np.asarray(a)
+    if arr.dtype == np.float32:
+        return np.ascontiguousarray(arr, dtype=np.float64)
     if arr.dtype != np.float64:
-        raise TypeError(f"{what}: the HIP kernels are fp64 (reference default PETSc.ScalarType); got {arr.dtype}")
+        raise TypeError(f"{what}: the HIP kernels take float64 (or float32, widened) arrays; got {arr.dtype}")
     return np.ascontiguousarray(arr)
+
+
+def _like(operand, *arrays):
+    """Results in the dtype of the operand array (the reference's kernels return what NumPy / torch promotion gives:
+    float32 in, float32 out; demo_hyperelasticity.py:452-456 'dtype follows the input')."""
+    if getattr(operand, "dtype", None) == np.float32:
+        return tuple(a.astype(np.float32) for a in arrays)
+    return arrays
 
 
 class _Outputs:
@@ -177,7 +191,7 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
                     c.set_option("vm_host_tangent", 0)
         else:
             c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
-        return C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1)   # :352
+        return _like(deps, C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1))   # :352
 
     def sigma_external(derivatives):
         if derivatives == (1,):
@@ -306,6 +320,8 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
         sizes = (n * gdim, n * gdim, n * gdim * gdim)
         outs = [np.empty(sz) if (fuse_by_identity or k == which) else None for k, sz in enumerate(sizes)]
         c.heat(A, B, gdim, n, MEM_HOST, T_, sig_, outs[0], outs[1], outs[2])
+        if getattr(T, "dtype", None) == np.float32:
+            outs = [o if o is None else o.astype(np.float32) for o in outs]
         if fuse_by_identity:
             holder["keep"] = (T, sigma)
             holder["val"] = outs
@@ -381,7 +397,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             unique_iters, counts = np.unique(niter, return_counts=True)   # :584
             on_summary({"unique_iters": unique_iters, "counts": counts, "max_yielding": float(np.max(yielding)),
                         "max_norm_res": float(np.nanmax(norm_res)) if np.isfinite(norm_res).any() else float("nan")})
-        return C_tang.reshape(-1), sigma.reshape(-1)                    # :593
+        return _like(deps, C_tang.reshape(-1), sigma.reshape(-1))     # :593
 
     def sigma_external(derivatives):
         if derivatives == (1,):
@@ -466,7 +482,7 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
         cx.icnn_eval(model, prec, n, MEM_HOST, F, dP, P)
-        return dP.reshape(-1), P.reshape(-1)                 # :456
+        return _like(Fvals, dP.reshape(-1), P.reshape(-1))   # :456
 
     def P_external(derivatives):
         if derivatives == (1,):
@@ -500,7 +516,7 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
         holder["ctx"].isihara(prm, n, MEM_HOST, F, dP, P)
-        return dP.reshape(-1), P.reshape(-1)
+        return _like(Fvals, dP.reshape(-1), P.reshape(-1))
 
     def P_external(derivatives):
         if derivatives == (1,):

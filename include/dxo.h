@@ -142,6 +142,8 @@ typedef struct dxo_placement_info {
     int32_t _pad;
     double probe_GBps[DXO_PLACEMENT_MAX];   /* streaming-write rate of each candidate                              */
     double calibration_ms;                  /* wall time of the whole call                                         */
+    double chosen_GBps;                     /* rate of the block kept, re-timed after all but the three best
+                                               candidates were freed (rates read low while many coexist)           */
 } dxo_placement_info;
 int dxo_output_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_output_free(dxo_ctx* ctx, void* ptr);

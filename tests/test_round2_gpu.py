@@ -62,9 +62,9 @@ def test_output_arena_calibrates_and_kernel_results_are_unchanged(ctx, oracle, m
             ctx.set_option(k, v)
     info = C.dxo_block.info
     assert info["mode"] == "hipMalloc_candidates", info
-    assert 1 <= info["candidates"] <= 4 and 0 <= info["chosen"] < info["candidates"]
+    assert 1 <= info["candidates"] <= 5 and 0 <= info["chosen"] < info["candidates"]   # 4 + the late lone allocation
     assert all(b > 1000.0 for b in info["probe_GBps"]), info             # every candidate was really timed (GB/s)
-    assert info["probe_GBps"][info["chosen"]] == max(info["probe_GBps"]) or info["probe_GBps"][info["chosen"]] >= 6800
+    assert info["chosen_GBps"] > 1000.0                                   # the final round's rate of the block kept
     g = torch.Generator(device="cuda:0").manual_seed(5)
     deps = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 3e-3, generator=g)
     sigma_n = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 100.0, generator=g)
@@ -325,3 +325,27 @@ def test_mgpu_world_of_one_matches_the_single_gpu_call(ctx, oracle, form):
             g.von_mises(PRM, d, n, GATHER_FULL, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s], [])      # a pointer list without an entry for the device
     finally:
         g.close()
+
+
+# ------------------------------------------------------------------------------------------------- float32 operands
+def test_float32_operands_are_widened_and_results_narrowed(ctx, oracle, golden):
+    """The reference's dispatcher is dtype-generic (test/test_multiaction.py:15-23 also runs float32); the kernels
+    compute in fp64, float32 operands come back as float32 (demo_hyperelasticity.py:452-456: dtype follows the input)."""
+    nc, nq, d = 64, 3, 4
+    deps, sigma_n, p = vm_inputs(nc * nq, d, seed=12)
+    ext = make_von_mises(sigma_n.astype(np.float32), p.astype(np.float32), ctx=ctx)
+    C, s, dp = ext((1,))(deps.astype(np.float32).reshape(nc, nq, d))
+    assert C.dtype == s.dtype == dp.dtype == np.float32
+    Co, so, dpo = oracle.von_mises(deps.astype(np.float32).astype(np.float64), sigma_n.astype(np.float32).astype(np.float64),
+                                   p.astype(np.float32).astype(np.float64))
+    assert_close_scaled(C, Co.astype(np.float32), 1e-6, "C_tang f32")
+    assert_close_scaled(s, so.astype(np.float32), 1e-6, "sigma f32")
+    g = golden("icnn_isihara.npz")
+    w = golden("icnn_isihara_weights.npz")
+    icnn = make_icnn({k: w[k] for k in w.files}, ctx=ctx)
+    dP, P = icnn((1,))(g["F"].astype(np.float32).reshape(-1, 2, 2))
+    assert dP.dtype == np.float32
+    assert np.max(np.abs(dP - g["dP_f32in"].reshape(-1))) <= 5e-6 * np.max(np.abs(g["dP_f32in"]))
+    assert np.max(np.abs(P - g["P_f32in"].reshape(-1))) <= 5e-6 * np.max(np.abs(g["P_f32in"]))
+    with pytest.raises(TypeError):
+        ext((1,))(deps.astype(np.complex128).reshape(nc, nq, d))
