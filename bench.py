@@ -202,6 +202,10 @@ def main():
                          "(dxo_vm_expand_tangent); compact_pipelined: the same in 4 pieces, rebuild overlapped with the "
                          "link traffic; full: RCCL all-gather of (C_tang, sigma, dp). The other modes are timed too "
                          "and reported under config.gather_modes.")
+    ap.add_argument("--dry-collective", action="store_true",
+                    help="logic check of the N > 1 path on a box with ONE GPU: all ranks share device 0 and the collectives "
+                         "run over gloo instead of RCCL (RCCL refuses two ranks on one device). The line it prints is marked "
+                         "`dry_collective` and is not a measurement.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
@@ -233,7 +237,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     n_dev = torch.cuda.device_count()   # counting devices does not initialise HIP
-    if n_dev < max(world, 1) or local_rank >= n_dev:
+    if args.dry_collective:
+        local_rank = 0
+    if n_dev < (1 if args.dry_collective else max(world, 1)) or local_rank >= n_dev:
         raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} needs {world} MI355X on this node, {n_dev} visible. "
                          "There is no CPU path to benchmark (only the cpu_baseline leg uses the oracle).")
     torch.cuda.set_device(local_rank)
@@ -243,7 +249,10 @@ def main():
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if args.dry_collective:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
     from dolfinx_external_operator_amd._build import build_library
@@ -451,6 +460,8 @@ def main():
             "value": value, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            **({"dry_collective": "NOT A MEASUREMENT: all ranks on one GPU, gloo collectives (logic check of the N > 1 path)"}
+               if args.dry_collective else {}),
             "config": {
                 "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
                             f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"

@@ -97,18 +97,19 @@ def all_gather_flat(local, group=None):
 _INTO_TENSOR_OK: dict[str, bool] = {}
 
 
-def _backend_has_into_tensor(group=None) -> bool:
-    """Does the group's backend implement all_gather_into_tensor? Decided ONCE per backend with a one-element
+def _backend_has_into_tensor(group=None, device=None) -> bool:
+    """Does the group's backend implement all_gather_into_tensor for tensors on `device`? Decided ONCE per
+    (backend, device type) with a one-element
     collective (every rank runs it at its first gather, so the ranks stay in step); after that a RuntimeError
     out of a gather is a real failure and propagates instead of being retried through another code path."""
     import torch
     import torch.distributed as dist
 
-    backend = str(dist.get_backend(group))
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    backend = f"{dist.get_backend(group)}/{dev.type}"
     ok = _INTO_TENSOR_OK.get(backend)
     if ok is None:
         world = dist.get_world_size(group)
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         probe_in = torch.zeros(1, dtype=torch.float64, device=dev)
         probe_out = torch.zeros(world, dtype=torch.float64, device=dev)
         try:
@@ -127,7 +128,7 @@ def all_gather_flat_into(out, local, group=None, async_op: bool = False):
     world = dist.get_world_size(group)
     if out.numel() != world * local.numel():
         raise ValueError(f"gather buffer has {out.numel()} elements, need {world * local.numel()}")
-    if _backend_has_into_tensor(group):
+    if _backend_has_into_tensor(group, local.device):
         return dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
     chunks = list(out.view(world, local.numel()).unbind(0))
     return dist.all_gather(chunks, local, group=group, async_op=async_op)

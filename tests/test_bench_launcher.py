@@ -66,3 +66,23 @@ def test_two_rank_launch_fails_for_lack_of_devices_not_of_a_launcher():
     assert "needs 2 MI355X on this node" in res.stderr, res.stderr[-2000:]
     assert "torch.distributed.run --nproc-per-node" not in res.stderr.split("bench: launching")[0]   # no "wrap me in torchrun" message
     assert res.stdout.strip() == ""
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_path_logic_on_one_gpu():
+    """The N > 1 control flow of bench.py (cell-block offsets into full-length arena buffers, the three gather modes,
+    the remote-tangent rebuild and its finiteness / symmetry check, max-over-ranks timing) with two ranks sharing the
+    one GPU of the test box and gloo collectives (`--dry-collective`): RCCL itself needs one device per rank and is
+    exercised with a world of one (tests/test_round2_gpu.py) and by the driver's 8-GPU run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "2", "--dry-collective", "--steps", "2",
+                          "--warmup", "1", "--nqp", "500000", "--no-probe"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "dry_collective" in line and line["config"]["rccl_ranks"] == 2
+    assert set(line["config"]["gather_modes"]) == {"compact", "compact_pipelined", "full"}
+    assert line["config"]["points_per_gpu"] % 128 == 0 and line["value"] > 0
