@@ -108,6 +108,8 @@ _SIGNATURES = {
     "dxo_mesh_destroy": (C.c_int, [_P, _P]),
     "dxo_operand_value_size": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dxo_eval_operand": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
+    "dxo_mesh_set_facet_tables": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "dxo_eval_operand_facets": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_von_mises_field": (C.c_int, [_P, C.POINTER(VmParams), _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "dxo_assign": (C.c_int, [_P, C.POINTER(AssignDesc), _P, _P, _P, C.c_int64]),
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),

@@ -223,6 +223,8 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_u) (void)hipFree(m->d_u);
     if (m->d_cells) (void)hipFree(m->d_cells);
     if (m->d_out) (void)hipFree(m->d_out);
+    if (m->d_facet_tab) (void)hipFree(m->d_facet_tab);
+    if (m->d_ents) (void)hipFree(m->d_ents);
     if (m->d_wq) (void)hipFree(m->d_wq);
     if (m->d_node_ptr) (void)hipFree(m->d_node_ptr);
     if (m->d_node_ent) (void)hipFree(m->d_node_ent);

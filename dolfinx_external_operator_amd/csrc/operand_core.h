@@ -353,6 +353,11 @@ struct dxo_mesh {
     double* d_out = nullptr;    // staging for host-resident outputs
     size_t out_cap = 0;
     double* d_wq = nullptr;     // quadrature weights (dxo_mesh_set_weights), needed by the adjoint kernels only
+    // codim-1 evaluation (dxo_mesh_set_facet_tables / dxo_eval_operand_facets): tables per LOCAL facet of the cell
+    int n_local_facets = 0, nq_facet = 0;
+    double* d_facet_tab = nullptr;      // phi_f [nf][nqf][ndofs] | dphi_f [nf][nqf][ndofs][G] | dpsi_f [nf][nqf][ngeom][G]
+    int32_t* d_ents = nullptr;          // staging for host-resident (cell, local facet) lists
+    size_t ents_cap = 0;
     // adjoint kernels, two-pass form: element vectors + the transposed dofmap (node -> its (cell, local node) entries)
     std::vector<int32_t> h_dofmap;     // host copy kept for building the transpose on first use
     int64_t* d_node_ptr = nullptr;     // [num_field_nodes + 1]

@@ -120,6 +120,38 @@ class DeviceMesh:
         self.ctx.check(rc, "dxo_eval_operand")
         return out
 
+    def set_facet_tables(self, phi, dphi, dpsi) -> None:
+        """Tables for codim-1 entities, one set per LOCAL facet of the cell, tabulated at the facet quadrature points
+        mapped into the reference cell (what Expression.eval does with `(cell, local_facet)` entities,
+        external_operator.py:402; test/test_codim_external_operator.py:76-84): phi (nf, nq, ndofs),
+        dphi (nf, nq, ndofs, gdim), dpsi (nf, nq, ngeom, gdim)."""
+        phi = np.ascontiguousarray(phi, dtype=np.float64)
+        dphi = np.ascontiguousarray(dphi, dtype=np.float64)
+        dpsi = np.ascontiguousarray(dpsi, dtype=np.float64)
+        if phi.ndim != 3 or dphi.shape != phi.shape + (self.gdim,) or dpsi.ndim != 4 or dpsi.shape[:2] != phi.shape[:2] \
+                or dpsi.shape[3] != self.gdim:
+            raise ValueError("facet tables: phi (nf, nq, ndofs), dphi (nf, nq, ndofs, gdim), dpsi (nf, nq, ngeom, gdim)")
+        rc = self.ctx.lib.dxo_mesh_set_facet_tables(self.ctx._h, self._h, phi.shape[0], phi.shape[1], phi.ctypes.data,
+                                                    dphi.ctypes.data, dpsi.ctypes.data)
+        self.ctx.check(rc, "dxo_mesh_set_facet_tables")
+        self.nq_facet = phi.shape[1]
+
+    def evaluate_facets(self, kind: str, bs: int, u, entities, out=None) -> np.ndarray:
+        """Host arrays in, host array (n_entities, nq_facet, value_size) out; entities (n, 2) = (cell, local facet)."""
+        D = self.value_size(kind, bs)
+        u = np.ascontiguousarray(_state(u), dtype=np.float64).reshape(-1)
+        if u.size != self.num_field_nodes * bs:
+            raise ValueError(f"field vector has {u.size} entries, expected {self.num_field_nodes * bs}")
+        ents = np.ascontiguousarray(entities, dtype=np.int32)
+        if ents.ndim != 2 or ents.shape[1] != 2:
+            raise ValueError("codim-1 entities must have shape (n, 2): (cell, local facet)")
+        if out is None:
+            out = np.empty((ents.shape[0], getattr(self, "nq_facet", 0), D))
+        rc = self.ctx.lib.dxo_eval_operand_facets(self.ctx._h, self._h, KINDS[kind], int(bs), MEM_HOST, u.ctypes.data,
+                                                  ents.ctypes.data, ents.shape[0], out.ctypes.data)
+        self.ctx.check(rc, "dxo_eval_operand_facets")
+        return out
+
     def evaluate_device(self, kind: str, bs: int, u_ptr: int, n_cells: int, out_ptr: int, cells_ptr: int | None = None) -> None:
         """Raw device pointers, asynchronous on the context's stream."""
         rc = self.ctx.lib.dxo_eval_operand(self.ctx._h, self._h, KINDS[kind], int(bs), MEM_DEVICE, C.c_void_p(u_ptr),
@@ -199,7 +231,10 @@ class DeviceOperand:
                                                and np.array_equal(entities, np.arange(self.mesh.num_cells)))):
             u = np.array(_state(self.field), dtype=np.float64).reshape(-1)      # snapshot, like Expression.eval's result
             return LazyOperand(self.mesh, self.kind, self.bs, u)
-        out = self.mesh.evaluate(self.kind, self.bs, self.field, entities)
+        if entities is not None and np.ndim(entities) == 2:
+            out = self.mesh.evaluate_facets(self.kind, self.bs, self.field, entities)    # (cell, local facet) pairs
+        else:
+            out = self.mesh.evaluate(self.kind, self.bs, self.field, entities)
         g = self.mesh.gdim
         if self.kind == "F":
             return out.reshape(out.shape[0], out.shape[1], g, g)

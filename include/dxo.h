@@ -304,6 +304,19 @@ int dxo_operand_value_size(int gdim, int bs, int kind);
 int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, const double* u,
                      const int32_t* cells, int64_t n_cells, double* out);
 
+/* Codim-1 entities. evaluate_operands hands its `entities` to Expression.eval unchanged (external_operator.py:340, 402);
+ * for an operator on a facet sub-mesh they are (cell, local_facet) pairs (test/test_codim_external_operator.py:76-84, 111)
+ * and the points are quadrature points of the reference FACET mapped into the reference cell per local facet.
+ * dxo_mesh_set_facet_tables uploads the tables tabulated at those mapped points, one set per local facet:
+ *   phi [n_local_facets][nq][ndofs], dphi [n_local_facets][nq][ndofs][gdim], dpsi [n_local_facets][nq][ngeom][gdim]
+ * (host pointers). dxo_eval_operand_facets: entities [n_entities][2] int32 = (cell, local facet); out
+ * [n_entities][nq][value_size]; the gradient is the full physical gradient at the facet points. mem applies to u,
+ * entities and out alike; with DXO_MEM_DEVICE the entity list is not range-checked. */
+int dxo_mesh_set_facet_tables(dxo_ctx* ctx, dxo_mesh* mesh, int n_local_facets, int nq, const double* phi,
+                              const double* dphi, const double* dpsi);
+int dxo_eval_operand_facets(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, const double* u,
+                            const int32_t* entities, int64_t n_entities, double* out);
+
 /* Operand evaluation FUSED in front of the von Mises return map: one launch for the demo's
  * evaluate_operands + evaluate_external_operators pair (demo_plasticity_von_mises.py:445-456) when the operand is
  * eps(u) of a vector Lagrange field on `mesh` (gdim 2 -> d = 4, gdim 3 -> d = 6). u: num_field_nodes*gdim doubles;

@@ -104,3 +104,21 @@ def tangent_apply(C_tang, v, weights, dofmap, geom_dofmap, x, phi, dphi, dpsi, n
     d = e.shape[2]
     t = np.einsum("cqrs,cqs->cqr", np.asarray(C_tang).reshape(e.shape[0], e.shape[1], d, d), e)
     return operand_adjoint(EPS_MANDEL, gdim, t, weights, dofmap, geom_dofmap, x, phi, dphi, dpsi, n_nodes)
+
+
+def eval_operand_facets(kind, bs, u, dofmap, geom_dofmap, x, phi_f, dphi_f, dpsi_f, entities):
+    """Codim-1 entities: (cell, local_facet) pairs as evaluate_operands hands them to Expression.eval
+    (src/dolfinx_external_operator/external_operator.py:340, 402; test/test_codim_external_operator.py:76-84).
+    Tables per local facet: phi_f (nf, nq, ndofs), dphi_f (nf, nq, ndofs, G), dpsi_f (nf, nq, ngeom, G), tabulated at the
+    facet quadrature points mapped into the reference cell. -> (n_entities, nq, value_size)."""
+    entities = np.asarray(entities, dtype=np.int64).reshape(-1, 2)
+    out = None
+    for f in np.unique(entities[:, 1]):
+        sel = np.flatnonzero(entities[:, 1] == f)
+        part = eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi_f[f], dphi_f[f], dpsi_f[f], entities[sel, 0])
+        if out is None:
+            out = np.empty((entities.shape[0],) + part.shape[1:])
+        out[sel] = part
+    if out is None:
+        raise ValueError("empty entity list: value size unknown")
+    return out

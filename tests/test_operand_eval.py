@@ -346,3 +346,76 @@ def test_value_and_gradient_in_one_pass_and_fused_heat(ctx, oracle, cell, n):
         assert Tv._value is None and sv._value is None               # neither operand array was ever materialised
     finally:
         dm.close()
+
+
+# ------------------------------------------------------------------------------------------------ codim-1 entities
+def _facet_case(cell, degree, seed):
+    from tools.synthetic import FACETS, facet_physical_points, facet_tables
+
+    m = structured_mesh(cell, CELLS[cell], degree, distort=0.0 if degree == 2 and cell in ("quadrilateral", "hexahedron") else 0.25, seed=seed)
+    phi_f, dphi_f, dpsi_f, ref_pts = facet_tables(m)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = 3 * m.num_cells
+    ents = np.stack([rng.integers(0, m.num_cells, n), rng.integers(0, len(FACETS[cell]), n)], axis=1).astype(np.int32)
+    return m, (phi_f, dphi_f, dpsi_f), ents, facet_physical_points(m, ents, ref_pts)
+
+
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_oracle_on_cell_facet_pairs(cell, degree):
+    """(cell, local_facet) entities as evaluate_operands hands them to Expression.eval (external_operator.py:340, 402;
+    test/test_codim_external_operator.py:76-84): polynomial fields of the element's degree are reproduced at the facet
+    points, with the FULL physical gradient. (Degree 2 on tensor cells needs undistorted cells to be exact.)"""
+    from oracle.operand_oracle import eval_operand_facets
+
+    m, (phi_f, dphi_f, dpsi_f), ents, xq = _facet_case(cell, degree, seed=5)
+    for bs in (1, m.gdim):
+        u, grad = poly_field(m.gdim, bs, degree, seed=20 + bs)
+        uvec = u(m.node_x).reshape(-1)
+        for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+            got = eval_operand_facets(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, phi_f, dphi_f, dpsi_f, ents)
+            want = expected(kind, grad(xq), u(xq))
+            assert got.shape == want.shape == (len(ents), phi_f.shape[1], want.shape[2])
+            assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", list(CELLS))
+@pytest.mark.parametrize("degree", [1, 2])
+def test_hip_on_cell_facet_pairs(ctx, cell, degree):
+    from dolfinx_external_operator_amd import DeviceMesh, Operand, QuadratureExternalOperator, evaluate_operands
+    from oracle.operand_oracle import eval_operand_facets
+
+    m, tabs, ents, xq = _facet_case(cell, degree, seed=6)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        with pytest.raises(ValueError, match="dxo_mesh_set_facet_tables"):
+            dm.evaluate_facets("value", 1, np.zeros(m.node_x.shape[0]), ents)
+        dm.set_facet_tables(*tabs)
+        rng = np.random.Generator(np.random.PCG64(3))
+        for bs in (1, m.gdim):
+            u, grad = poly_field(m.gdim, bs, degree, seed=30 + bs)
+            uvec = u(m.node_x).reshape(-1)
+            rough = rng.normal(size=uvec.size)
+            for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+                got = dm.evaluate_facets(kind, bs, uvec, ents)
+                want = expected(kind, grad(xq), u(xq))
+                assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
+                ref = eval_operand_facets(KIND_ID[kind], bs, rough, m.dofmap, m.geom_dofmap, m.x, *tabs, ents)
+                got = dm.evaluate_facets(kind, bs, rough, ents)
+                assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (cell, degree, bs, kind)
+        # through the dispatcher: a 2-D entity array reaches the operand's eval unchanged and comes back (n, nq_f, ...)
+        field = rng.normal(size=m.node_x.shape[0])
+        operand = dm.operand("value", field, bs=1)
+        op = QuadratureExternalOperator(operand, num_cells=len(ents), num_points=tabs[0].shape[1], value_shape=(),
+                                        external_function=lambda d: (lambda x: np.cos(x).reshape(-1)))
+        table = evaluate_operands([op], entities=ents)
+        ref = eval_operand_facets(VALUE, 1, field, m.dofmap, m.geom_dofmap, m.x, *tabs, ents)[..., 0]
+        assert table[operand].shape == ref.shape and np.abs(table[operand] - ref).max() <= 1e-13 * np.abs(ref).max()
+        bad = ents.copy()
+        bad[0, 1] = 7
+        with pytest.raises(ValueError, match="entity outside"):
+            dm.evaluate_facets("value", 1, field, bad)
+        assert dm.evaluate_facets("value", 1, field, np.empty((0, 2), dtype=np.int32)).shape == (0, tabs[0].shape[1], 1)
+    finally:
+        dm.close()

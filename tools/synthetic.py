@@ -182,3 +182,63 @@ def structured_mesh(cell: str, n: tuple[int, ...], degree: int = 2, distort: flo
     node_x = np.zeros((int(np.prod(fshape)), gdim))
     node_x[dm.reshape(-1)] = np.einsum("av,cvj->caj", psi_nodes, x[geom]).reshape(-1, gdim)
     return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi, weights)
+
+
+# ---------------------------------------------------------------------------------------------- codim-1 (facets)
+# Local facets of the reference cells as lists of local VERTEX indices (vertices in this module's lattice order:
+# triangle (0,0),(1,0),(0,1); quadrilateral (0,0),(1,0),(0,1),(1,1); tetrahedron origin, e_x, e_y, e_z; hexahedron x
+# fastest). Simplices: facet i is opposite vertex i (the DOLFINx convention); tensor cells: one facet per side.
+FACETS = {
+    "triangle": [(1, 2), (0, 2), (0, 1)],
+    "quadrilateral": [(0, 1), (0, 2), (1, 3), (2, 3)],
+    "tetrahedron": [(1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2)],
+    "hexahedron": [(0, 1, 2, 3), (0, 1, 4, 5), (0, 2, 4, 6), (1, 3, 5, 7), (2, 3, 6, 7), (4, 5, 6, 7)],
+}
+_FACET_CELL = {"triangle": "interval", "quadrilateral": "interval", "tetrahedron": "triangle", "hexahedron": "quadrilateral"}
+
+
+def facet_quadrature_degree2(cell: str):
+    """Reference points and weights on the facet's own reference cell (interval [0,1], triangle, unit square)."""
+    fc = _FACET_CELL[cell]
+    if fc == "interval":
+        g = 0.5 - 0.5 / np.sqrt(3.0)
+        return np.array([[g], [1.0 - g]]), np.full(2, 0.5)
+    return quadrature_degree2(fc)
+
+
+def facet_points_in_cell(cell: str, facet_points: np.ndarray) -> np.ndarray:
+    """(n_local_facets, nq, tdim): the facet quadrature points mapped into the reference CELL, per local facet — what
+    DOLFINx does before tabulating an Expression on (cell, local_facet) entities."""
+    verts = LagrangeElement(cell, 1).nodes                     # reference vertices, lattice order
+    out = []
+    for f in FACETS[cell]:
+        v = verts[list(f)]
+        s = np.asarray(facet_points)
+        if len(f) == 2:                                        # interval
+            pts = v[0] + s[:, :1] * (v[1] - v[0])
+        elif len(f) == 3:                                      # triangle: affine
+            pts = v[0] + s[:, :1] * (v[1] - v[0]) + s[:, 1:2] * (v[2] - v[0])
+        else:                                                  # quadrilateral face: bilinear, lattice order (x fastest)
+            a, b = s[:, :1], s[:, 1:2]
+            pts = (1 - a) * (1 - b) * v[0] + a * (1 - b) * v[1] + (1 - a) * b * v[2] + a * b * v[3]
+        out.append(pts)
+    return np.array(out)
+
+
+def facet_tables(mesh: "SyntheticMesh"):
+    """phi_f (nf, nq, ndofs), dphi_f (nf, nq, ndofs, gdim), dpsi_f (nf, nq, ngeom, gdim), ref points (nf, nq, gdim)."""
+    fpts, _ = facet_quadrature_degree2(mesh.cell)
+    pts = facet_points_in_cell(mesh.cell, fpts)
+    fe, geo = LagrangeElement(mesh.cell, mesh.degree), LagrangeElement(mesh.cell, 1)
+    tabs = [fe.tabulate(p) for p in pts]
+    return (np.array([t[0] for t in tabs]), np.array([t[1] for t in tabs]), np.array([geo.tabulate(p)[1] for p in pts]), pts)
+
+
+def facet_physical_points(mesh: "SyntheticMesh", entities: np.ndarray, ref_points: np.ndarray) -> np.ndarray:
+    """(n_entities, nq, gdim) physical positions of the facet points of the (cell, local_facet) entities."""
+    geo = LagrangeElement(mesh.cell, 1)
+    out = np.empty((len(entities), ref_points.shape[1], mesh.gdim))
+    for i, (c, f) in enumerate(np.asarray(entities)):
+        psi, _ = geo.tabulate(ref_points[f])
+        out[i] = psi @ mesh.x[mesh.geom_dofmap[c]]
+    return out
