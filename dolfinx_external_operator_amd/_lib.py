@@ -175,7 +175,10 @@ def load_library(path: str | pathlib.Path | None = None) -> C.CDLL:
     with _lib_lock:
         if _lib is not None and path is None:
             return _lib
-        p = pathlib.Path(path) if path is not None else LIB_PATH
+        import os
+
+        override = os.environ.get("DXO_HIP_LIBRARY")   # experiments: another build of the same ABI (scripts/exp)
+        p = pathlib.Path(path) if path is not None else (pathlib.Path(override) if override else LIB_PATH)
         if not p.exists():
             raise DxoError(
                 f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -248,11 +248,16 @@ __device__ __forceinline__ void pipe_commit(const OperandDev& m, const OperandPi
 
 // ---- per-lane gradient from the gathered data -> `o` (D values of this lane's point). Returns false for lanes
 // without a point. Shared by the standalone kernel and by kernels that consume the operand in place.
-template <int G, int BS, int KIND>
+#ifndef DXO_OP_UNROLL
+#define DXO_OP_UNROLL 3
+#endif
+// ND_CT / NG_CT: nodes / vertices per cell known at compile time (0 = read them from the mesh descriptor): constant
+// trip counts let the compiler address the LDS tables with immediates and pipeline the reads across the whole loop.
+template <int G, int BS, int KIND, int ND_CT = 0, int NG_CT = 0>
 __device__ __forceinline__ bool operand_compute_geo(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
                                                     double (&o)[OperandShape<G, BS, KIND>::D], double (&K)[G][G],
                                                     double& detJ) {
-    const int nd = m.ndofs, ng = m.ngeom;
+    const int nd = ND_CT ? ND_CT : m.ndofs, ng = NG_CT ? NG_CT : m.ngeom;
     const OperandLayout<G> L(m);
     const int su = op_odd(nd * BS);
     double* U = W;
@@ -286,8 +291,10 @@ __device__ __forceinline__ bool operand_compute_geo(const OperandDev& m, const d
             for (int k = 0; k < G; ++k) gref[i][k] = 0.0;
         }
         const double* Uc = U + c * su;
-        // partial unroll: batches the LDS reads of three nodes so their latency overlaps the FMAs of the previous ones
-#pragma unroll 3
+        // unrolled (fully when the node count is a compile-time constant, else by three): batches the LDS reads of several
+        // nodes so their latency overlaps the FMAs of the previous ones. Measured on vm_field<3>, Q2 hexahedra, 10^7 points
+        // (scripts/exp/vmfield_ab.py): run-time count x3 1.026 ms, compile-time x3 1.002, x9 1.001, x27 0.973.
+#pragma unroll(ND_CT ? ND_CT : DXO_OP_UNROLL)
         for (int a = 0; a < nd; ++a) {
             double ua[BS];
 #pragma unroll
@@ -322,11 +329,11 @@ __device__ __forceinline__ bool operand_compute_geo(const OperandDev& m, const d
     return active;
 }
 
-template <int G, int BS, int KIND>
+template <int G, int BS, int KIND, int ND_CT = 0, int NG_CT = 0>
 __device__ __forceinline__ bool operand_compute(const OperandDev& m, const double* tab, double* W, int ncell, int lane,
                                                 double (&o)[OperandShape<G, BS, KIND>::D]) {
     double K[G][G], detJ;
-    return operand_compute_geo<G, BS, KIND>(m, tab, W, ncell, lane, o, K, detJ);
+    return operand_compute_geo<G, BS, KIND, ND_CT, NG_CT>(m, tab, W, ncell, lane, o, K, detJ);
 }
 
 // gather + compute for one group (no pipelining): entity lists and elements too large for the register pipeline

@@ -18,8 +18,14 @@
 
 namespace {
 
-template <int G, bool NT>
-__global__ __launch_bounds__(DXO_BLOCK, 3) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
+#ifndef DXO_VMF_WAVES
+#define DXO_VMF_WAVES 3
+#endif
+#ifndef DXO_OP_CT
+#define DXO_OP_CT 1
+#endif
+template <int G, bool NT, int ND_CT = 0, int NG_CT = 0>
+__global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
                                                          const double* __restrict__ p, double* __restrict__ C_tang,
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(DXO_BLOCK, 3) void vm_field(VmConst c, OperandDev m
             pipe_commit<G, G>(m, pf, W, ncell, lane);
             pipe_load_values<G, G>(m, pf, u);
             pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
-            active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, ncell, lane, e);
+            active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e);
         } else {
             active = operand_point<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, e);
         }
@@ -143,6 +149,11 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;
+    if (DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8) {   // Q2 hexahedra: trip counts known at compile time
+        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
+        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
+        return DXO_OK;
+    }
     if (L.mesh->gdim == 2) {
         if (nt) hipLaunchKernelGGL((vm_field<2, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
         else    hipLaunchKernelGGL((vm_field<2, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
