@@ -11,6 +11,9 @@ struct VmConst {
     double sigma_0, H;
     double mu3_H;             // 3 mu + H
     double ratio;             // 3 mu / (3 mu + H)
+    int mark_indeterminate;   // 1: a point with f_elastic == 0 EXACTLY (the reference's 0/0, :318) returns dp = -0.0, so a
+                              // consumer that rebuilds the tangent from (sigma, dp) can reproduce the NaN tangent
+    int _pad;
 };
 
 VmConst make_const(const dxo_vm_params& p) {
@@ -24,6 +27,8 @@ VmConst make_const(const dxo_vm_params& p) {
     c.H = p.H;
     c.mu3_H = 3 * mu + p.H;
     c.ratio = 3 * mu / (3 * mu + p.H);
+    c.mark_indeterminate = 0;
+    c._pad = 0;
     return c;
 }
 
@@ -59,6 +64,7 @@ __device__ __forceinline__ void vm_return_map(const VmConst& c, const double (&d
     }
     a = c.mu3 * (c.ratio - beta);                                // :324
     b = c.mu2 * beta;
+    if (c.mark_indeterminate && f_el == 0.0) dp = -0.0;          // value unchanged (0), sign bit = "n_elas was 0/0"
 }
 
 // Entry (i, j) of C_elas and of `deviatoric` on the Mandel vector (:193-204).

@@ -27,6 +27,9 @@
 //   operations of one wave execute in order; only the compiler must be kept from reordering.
 #include <emmintrin.h>
 
+#include <cmath>
+#include <limits>
+
 #include "dxo_common.h"
 #include "vm_core.h"
 
@@ -140,7 +143,7 @@ struct VmLaunch {
     int d;
     // host half of the DXO_MEM_HOST pipeline with option "vm_host_tangent" = 1 (see vm_host_rebuild)
     const double* h_sigma = nullptr;
-    const double* h_dp = nullptr;
+    double* h_dp = nullptr;
     double* h_C_tang = nullptr;
 };
 
@@ -302,7 +305,7 @@ int vm_expand_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void
 // array is write-only here and larger than any cache. Product code of the host pipeline, not a CPU fallback: the
 // return map itself always runs on the GPU.
 template <int D>
-void vm_host_rebuild_range(const VmConst& c, const double* __restrict__ sigma, const double* __restrict__ dp,
+void vm_host_rebuild_range(const VmConst& c, const double* __restrict__ sigma, double* __restrict__ dp,
                            double* __restrict__ C_tang, int64_t b, int64_t e) {
     const bool stream = (((uintptr_t)C_tang) & 15u) == 0;   // D*D*8 is a multiple of 16: every point block is aligned
     for (int64_t i = b; i < e; ++i) {
@@ -313,7 +316,15 @@ void vm_host_rebuild_range(const VmConst& c, const double* __restrict__ sigma, c
         double ss = 0.0;
         for (int k = 0; k < D; ++k) ss += s[k] * s[k];
         const double sigma_eq = std::sqrt(3.0 / 2.0 * ss);
-        const double dpi = dp[i];
+        double dpi = dp[i];
+        if (dpi == 0.0 && std::signbit(dpi)) {
+            // the kernel's mark for f_elastic == 0 exactly: the reference's n_elas = s/sigma_eq * 0/0 is NaN there (:318)
+            // and with it every tangent entry; dp itself is +0 in the reference
+            dp[i] = 0.0;
+            double* Cn = C_tang + i * (D * D);
+            for (int k = 0; k < D * D; ++k) Cn[k] = std::numeric_limits<double>::quiet_NaN();
+            continue;
+        }
         const double beta = c.mu3 * dpi / (sigma_eq + c.mu3 * dpi);
         const double ind = dpi > 0.0 ? 1.0 : 0.0;
         for (int k = 0; k < D; ++k) nrm[k] = s[k] / sigma_eq * ind;
@@ -336,7 +347,7 @@ int vm_host_rebuild(dxo_ctx* ctx, void* user, int64_t first, int64_t m) {
     const VmLaunch& L = *static_cast<const VmLaunch*>(user);
     const int d = L.d;
     const double* sg = L.h_sigma + first * d;
-    const double* dp = L.h_dp + first;
+    double* dp = L.h_dp + first;
     double* Ct = L.h_C_tang + first * d * d;
     dxo_host_parallel_for(ctx, m, 4096, [&](int64_t b, int64_t e) {
         if (d == 4) vm_host_rebuild_range<4>(L.c, sg, dp, Ct, b, e);
@@ -403,6 +414,7 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
         L.h_sigma = sigma;
         L.h_dp = dp;
         L.h_C_tang = C_tang;
+        L.c.mark_indeterminate = 1;
         std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
         // smaller chunks than the copy mode: the host half of a chunk runs on the calling thread between two enqueues,
         // so the un-overlapped tail of the call is the rebuild of the last DXO_HOST_SLOTS chunks

@@ -120,7 +120,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = False, host_tangent: str = "copy") -> Callable:
+                   reuse_outputs: bool = False, host_tangent: str = "rebuild") -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -130,10 +130,12 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     (outputs are then CUDA tensors on the same device, launched on torch's current stream).
     Results are arrays of their own, as in the reference (page-locked blocks recycled only after the caller has
     dropped them, see _Outputs); reuse_outputs=True opts into ONE set of buffers that the next call overwrites.
-    host_tangent (NumPy operands only): "copy" brings C_tang back over PCIe (344 B/point at d = 6, bit-identical to a
-    device call); "rebuild" moves only (sigma, dp) (56 B/point) and fills the C_tang array on the host from them
-    while later chunks are in flight (ctx option vm_host_tangent, include/dxo.h) — the tangent then agrees with the
-    device tangent to rounding and the reference's 0/0 point at f_el == 0 exactly comes out as C_elas.
+    host_tangent (NumPy operands only): "rebuild" (default) moves only (sigma, dp) back over PCIe (56 instead of 344
+    B/point at d = 6) and fills the C_tang array on the host from them while later chunks are in flight (ctx option
+    vm_host_tangent, include/dxo.h): 2-3x the end-to-end rate; sigma and dp are bit-identical to the device path, the
+    tangent agrees with it to rounding (5e-16 of its scale measured; same 1e-13 parity bound against the reference) and
+    the reference's NaN tangent at f_el == 0 exactly (:318) is reproduced. "copy" brings C_tang itself back
+    (bit-identical to a device call).
     `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors carved from the context's
     placement-calibrated output arena (Context.output_arena); pass them as `out=` to the device call.
     """

@@ -349,3 +349,41 @@ def test_float32_operands_are_widened_and_results_narrowed(ctx, oracle, golden):
     assert np.max(np.abs(P - g["P_f32in"].reshape(-1))) <= 5e-6 * np.max(np.abs(g["P_f32in"]))
     with pytest.raises(TypeError):
         ext((1,))(deps.astype(np.complex128).reshape(nc, nq, d))
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_default_factory_path_reproduces_the_reference_nan_points(ctx, oracle, golden, d):
+    """make_von_mises' default NumPy path rebuilds C_tang on the host from (sigma, dp). The reference has two NaN
+    cases (demo_plasticity_von_mises.py:318-319): sigma_eq == 0 (sigma is NaN too: in the goldens) and f_elastic == 0
+    EXACTLY, where only n_elas = s/sigma_eq * 0/0 and with it the tangent is NaN while sigma and dp = +0 are finite —
+    no trace in (sigma, dp), so the kernel marks such points in the sign bit of dp and the host half writes the NaN
+    tangent. An exact f_elastic == 0 needs H a power of two here: f = (sigma_eq - sigma_0) - H p with p = (sigma_eq -
+    sigma_0) / H is then zero in every evaluation order."""
+    g = golden(f"von_mises_d{d}.npz")
+    deps = g["deps"].reshape(-1, 1, d)
+    ext = make_von_mises(g["sigma_n"].reshape(-1), g["p"].reshape(-1), ctx=ctx)                 # host_tangent="rebuild"
+    C, s, dp = ext((1,))(deps)
+    assert np.isnan(g["C_tang"]).any(), "the golden holds the reference's sigma_eq == 0 point"
+    assert_close_scaled(C, g["C_tang"], 1e-13, "C_tang (rebuilt on the host)")                    # includes the NaN pattern
+    assert_close_scaled(s, g["sigma"], 1e-13, "sigma")
+    assert_close_scaled(dp, g["dp"], 1e-13, "dp")
+    # f_elastic == 0 exactly, between ordinary points
+    n = 300
+    e, sn, p = vm_inputs(n, d, seed=2)
+    x = 300.0 / np.sqrt(1.5)
+    for i in (0, 137, n - 1):
+        e[i] = 0.0
+        sn[i] = 0.0
+        sn[i, 3] = x
+        p[i] = (np.sqrt(1.5 * (x * x)) - SIGMA_0) / 512.0
+    Co, so, dpo = oracle.von_mises(e, sn, p, H=512.0)
+    assert np.isnan(Co[[0, 137, n - 1]]).all() and np.isfinite(so).all() and np.isfinite(dpo).all()
+    outs = {}
+    for mode in ("rebuild", "copy"):
+        f = make_von_mises(sn.reshape(-1), p, ctx=ctx, H=512.0, host_tangent=mode)((1,))
+        outs[mode] = f(e.reshape(n, 1, d))
+        Cg, sg, dpg = outs[mode]
+        assert_close_scaled(Cg, Co, 1e-13, f"C_tang {mode}")                                      # NaN at exactly the three points
+        assert_close_scaled(sg, so, 1e-13, f"sigma {mode}")
+        assert np.array_equal(dpg == 0.0, dpo == 0.0) and not np.signbit(dpg[dpg == 0.0]).any()   # the mark does not leak out
+    assert np.array_equal(outs["rebuild"][1], outs["copy"][1]) and np.array_equal(outs["rebuild"][2], outs["copy"][2])
