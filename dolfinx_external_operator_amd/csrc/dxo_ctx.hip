@@ -224,6 +224,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "placement_good_GBps")) return &c->placement_good_GBps;
     if (!std::strcmp(key, "host_threads")) return &c->host_threads;
     if (!std::strcmp(key, "vm_rebuild_chunk_points")) return &c->vm_rebuild_chunk_points;
+    if (!std::strcmp(key, "vm_rebuild_min_points")) return &c->vm_rebuild_min_points;
     return nullptr;
 }
 

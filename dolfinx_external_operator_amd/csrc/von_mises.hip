@@ -409,7 +409,7 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     }
     const size_t sd = sizeof(double);
     std::vector<dxo_span> in = {{deps, nullptr, d * sd}, {sigma_n, nullptr, d * sd}, {p, nullptr, sd}};
-    if (ctx->vm_host_tangent) {
+    if (ctx->vm_host_tangent && n >= ctx->vm_rebuild_min_points) {
         // (sigma, dp) over PCIe, C_tang rebuilt by the host threads from each chunk as it lands (vm_host_rebuild)
         L.h_sigma = sigma;
         L.h_dp = dp;

@@ -112,7 +112,7 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0
- * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^16), and the "placement_*" options
+ * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^16), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
  * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);

@@ -110,8 +110,9 @@ def test_host_tangent_rebuild_matches_the_device_tangent(ctx, d, n):
     bit-identical to the copy mode; the tangent agrees to rounding (1e-13 of its scale), elastic points exactly."""
     deps, sigma_n, p = vm_inputs(n, d, seed=100 + n % 97 + d)
     outs = {}
-    old_chunk = ctx.get_option("host_chunk_points")
+    old_chunk, old_min = ctx.get_option("host_chunk_points"), ctx.get_option("vm_rebuild_min_points")
     ctx.set_option("host_chunk_points", 65536)     # several chunks at the largest size: the hook runs per chunk
+    ctx.set_option("vm_rebuild_min_points", 0)     # also the small sizes go through the rebuild (default: >= 2^18 points)
     try:
         for mode in (0, 1):
             ctx.set_option("vm_host_tangent", mode)
@@ -122,6 +123,7 @@ def test_host_tangent_rebuild_matches_the_device_tangent(ctx, d, n):
     finally:
         ctx.set_option("vm_host_tangent", 0)
         ctx.set_option("host_chunk_points", old_chunk)
+        ctx.set_option("vm_rebuild_min_points", old_min)
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     assert_close_scaled(outs[1][0], outs[0][0], 1e-13, "host-rebuilt C_tang")
     el = outs[0][2] == 0.0
@@ -133,7 +135,12 @@ def test_host_tangent_rebuild_through_the_factory(ctx, oracle):
     nc, nq, d = 400, 8, 6
     deps, sigma_n, p = vm_inputs(nc * nq, d, seed=9)
     ext = make_von_mises(sigma_n, p, ctx=ctx, host_tangent="rebuild")
-    C, s, dp = ext((1,))(deps.reshape(nc, nq, d))
+    old_min = ctx.get_option("vm_rebuild_min_points")
+    ctx.set_option("vm_rebuild_min_points", 0)
+    try:
+        C, s, dp = ext((1,))(deps.reshape(nc, nq, d))
+    finally:
+        ctx.set_option("vm_rebuild_min_points", old_min)
     assert ctx.get_option("vm_host_tangent") == 0                              # the option does not leak out of the call
     Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
     assert_close_scaled(C, Co, 1e-13, "C_tang")
@@ -379,6 +386,8 @@ def test_default_factory_path_reproduces_the_reference_nan_points(ctx, oracle, g
     Co, so, dpo = oracle.von_mises(e, sn, p, H=512.0)
     assert np.isnan(Co[[0, 137, n - 1]]).all() and np.isfinite(so).all() and np.isfinite(dpo).all()
     outs = {}
+    old_min = ctx.get_option("vm_rebuild_min_points")
+    ctx.set_option("vm_rebuild_min_points", 0)
     for mode in ("rebuild", "copy"):
         f = make_von_mises(sn.reshape(-1), p, ctx=ctx, H=512.0, host_tangent=mode)((1,))
         outs[mode] = f(e.reshape(n, 1, d))
@@ -386,4 +395,5 @@ def test_default_factory_path_reproduces_the_reference_nan_points(ctx, oracle, g
         assert_close_scaled(Cg, Co, 1e-13, f"C_tang {mode}")                                      # NaN at exactly the three points
         assert_close_scaled(sg, so, 1e-13, f"sigma {mode}")
         assert np.array_equal(dpg == 0.0, dpo == 0.0) and not np.signbit(dpg[dpg == 0.0]).any()   # the mark does not leak out
+    ctx.set_option("vm_rebuild_min_points", old_min)
     assert np.array_equal(outs["rebuild"][1], outs["copy"][1]) and np.array_equal(outs["rebuild"][2], outs["copy"][2])
