@@ -157,6 +157,60 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
     return out
 
 
+def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 20, steps=5):
+    """After the result line is out: the same split + exchange through the C ABI's own RCCL path (dxo_mgpu_create_rank /
+    dxo_mgpu_von_mises, csrc/mgpu.hip) on a small batch, compared with torch.distributed's all-gather of the same
+    blocks. Reported on stderr only (it must never cost the headline): a watchdog ends the process with exit code 0 if
+    a collective does not come back."""
+    import threading
+
+    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_FULL, MultiGpu
+
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(120.0):
+            log(f"bench rank {rank}: library_gather_check did not finish in 120 s — leaving (the result line is already out)")
+            os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    uid = [MultiGpu.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    mg = MultiGpu.from_rank(ctx, uid[0], rank, world)
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)
+    deps = torch.empty(n, d, dtype=torch.float64, device=device).normal_(0.0, 3e-3, generator=g)
+    sigma_n = torch.empty(n, d, dtype=torch.float64, device=device).normal_(0.0, 100.0, generator=g)
+    p = torch.empty(n, dtype=torch.float64, device=device).normal_(0.0, 1e-3, generator=g).abs_()
+    out = {}
+    for mode, name in ((GATHER_FULL, "full"), (GATHER_COMPACT, "compact")):
+        C = torch.zeros(world * n * d * d, dtype=torch.float64, device=device)
+        s = torch.zeros(world * n * d, dtype=torch.float64, device=device)
+        dp = torch.zeros(world * n, dtype=torch.float64, device=device)
+        mg.von_mises(prm, d, n, mode, [deps], [sigma_n], [p], [C], [s], [dp])
+        mg.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mg.von_mises(prm, d, n, mode, [deps], [sigma_n], [p], [C], [s], [dp])
+        mg.synchronize()
+        out[name] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "C": C, "s": s, "dp": dp}
+    # reference: every rank's own block through torch.distributed
+    own = slice(rank * n * d, (rank + 1) * n * d)
+    s_ref = torch.empty_like(out["full"]["s"])
+    dist.all_gather_into_tensor(s_ref, out["full"]["s"][own].clone())
+    err_s = float((out["full"]["s"] - s_ref).abs().max())
+    err_cs = float((out["compact"]["s"] - s_ref).abs().max())
+    scale = float(out["full"]["C"].abs().max())
+    err_C = float((out["compact"]["C"] - out["full"]["C"]).abs().max()) / scale      # rebuilt remote tangents vs gathered ones
+    mg.close()
+    done.set()
+    ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13
+    log(json.dumps({"library_gather_check": "ok" if ok else "MISMATCH", "rank": rank, "rccl_ranks_in_libdxo": world, "points_per_rank": n,
+                    "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
+                    "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C}))
+    return ok
+
+
 def launch_ranks(n_gpus: int, argv: list[str]) -> int:
     """Parent side of `python bench.py --gpus N` (N > 1): one rank per GPU under torch.distributed.run, started as a
     child process. This function runs BEFORE torch is imported and makes no HIP / torch.cuda call, so the parent never
@@ -206,6 +260,8 @@ def main():
                     help="logic check of the N > 1 path on a box with ONE GPU: all ranks share device 0 and the collectives "
                          "run over gloo instead of RCCL (RCCL refuses two ranks on one device). The line it prints is marked "
                          "`dry_collective` and is not a measurement.")
+    ap.add_argument("--no-library-gather", action="store_true",
+                    help="skip the dxo_mgpu_* (RCCL inside libdxo_hip.so) cross-check that runs after the result line at N > 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
@@ -504,6 +560,24 @@ def main():
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if dist_on:
+        # nothing after the result line may cost it: whatever is still running 180 s from now (a collective of the
+        # cross-check or the final barrier that does not come back) is abandoned with exit code 0
+        import threading
+
+        def _leave():
+            time.sleep(180.0)
+            log(f"bench rank {rank}: post-result phase still running after 180 s — leaving")
+            os._exit(0)
+
+        threading.Thread(target=_leave, daemon=True).start()
+    if dist_on and not args.dry_collective and not args.no_library_gather:
+        try:    # evidence for dxo_mgpu_* with more than one rank; stderr only, after the result line
+            C_tang = sigma = dp = C_full = sigma_full = dp_full = None
+            torch.cuda.empty_cache()
+            library_gather_check(torch, dist, ctx, prm, d, rank, world, device)
+        except Exception as exc:   # noqa: BLE001
+            log(f"bench rank {rank}: library_gather_check failed: {exc!r}")
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
