@@ -31,8 +31,7 @@ void dxo_arena_release_all(dxo_ctx* ctx);
 
 // Host worker threads of a context (dxo_ctx.hip): the host half of the DXO_MEM_HOST pipeline (tangent rebuild from
 // the returned state while later chunks are still on the PCIe link). Created on first use, joined by dxo_ctx_destroy.
-struct dxo_host_pool;
-void dxo_host_pool_destroy(dxo_host_pool* pool);
+struct dxo_host_pool;   // csrc/host_pool.h
 
 struct dxo_ctx {
     int device = 0;

@@ -6,86 +6,11 @@
 #include <thread>
 
 #include "dxo_common.h"
+#include "host_pool.h"
 
 // ---------------------------------------------------------------------------------------------- host worker threads
-struct dxo_host_pool {
-    std::vector<std::thread> threads;
-    std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    const std::function<void(int64_t, int64_t)>* fn = nullptr;
-    int64_t n = 0, grain = 1, next = 0;
-    int active = 0;          // workers inside the current job
-    uint64_t generation = 0;
-    bool stop = false;
-
-    void worker() {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv_work.wait(lk, [&] { return stop || generation != seen; });
-            if (stop) return;
-            seen = generation;
-            ++active;
-            while (next < n) {
-                const int64_t b = next, e = b + grain < n ? b + grain : n;
-                next = e;
-                lk.unlock();
-                (*fn)(b, e);
-                lk.lock();
-            }
-            if (--active == 0) cv_done.notify_all();
-        }
-    }
-};
-
-void dxo_host_pool_destroy(dxo_host_pool* pool) {
-    if (!pool) return;
-    {
-        std::lock_guard<std::mutex> lk(pool->m);
-        pool->stop = true;
-    }
-    pool->cv_work.notify_all();
-    for (auto& t : pool->threads) t.join();
-    delete pool;
-}
-
 void dxo_host_parallel_for(dxo_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& fn) {
-    if (n <= 0) return;
-    if (grain < 1) grain = 1;
-    int want = (int)c->host_threads;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && want > hw) want = hw;
-    if (want <= 1 || n <= grain) {
-        fn(0, n);
-        return;
-    }
-    if (c->pool && (int)c->pool->threads.size() != want - 1) {   // host_threads changed
-        dxo_host_pool_destroy(c->pool);
-        c->pool = nullptr;
-    }
-    if (!c->pool) {
-        c->pool = new dxo_host_pool();
-        for (int i = 0; i < want - 1; ++i) c->pool->threads.emplace_back([p = c->pool] { p->worker(); });
-    }
-    dxo_host_pool* p = c->pool;
-    std::unique_lock<std::mutex> lk(p->m);
-    p->fn = &fn;
-    p->n = n;
-    p->grain = grain;
-    p->next = 0;
-    ++p->generation;
-    p->cv_work.notify_all();
-    // the calling thread works too
-    while (p->next < p->n) {
-        const int64_t b = p->next, e = b + grain < n ? b + grain : n;
-        p->next = e;
-        lk.unlock();
-        fn(b, e);
-        lk.lock();
-    }
-    p->cv_done.wait(lk, [&] { return p->active == 0; });
-    // a worker that has not woken up yet will find next == n and leave at once; make sure none is still inside fn
-    p->fn = nullptr;
+    dxo_pool_parallel_for(c->pool, (int)c->host_threads, n, grain, fn);
 }
 
 namespace {

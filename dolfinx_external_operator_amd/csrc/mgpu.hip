@@ -101,10 +101,6 @@ int nccl_fail(dxo_mgpu* g, ncclResult_t r, const char* where) {
 
 int need_rccl(dxo_mgpu* g) {
     if (rccl()) return DXO_OK;
-    static Rccl* dummy = nullptr;
-    (void)dummy;
-    // re-read the reason
-    for (const char* name : {"librccl.so.1"}) (void)name;
     return mg_fail(g, DXO_E_NODEVICE, "RCCL is not available in this process (librccl.so.1 could not be loaded)");
 }
 

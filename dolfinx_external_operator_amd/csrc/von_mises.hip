@@ -25,13 +25,9 @@
 //        per CU, and every C_tang store instruction writes 1 KiB of consecutive bytes.
 //   No cross-wave communication, hence no __syncthreads(): LDS slices are wave-private and DS
 //   operations of one wave execute in order; only the compiler must be kept from reordering.
-#include <emmintrin.h>
-
-#include <cmath>
-#include <limits>
-
 #include "dxo_common.h"
 #include "vm_core.h"
+#include "vm_host.h"
 
 namespace {
 
@@ -304,54 +300,16 @@ int vm_expand_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void
 // formulas and operation order as vm_tangent_state / vm_store_tangent; streaming (non-temporal) stores because the
 // array is write-only here and larger than any cache. Product code of the host pipeline, not a CPU fallback: the
 // return map itself always runs on the GPU.
-template <int D>
-void vm_host_rebuild_range(const VmConst& c, const double* __restrict__ sigma, double* __restrict__ dp,
-                           double* __restrict__ C_tang, int64_t b, int64_t e) {
-    const bool stream = (((uintptr_t)C_tang) & 15u) == 0;   // D*D*8 is a multiple of 16: every point block is aligned
-    for (int64_t i = b; i < e; ++i) {
-        const double* sg = sigma + i * D;
-        const double mean = (sg[0] + sg[1] + sg[2]) * (1.0 / 3.0);
-        double s[D], nrm[D];
-        for (int k = 0; k < D; ++k) s[k] = k < 3 ? sg[k] - mean : sg[k];
-        double ss = 0.0;
-        for (int k = 0; k < D; ++k) ss += s[k] * s[k];
-        const double sigma_eq = std::sqrt(3.0 / 2.0 * ss);
-        double dpi = dp[i];
-        if (dpi == 0.0 && std::signbit(dpi)) {
-            // the kernel's mark for f_elastic == 0 exactly: the reference's n_elas = s/sigma_eq * 0/0 is NaN there (:318)
-            // and with it every tangent entry; dp itself is +0 in the reference
-            dp[i] = 0.0;
-            double* Cn = C_tang + i * (D * D);
-            for (int k = 0; k < D * D; ++k) Cn[k] = std::numeric_limits<double>::quiet_NaN();
-            continue;
-        }
-        const double beta = c.mu3 * dpi / (sigma_eq + c.mu3 * dpi);
-        const double ind = dpi > 0.0 ? 1.0 : 0.0;
-        for (int k = 0; k < D; ++k) nrm[k] = s[k] / sigma_eq * ind;
-        const double a = c.mu3 * (c.ratio - beta), bb = c.mu2 * beta;
-        double* Ct = C_tang + i * (D * D);
-        for (int r = 0; r < D; ++r)
-            for (int q = 0; q < D; q += 2) {
-                const double v0 = ((r < 3 && q < 3) ? c.lmbda : 0.0) + (r == q ? c.mu2 : 0.0) - a * (nrm[r] * nrm[q]) -
-                                  bb * ((r == q ? 1.0 : 0.0) - ((r < 3 && q < 3) ? 1.0 / 3.0 : 0.0));
-                const double v1 = ((r < 3 && q + 1 < 3) ? c.lmbda : 0.0) + (r == q + 1 ? c.mu2 : 0.0) - a * (nrm[r] * nrm[q + 1]) -
-                                  bb * ((r == q + 1 ? 1.0 : 0.0) - ((r < 3 && q + 1 < 3) ? 1.0 / 3.0 : 0.0));
-                if (stream) _mm_stream_pd(Ct + r * D + q, _mm_set_pd(v1, v0));
-                else { Ct[r * D + q] = v0; Ct[r * D + q + 1] = v1; }
-            }
-    }
-    if (stream) _mm_sfence();
-}
-
 int vm_host_rebuild(dxo_ctx* ctx, void* user, int64_t first, int64_t m) {
     const VmLaunch& L = *static_cast<const VmLaunch*>(user);
     const int d = L.d;
     const double* sg = L.h_sigma + first * d;
     double* dp = L.h_dp + first;
     double* Ct = L.h_C_tang + first * d * d;
+    const VmHostConst hc{L.c.lmbda, L.c.mu2, L.c.mu3, L.c.ratio};
     dxo_host_parallel_for(ctx, m, 4096, [&](int64_t b, int64_t e) {
-        if (d == 4) vm_host_rebuild_range<4>(L.c, sg, dp, Ct, b, e);
-        else vm_host_rebuild_range<6>(L.c, sg, dp, Ct, b, e);
+        if (d == 4) vm_host_rebuild_range<4>(hc, sg, dp, Ct, b, e);
+        else vm_host_rebuild_range<6>(hc, sg, dp, Ct, b, e);
     });
     return DXO_OK;
 }

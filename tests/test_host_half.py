@@ -1,0 +1,58 @@
+"""The host half of `dxo_von_mises(DXO_MEM_HOST)` with `vm_host_tangent = 1` (product code: csrc/vm_host.h on
+csrc/host_pool.h) against the oracle, on the CPU (not gpu). The GPU half is covered by tests/test_round2_gpu.py; this
+file pins the CPU-side arithmetic: C_tang rebuilt from the RETURNED (sigma, dp) equals the oracle's tangent
+(demo_plasticity_von_mises.py:318-324) to rounding, elastic points give C_elas bit for bit, NaN sigma gives a NaN
+tangent, and the sign-bit mark of the reference's 0/0 point comes out as NaN with dp restored to +0."""
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, vm_inputs
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def host_rebuild(tmp_path_factory):
+    out = tmp_path_factory.mktemp("host_half") / "libhost_half.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT / 'dolfinx_external_operator_amd' / 'csrc'}",
+                    str(ROOT / "tests" / "helpers" / "host_half.cpp"), "-o", str(out), "-lpthread"], check=True)
+    lib = C.CDLL(str(out))
+    lib.host_rebuild.argtypes = [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def run(sigma, dp, E=70e3, nu=0.3, H=70e3 * 700.0 / (70e3 - 700.0), threads=4):
+        n, d = sigma.shape
+        sigma = np.ascontiguousarray(sigma)
+        dp = np.ascontiguousarray(dp).copy()
+        Ct = np.full(n * d * d + 4, -7.0)
+        assert lib.host_rebuild(d, n, E, nu, H, threads, sigma.ctypes.data, dp.ctypes.data, Ct.ctypes.data) == 0
+        assert np.all(Ct[n * d * d:] == -7.0)
+        return Ct[: n * d * d].reshape(n, d, d), dp
+
+    return run
+
+
+@pytest.mark.parametrize("d", [4, 6])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_rebuilt_tangent_matches_the_oracle(oracle, host_rebuild, d, threads):
+    deps, sigma_n, p = vm_inputs(3001, d, seed=31 + d)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    Ct, dp_back = host_rebuild(so, dpo, threads=threads)
+    assert np.array_equal(dp_back, dpo)
+    assert_close_scaled(Ct, Co, 1e-13, "host-rebuilt C_tang vs oracle")
+    el = dpo == 0.0
+    assert el.any() and np.array_equal(Ct[el], Co[el])            # elastic points: C_elas bit for bit
+
+
+def test_nan_cases(oracle, host_rebuild, golden):
+    g = golden("von_mises_d4.npz")                                 # holds the reference's sigma_eq == 0 point (sigma NaN)
+    Ct, _ = host_rebuild(g["sigma"].reshape(-1, 4), g["dp"].reshape(-1), *[float(x) for x in g["params"][[0, 1, 3]]])
+    assert_close_scaled(Ct, g["C_tang"], 1e-13, "rebuilt vs reference golden (NaN pattern included)")
+    # the kernel's mark for f_elastic == 0 exactly: dp = -0.0  ->  NaN tangent, dp = +0
+    sigma = np.array([[10.0, -5.0, 3.0, 40.0], [1.0, 2.0, 3.0, 4.0]])
+    Ct, dp_back = host_rebuild(sigma, np.array([-0.0, 0.0]))
+    assert np.isnan(Ct[0]).all() and np.isfinite(Ct[1]).all()
+    assert not np.signbit(dp_back).any()
