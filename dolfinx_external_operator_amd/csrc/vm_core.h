@@ -53,13 +53,21 @@ __device__ __forceinline__ void vm_return_map(const VmConst& c, const double (&d
     for (int i = 0; i < D; ++i) ss += s[i] * s[i];
     const double sigma_eq = sqrt(3.0 / 2.0 * ss);                 // :311
     const double f_el = sigma_eq - c.sigma_0 - c.H * p;          // :313
-    const double f_plus = (f_el + sqrt(f_el * f_el)) / 2.0;      // :314
+    // :314 f_plus = (f + sqrt(f^2)) / 2. sqrt(fl(f*f)) == |f| exactly for every double whose square neither overflows
+    // nor underflows, so |f| is used (f is of the order of sigma_0)
+    const double f_plus = (f_el + fabs(f_el)) / 2.0;
     dp = f_plus / c.mu3_H;                                       // :316
-    // n_elas = s / sigma_eq * f_plus / f_el (:318); 0/0 -> NaN exactly as the reference
-    const double beta = c.mu3 * dp / sigma_eq;                   // :319
+    // n_elas = s / sigma_eq * f_plus / f_el (:318) and beta = 3 mu dp / sigma_eq (:319): the two quotients 1/sigma_eq and
+    // f_plus/f_el are formed ONCE and multiplied in (an fp64 division is ~11 VALU instructions; the reference's form has
+    // 2 per component + 1 = 13 of them, which was a third of this function). Same special values as the reference:
+    // f_el == 0 gives 0 * inf = NaN in every n (0/0 there), sigma_eq == 0 gives 0 * inf = NaN in n and beta, an elastic
+    // point gives n = +-0 and beta = 0. Finite results differ from the two-division form by at most a rounding each.
+    const double r_eq = 1.0 / sigma_eq;
+    const double ratio_f = f_plus / f_el;
+    const double beta = c.mu3 * dp * r_eq;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        nrm[i] = s[i] / sigma_eq * f_plus / f_el;
+        nrm[i] = s[i] * r_eq * ratio_f;
         sig[i] = se[i] - beta * s[i];                            // :321
     }
     a = c.mu3 * (c.ratio - beta);                                // :324
@@ -114,25 +122,40 @@ struct VmTile {
 // Phase C of a wave tile: the 64 points' tangent state (n[D], a, b per point) sits in the wave's LDS slice Y;
 // lanes walk the tile's C_tang block in OUTPUT order (16-byte chunk q = it*64 + lane), so every store
 // instruction of the wave covers 1 KiB of consecutive addresses.
+// The chunk's coordinates — point pt = q / CH_CT, row i and column pair j0 inside the point's D x D block — are
+// carried from one iteration to the next (q grows by 64 = A * CH_CT + R: k += R with a carry into pt) instead of
+// being divided out of q each time, and C_elas / deviatoric enter through four 0/1 flags
+//   e = [i < 3 and j < 3],  d = [i == j]:   C_elas(i,j) = e lambda + d 2mu,   dev(i,j) = d - e/3
+// (the same values as c_elas_ij / dev_ij, so elastic points still return C_elas bit for bit). Round 1's form
+// (divisions by 18 and 3, nested selects) cost 54 VALU instructions per 16-byte store — 970 of the ~1 300 per tile,
+// which is what made the fused strain + return-map kernel VALU-bound (profiles: 2 250 VALU instructions per tile).
 template <int D, bool NT>
 __device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double* Y, dxo_f64x2* g_c, int nct, int lane) {
     using T = VmTile<D>;
     const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
+    constexpr int A = DXO_WAVE / T::CH_CT, R = DXO_WAVE % T::CH_CT;
+    int pt = lane / T::CH_CT;               // chunk q = lane of iteration 0
+    int k = lane - pt * T::CH_CT;           // chunk inside the point's block
+    int q = lane;
     // partial unroll: a full unroll lets the scheduler hoist all 3*CH_CT LDS reads and spill
 #pragma unroll T::CH_VEC
     for (int it = 0; it < T::CH_CT; ++it) {
-        const int q = it * DXO_WAVE + lane;     // 16-byte chunk index inside the tile's C_tang block
-        const int pt = q / T::CH_CT;            // local point
-        const int k = q - pt * T::CH_CT;        // chunk inside the point's d x d block
-        const int i = k / T::CH_VEC;            // row
-        const int j0 = (k - i * T::CH_VEC) * 2; // first of two columns
+        const int i = D == 6 ? (k * 11) >> 5 : k / T::CH_VEC;   // k / 3 for k < 18
+        const int j0 = (k - i * T::CH_VEC) * 2;                 // first of two columns
         const double n_i = Y[pt * T::ST + i];
         const dxo_f64x2 n_j = Y2[pt * (T::ST / 2) + (j0 >> 1)];
         const dxo_f64x2 ab = Y2[pt * (T::ST / 2) + T::CH_VEC];
+        const double e0 = (i < 3 && j0 < 3) ? 1.0 : 0.0, e1 = (i < 3 && j0 + 1 < 3) ? 1.0 : 0.0;
+        const double d0 = i == j0 ? 1.0 : 0.0, d1 = i == j0 + 1 ? 1.0 : 0.0;
         dxo_f64x2 out;
-        out.x = c_elas_ij(c, i, j0) - ab.x * (n_i * n_j.x) - ab.y * dev_ij(i, j0);
-        out.y = c_elas_ij(c, i, j0 + 1) - ab.x * (n_i * n_j.y) - ab.y * dev_ij(i, j0 + 1);
+        out.x = (e0 * c.lmbda + d0 * c.mu2) - ab.x * (n_i * n_j.x) - ab.y * (d0 - e0 * (1.0 / 3.0));
+        out.y = (e1 * c.lmbda + d1 * c.mu2) - ab.x * (n_i * n_j.y) - ab.y * (d1 - e1 * (1.0 / 3.0));
         if (q < nct) store16<NT>(g_c + q, out);
+        q += DXO_WAVE;
+        k += R;
+        const bool carry = k >= T::CH_CT;
+        pt += carry ? A + 1 : A;
+        k -= carry ? T::CH_CT : 0;
     }
 }
 

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1
 pass() {  # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o op -- python3 scripts/bench_operand.py --launches 2 --case ${CASE:-0} > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o op -- python3 scripts/bench_operand.py --launches 2 --case ${CASE:-0} --operand-cell ${OPCELL:-0} > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
 }
 pass hbm_r FETCH_SIZE
 pass hbm_w WRITE_SIZE
