@@ -126,9 +126,11 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
     for n in sizes:
         bufs = [ctx.pinned_empty(m) for m in (n * d, n * d, n, n * d * d, n * d, n)]
         deps, sigma_n, p, C_tang, sigma, dp = bufs
-        deps[:] = rng.normal(0.0, 3e-3, size=n * d)
-        sigma_n[:] = rng.normal(0.0, 100.0, size=n * d)
-        p[:] = np.abs(rng.normal(0.0, 1e-3, size=n))
+        blk = min(n, 1_000_000)    # one seeded block of 10^6 points, repeated: the path is pointwise, so repetition is immaterial
+        reps = -(-n // blk)
+        deps[:] = np.tile(rng.normal(0.0, 3e-3, size=blk * d), reps)[: n * d]
+        sigma_n[:] = np.tile(rng.normal(0.0, 100.0, size=blk * d), reps)[: n * d]
+        p[:] = np.tile(np.abs(rng.normal(0.0, 1e-3, size=blk)), reps)[:n]
         entry = {"points": n}
         ref_C = None
         for mode, name in ((0, "copy"), (1, "rebuild")):
