@@ -1,24 +1,23 @@
 #!/bin/bash
-# Variants of the fused strain + return-map kernel (vm_field) for A/B timing: same ABI, other -D macros.
+# Variants of libdxo_hip.so for A/B timing: same ABI, some translation units rebuilt with other -D macros.
 # usage: bash scripts/exp/build_variants.sh   -> dolfinx_external_operator_amd/build_exp/libdxo_<name>.so
-# run one with: DXO_HIP_LIBRARY=.../libdxo_<name>.so python scripts/bench_operand.py --case 0 --operand-cell 0
+# run with: python scripts/exp/vmfield_ab.py (fused strain + return map) or
+#           DXO_HIP_LIBRARY=.../libdxo_<name>.so python bench.py --no-cpu --no-e2e
 set -e
 cd "$(dirname "$0")/../.."
 P=dolfinx_external_operator_amd
+python -c "import sys; sys.path.insert(0,'.'); from dolfinx_external_operator_amd._build import build_library; build_library()"
 mkdir -p $P/build_exp
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -I$P/csrc"
-OTHERS=$(ls $P/build/*.o | grep -v "vm_field.o\|operand.o")
+UNITS="vm_field von_mises operand"
 build() {  # name, macros...
   name=$1; shift
-  hipcc $FLAGS "$@" -c $P/csrc/vm_field.hip -o $P/build_exp/vm_field_$name.o &
-  hipcc $FLAGS "$@" -c $P/csrc/operand.hip -o $P/build_exp/operand_$name.o &
+  objs=$(ls $P/build/*.o | grep -v "/vm_field.o\|/von_mises.o\|/operand.o")
+  for u in $UNITS; do hipcc $FLAGS "$@" -c $P/csrc/$u.hip -o $P/build_exp/${u}_$name.o & done
   wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build_exp/libdxo_$name.so $OTHERS $P/build_exp/vm_field_$name.o $P/build_exp/operand_$name.o -ldl -lpthread
+  for u in $UNITS; do objs="$objs $P/build_exp/${u}_$name.o"; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build_exp/libdxo_$name.so $objs -ldl -lpthread
   echo built $name
 }
-build rt3   -DDXO_OP_CT=0 -DDXO_OP_UNROLL=3
-build ct3   -DDXO_OP_CT=1 -DDXO_OP_UNROLL=3
-build ct9   -DDXO_OP_CT=1 -DDXO_OP_UNROLL=9
-build ct27  -DDXO_OP_CT=1 -DDXO_OP_UNROLL=27
-build ct9w2 -DDXO_OP_CT=1 -DDXO_OP_UNROLL=9 -DDXO_VMF_WAVES=2
-build ct9w4 -DDXO_OP_CT=1 -DDXO_OP_UNROLL=9 -DDXO_VMF_WAVES=4
+build carried -DDXO_VM_STORE_FIXED=0      # tangent store with carried (pt, k) indices, 18 full-width stores per tile
+build rt3     -DDXO_OP_CT=0               # fused kernel with run-time node counts
