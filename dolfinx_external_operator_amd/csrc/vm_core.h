@@ -129,47 +129,13 @@ struct VmTile {
 // (the same values as c_elas_ij / dev_ij, so elastic points still return C_elas bit for bit). Round 1's form
 // (divisions by 18 and 3, nested selects) cost 54 VALU instructions per 16-byte store — 970 of the ~1 300 per tile,
 // which is what made the fused strain + return-map kernel VALU-bound (profiles: 2 250 VALU instructions per tile).
-#ifndef DXO_VM_STORE_FIXED
-#define DXO_VM_STORE_FIXED 1
-#endif
+// Tried and dropped for d = 6: three whole points per store instruction (54 active lanes, a lane's chunk fixed for the
+// tile: ~10 VALU per store) — the 864-byte stores leave partial 128-byte lines and vm_tile lost 8 % (4 870 vs 5 270
+// GB/s on the same box), so every store instruction keeps covering 1 KiB.
 template <int D, bool NT>
 __device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double* Y, dxo_f64x2* g_c, int nct, int lane) {
     using T = VmTile<D>;
     const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
-    if constexpr (D == 6 && DXO_VM_STORE_FIXED) {
-        // d = 6: 18 chunks per point do not divide 64, so in the scheme below a lane's (row, column pair) changes from
-        // store to store. Here a wave instruction covers THREE whole points with its first 54 lanes (864 consecutive
-        // bytes, 10 lanes idle): a lane's chunk k = lane % 18 — hence i, j0, its C_elas and dev entries — is fixed for the
-        // whole tile, the LDS and global addresses advance by constants, and a store costs ~10 VALU instructions
-        // instead of 33-40; 22 stores per tile instead of 18.
-        constexpr int PPI = DXO_WAVE / T::CH_CT;                  // 3 points per instruction
-        const int ptl = lane / T::CH_CT, k = lane - ptl * T::CH_CT;
-        const int i = (k * 11) >> 5, j0 = (k - i * 3) * 2;        // k / 3, first of two columns
-        const bool lane_on = lane < PPI * T::CH_CT;
-        const double e0 = (i < 3 && j0 < 3) ? 1.0 : 0.0, e1 = (i < 3 && j0 + 1 < 3) ? 1.0 : 0.0;
-        const double d0 = i == j0 ? 1.0 : 0.0, d1 = i == j0 + 1 ? 1.0 : 0.0;
-        const double cel0 = e0 * c.lmbda + d0 * c.mu2, cel1 = e1 * c.lmbda + d1 * c.mu2;
-        const double dev0 = d0 - e0 * (1.0 / 3.0), dev1 = d1 - e1 * (1.0 / 3.0);
-        const double* Yn = Y + ptl * T::ST + i;
-        const dxo_f64x2* Yj = Y2 + ptl * (T::ST / 2) + (j0 >> 1);
-        const dxo_f64x2* Yab = Y2 + ptl * (T::ST / 2) + T::CH_VEC;
-        dxo_f64x2* g = g_c + ptl * T::CH_CT + k;
-        int q = ptl * T::CH_CT + k;
-        constexpr int ITERS = (T::PTS + PPI - 1) / PPI;
-#pragma unroll 2
-        for (int it = 0; it < ITERS; ++it) {
-            const double n_i = Yn[it * (PPI * T::ST)];
-            const dxo_f64x2 n_j = Yj[it * (PPI * T::ST / 2)];
-            const dxo_f64x2 ab = Yab[it * (PPI * T::ST / 2)];
-            dxo_f64x2 out;
-            out.x = cel0 - ab.x * (n_i * n_j.x) - ab.y * dev0;
-            out.y = cel1 - ab.x * (n_i * n_j.y) - ab.y * dev1;
-            if (lane_on && q < nct) store16<NT>(g, out);
-            g += PPI * T::CH_CT;
-            q += PPI * T::CH_CT;
-        }
-        return;
-    }
     constexpr int A = DXO_WAVE / T::CH_CT, R = DXO_WAVE % T::CH_CT;
     int pt = lane / T::CH_CT;               // chunk q = lane of iteration 0
     int k = lane - pt * T::CH_CT;           // chunk inside the point's block

@@ -19,5 +19,5 @@ build() {  # name, macros...
   hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build_exp/libdxo_$name.so $objs -ldl -lpthread
   echo built $name
 }
-build carried -DDXO_VM_STORE_FIXED=0      # tangent store with carried (pt, k) indices, 18 full-width stores per tile
+build base                               # same flags as the product (sanity: must time like libdxo_hip.so)
 build rt3     -DDXO_OP_CT=0               # fused kernel with run-time node counts
