@@ -132,7 +132,9 @@ struct VmTile {
 // Tried and dropped for d = 6: three whole points per store instruction (54 active lanes, a lane's chunk fixed for the
 // tile: ~10 VALU per store) — the 864-byte stores leave partial 128-byte lines and vm_tile lost 8 % (4 870 vs 5 270
 // GB/s on the same box), so every store instruction keeps covering 1 KiB.
-template <int D, bool NT>
+// FULL: the tile has all 64 points — no per-lane guard, hence no exec-mask branch around each store and the scheduler
+// may run the LDS reads of one iteration under the arithmetic of the previous one.
+template <int D, bool NT, bool FULL = false>
 __device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double* Y, dxo_f64x2* g_c, int nct, int lane) {
     using T = VmTile<D>;
     const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
@@ -153,7 +155,7 @@ __device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double*
         dxo_f64x2 out;
         out.x = (e0 * c.lmbda + d0 * c.mu2) - ab.x * (n_i * n_j.x) - ab.y * (d0 - e0 * (1.0 / 3.0));
         out.y = (e1 * c.lmbda + d1 * c.mu2) - ab.x * (n_i * n_j.y) - ab.y * (d1 - e1 * (1.0 / 3.0));
-        if (q < nct) store16<NT>(g_c + q, out);
+        if (FULL || q < nct) store16<NT>(g_c + q, out);
         q += DXO_WAVE;
         k += R;
         const bool carry = k >= T::CH_CT;

@@ -29,6 +29,17 @@
 #include "vm_core.h"
 #include "vm_host.h"
 
+#ifndef DXO_VM_NT_LOADS
+#define DXO_VM_NT_LOADS 0    // non-temporal input loads (scripts/exp/vmtile_ab.py)
+#endif
+#ifndef DXO_VM_FULL_PATH
+#define DXO_VM_FULL_PATH 1   // guard-free body for tiles of 64 points
+#endif
+#ifndef DXO_VM_MIN_BLOCKS
+#define DXO_VM_MIN_BLOCKS 2  // __launch_bounds__ second argument of vm_tile: 70-90 VGPRs either way; the schedule under 2 was 4 % faster
+                             // on a slow-clocked box (5 450 vs 5 245 GB/s) and equal (+-0.3 %) on the others (scripts/exp/vmtile_ab.py)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------ variant 0: lane = point
@@ -58,8 +69,78 @@ __global__ __launch_bounds__(DXO_BLOCK) void vm_point(VmConst c, int64_t n, cons
 }
 
 // ------------------------------------------------------------------ variant 1: wave = 64-point tile (helpers: vm_core.h)
+// one tile of `npts` points starting at point p0; FULL = (npts == 64): every guard folds away
+template <int D, bool NT, bool FULL>
+__device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int npts, int lane, double* X, double* Y,
+                                             const double* __restrict__ deps, const double* __restrict__ sigma_n,
+                                             const double* __restrict__ p, double* __restrict__ C_tang,
+                                             double* __restrict__ sigma, double* __restrict__ dp_out) {
+    using T = VmTile<D>;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
+    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
+    const int nvec = npts * T::CH_VEC;                              // valid 16-byte chunks of a [npts][D] block
+
+    // ---- A: lane-linear global loads -> LDS -> point-per-lane registers
+    const dxo_f64x2* g_e = reinterpret_cast<const dxo_f64x2*>(deps + p0 * D);
+    const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
+    dxo_f64x2 ve[T::CH_VEC], vs[T::CH_VEC];
+#pragma unroll
+    for (int k = 0; k < T::CH_VEC; ++k) {
+        const int idx = k * DXO_WAVE + lane;
+        const bool ok = FULL || idx < nvec;
+#if DXO_VM_NT_LOADS
+        ve[k] = ok ? __builtin_nontemporal_load(g_e + idx) : dxo_f64x2{0.0, 0.0};
+        vs[k] = ok ? __builtin_nontemporal_load(g_s + idx) : dxo_f64x2{0.0, 0.0};
+#else
+        ve[k] = ok ? g_e[idx] : dxo_f64x2{0.0, 0.0};
+        vs[k] = ok ? g_s[idx] : dxo_f64x2{0.0, 0.0};
+#endif
+    }
+    const double p_l = (FULL || lane < npts) ? p[p0 + lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < T::CH_VEC; ++k) {
+        X2[k * DXO_WAVE + lane] = ve[k];
+        Y2[k * DXO_WAVE + lane] = vs[k];
+    }
+    wave_lds_fence();
+    double e[D], sn[D];
+#pragma unroll
+    for (int k = 0; k < T::CH_VEC; ++k) {
+        const dxo_f64x2 a2 = X2[lane * T::CH_VEC + k];
+        const dxo_f64x2 b2 = Y2[lane * T::CH_VEC + k];
+        e[2 * k] = a2.x;
+        e[2 * k + 1] = a2.y;
+        sn[2 * k] = b2.x;
+        sn[2 * k + 1] = b2.y;
+    }
+    wave_lds_fence();  // staging slices are about to be reused
+
+    // ---- B: radial return of this lane's point
+    double sig[D], nrm[D], dp, a, b;
+    vm_return_map<D>(c, e, sn, p_l, sig, dp, nrm, a, b);
+
+    // ---- C: sigma -> X (point-per-lane), state -> Y, then output-ordered coalesced stores
+#pragma unroll
+    for (int k = 0; k < T::CH_VEC; ++k) {
+        X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
+        Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+    }
+    Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+    wave_lds_fence();
+
+    if (FULL || lane < npts) store8<NT>(dp_out + p0 + lane, dp);
+    dxo_f64x2* g_o = reinterpret_cast<dxo_f64x2*>(sigma + p0 * D);
+#pragma unroll
+    for (int k = 0; k < T::CH_VEC; ++k) {
+        const int idx = k * DXO_WAVE + lane;
+        if (FULL || idx < nvec) store16<NT>(g_o + idx, X2[idx]);
+    }
+    vm_store_tangent<D, NT, FULL>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
+    wave_lds_fence();  // next tile overwrites X / Y
+}
+
 template <int D, bool NT>
-__global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
+__global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
                                                      const double* __restrict__ sigma_n,
                                                      const double* __restrict__ p, double* __restrict__ C_tang,
                                                      double* __restrict__ sigma, double* __restrict__ dp_out) {
@@ -69,68 +150,17 @@ __global__ __launch_bounds__(DXO_BLOCK, 4) void vm_tile(VmConst c, int64_t n, co
     const int wave = threadIdx.x >> 6;
     double* X = lds + wave * T::WAVE_DOUBLES;
     double* Y = X + T::X_DOUBLES;
-    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
-    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
 
     const int64_t n_tiles = (n + T::PTS - 1) / T::PTS;
     const int64_t tile_stride = (int64_t)gridDim.x * T::WAVES;
     for (int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t p0 = tile * T::PTS;
         const int npts = (n - p0 < T::PTS) ? (int)(n - p0) : T::PTS;  // wave-uniform
-        const int nvec = npts * T::CH_VEC;                              // valid 16-byte chunks of a [npts][D] block
-
-        // ---- A: lane-linear global loads -> LDS -> point-per-lane registers
-        const dxo_f64x2* g_e = reinterpret_cast<const dxo_f64x2*>(deps + p0 * D);
-        const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
-        dxo_f64x2 ve[T::CH_VEC], vs[T::CH_VEC];
-#pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            const int idx = k * DXO_WAVE + lane;
-            const bool ok = idx < nvec;
-            ve[k] = ok ? g_e[idx] : dxo_f64x2{0.0, 0.0};
-            vs[k] = ok ? g_s[idx] : dxo_f64x2{0.0, 0.0};
-        }
-        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
-#pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            X2[k * DXO_WAVE + lane] = ve[k];
-            Y2[k * DXO_WAVE + lane] = vs[k];
-        }
-        wave_lds_fence();
-        double e[D], sn[D];
-#pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            const dxo_f64x2 a2 = X2[lane * T::CH_VEC + k];
-            const dxo_f64x2 b2 = Y2[lane * T::CH_VEC + k];
-            e[2 * k] = a2.x;
-            e[2 * k + 1] = a2.y;
-            sn[2 * k] = b2.x;
-            sn[2 * k + 1] = b2.y;
-        }
-        wave_lds_fence();  // staging slices are about to be reused
-
-        // ---- B: radial return of this lane's point
-        double sig[D], nrm[D], dp, a, b;
-        vm_return_map<D>(c, e, sn, p_l, sig, dp, nrm, a, b);
-
-        // ---- C: sigma -> X (point-per-lane), state -> Y, then output-ordered coalesced stores
-#pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
-            Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
-        }
-        Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
-        wave_lds_fence();
-
-        if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);
-        dxo_f64x2* g_o = reinterpret_cast<dxo_f64x2*>(sigma + p0 * D);
-#pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            const int idx = k * DXO_WAVE + lane;
-            if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
-        }
-        vm_store_tangent<D, NT>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
-        wave_lds_fence();  // next tile overwrites X / Y
+#if DXO_VM_FULL_PATH
+        if (npts == T::PTS) vm_tile_body<D, NT, true>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
+        else
+#endif
+            vm_tile_body<D, NT, false>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
     }
 }
 
