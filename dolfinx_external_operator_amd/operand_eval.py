@@ -76,28 +76,40 @@ class DeviceMesh:
             dm.set_weights(mesh.weights)
         return dm
 
-    @classmethod
-    def from_dolfinx(cls, V, quadrature_points, **kw):
-        """From a DOLFINx function space `V` (blocked Lagrange) and the reference quadrature points the operator's
-        quadrature element uses (`basix.make_quadrature(...)[0]`). Not exercised on the GPU box (no DOLFINx there)."""
+    @staticmethod
+    def tables_from_dolfinx(V, quadrature_points) -> dict:
+        """The constructor arguments for a DOLFINx function space `V` (blocked Lagrange) and the reference quadrature
+        points the operator's quadrature element uses (`basix.make_quadrature(...)[0]`), as plain arrays.
+        basix's `tabulate(1, points)` returns (1 + tdim, npoints, ndofs, value_size) with index 0 the values and
+        1 + k the derivative along reference axis k; field tables and dofmap both come from `V`, geometry tables and
+        geometry dofmap both from `mesh.geometry`, so basix's node numbering never has to be known here.
+        Elements whose dofs need per-cell transformations (Lagrange degree >= 3 on unordered meshes) are refused: the
+        kernels apply none."""
         import basix
 
+        if getattr(V.element, "needs_dof_transformations", False):
+            raise NotImplementedError("DeviceMesh: elements that need dof transformations are not supported")
         mesh = V.mesh
         gdim = mesh.geometry.dim
         quadrature_points = np.asarray(quadrature_points, dtype=np.float64)
-        # scalar sub-element of the (blocked) Lagrange space: values (1 + tdim, nq, ndofs, 1)
         tab = V.element.basix_element.tabulate(1, quadrature_points)
         # the coordinate element as a basix element of the same family / degree / variant as mesh.geometry.cmap
         cmap = mesh.geometry.cmap
         cell = getattr(basix.CellType, mesh.topology.cell_name())
         cel = basix.create_element(basix.ElementFamily.P, cell, cmap.degree, basix.LagrangeVariant(int(cmap.variant)))
         ctab = cel.tabulate(1, quadrature_points)
-        phi = tab[0, :, :, 0]
-        dphi = np.moveaxis(tab[1:, :, :, 0], 0, 2)
-        dpsi = np.moveaxis(ctab[1:, :, :, 0], 0, 2)
+        if tab.shape[3] != 1:
+            raise ValueError("DeviceMesh: the space's basix element must be the SCALAR sub-element of a blocked space")
         n_nodes = V.dofmap.index_map.size_local + V.dofmap.index_map.num_ghosts
-        return cls(gdim=gdim, phi=phi, dphi=dphi, dpsi=dpsi, dofmap=V.dofmap.list, geom_dofmap=mesh.geometry.dofmap,
-                   x=mesh.geometry.x, num_field_nodes=n_nodes, **kw)
+        return dict(gdim=gdim, phi=tab[0, :, :, 0], dphi=np.moveaxis(tab[1:, :, :, 0], 0, 2),
+                    dpsi=np.moveaxis(ctab[1:, :, :, 0], 0, 2), dofmap=V.dofmap.list, geom_dofmap=mesh.geometry.dofmap,
+                    x=mesh.geometry.x, num_field_nodes=n_nodes)
+
+    @classmethod
+    def from_dolfinx(cls, V, quadrature_points, **kw):
+        """From a DOLFINx function space and reference quadrature points (see `tables_from_dolfinx`). DOLFINx is not
+        installed on the GPU box; tests drive this with stand-in objects that follow basix's documented layouts."""
+        return cls(**cls.tables_from_dolfinx(V, quadrature_points), **kw)
 
     def value_size(self, kind: str, bs: int) -> int:
         r = self.ctx.lib.dxo_operand_value_size(self.gdim, int(bs), KINDS[kind])
