@@ -115,6 +115,9 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
       copy     (C_tang, sigma, dp) come back over PCIe: 344 B/point at d = 6, bit-identical to a device call
       rebuild  only (sigma, dp) cross PCIe (56 B/point); the caller's C_tang array is rebuilt from them by the
                context's host threads while later chunks are in flight (option vm_host_tangent = 1)
+      resident rebuild + the history variables sigma_n, p in a device mirror (dxo_vm_state, uploaded once before the
+               timed calls: they change only at the end of a load step, demo_plasticity_von_mises.py:564-565, while
+               every Newton iteration in between calls the operator): 48 B/point up, 56 B/point down
     Reported beside the headline, never as `value`. Times are medians over `calls` calls; h2d/kernel/d2h are sums
     of the per-chunk event times (they overlap, so they do not add up to total_ms)."""
     import numpy as np
@@ -152,6 +155,24 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
                 entry["rebuild_vs_copy_max_rel_err"] = err
                 if not err < 1e-12:
                     raise SystemExit(f"bench: host-rebuilt tangent differs from the device tangent ({err:.2e})")
+        ref_s, ref_dp, ref_C = sigma[: 4096 * d].copy(), dp[:4096].copy(), C_tang[: 4096 * d * d].copy()
+        st = ctx.vm_state(d, n)
+        t0 = time.perf_counter()
+        st.upload(sigma_n, p)
+        upload_ms = (time.perf_counter() - t0) * 1e3
+        rows = []
+        for _ in range(calls + 1):
+            t0 = time.perf_counter()
+            st.call(prm, MEM_HOST, deps, C_tang, sigma, dp)
+            wall = time.perf_counter() - t0
+            rows.append((wall, ctx.last_timing()))
+        rows = sorted(rows[1:], key=lambda r: r[0])
+        wall, t = rows[len(rows) // 2]
+        entry["resident"] = {"qp_per_s": n / wall, "total_ms": wall * 1e3, "h2d_ms": t["h2d_ms"], "kernel_ms": t["kernel_ms"],
+                             "d2h_ms": t["d2h_ms"], "pcie_bytes_per_qp": 8 * d + 8 * (d + 1), "state_upload_once_ms": upload_ms}
+        st.close()
+        if not (np.array_equal(sigma[: 4096 * d], ref_s) and np.array_equal(dp[:4096], ref_dp) and np.array_equal(C_tang[: 4096 * d * d], ref_C)):
+            raise SystemExit("bench: the resident-state call differs from the plain host call")
         ctx.set_option("vm_host_tangent", 0)
         for b in bufs:
             ctx.pinned_free(b)

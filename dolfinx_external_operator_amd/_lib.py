@@ -94,6 +94,14 @@ _SIGNATURES = {
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
+    "dxo_vm_state_create": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "dxo_vm_state_destroy": (None, [_P, _P]),
+    "dxo_vm_state_upload": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "dxo_vm_state_download": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "dxo_vm_state_commit": (C.c_int, [_P, _P]),
+    "dxo_vm_state_pointers": (C.c_int, [_P, _P] + [C.POINTER(_P)] * 4),
+    "dxo_von_mises_state": (C.c_int, [_P, C.POINTER(VmParams), _P, C.c_int, _P, _P, _P, _P]),
+    "dxo_von_mises_field_state": (C.c_int, [_P, C.POINTER(VmParams), _P, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_device_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_device_free": (C.c_int, [_P, _P]),
     "dxo_copy": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
@@ -372,6 +380,10 @@ class Context:
                                     _ptr(p), _ptr(C_tang), _ptr(sigma), _ptr(dp))
         self.check(rc, "dxo_von_mises")
 
+    def vm_state(self, d: int, n: int) -> "VmState":
+        """Device mirror of the von Mises history variables for n points (dxo_vm_state_*, include/dxo.h)."""
+        return VmState(self, d, n)
+
     def mohr_coulomb(self, prm: McParams, n: int, mem: int, deps, sigma_n, C_tang, sigma, niter=None, yielding=None,
                      norm_res=None, dlambda=None) -> None:
         rc = self.lib.dxo_mohr_coulomb(self._h, C.byref(prm), int(n), int(mem), _ptr(deps), _ptr(sigma_n), _ptr(C_tang),
@@ -547,6 +559,55 @@ class _CudaArrayView:
 
 GATHER_NONE, GATHER_FULL, GATHER_COMPACT = 0, 1, 2
 MGPU_ID_BYTES = 128
+
+
+class VmState:
+    """dxo_vm_state: sigma_n, p (and the last call's sigma, dp) resident on the context's GPU.
+
+    upload(sigma_n, p) once and after any change of the caller's arrays other than the load-step update;
+    call(...) = dxo_von_mises_state; commit() = `p += dp; sigma_n <- sigma` on the device
+    (demo_plasticity_von_mises.py:564-565)."""
+
+    def __init__(self, ctx: "Context", d: int, n: int):
+        self.ctx, self.d, self.n = ctx, int(d), int(n)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dxo_vm_state_create(ctx._h, self.d, self.n, C.byref(h)), "dxo_vm_state_create")
+        self._h = h
+        self._fin = weakref.finalize(self, VmState._destroy, ctx, h)
+
+    @staticmethod
+    def _destroy(ctx, h):
+        ctx.lib.dxo_vm_state_destroy(ctx._h, h)   # with a closed context (NULL) the library still frees the device block
+
+    def close(self) -> None:
+        self._fin()
+
+    def upload(self, sigma_n, p, mem: int = MEM_HOST) -> None:
+        self.ctx.check(self.ctx.lib.dxo_vm_state_upload(self.ctx._h, self._h, int(mem), _ptr(sigma_n), _ptr(p)), "dxo_vm_state_upload")
+
+    def download(self, sigma_n=None, p=None, mem: int = MEM_HOST):
+        if mem == MEM_HOST:
+            sigma_n = np.empty(self.n * self.d) if sigma_n is None else sigma_n
+            p = np.empty(self.n) if p is None else p
+        self.ctx.check(self.ctx.lib.dxo_vm_state_download(self.ctx._h, self._h, int(mem), _ptr(sigma_n), _ptr(p)), "dxo_vm_state_download")
+        return sigma_n, p
+
+    def commit(self) -> None:
+        self.ctx.check(self.ctx.lib.dxo_vm_state_commit(self.ctx._h, self._h), "dxo_vm_state_commit")
+
+    def pointers(self) -> dict:
+        out = [C.c_void_p() for _ in range(4)]
+        self.ctx.check(self.ctx.lib.dxo_vm_state_pointers(self.ctx._h, self._h, *(C.byref(o) for o in out)), "dxo_vm_state_pointers")
+        return dict(zip(("sigma_n", "p", "sigma", "dp"), (o.value for o in out)))
+
+    def call(self, prm: VmParams, mem: int, deps, C_tang, sigma=None, dp=None) -> None:
+        rc = self.ctx.lib.dxo_von_mises_state(self.ctx._h, C.byref(prm), self._h, int(mem), _ptr(deps), _ptr(C_tang), _ptr(sigma), _ptr(dp))
+        self.ctx.check(rc, "dxo_von_mises_state")
+
+    def call_field(self, prm: VmParams, mesh_handle, mem: int, u, C_tang, sigma=None, dp=None) -> None:
+        rc = self.ctx.lib.dxo_von_mises_field_state(self.ctx._h, C.byref(prm), mesh_handle, self._h, int(mem), _ptr(u), _ptr(C_tang),
+                                                    _ptr(sigma), _ptr(dp))
+        self.ctx.check(rc, "dxo_von_mises_field_state")
 
 
 class MultiGpu:

@@ -68,7 +68,7 @@ struct dxo_ctx {
     std::vector<dxo_arena_block> arena;
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
     int64_t host_threads = 32;          // worker threads of the host half of the pipeline (capped by the hardware's)
-    int64_t vm_rebuild_chunk_points = 1 << 16;   // pipeline chunk of the vm_host_tangent = 1 mode
+    int64_t vm_rebuild_chunk_points = 1 << 17;   // pipeline chunk of the vm_host_tangent = 1 mode
     int64_t vm_rebuild_min_points = 1 << 18;     // smaller batches are latency-bound, not PCIe-bound: they take the copy mode
     // small-batch path of the host pipeline: one pinned staging buffer, one H2D, one D2H, events made once
     void* small_pinned = nullptr;
@@ -115,6 +115,21 @@ struct dxo_span {
     const void* in = nullptr;   // for inputs
     void* out = nullptr;        // for outputs
     size_t bytes_pp = 0;
+    // Array that LIVES on the device (dxo_vm_state): an input with `dev` is neither staged nor copied — the chunk's
+    // kernel reads dev + first*bytes_pp; an output with `dev` is written there by the kernel and, when `out` is set,
+    // copied to the host from there.
+    void* dev = nullptr;
+};
+
+// Device mirror of the von Mises history variables plus the results of the last call (include/dxo.h, dxo_vm_state_*):
+// ONE allocation, [sigma_n n*d | sigma n*d | p n | dp n] doubles, every part on a 256-byte border.
+struct dxo_vm_state {
+    int d = 0;
+    int64_t n = 0;
+    void* blob = nullptr;
+    double *sigma_n = nullptr, *sigma = nullptr, *p = nullptr, *dp = nullptr;
+    bool uploaded = false;     // sigma_n / p hold data
+    bool has_result = false;   // sigma / dp hold the results of a call made after the last upload / commit
 };
 
 // Launch callback for the chunked host pipeline: device pointers of the chunk, in the same

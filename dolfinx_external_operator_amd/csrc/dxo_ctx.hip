@@ -307,7 +307,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         // the number of driver calls, not bytes. Inputs are packed into ONE pinned staging buffer and go up in one copy,
         // the outputs come back in one copy; events are created once per context.
         size_t in_bytes = 0, out_bytes = 0;
-        for (const auto& s : inputs) in_bytes += round_up(s.bytes_pp * (size_t)n, 256);
+        for (const auto& s : inputs)
+            if (!s.dev) in_bytes += round_up(s.bytes_pp * (size_t)n, 256);
         for (const auto& s : outputs) out_bytes += round_up(s.bytes_pp * (size_t)n, 256);
         if ((int64_t)(in_bytes + out_bytes) <= c->host_small_bytes) {
             const size_t need = in_bytes + out_bytes;
@@ -342,22 +343,34 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
             std::vector<void*> d_in(inputs.size()), d_out(outputs.size());
             size_t off = 0;
             for (size_t k = 0; k < inputs.size(); ++k) {
+                if (inputs[k].dev) {
+                    d_in[k] = inputs[k].dev;
+                    continue;
+                }
                 std::memcpy(hbase + off, inputs[k].in, inputs[k].bytes_pp * (size_t)n);
                 d_in[k] = dbase + off;
                 off += round_up(inputs[k].bytes_pp * (size_t)n, 256);
             }
             if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[0], s));
-            DXO_HIP(c, hipMemcpyAsync(dbase, hbase, in_bytes, hipMemcpyHostToDevice, s));
+            if (in_bytes) DXO_HIP(c, hipMemcpyAsync(dbase, hbase, in_bytes, hipMemcpyHostToDevice, s));
             if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[1], s));
             const size_t out_base = off;
             for (size_t k = 0; k < outputs.size(); ++k) {
-                d_out[k] = dbase + off;
+                d_out[k] = outputs[k].dev ? outputs[k].dev : (void*)(dbase + off);
                 off += round_up(outputs[k].bytes_pp * (size_t)n, 256);
             }
             int rc = launch(c, user, n, d_in.data(), d_out.data(), s);
             if (rc != DXO_OK) return rc;
             DXO_HIP(c, hipGetLastError());
             if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[2], s));
+            {   // device-resident outputs join the staging block so that ONE copy brings everything back
+                size_t o2 = out_base;
+                for (size_t k = 0; k < outputs.size(); ++k) {
+                    if (outputs[k].dev && outputs[k].out)
+                        DXO_HIP(c, hipMemcpyAsync(dbase + o2, outputs[k].dev, outputs[k].bytes_pp * (size_t)n, hipMemcpyDeviceToDevice, s));
+                    o2 += round_up(outputs[k].bytes_pp * (size_t)n, 256);
+                }
+            }
             DXO_HIP(c, hipMemcpyAsync(hbase + out_base, dbase + out_base, out_bytes, hipMemcpyDeviceToHost, s));
             if (timed) DXO_HIP(c, hipEventRecord(c->small_ev[3], s));
             DXO_HIP(c, hipStreamSynchronize(s));
@@ -387,8 +400,11 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
     if (chunk < n) chunk = chunk / DXO_WAVE * DXO_WAVE;  // interior chunk borders on whole wave tiles
     // slot layout: every span starts on a 256-byte border
     size_t need = 0;
-    for (const auto& s : inputs) need += round_up(s.bytes_pp * (size_t)chunk, 256);
-    for (const auto& s : outputs) need += round_up(s.bytes_pp * (size_t)chunk, 256);
+    for (const auto& s : inputs)
+        if (!s.dev) need += round_up(s.bytes_pp * (size_t)chunk, 256);
+    for (const auto& s : outputs)
+        if (!s.dev) need += round_up(s.bytes_pp * (size_t)chunk, 256);
+    if (need < 256) need = 256;
     if (need > c->slot_bytes) {
         for (int i = 0; i < DXO_HOST_SLOTS; ++i) {
             DXO_HIP(c, hipStreamSynchronize(c->slot_stream[i]));
@@ -503,6 +519,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         size_t off = 0;
         hipError_t e = hipEventRecord(ev[slot].e[0], s);
         for (size_t k = 0; k < inputs.size() && e == hipSuccess; ++k) {
+            if (inputs[k].dev) {
+                d_in[k] = (char*)inputs[k].dev + (size_t)done * inputs[k].bytes_pp;
+                continue;
+            }
             d_in[k] = base + off;
             off += round_up(inputs[k].bytes_pp * (size_t)chunk, 256);
             e = hipMemcpyAsync(d_in[k], (const char*)inputs[k].in + (size_t)done * inputs[k].bytes_pp,
@@ -511,6 +531,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         if (e == hipSuccess) e = hipEventRecord(ev[slot].e[1], s);
         if (e != hipSuccess) { rc = dxo_hip_fail(c, e, "host pipeline H2D"); break; }
         for (size_t k = 0; k < outputs.size(); ++k) {
+            if (outputs[k].dev) {
+                d_out[k] = (char*)outputs[k].dev + (size_t)done * outputs[k].bytes_pp;
+                continue;
+            }
             d_out[k] = base + off;
             off += round_up(outputs[k].bytes_pp * (size_t)chunk, 256);
         }

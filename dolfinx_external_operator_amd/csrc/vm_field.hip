@@ -15,6 +15,7 @@
 #include "dxo_common.h"
 #include "operand_core.h"
 #include "vm_core.h"
+#include "vm_host.h"
 
 namespace {
 
@@ -130,6 +131,10 @@ struct FieldLaunch {
     const dxo_mesh* mesh;
     const double* d_u;
     int64_t next_cell;     // host pipeline: chunks arrive in order, each covers the next n_chunk cells
+    // host half (option vm_host_tangent, see von_mises.hip): the caller's arrays, whole
+    const double* h_sigma = nullptr;
+    double* h_dp = nullptr;
+    double* h_C_tang = nullptr;
 };
 
 int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_cells, const double* sigma_n,
@@ -172,7 +177,94 @@ int field_chunk(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const* d_in, vo
                         (double*)d_out[1], (double*)d_out[2], s);
 }
 
+// post hook of the host pipeline: C_tang of the chunk's cells from the (sigma, dp) that have just landed
+int field_host_rebuild(dxo_ctx* ctx, void* user, int64_t first_cell, int64_t n_cells) {
+    const FieldLaunch& L = *static_cast<const FieldLaunch*>(user);
+    const int nq = L.mesh->dev.nq, d = L.mesh->gdim == 2 ? 4 : 6;
+    const int64_t first = first_cell * nq, m = n_cells * nq;
+    const double* sg = L.h_sigma + first * d;
+    double* dp = L.h_dp + first;
+    double* Ct = L.h_C_tang + first * d * d;
+    const VmHostConst hc{L.c.lmbda, L.c.mu2, L.c.mu3, L.c.ratio};
+    dxo_host_parallel_for(ctx, m, 512, [&](int64_t b, int64_t e) {
+        if (d == 4) vm_host_rebuild_range<4>(hc, sg, dp, Ct, b, e);
+        else vm_host_rebuild_range<6>(hc, sg, dp, Ct, b, e);
+    });
+    return DXO_OK;
+}
+
+int field_upload_u(dxo_ctx* ctx, dxo_mesh* mesh, const double* u) {
+    const size_t ub = (size_t)mesh->num_field_nodes * mesh->gdim * sizeof(double);
+    if (mesh->u_cap < ub) {
+        if (mesh->d_u) DXO_HIP(ctx, hipFree(mesh->d_u));
+        mesh->d_u = nullptr;
+        mesh->u_cap = 0;
+        DXO_HIP(ctx, hipMalloc((void**)&mesh->d_u, ub));
+        mesh->u_cap = ub;
+    }
+    DXO_HIP(ctx, hipMemcpy(mesh->d_u, u, ub, hipMemcpyHostToDevice));
+    return DXO_OK;
+}
+
 }  // namespace
+
+// Fused strain + return map with the history variables in a dxo_vm_state (von_mises.hip): of a host call only the dof
+// vector goes up (one value per dof, not per quadrature point) and, with option vm_host_tangent, only (sigma, dp) come
+// back — 56 instead of 448 B/point (d = 6) on the PCIe link.
+extern "C" int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, dxo_vm_state* st, int mem,
+                                         const double* u, double* C_tang, double* sigma, double* dp) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!prm || !mesh || !st) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field_state: NULL params, mesh or state");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises_field_state: bad mem");
+    if (!st->uploaded) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field_state: dxo_vm_state_upload has not been called");
+    const int64_t nc = mesh->num_cells;
+    const int G = mesh->gdim, D = G == 2 ? 4 : 6, nq = mesh->dev.nq;
+    if (st->d != D || st->n != nc * nq)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field_state: the state does not cover num_cells*nq points of this mesh's d");
+    if (nc == 0) return DXO_OK;
+    if (!u || !C_tang) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field_state: NULL array");
+    if (((uintptr_t)u | (uintptr_t)C_tang | (uintptr_t)sigma | (uintptr_t)dp) & 7u)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_field_state: arrays must be 8-byte aligned");
+    FieldLaunch L{make_const(*prm), mesh, u, 0};
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    st->has_result = false;
+    if (mem == DXO_MEM_DEVICE) {
+        if ((uintptr_t)C_tang & 15u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_field_state: device C_tang must be 16-byte aligned");
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = field_launch(ctx, L, 0, nc, st->sigma_n, st->p, C_tang, st->sigma, st->dp, s);
+        if (rc != DXO_OK) return rc;
+        if (sigma) DXO_HIP(ctx, hipMemcpyAsync(sigma, st->sigma, (size_t)st->n * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (dp) DXO_HIP(ctx, hipMemcpyAsync(dp, st->dp, (size_t)st->n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        rc = dxo_device_end(ctx, s);
+        if (rc == DXO_OK) st->has_result = true;
+        return rc;
+    }
+    if (!sigma || !dp) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field_state: host sigma / dp are required");
+    int rc = field_upload_u(ctx, mesh, u);
+    if (rc != DXO_OK) return rc;
+    L.d_u = mesh->d_u;
+    const size_t sd = sizeof(double) * (size_t)nq;
+    std::vector<dxo_span> in = {{nullptr, nullptr, D * sd, st->sigma_n}, {nullptr, nullptr, sd, st->p}};
+    if (ctx->vm_host_tangent && st->n >= ctx->vm_rebuild_min_points) {
+        L.h_sigma = sigma;
+        L.h_dp = dp;
+        L.h_C_tang = C_tang;
+        L.c.mark_indeterminate = 1;
+        std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        const int64_t saved_chunk = ctx->host_chunk_points;
+        if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild);
+        ctx->host_chunk_points = saved_chunk;
+    } else {
+        std::vector<dxo_span> out = {{nullptr, C_tang, D * D * sd}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq);
+    }
+    if (rc == DXO_OK) st->has_result = true;
+    return rc;
+}
 
 extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                                    const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp) {
@@ -200,18 +292,23 @@ extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_m
     }
     // host arrays: the field vector goes up whole (it is small: one value per dof, not per quadrature point), the
     // state and the outputs stream through the chunked pipeline in units of CELLS
-    const size_t ub = (size_t)mesh->num_field_nodes * G * sizeof(double);
-    if (mesh->u_cap < ub) {
-        if (mesh->d_u) DXO_HIP(ctx, hipFree(mesh->d_u));
-        mesh->d_u = nullptr;
-        mesh->u_cap = 0;
-        DXO_HIP(ctx, hipMalloc((void**)&mesh->d_u, ub));
-        mesh->u_cap = ub;
-    }
-    DXO_HIP(ctx, hipMemcpy(mesh->d_u, u, ub, hipMemcpyHostToDevice));
+    int rc = field_upload_u(ctx, mesh, u);
+    if (rc != DXO_OK) return rc;
     L.d_u = mesh->d_u;
     const size_t sd = sizeof(double) * (size_t)nq;
     std::vector<dxo_span> in = {{sigma_n, nullptr, D * sd}, {p, nullptr, sd}};
+    if (ctx->vm_host_tangent && nc * nq >= ctx->vm_rebuild_min_points) {   // (sigma, dp) back, C_tang rebuilt on the host
+        L.h_sigma = sigma;
+        L.h_dp = dp;
+        L.h_C_tang = C_tang;
+        L.c.mark_indeterminate = 1;
+        std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
+        const int64_t saved_chunk = ctx->host_chunk_points;
+        if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild);
+        ctx->host_chunk_points = saved_chunk;
+        return rc;
+    }
     std::vector<dxo_span> out = {{nullptr, C_tang, D * D * sd}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
     return dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq);
 }

@@ -337,7 +337,7 @@ int vm_host_rebuild(dxo_ctx* ctx, void* user, int64_t first, int64_t m) {
     double* dp = L.h_dp + first;
     double* Ct = L.h_C_tang + first * d * d;
     const VmHostConst hc{L.c.lmbda, L.c.mu2, L.c.mu3, L.c.ratio};
-    dxo_host_parallel_for(ctx, m, 4096, [&](int64_t b, int64_t e) {
+    dxo_host_parallel_for(ctx, m, 512, [&](int64_t b, int64_t e) {
         if (d == 4) vm_host_rebuild_range<4>(hc, sg, dp, Ct, b, e);
         else vm_host_rebuild_range<6>(hc, sg, dp, Ct, b, e);
     });
@@ -416,6 +416,147 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
 }
 
+// ------------------------------------------------------------------ device-resident history variables
+// The reference's callback reads sigma_n and p from closure-captured arrays at every call
+// (demo_plasticity_von_mises.py:347-348) although they only change at the end of a load step (:564-565). Uploading them
+// with every Newton iteration is 56 of the 104 B/point a host call sends (d = 6); with a dxo_vm_state they cross the
+// link once, the kernel reads them from HBM, leaves (sigma, dp) of the call beside them, and dxo_vm_state_commit applies
+// the load-step update on the device while the caller applies the reference's two statements to its host arrays.
+extern "C" int dxo_vm_state_create(dxo_ctx* ctx, int d, int64_t n, dxo_vm_state** out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!out) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_create: out is NULL");
+    *out = nullptr;
+    if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_state_create: d must be 4 or 6");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_state_create: n < 0");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t bs = up((size_t)n * d * sizeof(double)), bp = up((size_t)n * sizeof(double));
+    void* blob = nullptr;
+    DXO_HIP(ctx, hipMalloc(&blob, 2 * bs + 2 * bp + 256));
+    dxo_vm_state* st = new dxo_vm_state;
+    st->d = d;
+    st->n = n;
+    st->blob = blob;
+    char* b = static_cast<char*>(blob);
+    st->sigma_n = reinterpret_cast<double*>(b);
+    st->sigma = reinterpret_cast<double*>(b + bs);
+    st->p = reinterpret_cast<double*>(b + 2 * bs);
+    st->dp = reinterpret_cast<double*>(b + 2 * bs + bp);
+    *out = st;
+    return DXO_OK;
+}
+
+extern "C" void dxo_vm_state_destroy(dxo_ctx* ctx, dxo_vm_state* st) {
+    if (!st) return;
+    if (ctx) {
+        DXO_LOCK(ctx);
+        (void)hipSetDevice(ctx->device);
+        (void)dxo_ctx_synchronize(ctx);
+        if (st->blob) (void)hipFree(st->blob);
+    } else if (st->blob) {
+        (void)hipFree(st->blob);
+    }
+    delete st;
+}
+
+extern "C" int dxo_vm_state_upload(dxo_ctx* ctx, dxo_vm_state* st, int mem, const double* sigma_n, const double* p) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_upload: state is NULL");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_vm_state_upload: bad mem");
+    if (st->n > 0 && (!sigma_n || !p)) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_upload: NULL array");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    const hipMemcpyKind k = mem == DXO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (st->n > 0) {
+        DXO_HIP(ctx, hipMemcpyAsync(st->sigma_n, sigma_n, (size_t)st->n * st->d * sizeof(double), k, s));
+        DXO_HIP(ctx, hipMemcpyAsync(st->p, p, (size_t)st->n * sizeof(double), k, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));   // the next call may read the mirror from any of the pipeline's streams
+    }
+    st->uploaded = true;
+    st->has_result = false;
+    return DXO_OK;
+}
+
+extern "C" int dxo_vm_state_download(dxo_ctx* ctx, dxo_vm_state* st, int mem, double* sigma_n, double* p) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_download: state is NULL");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_vm_state_download: bad mem");
+    if (!st->uploaded) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_state_download: nothing has been uploaded");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    const hipMemcpyKind k = mem == DXO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (st->n > 0) {
+        if (sigma_n) DXO_HIP(ctx, hipMemcpyAsync(sigma_n, st->sigma_n, (size_t)st->n * st->d * sizeof(double), k, s));
+        if (p) DXO_HIP(ctx, hipMemcpyAsync(p, st->p, (size_t)st->n * sizeof(double), k, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return DXO_OK;
+}
+
+extern "C" int dxo_vm_state_pointers(dxo_ctx* ctx, dxo_vm_state* st, double** sigma_n, double** p, double** sigma, double** dp) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_pointers: state is NULL");
+    if (sigma_n) *sigma_n = st->sigma_n;
+    if (p) *p = st->p;
+    if (sigma) *sigma = st->sigma;
+    if (dp) *dp = st->dp;
+    return DXO_OK;
+}
+
+extern "C" int dxo_von_mises_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_vm_state* st, int mem, const double* deps,
+                                   double* C_tang, double* sigma, double* dp) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!prm || !st) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_state: NULL params or state");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises_state: bad mem");
+    if (!st->uploaded) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_state: dxo_vm_state_upload has not been called");
+    const int d = st->d;
+    const int64_t n = st->n;
+    if (n == 0) return DXO_OK;
+    if (!deps || !C_tang) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_state: NULL array");
+    if (((uintptr_t)deps | (uintptr_t)C_tang | (uintptr_t)sigma | (uintptr_t)dp) & 7u)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_state: arrays must be 8-byte aligned");
+    VmLaunch L{make_const(*prm), d};
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    st->has_result = false;
+    const size_t sd = sizeof(double);
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = vm_launch(ctx, L, n, deps, st->sigma_n, st->p, C_tang, st->sigma, st->dp, s);
+        if (rc != DXO_OK) return rc;
+        if (sigma) DXO_HIP(ctx, hipMemcpyAsync(sigma, st->sigma, (size_t)n * d * sd, hipMemcpyDeviceToDevice, s));
+        if (dp) DXO_HIP(ctx, hipMemcpyAsync(dp, st->dp, (size_t)n * sd, hipMemcpyDeviceToDevice, s));
+        rc = dxo_device_end(ctx, s);
+        if (rc == DXO_OK) st->has_result = true;
+        return rc;
+    }
+    if (!sigma || !dp) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_state: host sigma / dp are required");
+    std::vector<dxo_span> in = {{deps, nullptr, d * sd}, {nullptr, nullptr, d * sd, st->sigma_n}, {nullptr, nullptr, sd, st->p}};
+    int rc;
+    if (ctx->vm_host_tangent && n >= ctx->vm_rebuild_min_points) {
+        L.h_sigma = sigma;
+        L.h_dp = dp;
+        L.h_C_tang = C_tang;
+        L.c.mark_indeterminate = 1;   // the mark (dp = -0.0) stays in the mirror's dp: p + (-0.0) == p at the commit
+        std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        const int64_t saved_chunk = ctx->host_chunk_points;
+        if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
+        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+        ctx->host_chunk_points = saved_chunk;
+    } else {
+        std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
+    }
+    if (rc == DXO_OK) st->has_result = true;
+    return rc;
+}
+
 // ------------------------------------------------------------------ history update
 // End of a load step in the reference: `p.x.petsc_vec.axpy(1.0, dp.x.petsc_vec)` and
 // `sigma_n.x.array[:] = sigma.ref_coefficient.x.array` (demo_plasticity_von_mises.py:564-565). With the state
@@ -449,4 +590,17 @@ extern "C" int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, co
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(vm_commit, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, n * d, p, dp, sigma_n, sigma);
     return dxo_device_end(ctx, s);
+}
+
+extern "C" int dxo_vm_state_commit(dxo_ctx* ctx, dxo_vm_state* st) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_commit: state is NULL");
+    if (!st->has_result)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_state_commit: no call since the last upload / commit — nothing to commit");
+    int rc = dxo_vm_commit_state(ctx, st->d, st->n, st->p, st->dp, st->sigma_n, st->sigma);
+    if (rc != DXO_OK) return rc;
+    DXO_HIP(ctx, hipStreamSynchronize(dxo_launch_stream(ctx)));   // the pipeline's streams read the mirror next
+    st->has_result = false;
+    return DXO_OK;
 }

@@ -120,7 +120,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = False, host_tangent: str = "rebuild") -> Callable:
+                   reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host") -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -138,6 +138,16 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     (bit-identical to a device call).
     `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors carved from the context's
     placement-calibrated output arena (Context.output_arena); pass them as `out=` to the device call.
+    state (NumPy operands only): "host" (default) is the reference's contract — sigma_n and p are re-read from the
+    holders and uploaded at every call (:347-348). "resident" keeps a device mirror (dxo_vm_state, include/dxo.h): the
+    holders are uploaded at the first call and from then on only `deps` (or the dof vector of a lazy operand) crosses
+    the link on the way up — 48 instead of 104 B/point at d = 6. The mirror follows the caller in two ways:
+      external_function.commit_state()   after the reference's load-step update `p += dp; sigma_n[:] = sigma`
+                                         (:564-565) on the host arrays: the same update on the device, no transfer;
+      external_function.state_changed()  after ANY other change of the holders: re-upload at the next call.
+    As a tripwire (not a guarantee) every call compares 2 048 strided samples of the holders with what they were when the
+    mirror was last known to match; a difference re-uploads and warns. external_function.check_state() downloads the
+    mirror and returns max |mirror - holders| (tests, debugging).
     """
     if H is None:
         E_tangent = E / 100.0                      # :186
@@ -145,7 +155,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     prm = VmParams(float(E), float(nu), float(sigma_0), float(H))
     if host_tangent not in ("copy", "rebuild"):
         raise ValueError('host_tangent must be "copy" or "rebuild"')
+    if state not in ("host", "resident"):
+        raise ValueError('state must be "host" or "resident"')
     holder = {"ctx": ctx, "out": None}
+    mirror = _StateMirror(sigma_n, p) if state == "resident" else None
 
     def _ctx() -> Context:
         if holder["ctx"] is None:
@@ -167,7 +180,15 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
                 raise ValueError(f"state size mismatch: sigma_n {sigma_n_.size} (want {n * d}), p {p_.size} (want {n})")
             out = holder["out"]
             C_tang_, sigma_, dp_ = out.get("C_tang", n * d * d), out.get("sigma", n * d), out.get("dp", n)
-            deps.mesh.von_mises(prm, deps.u, sigma_n_, p_, C_tang_, sigma_, dp_)
+            with c._lock:   # vm_host_tangent is a per-context option: set, call, restore as one unit
+                c.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
+                try:
+                    if mirror is not None:
+                        mirror.sync(c, d, n, sigma_n_, p_).call_field(prm, deps.mesh._h, MEM_HOST, deps.u, C_tang_, sigma_, dp_)
+                    else:
+                        deps.mesh.von_mises(prm, deps.u, sigma_n_, p_, C_tang_, sigma_, dp_)
+                finally:
+                    c.set_option("vm_host_tangent", 0)
             return C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1)
         deps = np.asarray(deps)
         num_cells, num_quadrature_points, d = deps.shape      # :344
@@ -184,15 +205,15 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         C_tang_ = out.get("C_tang", n * d * d)
         sigma_ = out.get("sigma", n * d)
         dp_ = out.get("dp", n)
-        if host_tangent == "rebuild":
-            with c._lock:   # the option is per context: set, call, restore without another thread's call in between
-                c.set_option("vm_host_tangent", 1)
-                try:
+        with c._lock:   # the option is per context: set, call, restore without another thread's call in between
+            c.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
+            try:
+                if mirror is not None:
+                    mirror.sync(c, d, n, sigma_n_, p_).call(prm, MEM_HOST, deps_, C_tang_, sigma_, dp_)
+                else:
                     c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
-                finally:
-                    c.set_option("vm_host_tangent", 0)
-        else:
-            c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
+            finally:
+                c.set_option("vm_host_tangent", 0)
         return _like(deps, C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1))   # :352
 
     def sigma_external(derivatives):
@@ -205,10 +226,74 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         memory owned by the dxo_ctx, dxo_output_arena): the persistent coefficient buffers of a solver."""
         return _ctx().output_tensors((n_points * d * d, n_points * d, n_points))
 
+    def _need_mirror():
+        if mirror is None:
+            raise RuntimeError('make_von_mises(..., state="resident") keeps a device mirror; this operator re-reads its state at every call')
+        return mirror
+
     sigma_external.params = prm
     sigma_external.context = _ctx
     sigma_external.arena = arena
+    sigma_external.commit_state = lambda: _need_mirror().commit()
+    sigma_external.state_changed = lambda: _need_mirror().invalidate()
+    sigma_external.check_state = lambda: _need_mirror().check()
     return sigma_external
+
+
+class _StateMirror:
+    """Host-side bookkeeping of a dxo_vm_state for make_von_mises(state="resident")."""
+
+    SAMPLES = 2048
+
+    def __init__(self, sigma_n_holder, p_holder):
+        self.holders = (sigma_n_holder, p_holder)
+        self.state = None            # _lib.VmState
+        self.fresh = False           # mirror == holders as far as we know
+        self.samples = None          # (sigma_n samples, p samples) taken when the mirror was last known to match
+        self.resample = False
+
+    def _take(self, sigma_n_, p_):
+        ks = max(sigma_n_.size // self.SAMPLES, 1)
+        kp = max(p_.size // self.SAMPLES, 1)
+        return sigma_n_[::ks].copy(), p_[::kp].copy()
+
+    def sync(self, c: Context, d: int, n: int, sigma_n_, p_):
+        """The VmState to call, uploaded first if the mirror is not known to match the holders."""
+        if self.state is None or self.state.ctx is not c or self.state.d != d or self.state.n != n:
+            if self.state is not None:
+                self.state.close()
+            self.state, self.fresh = c.vm_state(d, n), False
+        if self.fresh and not self.resample:
+            a, b = self._take(sigma_n_, p_)
+            if not (np.array_equal(a, self.samples[0], equal_nan=True) and np.array_equal(b, self.samples[1], equal_nan=True)):
+                import warnings
+
+                warnings.warn("make_von_mises(state='resident'): sigma_n / p changed without commit_state() / state_changed(); "
+                              "re-uploading them", RuntimeWarning, stacklevel=4)
+                self.fresh = False
+        if not self.fresh:
+            self.state.upload(sigma_n_, p_)
+            self.fresh, self.resample = True, True
+        if self.resample:
+            self.samples, self.resample = self._take(sigma_n_, p_), False
+        return self.state
+
+    def commit(self):
+        if self.state is None or not self.fresh:
+            return                      # nothing on the device yet (or already marked stale): the next call uploads
+        self.state.commit()
+        self.resample = True            # the caller's arrays carry the same update; sample them at the next call
+
+    def invalidate(self):
+        self.fresh = False
+
+    def check(self) -> float:
+        if self.state is None:
+            raise RuntimeError("no call has been made yet")
+        sn, pp = self.state.download()
+        hs = _as_f64_host(_state_array(self.holders[0]), "sigma_n").reshape(-1)
+        hp = _as_f64_host(_state_array(self.holders[1]), "p").reshape(-1)
+        return float(max(np.max(np.abs(sn - hs), initial=0.0), np.max(np.abs(pp - hp), initial=0.0)))
 
 
 def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p, out=None):

@@ -112,7 +112,7 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0
- * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^16), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
+ * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
  * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
@@ -174,6 +174,32 @@ int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t
  *   p[n] += dp[n];  sigma_n[n][d] = sigma[n][d].   One fused pass, asynchronous on the ctx stream. */
 int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, const double* dp,
                         double* sigma_n, const double* sigma);
+
+/* ---- History variables resident on the device -------------------------------------------------
+ * The reference's callback re-reads sigma_n and p from closure-captured host arrays at every call
+ * (demo_plasticity_von_mises.py:347-348) although they change only at the end of a load step (:564-565). A dxo_vm_state
+ * is their device mirror for n points of Mandel length d, plus the (sigma, dp) of the last call:
+ *   dxo_vm_state_upload    host (or device) arrays -> mirror; blocking. Call it once, and again whenever the caller
+ *                          changed its arrays in any other way than the load-step update below.
+ *   dxo_von_mises_state    dxo_von_mises with sigma_n, p read from the mirror. `mem` says where deps and the outputs
+ *                          live. DXO_MEM_HOST: only deps goes up (48 of 104 B/point at d = 6); option vm_host_tangent
+ *                          applies as in dxo_von_mises. DXO_MEM_DEVICE: sigma / dp may be NULL (results stay in the
+ *                          mirror, see dxo_vm_state_pointers).
+ *   dxo_vm_state_commit    p += dp; sigma_n <- sigma inside the mirror with the results of the LAST call — what the
+ *                          caller does to its host arrays at :564-565. Blocking. DXO_E_SIZE if there was no call since
+ *                          the last upload / commit.
+ *   dxo_vm_state_download  mirror -> caller's arrays (either may be NULL): checks and checkpoints.
+ *   dxo_vm_state_pointers  the device arrays themselves: sigma_n[n][d], p[n], sigma[n][d], dp[n] (any may be NULL).
+ * Results are bit-identical to dxo_von_mises on the same values. One state belongs to one ctx. */
+typedef struct dxo_vm_state dxo_vm_state;
+int dxo_vm_state_create(dxo_ctx* ctx, int d, int64_t n, dxo_vm_state** out);
+void dxo_vm_state_destroy(dxo_ctx* ctx, dxo_vm_state* state);
+int dxo_vm_state_upload(dxo_ctx* ctx, dxo_vm_state* state, int mem, const double* sigma_n, const double* p);
+int dxo_vm_state_download(dxo_ctx* ctx, dxo_vm_state* state, int mem, double* sigma_n, double* p);
+int dxo_vm_state_commit(dxo_ctx* ctx, dxo_vm_state* state);
+int dxo_vm_state_pointers(dxo_ctx* ctx, dxo_vm_state* state, double** sigma_n, double** p, double** sigma, double** dp);
+int dxo_von_mises_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_vm_state* state, int mem, const double* deps,
+                        double* C_tang, double* sigma, double* dp);
 
 /* Device memory owned by the caller but allocated through the library (hipMalloc / hipFree / hipMemcpyAsync on
  * the ctx stream + synchronise), so a host program without its own HIP binding can keep state on the GPU.
@@ -324,6 +350,10 @@ int dxo_eval_operand_facets(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int 
  * dxo_von_mises. The strain increment is never written to memory. */
 int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                         const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
+/* The same with the history variables in a dxo_vm_state (n = num_cells*nq, d as the mesh gives it): a host call sends the
+ * dof vector only. Option vm_host_tangent applies to both entry points (DXO_MEM_HOST). */
+int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, dxo_vm_state* state, int mem,
+                              const double* u, double* C_tang, double* sigma, double* dp);
 
 /* ---- the consumer side on the device, DEVICE memory only ---------------------------------
  * In the reference the coefficient is consumed by DOLFINx assembly of inner(sigma, eps(v)) dx and of the Jacobian

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Does the INPUT allocation matter? vm_tile (d = 6, 10^7 points) with the outputs fixed in one arena block and the
+inputs copied into K different allocations; then the reverse with torch.empty outputs. One JSON line each."""
+import json
+import pathlib
+import statistics
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams  # noqa: E402
+
+dev = torch.device("cuda:0")
+n, d = 10_000_000, 6
+E = 70e3
+prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+ctx = Context(0)
+stream = torch.cuda.current_stream()
+ctx.set_stream(stream.cuda_stream)
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+src = torch.empty(n * 13, dtype=torch.float64, device=dev)
+src[:n * 6].normal_(0.0, 3e-3, generator=g)
+src[n * 6:n * 12].normal_(0.0, 100.0, generator=g)
+src[n * 12:].normal_(0.0, 1e-3, generator=g).abs_()
+outs = ctx.output_tensors((n * d * d, n * d, n))
+print(json.dumps({"placement": outs[0].dxo_block.info}), flush=True)
+
+
+def timeit(inp, out_ptrs):
+    p0 = inp.data_ptr()
+    args = (p0, p0 + n * 48, p0 + n * 96, *out_ptrs)
+    for _ in range(5):
+        ctx.von_mises(prm, d, n, MEM_DEVICE, *args)
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(20):
+            ctx.von_mises(prm, d, n, MEM_DEVICE, *args)
+        b.record(stream)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / 20)
+    return 448 * n / statistics.median(ts) / 1e6
+
+
+keep = []
+rates = []
+for k in range(10):
+    inp = torch.empty_like(src)
+    inp.copy_(src)
+    keep.append(inp)
+    rates.append(round(timeit(inp, tuple(o.data_ptr() for o in outs)), 1))
+print(json.dumps({"inputs_in_10_allocations_outputs_fixed_GBps": rates}), flush=True)
+best_in = keep[max(range(10), key=lambda i: rates[i])]
+rates = []
+outs_k = []
+for k in range(8):
+    o = torch.empty(n * 43, dtype=torch.float64, device=dev)
+    outs_k.append(o)
+    rates.append(round(timeit(best_in, (o.data_ptr(), o.data_ptr() + n * 288, o.data_ptr() + n * 336)), 1))
+print(json.dumps({"outputs_in_8_torch_allocations_best_input_GBps": rates}), flush=True)
+# three output arrays in three separate allocations
+sep = [torch.empty(n * 36, dtype=torch.float64, device=dev), torch.empty(n * 6, dtype=torch.float64, device=dev),
+       torch.empty(n, dtype=torch.float64, device=dev)]
+print(json.dumps({"outputs_in_three_separate_allocations_GBps": round(timeit(best_in, tuple(o.data_ptr() for o in sep)), 1)}), flush=True)

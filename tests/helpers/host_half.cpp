@@ -10,6 +10,30 @@
 #include "host_pool.h"
 #include "vm_host.h"
 
+// form: 0 = the product's run-time choice, 1 = portable SSE2 form, 2 = AVX2 + FMA form (-3 if the CPU lacks it)
+extern "C" int host_rebuild_form(int form, int d, int64_t n, double E, double nu, double H, int threads, const double* sigma,
+                                 double* dp, double* C_tang) {
+    const double lmbda = E * nu / (1.0 + nu) / (1.0 - 2.0 * nu), mu = E / 2.0 / (1.0 + nu);
+    const VmHostConst c{lmbda, 2.0 * mu, 3 * mu, 3 * mu / (3 * mu + H)};
+    if (d != 4 && d != 6) return -2;
+    if (form == 2 && !(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"))) return -3;
+    dxo_host_pool* pool = nullptr;
+    dxo_pool_parallel_for(pool, threads, n, 256, [&](int64_t b, int64_t e) {
+        if (form == 1) {
+            if (d == 4) vm_host_rebuild_range_sse2<4>(c, sigma, dp, C_tang, b, e);
+            else vm_host_rebuild_range_sse2<6>(c, sigma, dp, C_tang, b, e);
+        } else if (form == 2) {
+            if (d == 4) vm_host_rebuild_range_avx2<4>(c, sigma, dp, C_tang, b, e);
+            else vm_host_rebuild_range_avx2<6>(c, sigma, dp, C_tang, b, e);
+        } else {
+            if (d == 4) vm_host_rebuild_range<4>(c, sigma, dp, C_tang, b, e);
+            else vm_host_rebuild_range<6>(c, sigma, dp, C_tang, b, e);
+        }
+    });
+    dxo_host_pool_destroy(pool);
+    return 0;
+}
+
 extern "C" int host_rebuild(int d, int64_t n, double E, double nu, double H, int threads, const double* sigma, double* dp,
                             double* C_tang) {
     const double lmbda = E * nu / (1.0 + nu) / (1.0 - 2.0 * nu), mu = E / 2.0 / (1.0 + nu);   // demo_plasticity_von_mises.py:190-191
