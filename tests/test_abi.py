@@ -55,6 +55,13 @@ def test_argument_errors_without_a_device(hip_library):
     assert lib.dxo_von_mises(None, None, 4, 0, 0, None, None, None, None, None, None) == -1
     assert lib.dxo_heat(None, 1.0, 1.0, 2, 0, 0, None, None, None, None, None) == -1
     assert lib.dxo_ctx_destroy(None) == -1
+    h = C.c_void_p()
+    assert lib.dxo_vm_state_create(None, 6, 10, C.byref(h)) == -1  # dxo_vm_state_*: a NULL ctx is refused before any HIP call
+    assert lib.dxo_vm_state_upload(None, None, 0, None, None) == -1
+    assert lib.dxo_vm_state_commit(None, None) == -1
+    assert lib.dxo_von_mises_state(None, None, None, 0, None, None, None, None) == -1
+    assert lib.dxo_von_mises_field_state(None, None, None, None, 0, None, None, None, None) == -1
+    lib.dxo_vm_state_destroy(None, None)                           # no-op
     n = C.c_int(-5)
     rc = lib.dxo_device_count(C.byref(n))
     assert rc in (0, -7) and n.value >= 0
