@@ -127,6 +127,8 @@ _SIGNATURES = {
     "dxo_heat_field": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_mgpu_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "dxo_mgpu_create_local": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "dxo_mgpu_von_mises_host": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64] + [_P] * 6),
     "dxo_mgpu_unique_id": (C.c_int, [_P]),
     "dxo_mgpu_create_rank": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "dxo_mgpu_destroy": (C.c_int, [_P]),
@@ -616,6 +618,8 @@ class MultiGpu:
     MultiGpu(devices=[0, 1, ...])                       one process driving several GPUs (ncclCommInitAll)
     MultiGpu.from_rank(ctx, unique_id, rank, world)     one process per GPU; `unique_id = MultiGpu.unique_id()` on
                                                         rank 0, broadcast by the caller (128 bytes)
+    MultiGpu.local(devices=[0, 1, ...])                 contexts only, no communicator, RCCL never loaded: for
+                                                        `von_mises_host` (NumPy arrays sharded over the GPUs' PCIe links)
     Pointer-list arguments take one device pointer (int or tensor with data_ptr()) per LOCAL device."""
 
     def __init__(self, devices=None, n_dev: int | None = None, _handle=None, _ctx=None):
@@ -633,6 +637,26 @@ class MultiGpu:
             raise DxoError(f"dxo_mgpu_create({list(devices)}) failed with {ERRORS.get(rc, rc)}: needs that many MI355X and "
                            "RCCL (librccl.so.1); there is no CPU fallback")
         self._h = h
+
+    @classmethod
+    def local(cls, devices) -> "MultiGpu":
+        lib = load_library()
+        arr = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = _P()
+        rc = lib.dxo_mgpu_create_local(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise DxoError(f"dxo_mgpu_create_local({list(devices)}) failed with {ERRORS.get(rc, rc)}: no such MI355X; there is no CPU fallback")
+        return cls(_handle=h)
+
+    def set_option(self, key: str, value: int) -> None:
+        """The option on every local context."""
+        for i in range(self.local_count):
+            self._check(self.lib.dxo_ctx_set_option(_P(self.ctx_handle(i)), key.encode(), int(value)), f"set_option({key})")
+
+    def von_mises_host(self, prm: VmParams, d: int, n: int, deps, sigma_n, p, C_tang, sigma, dp) -> None:
+        """dxo_mgpu_von_mises_host: HOST arrays of all n points, one contiguous block per local device, no collective."""
+        rc = self.lib.dxo_mgpu_von_mises_host(self._h, C.byref(prm), int(d), int(n), *(_ptr(a) for a in (deps, sigma_n, p, C_tang, sigma, dp)))
+        self._check(rc, "dxo_mgpu_von_mises_host")
 
     @staticmethod
     def unique_id() -> bytes:

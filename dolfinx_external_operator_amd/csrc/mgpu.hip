@@ -25,6 +25,10 @@
 
 #include <rccl/rccl.h>
 
+#include <thread>
+
+#include "host_pool.h"
+
 #include "dxo_common.h"
 
 struct dxo_mgpu {
@@ -33,6 +37,7 @@ struct dxo_mgpu {
     std::vector<dxo_ctx*> ctx;     // one per local device
     std::vector<bool> own_ctx;
     std::vector<ncclComm_t> comm;
+    bool local_only = false;       // dxo_mgpu_create_local: contexts without a communicator (host-sharded calls only)
     std::string err;
 };
 
@@ -100,6 +105,8 @@ int nccl_fail(dxo_mgpu* g, ncclResult_t r, const char* where) {
     } while (0)
 
 int need_rccl(dxo_mgpu* g) {
+    if (g->local_only)
+        return mg_fail(g, DXO_E_OPTION, "this group was made by dxo_mgpu_create_local: it has no communicator (host-sharded calls only)");
     if (rccl()) return DXO_OK;
     return mg_fail(g, DXO_E_NODEVICE, "RCCL is not available in this process (librccl.so.1 could not be loaded)");
 }
@@ -127,7 +134,7 @@ dxo_ctx* dxo_mgpu_ctx(dxo_mgpu* g, int i) {
 
 int dxo_mgpu_destroy(dxo_mgpu* g) {
     if (!g) return DXO_E_NULL;
-    Rccl* R = rccl();
+    Rccl* R = g->local_only ? nullptr : rccl();   // a local group never loads RCCL
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         if (g->ctx[i]) {
             (void)hipSetDevice(g->ctx[i]->device);
@@ -181,6 +188,78 @@ int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out) {
         return code;
     }
     *out = g;
+    return DXO_OK;
+}
+
+// Contexts only, no communicator: for calls whose data path has no exchange step (dxo_mgpu_von_mises_host). RCCL is
+// not loaded. A device may appear more than once (two pipelines on one GPU: the single-GPU test of the sharded path).
+int dxo_mgpu_create_local(const int* devices, int n_dev, dxo_mgpu** out) {
+    if (!out) return DXO_E_NULL;
+    *out = nullptr;
+    if (n_dev < 1) return DXO_E_SIZE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return DXO_E_NODEVICE;
+    }
+    dxo_mgpu* g = new dxo_mgpu();
+    g->world = n_dev;
+    g->local_only = true;
+    g->comm.assign((size_t)n_dev, nullptr);
+    for (int i = 0; i < n_dev; ++i) {
+        const int dev = devices ? devices[i] : i;
+        dxo_ctx* c = nullptr;
+        const int rc = dev < 0 || dev >= count ? DXO_E_NODEVICE : dxo_ctx_create(dev, &c);
+        if (rc != DXO_OK) {
+            dxo_mgpu_destroy(g);
+            return rc;
+        }
+        g->ctx.push_back(c);
+        g->own_ctx.push_back(true);
+        g->rank.push_back(i);
+    }
+    *out = g;
+    return DXO_OK;
+}
+
+// Host arrays of ALL n points, split into one contiguous block per local device (borders on 64-point tiles); every
+// device runs dxo_von_mises(DXO_MEM_HOST) on its block from its own thread — its own chunked H2D / kernel / D2H pipeline
+// over its own PCIe link — and the results land in the caller's arrays directly: no exchange step, no collective.
+// This is how a single-process caller with NumPy arrays uses N GPUs: the host path is PCIe-bound, so N
+// links are what scales it. Context options (vm_host_tangent, host_chunk_points ...) are those of each local context
+// (dxo_mgpu_ctx); the contexts' host worker threads share the process's CPU budget.
+int dxo_mgpu_von_mises_host(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n, const double* deps, const double* sigma_n,
+                            const double* p, double* C_tang, double* sigma, double* dp) {
+    if (!g) return DXO_E_NULL;
+    if (!prm) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises_host: params is NULL");
+    if (d != 4 && d != 6) return mg_fail(g, DXO_E_DIM, "dxo_mgpu_von_mises_host: d must be 4 or 6");
+    if (n < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_von_mises_host: n < 0");
+    if (n > 0 && (!deps || !sigma_n || !p || !C_tang || !sigma || !dp)) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises_host: NULL array");
+    if (n == 0) return DXO_OK;
+    const int64_t L = (int64_t)g->ctx.size();
+    int64_t block = (n + L - 1) / L;
+    block = (block + DXO_WAVE - 1) / DXO_WAVE * DXO_WAVE;
+    // the workers of all contexts together stay inside the CPU budget of the process (host_pool.h)
+    const int share = (int)((dxo_host_cpu_budget() - 2) / L);
+    std::vector<int64_t> saved((size_t)L, 0);
+    for (int64_t i = 0; i < L; ++i) {
+        (void)dxo_ctx_get_option(g->ctx[(size_t)i], "host_threads", &saved[(size_t)i]);
+        if (saved[(size_t)i] > share) (void)dxo_ctx_set_option(g->ctx[(size_t)i], "host_threads", share > 1 ? share : 1);
+    }
+    std::vector<int> rc((size_t)L, DXO_OK);
+    std::vector<std::thread> th;
+    for (int64_t i = 0; i < L; ++i) {
+        const int64_t b = i * block, e = b + block < n ? b + block : n;
+        if (b >= e) break;
+        th.emplace_back([=, &rc] {
+            rc[(size_t)i] = dxo_von_mises(g->ctx[(size_t)i], prm, d, e - b, DXO_MEM_HOST, deps + b * d, sigma_n + b * d, p + b,
+                                          C_tang + b * d * d, sigma + b * d, dp + b);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int64_t i = 0; i < L; ++i) (void)dxo_ctx_set_option(g->ctx[(size_t)i], "host_threads", saved[(size_t)i]);
+    for (int64_t i = 0; i < L; ++i)
+        if (rc[(size_t)i] != DXO_OK) return mg_fail(g, rc[(size_t)i], dxo_last_error(g->ctx[(size_t)i]));
     return DXO_OK;
 }
 

@@ -427,6 +427,9 @@ int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, co
 #define DXO_GATHER_COMPACT 2
 typedef struct dxo_mgpu dxo_mgpu;
 int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out);
+/* Contexts only, no communicator and no RCCL: for dxo_mgpu_von_mises_host, whose data path has no exchange step. The
+ * collective entry points return DXO_E_OPTION on such a group. A device may be listed more than once. */
+int dxo_mgpu_create_local(const int* devices, int n_dev, dxo_mgpu** out);
 int dxo_mgpu_unique_id(void* id128);
 int dxo_mgpu_create_rank(dxo_ctx* ctx, const void* id128, int rank, int world, dxo_mgpu** out);
 int dxo_mgpu_destroy(dxo_mgpu* g);
@@ -444,6 +447,13 @@ int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank)
 int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_per_rank, int gather,
                        const double* const* deps, const double* const* sigma_n, const double* const* p,
                        double* const* C_tang, double* const* sigma, double* const* dp);
+
+/* HOST arrays of all n points sharded over the local devices, no collective: contiguous blocks (borders on 64-point
+ * tiles), one dxo_von_mises(DXO_MEM_HOST) per device, concurrently, each over its own PCIe link; results land in the
+ * caller's arrays. The NumPy path is PCIe-bound, so the links are what scales it. Works on any group (create,
+ * create_local; with create_rank it is the single local device). Options are those of the local contexts (dxo_mgpu_ctx). */
+int dxo_mgpu_von_mises_host(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n, const double* deps,
+                            const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
 
 /* ---- HBM stream probe (measurement aid, device memory only) --------------------------------
  * Moves data with no arithmetic in the read : write mix of a constitutive kernel, lane-linear 16-byte

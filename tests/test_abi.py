@@ -74,6 +74,9 @@ def test_mgpu_entry_points_reject_bad_arguments_without_a_device(hip_library):
     assert lib.dxo_mgpu_create(None, 1, None) == -1                # DXO_E_NULL
     assert lib.dxo_mgpu_create(None, 0, C.byref(h)) == -3          # DXO_E_SIZE
     assert lib.dxo_mgpu_destroy(None) == -1
+    assert lib.dxo_mgpu_create_local(None, 1, None) == -1
+    assert lib.dxo_mgpu_create_local(None, 0, C.byref(h)) == -3
+    assert lib.dxo_mgpu_von_mises_host(None, None, 6, 0, None, None, None, None, None, None) == -1
     assert lib.dxo_mgpu_size(None) == -1
     assert lib.dxo_mgpu_unique_id(None) == -1
     assert lib.dxo_mgpu_create_rank(None, None, 0, 1, C.byref(h)) == -1

@@ -177,3 +177,36 @@ def test_lazy_operand_with_resident_state(ctx, cell, n, host_tangent):
         sigma_n[:] = got[1].reshape(npts, d)
         ext_r.commit_state()
         assert ext_r.check_state() == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NumPy arrays sharded over several pipelines without a collective (dxo_mgpu_create_local + dxo_mgpu_von_mises_host).
+# A 1-GPU box lists device 0 several times: every entry is its own context, streams and thread, so the split, the
+# concurrency and the thread-budget sharing are the real thing; only the extra PCIe links are missing.
+@pytest.mark.parametrize("n_dev", [1, 2, 3])
+@pytest.mark.parametrize("n", [0, 5, 100_003, 700_001])
+@pytest.mark.parametrize("rebuild", [0, 1])
+def test_host_arrays_sharded_over_local_pipelines(ctx, n_dev, n, rebuild):
+    from dolfinx_external_operator_amd._lib import MultiGpu
+
+    d = 6
+    deps, sigma_n, p = vm_inputs(max(n, 1), d, seed=12)
+    deps, sigma_n, p = deps[:n], sigma_n[:n], p[:n]
+    ref = _plain(ctx, d, n, deps, sigma_n, p, rebuild)
+    g = MultiGpu.local([0] * n_dev)
+    try:
+        assert g.local_count == n_dev and g.world == n_dev
+        g.set_option("vm_host_tangent", rebuild)
+        g.set_option("vm_rebuild_min_points", 1 << 14)                # the blocks of the smaller cases take the rebuild path too
+        C, s, dp = np.full(n * d * d, np.nan), np.full(n * d, np.nan), np.full(n, np.nan)
+        g.von_mises_host(PRM, d, n, deps, sigma_n, p, C, s, dp)
+        np.testing.assert_array_equal(s, ref[1])
+        np.testing.assert_array_equal(dp, ref[2])
+        if rebuild and n < (1 << 18):                                 # the plain call above stayed in copy mode below its threshold
+            assert_close_scaled(C, ref[0], 1e-14, "host-rebuilt tangent")
+        else:
+            np.testing.assert_array_equal(C, ref[0])
+        with pytest.raises(ValueError, match="no communicator"):     # a local group has no exchange step
+            g.all_gather([0] * n_dev, 16)
+    finally:
+        g.close()
