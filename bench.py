@@ -292,7 +292,7 @@ def main():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
-    ap.add_argument("--placement", type=int, default=12,
+    ap.add_argument("--placement", type=int, default=16,
                     help="candidates of the LIBRARY's output-arena calibration (ctx option placement_candidates; "
                          "0/1 = plain hipMalloc). The bench itself selects nothing. See DESIGN.md 3.1.")
     args = ap.parse_args()
@@ -381,7 +381,14 @@ def main():
     else:
         ctx.set_option("placement_candidates", min(args.placement, 3) if gather_on else args.placement)
         ctx.set_option("placement_mode", 2)
-    C_full, sigma_full, dp_full = ctx.output_tensors((N_full * d * d, N_full * d, N_full))
+        if gather_on:
+            # the gathered arrays are RCCL send / receive buffers: plain hipMalloc blocks only (a virtual range backed by
+            # 2 MB chunks cannot be exported with hipIpcGetMemHandle, which RCCL may use for peer access)
+            ctx.set_option("placement_vmm", 0)
+    if gather_on:
+        C_full, sigma_full, dp_full = ctx.output_tensors((N_full * d * d, N_full * d, N_full))
+    else:   # what make_von_mises(...).arena(n, d) hands out: candidates timed with the kernel itself (dxo_vm_output_alloc)
+        C_full, sigma_full, dp_full = ctx.vm_output_tensors(N_full, d)
     placement = dict(C_full.dxo_block.info)
     C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]
     sigma = sigma_full[own * n * d:(own + 1) * n * d]

@@ -64,8 +64,9 @@ PLACEMENT_MAX = 32
 
 class PlacementInfo(C.Structure):
     """dxo_placement_info — what dxo_output_alloc's calibration saw."""
-    _fields_ = [("mode", C.c_int32), ("candidates", C.c_int32), ("chosen", C.c_int32), ("_pad", C.c_int32),
-                ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double), ("chosen_GBps", C.c_double)]
+    _fields_ = [("mode", C.c_int16), ("probe_kind", C.c_int16), ("candidates", C.c_int32), ("chosen", C.c_int32), ("vmm_mask", C.c_uint32),
+                ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double), ("chosen_GBps", C.c_double),
+                ("tuned_blocks_per_cu", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DeviceInfo(C.Structure):
@@ -91,6 +92,7 @@ _SIGNATURES = {
     "dxo_output_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_output_free": (C.c_int, [_P, _P]),
     "dxo_output_info": (C.c_int, [_P, _P, C.POINTER(PlacementInfo)]),
+    "dxo_vm_output_alloc": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
@@ -485,8 +487,12 @@ class Context:
     def output_info(self, ptr: int) -> dict:
         info = PlacementInfo()
         self.check(self.lib.dxo_output_info(self._h, _P(ptr), C.byref(info)), "dxo_output_info")
-        return {"mode": {0: "hipMalloc", 2: "hipMalloc_candidates"}[info.mode],
+        kinds = ["2MB_chunks" if (info.vmm_mask >> k) & 1 else "hipMalloc" for k in range(info.candidates)]
+        return {"mode": {0: "hipMalloc", 2: "candidates"}[info.mode],
                 "candidates": info.candidates, "chosen": info.chosen,
+                "chosen_kind": kinds[info.chosen] if 0 <= info.chosen < len(kinds) else "hipMalloc",
+                "kinds": kinds, "probe": {0: "store_stream", 1: "six_stream_mix", 2: "vm_tile"}.get(info.probe_kind, str(info.probe_kind)),
+                "tuned_blocks_per_cu": info.tuned_blocks_per_cu,
                 "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
                 "chosen_GBps": round(info.chosen_GBps, 1), "calibration_ms": info.calibration_ms}
 
@@ -512,6 +518,23 @@ class Context:
             out.append(t)
         return out
 
+    def vm_output_tensors(self, n: int, d: int):
+        """(C_tang, sigma, dp) for n points as flat fp64 CUDA tensors in ONE arena block calibrated with the von Mises
+        kernel itself (dxo_vm_output_alloc): candidates are timed running vm_tile in two launch shapes and the pair
+        (block, shape) that makes the kernel fastest is kept; the kernel picks the shape up whenever it writes there."""
+        import torch
+
+        ptrs = [_P() for _ in range(3)]
+        self.check(self.lib.dxo_vm_output_alloc(self._h, int(d), int(n), *(C.byref(q) for q in ptrs)), "dxo_vm_output_alloc")
+        block = _ArenaBlock(self, 0, ptr=ptrs[0].value)
+        out = []
+        for q, m in zip(ptrs, (n * d * d, n * d, n)):
+            view = _CudaArrayView(block, q.value, int(m), "<f8")
+            t = torch.as_tensor(view, device=torch.device("cuda", self.device)) if m else torch.empty(0, dtype=torch.float64, device=torch.device("cuda", self.device))
+            t.dxo_block = block
+            out.append(t)
+        return out
+
     def device_alloc(self, nbytes: int) -> int:
         p = _P()
         self.check(self.lib.dxo_device_alloc(self._h, int(nbytes), C.byref(p)), "dxo_device_alloc")
@@ -533,10 +556,10 @@ class Context:
 class _ArenaBlock:
     """Owner object of one dxo_output_alloc block; freed when the last tensor view and this object are gone."""
 
-    def __init__(self, ctx: Context, nbytes: int):
+    def __init__(self, ctx: Context, nbytes: int, ptr: int | None = None):
         self.ctx = ctx
         self.nbytes = nbytes
-        self.ptr = ctx.output_alloc(nbytes)
+        self.ptr = ctx.output_alloc(nbytes) if ptr is None else ptr   # ptr: a block the library has already handed out
         self.info = ctx.output_info(self.ptr)
         self._fin = weakref.finalize(self, _ArenaBlock._release, weakref.ref(ctx), self.ptr)
         self._fin.atexit = False

@@ -21,7 +21,9 @@
 // 6.8 in place_exp9 S2), keeping the ranges mapped side by side as aliases made all of them slower (4.9-5.1 TB/s),
 // and one remap sequence ended in a GPU memory-access fault on this ROCm build (profiles/r02_place_exp9.txt).
 //
-// Option "placement_mode": 2 = hipMalloc candidates as above (default), 0 = plain hipMalloc. Blocks below
+// Round 2, later: the candidates need not all be hipMalloc blocks — see "candidates" below (option "placement_vmm").
+//
+// Option "placement_mode": 2 = candidates as above (default), 0 = plain hipMalloc. Blocks below
 // "placement_min_bytes" (1 GiB) are plain hipMalloc: a working set that small lives in the 256 MB Infinity Cache /
 // L2 and has no placement class.
 #include <algorithm>
@@ -41,29 +43,143 @@ __global__ __launch_bounds__(DXO_BLOCK) void arena_write_sweep(int64_t n_tiles, 
     }
 }
 
-size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-void launch_sweep(dxo_ctx* c, void* p, size_t bytes, hipStream_t s) {
-    const int64_t n_tiles = (int64_t)(bytes / 16384);
-    if (n_tiles > 0) hipLaunchKernelGGL(arena_write_sweep, dim3(c->compute_units * 16), dim3(DXO_BLOCK), 0, s, n_tiles, (dxo_f64x2*)p);
+// The sweep of the constitutive kernels themselves (von Mises d = 6 proportions): per 64-point tile 13 KiB read from
+// three input streams (6 : 6 : 1 rows of 1 KiB) and 43 KiB written to three output streams (36 : 6 : 1) laid out one
+// after the other in the candidate, as dxo_von_mises' callers lay out (C_tang, sigma, dp). A block can be fast for ONE
+// store stream and ordinary for this pattern: blocks backed by 2 MB chunks topped the single-stream ranking
+// (6.3-6.6 TB/s) and then ran vm_tile at 5.6-6.0 TB/s, below hipMalloc blocks that had probed lower — six concurrent
+// streams need six times the address-translation reach. So the candidates are ranked with this sweep.
+__global__ __launch_bounds__(DXO_BLOCK) void arena_mix_sweep(int64_t n_tiles, const dxo_f64x2* __restrict__ src, dxo_f64x2* __restrict__ dst) {
+    const int lane = threadIdx.x & (DXO_WAVE - 1), wave = threadIdx.x >> 6;
+    const dxo_f64x2 *i0 = src, *i1 = src + n_tiles * (6 * DXO_WAVE), *i2 = src + n_tiles * (12 * DXO_WAVE);
+    dxo_f64x2 *o0 = dst, *o1 = dst + n_tiles * (36 * DXO_WAVE), *o2 = dst + n_tiles * (42 * DXO_WAVE);
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+        dxo_f64x2 a = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a += i0[t * (6 * DXO_WAVE) + k * DXO_WAVE + lane] + i1[t * (6 * DXO_WAVE) + k * DXO_WAVE + lane];
+        a += i2[t * DXO_WAVE + lane];
+        __builtin_nontemporal_store(a, o2 + t * DXO_WAVE + lane);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __builtin_nontemporal_store(a, o1 + t * (6 * DXO_WAVE) + k * DXO_WAVE + lane);
+#pragma unroll 6
+        for (int k = 0; k < 36; ++k) __builtin_nontemporal_store(a, o0 + t * (36 * DXO_WAVE) + k * DXO_WAVE + lane);
+    }
 }
 
-// GB/s of `launches` back-to-back sweeps over [p, p + bytes); 0 on error. The block must have been swept before
-// (launch_sweep): the first passes over a fresh allocation run ~20 % slower than its steady state (measured: every
-// candidate of a 12-candidate search read 4.8-5.2 TB/s when timed right after hipMalloc, gpurun_out r02c).
-double probe_range(dxo_ctx* c, void* p, size_t bytes, hipStream_t s, int launches = 4) {
-    if (bytes < 16384) return 0.0;
+size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// GB/s of `launches` back-to-back sweeps of `shape` over the block; 0 on error. The block must have been swept before:
+// the first passes over a fresh allocation run ~20 % slower than its steady state (measured: every candidate of a
+// 12-candidate search read 4.8-5.2 TB/s when timed right after hipMalloc, gpurun_out r02c).
+double time_shape(dxo_ctx* c, const dxo_arena_probe& pr, void* p, int shape, hipStream_t s, int launches) {
     if (hipEventRecord(c->ev_start, s) != hipSuccess) return 0.0;
-    for (int l = 0; l < launches; ++l) launch_sweep(c, p, bytes, s);
+    for (int l = 0; l < launches; ++l) pr.launch(p, shape, s);
     if (hipEventRecord(c->ev_stop, s) != hipSuccess || hipEventSynchronize(c->ev_stop) != hipSuccess) return 0.0;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess || ms <= 0.f) return 0.0;
-    return (double)(bytes / 16384) * 16384.0 * launches / (ms * 1e-3) / 1e9;
+    return pr.bytes_per_launch * launches / (ms * 1e-3) / 1e9;
 }
 
-// ordinary allocations, all candidates alive until the choice is made (a freed block would be handed out again).
+// best rate over the probe's launch shapes; *shape_out = the shape that gave it
+double probe_block(dxo_ctx* c, const dxo_arena_probe& pr, void* p, hipStream_t s, int launches, int* shape_out) {
+    double best = 0.0;
+    int best_shape = pr.shapes.empty() ? 0 : pr.shapes[0];
+    for (int sh : pr.shapes) {
+        const double bw = time_shape(c, pr, p, sh, s, launches);
+        if (bw > best) { best = bw; best_shape = sh; }
+    }
+    if (shape_out) *shape_out = best_shape;
+    return best;
+}
+
+void warm_block(const dxo_arena_probe& pr, void* p, hipStream_t s) {
+    for (int sh : pr.shapes) pr.launch(p, sh, s);
+    if (pr.shapes.size() < 2) pr.launch(p, pr.shapes.empty() ? 0 : pr.shapes[0], s);
+}
+
+// ---- candidates. Two kinds (option "placement_vmm", default on: three of every four candidates are of the second kind):
+//   hipMalloc            one driver allocation;
+//   2 MB chunks          a virtual range (hipMemAddressReserve) backed by 2 MB physical chunks (hipMemCreate), each
+//                        mapped ONCE (hipMemMap). Over ~90 slabs on nine boxes (scripts/exp/place_exp11.hip,
+//                        place_exp12.hip) such slabs came out in the fast class about twice as often as hipMalloc
+//                        blocks (53-77 % against 25-37 %; physically contiguous hipDeviceMallocContiguous blocks: never),
+//                        also on boxes where no hipMalloc candidate did. Building one takes 50-200 ms per 3.4 GB. Teardown
+//                        is hipMemUnmap + hipMemRelease + hipMemAddressFree; nothing is ever mapped twice (the remap
+//                        sequences of place_exp9 are what faulted), place_exp12 cycles build / partial teardown /
+//                        reuse without a fault and with the survivor's data intact.
+struct VmmBacking {
+    size_t va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+constexpr size_t VMM_CHUNK = (size_t)2 << 20;
+
+struct Cand {
+    void* p = nullptr;
+    VmmBacking* vmm = nullptr;
+};
+
+void cand_free(Cand& c) {
+    if (!c.p) return;
+    if (c.vmm) {
+        (void)hipMemUnmap(c.p, c.vmm->va_bytes);
+        for (auto& h : c.vmm->chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(c.p, c.vmm->va_bytes);
+        delete c.vmm;
+    } else {
+        (void)hipFree(c.p);
+    }
+    c = Cand();
+}
+
+bool cand_alloc(dxo_ctx* c, size_t bytes, bool vmm, Cand& out) {
+    out = Cand();
+    if (!vmm) {
+        if (hipMalloc(&out.p, bytes) != hipSuccess) { (void)hipGetLastError(); out.p = nullptr; return false; }
+        return true;
+    }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    VmmBacking* b = new VmmBacking();
+    const size_t nch = (bytes + VMM_CHUNK - 1) / VMM_CHUNK;
+    b->va_bytes = nch * VMM_CHUNK;
+    void* va = nullptr;
+    bool ok = hipMemAddressReserve(&va, b->va_bytes, VMM_CHUNK, nullptr, 0) == hipSuccess;
+    size_t mapped = 0;
+    if (ok) {
+        b->chunks.reserve(nch);
+        for (size_t i = 0; i < nch && ok; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            ok = hipMemCreate(&h, VMM_CHUNK, &prop, 0) == hipSuccess;
+            if (!ok) break;
+            b->chunks.push_back(h);
+            ok = hipMemMap((char*)va + i * VMM_CHUNK, VMM_CHUNK, 0, h, 0) == hipSuccess;
+            if (ok) ++mapped;
+        }
+        if (ok) ok = hipMemSetAccess(va, b->va_bytes, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        if (va) {
+            if (mapped) (void)hipMemUnmap(va, mapped * VMM_CHUNK);
+            for (auto& h : b->chunks) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(va, b->va_bytes);
+        }
+        delete b;
+        return false;
+    }
+    out.p = va;
+    out.vmm = b;
+    return true;
+}
+
+// all candidates alive until the choice is made (a freed block would be handed out again).
 // Groups of four: allocate, sweep each twice untimed, then time each — so no block is timed in its first passes.
-bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStream_t s) {
+bool alloc_by_candidates(dxo_ctx* c, size_t bytes, const dxo_arena_probe& pr, dxo_arena_block& blk, hipStream_t s) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     int K = (int)c->placement_candidates;
@@ -71,30 +187,39 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStre
     const size_t cap = (size_t)(0.6 * (double)free_b) / (bytes ? bytes : 1);
     if ((size_t)K > cap) K = (int)cap;
     if (K < 1) K = 1;
-    std::vector<void*> cand;
+    bool use_vmm = c->placement_vmm != 0;
+    blk.info.probe_kind = (int16_t)pr.kind;
+    const double good_GBps = pr.good_GBps > 0.0 ? pr.good_GBps : 1e30;
+    int tuned[DXO_PLACEMENT_MAX];
+    for (int& t : tuned) t = 0;
+    std::vector<Cand> cand;
     int best = -1;
     double best_bw = -1.0;
     bool good = false, oom = false;
+    auto add = [&](bool vmm) -> bool {
+        Cand cd;
+        if (vmm && !cand_alloc(c, bytes, true, cd)) { use_vmm = false; vmm = false; }   // no virtual-memory API here: hipMalloc only
+        if (!vmm && !cand_alloc(c, bytes, false, cd)) return false;
+        if (cd.vmm) blk.info.vmm_mask |= 1u << cand.size();
+        cand.push_back(cd);
+        return true;
+    };
     while ((int)cand.size() < K && !good && !oom) {
         const int first = (int)cand.size();
-        for (int k = first; k < K && k < first + 4; ++k) {
-            void* p = nullptr;
-            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); oom = true; break; }
-            cand.push_back(p);
-        }
-        for (int rep = 0; rep < 2; ++rep)
-            for (int k = first; k < (int)cand.size(); ++k) launch_sweep(c, cand[k], bytes, s);
+        for (int k = first; k < K && k < first + 4; ++k)
+            if (!add(use_vmm && (k & 3) != 0)) { oom = true; break; }   // one hipMalloc block, three of 2 MB chunks, per group of four
+        for (int k = first; k < (int)cand.size(); ++k) warm_block(pr, cand[(size_t)k].p, s);
         if (hipStreamSynchronize(s) != hipSuccess) break;
         for (int k = first; k < (int)cand.size(); ++k) {
-            const double bw = probe_range(c, cand[k], bytes, s);
+            const double bw = probe_block(c, pr, cand[(size_t)k].p, s, 4, &tuned[k]);
             blk.info.probe_GBps[k] = bw;
             blk.info.candidates = k + 1;
             if (bw > best_bw) { best_bw = bw; best = k; }
-            if (bw >= (double)c->placement_good_GBps) { good = true; break; }
+            if (bw >= good_GBps) { good = true; break; }
         }
     }
     if (best < 0) {
-        for (void* p : cand) (void)hipFree(p);
+        for (auto& cd : cand) cand_free(cd);
         return false;
     }
     // second look: while many candidates coexist every rate reads low (fast ones ~6.0 instead of ~6.9 TB/s) and on a
@@ -105,52 +230,72 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, dxo_arena_block& blk, hipStre
     std::sort(order.begin(), order.end(), [&](int a, int b) { return blk.info.probe_GBps[a] > blk.info.probe_GBps[b]; });
     size_t keep = order.size() < 3 ? order.size() : 3;
     (void)hipStreamSynchronize(s);
-    for (size_t r = keep; r < order.size(); ++r) {
-        (void)hipFree(cand[(size_t)order[r]]);
-        cand[(size_t)order[r]] = nullptr;
-    }
+    for (size_t r = keep; r < order.size(); ++r) cand_free(cand[(size_t)order[r]]);
     double final_bw = blk.info.probe_GBps[best];
     if (!good && order.size() > 1) {
         // one more allocation made now that the others are gone joins the final round: on boxes whose candidates all
         // read alike, a block allocated on its own was 3-10 % faster than the pick of the crowd (three runs)
-        void* late = nullptr;
-        if ((int)cand.size() < DXO_PLACEMENT_MAX && hipMalloc(&late, bytes) == hipSuccess) {
-            launch_sweep(c, late, bytes, s);
-            launch_sweep(c, late, bytes, s);
+        bool late = false;
+        if ((int)cand.size() < DXO_PLACEMENT_MAX && add(use_vmm)) {
+            late = true;
+            warm_block(pr, cand.back().p, s);
             (void)hipStreamSynchronize(s);
-            order.insert(order.begin() + (long)keep, (int)cand.size());
-            cand.push_back(late);
+            order.insert(order.begin() + (long)keep, (int)cand.size() - 1);
             blk.info.probe_GBps[cand.size() - 1] = 0.0;
             ++keep;
-        } else {
-            (void)hipGetLastError();
         }
         best = -1;
         final_bw = -1.0;
         for (size_t r = 0; r < keep; ++r) {
             const int k = order[r];
-            const double bw = probe_range(c, cand[(size_t)k], bytes, s, 6);
+            const double bw = probe_block(c, pr, cand[(size_t)k].p, s, 6, &tuned[k]);
             if (k == (int)cand.size() - 1 && late) { blk.info.probe_GBps[k] = bw; blk.info.candidates = (int)cand.size(); }
             if (bw > final_bw) { final_bw = bw; best = k; }
         }
         if (best < 0) best = order[0];
     }
+    (void)hipStreamSynchronize(s);
     for (size_t k = 0; k < cand.size(); ++k)
-        if ((int)k != best && cand[k]) (void)hipFree(cand[k]);
-    blk.ptr = cand[(size_t)best];
+        if ((int)k != best) cand_free(cand[k]);
+    blk.ptr = cand[(size_t)best].p;
+    blk.vmm = cand[(size_t)best].vmm;
     blk.bytes = bytes;
     blk.info.chosen_GBps = final_bw;
     blk.info.mode = 2;
     blk.info.chosen = best;
+    blk.info.tuned_blocks_per_cu = tuned[best];
     return true;
+}
+
+void block_free(dxo_arena_block& b) {
+    Cand cd;
+    cd.p = b.ptr;
+    cd.vmm = static_cast<VmmBacking*>(b.vmm);
+    cand_free(cd);
+    b.ptr = nullptr;
+    b.vmm = nullptr;
 }
 
 }  // namespace
 
+bool dxo_arena_alloc_calibrated(dxo_ctx* c, size_t bytes, const dxo_arena_probe& probe, dxo_arena_block& blk, hipStream_t s) {
+    std::memset(&blk.info, 0, sizeof blk.info);
+    blk.info.chosen = -1;
+    return alloc_by_candidates(c, bytes, probe, blk, s);
+}
+
+void dxo_arena_register(dxo_ctx* c, const dxo_arena_block& blk) { c->arena.push_back(blk); }
+
+int dxo_arena_tuned_shape(dxo_ctx* c, const void* ptr) {
+    for (const auto& b : c->arena)
+        if (b.ptr && (const char*)ptr >= (const char*)b.ptr && (const char*)ptr < (const char*)b.ptr + b.bytes)
+            return b.info.mode == 2 ? b.info.tuned_blocks_per_cu : -1;
+    return -1;
+}
+
 void dxo_arena_release_all(dxo_ctx* c) {
-    for (auto& b : c->arena) {
-        if (b.ptr) (void)hipFree(b.ptr);
-    }
+    for (auto& b : c->arena)
+        if (b.ptr) block_free(b);
     c->arena.clear();
 }
 
@@ -167,8 +312,36 @@ extern "C" int dxo_output_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     const auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;   // calibration runs on the library's own stream and is synchronous
     bool done = false;
-    if ((int64_t)need >= c->placement_min_bytes && c->placement_candidates > 1) {
-        if (c->placement_mode >= 1) done = alloc_by_candidates(c, need, blk, s);
+    if ((int64_t)need >= c->placement_min_bytes && c->placement_candidates > 1 && c->placement_mode >= 1) {
+        // the generic probes: one stream of stores, or the kernels' six-stream read + write sweep (needs an input array)
+        dxo_arena_probe pr;
+        void* probe_src = nullptr;
+        const size_t tiles6 = need / (43 * 1024);
+        if (c->placement_probe != 0 && tiles6 > 0 && hipMalloc(&probe_src, tiles6 * 13 * 1024) == hipSuccess &&
+            hipMemsetAsync(probe_src, 0, tiles6 * 13 * 1024, s) == hipSuccess) {
+            const int grid = c->compute_units * 16;
+            pr.launch = [=](void* p, int, hipStream_t st) {
+                hipLaunchKernelGGL(arena_mix_sweep, dim3(grid), dim3(DXO_BLOCK), 0, st, (int64_t)tiles6, (const dxo_f64x2*)probe_src, (dxo_f64x2*)p);
+            };
+            pr.bytes_per_launch = (double)tiles6 * 56.0 * 1024.0;
+            pr.good_GBps = (double)c->placement_good_mix_GBps;
+            pr.kind = 1;
+        } else {
+            (void)hipGetLastError();
+            if (probe_src) (void)hipFree(probe_src);
+            probe_src = nullptr;
+            const int64_t tiles = (int64_t)(need / 16384);
+            const int grid = c->compute_units * 16;
+            pr.launch = [=](void* p, int, hipStream_t st) {
+                if (tiles > 0) hipLaunchKernelGGL(arena_write_sweep, dim3(grid), dim3(DXO_BLOCK), 0, st, tiles, (dxo_f64x2*)p);
+            };
+            pr.bytes_per_launch = (double)tiles * 16384.0;
+            pr.good_GBps = (double)c->placement_good_GBps;
+            pr.kind = 0;
+        }
+        done = need >= 16384 && alloc_by_candidates(c, need, pr, blk, s);
+        (void)hipStreamSynchronize(s);
+        if (probe_src) (void)hipFree(probe_src);
     }
     if (!done) {
         std::memset(&blk.info, 0, sizeof blk.info);
@@ -193,7 +366,7 @@ extern "C" int dxo_output_free(dxo_ctx* c, void* ptr) {
         c->arena.erase(c->arena.begin() + (long)i);
         DXO_HIP(c, hipSetDevice(c->device));
         DXO_HIP(c, hipDeviceSynchronize());
-        DXO_HIP(c, hipFree(b.ptr));
+        block_free(b);
         return DXO_OK;
     }
     return dxo_fail(c, DXO_E_NULL, "dxo_output_free: pointer was not returned by dxo_output_alloc on this context");

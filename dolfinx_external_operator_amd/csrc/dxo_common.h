@@ -25,9 +25,26 @@ struct dxo_arena_block {
     void* ptr = nullptr;
     size_t bytes = 0;
     dxo_placement_info info;
+    void* vmm = nullptr;   // arena.hip: backing of a block built from 2 MB physical chunks (virtual-memory API); NULL = hipMalloc
 };
 struct dxo_ctx;
 void dxo_arena_release_all(dxo_ctx* ctx);
+
+// How dxo_output_alloc's calibration exercises a candidate block (arena.hip). The generic probes are sweeps of
+// arena.hip's own; a kernel family can bring its own launch (dxo_vm_output_alloc: vm_tile itself) and a list of launch
+// shapes to try — the best shape of the block kept is remembered in its record (dxo_placement_info::tuned_blocks_per_cu).
+struct dxo_arena_probe {
+    std::function<void(void* block, int shape, hipStream_t s)> launch;   // one sweep over the whole block, asynchronous
+    std::vector<int> shapes = {0};
+    double bytes_per_launch = 0.0;   // what a launch moves (for the GB/s in the record)
+    double good_GBps = 0.0;          // early exit of the search (0: never)
+    int kind = 0;                    // dxo_placement_info::probe_kind
+};
+// bytes: size of the block; true on success (blk filled, registered by the caller)
+bool dxo_arena_alloc_calibrated(dxo_ctx* ctx, size_t bytes, const dxo_arena_probe& probe, dxo_arena_block& blk, hipStream_t s);
+void dxo_arena_register(dxo_ctx* ctx, const dxo_arena_block& blk);
+// tuned launch shape of the arena block that contains `ptr`, or -1
+int dxo_arena_tuned_shape(dxo_ctx* ctx, const void* ptr);
 
 // Host worker threads of a context (dxo_ctx.hip): the host half of the DXO_MEM_HOST pipeline (tangent rebuild from
 // the returned state while later chunks are still on the PCIe link). Created on first use, joined by dxo_ctx_destroy.
@@ -62,8 +79,11 @@ struct dxo_ctx {
     int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
     // output arena (arena.hip)
     int64_t placement_mode = 2;         // 0 plain hipMalloc, 2 (or any value >= 1) hipMalloc candidates
-    int64_t placement_candidates = 12;  // allocations / ranges tried at most (<= DXO_PLACEMENT_MAX)
+    int64_t placement_candidates = 16;  // allocations / ranges tried at most (<= DXO_PLACEMENT_MAX)
     int64_t placement_min_bytes = (int64_t)1 << 30;
+    int64_t placement_vmm = 1;          // three of every four candidates are built from 2 MB physical chunks (arena.hip)
+    int64_t placement_probe = 1;        // 1: rank candidates with the six-stream read + write sweep of the kernels, 0: one store stream
+    int64_t placement_good_mix_GBps = 6250;   // early-exit rate of the six-stream sweep (algorithmic GB/s)
     int64_t placement_good_GBps = 6800; // stop searching at the first candidate whose write sweep reaches this
     std::vector<dxo_arena_block> arena;
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host

@@ -25,6 +25,8 @@
 //        per CU, and every C_tang store instruction writes 1 KiB of consecutive bytes.
 //   No cross-wave communication, hence no __syncthreads(): LDS slices are wave-private and DS
 //   operations of one wave execute in order; only the compiler must be kept from reordering.
+#include <chrono>
+
 #include "dxo_common.h"
 #include "vm_core.h"
 #include "vm_host.h"
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst 
 struct VmLaunch {
     VmConst c;
     int d;
+    int shape = -1;   // >= 0: launch shape forced by a calibration (0 one tile per wave, k persistent workgroups per CU)
     // host half of the DXO_MEM_HOST pipeline with option "vm_host_tangent" = 1 (see vm_host_rebuild)
     const double* h_sigma = nullptr;
     double* h_dp = nullptr;
@@ -182,7 +185,19 @@ int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, co
     const bool tiled = ctx->vm_variant != 0 && can_tile;
     if (tiled) {
         const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
-        const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        // launch shape: the option when set; else the shape a calibration found best for the arena block written to
+        // (dxo_vm_output_alloc); else one tile per wave
+        int shape = L.shape;
+        if (shape < 0 && ctx->blocks_per_cu == 0 && !ctx->arena.empty()) shape = dxo_arena_tuned_shape(ctx, C_tang);
+        if (shape > 0) {
+            const int64_t cap = (int64_t)ctx->compute_units * shape;
+            const int64_t full = (n_tiles + DXO_BLOCK / DXO_WAVE - 1) / (DXO_BLOCK / DXO_WAVE);
+            grid = (int)(full < cap ? full : cap);
+        } else if (L.shape == 0) {
+            const int64_t full = (n_tiles + DXO_BLOCK / DXO_WAVE - 1) / (DXO_BLOCK / DXO_WAVE);
+            grid = (int)(full > 0x7fffffff ? 0x7fffffff : full);
+        }
         const bool nt = ctx->nontemporal != 0;
         if (L.d == 4) {
             if (nt) hipLaunchKernelGGL((vm_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
@@ -414,6 +429,84 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     }
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
     return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
+}
+
+// ------------------------------------------------------------------ output block calibrated with the kernel itself
+namespace {
+// synthetic inputs of the reference's distribution (deps ~ 3e-3, sigma_n ~ 100, p ~ 1e-3; mostly plastic): values only
+// matter in that they are ordinary finite numbers — the kernel is branch-free and HBM-bound
+__global__ __launch_bounds__(DXO_BLOCK) void vm_probe_fill(int64_t n_in, int64_t n_d, double* __restrict__ in) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += stride) {
+        uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;   // (-1, 1)
+        in[i] = i < n_d ? 4e-3 * u : (i < 2 * n_d ? 150.0 * u : 1e-3 * (u < 0 ? -u : u));
+    }
+}
+}  // namespace
+
+extern "C" int dxo_vm_output_alloc(dxo_ctx* ctx, int d, int64_t n, double** C_tang, double** sigma, double** dp) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!C_tang || !sigma || !dp) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_output_alloc: NULL result pointer");
+    *C_tang = *sigma = *dp = nullptr;
+    if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_vm_output_alloc: d must be 4 or 6");
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_output_alloc: n < 0");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t sd = sizeof(double);
+    const size_t off_s = up((size_t)n * d * d * sd), off_p = off_s + up((size_t)n * d * sd);
+    size_t bytes = off_p + up((size_t)n * sd);
+    if (bytes == 0) bytes = 256;
+    dxo_arena_block blk;
+    std::memset(&blk.info, 0, sizeof blk.info);
+    blk.info.chosen = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = ctx->stream;
+    bool done = false;
+    if ((int64_t)bytes >= ctx->placement_min_bytes && ctx->placement_candidates > 1 && ctx->placement_mode >= 1) {
+        double* in = nullptr;
+        const int64_t n_in = n * (2 * d + 1), n_d = n * d;
+        if (hipMalloc((void**)&in, (size_t)n_in * sd) == hipSuccess) {
+            hipLaunchKernelGGL(vm_probe_fill, dim3(ctx->compute_units * 8), dim3(DXO_BLOCK), 0, s, n_in, n_d, in);
+            const dxo_vm_params ref = {70e3, 0.3, 250.0, 70e3 * 700.0 / (70e3 - 700.0)};   // demo_plasticity_von_mises.py:185-188
+            VmLaunch L{make_const(ref), d};
+            dxo_arena_probe pr;
+            pr.shapes = {0, 32};
+            pr.kind = 2;
+            pr.bytes_per_launch = (double)n * (double)((2 * d + 1 + d * d + d + 1) * sd);
+            pr.good_GBps = 0.0;   // no early exit: the search is the point
+            pr.launch = [=](void* p, int shape, hipStream_t st) {
+                VmLaunch Ls = L;
+                Ls.shape = shape;
+                char* b = static_cast<char*>(p);
+                (void)vm_launch(ctx, Ls, n, in, in + n_d, in + 2 * n_d, (double*)b, (double*)(b + off_s), (double*)(b + off_p), st);
+            };
+            done = dxo_arena_alloc_calibrated(ctx, bytes, pr, blk, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(in);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (!done) {
+        std::memset(&blk.info, 0, sizeof blk.info);
+        blk.info.chosen = -1;
+        blk.vmm = nullptr;
+        DXO_HIP(ctx, hipMalloc(&blk.ptr, bytes));
+        blk.bytes = bytes;
+    }
+    DXO_HIP(ctx, hipStreamSynchronize(s));
+    blk.info.calibration_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    dxo_arena_register(ctx, blk);
+    char* b = static_cast<char*>(blk.ptr);
+    *C_tang = (double*)b;
+    *sigma = (double*)(b + off_s);
+    *dp = (double*)(b + off_p);
+    return DXO_OK;
 }
 
 // ------------------------------------------------------------------ device-resident history variables

@@ -136,8 +136,9 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     tangent agrees with it to rounding (5e-16 of its scale measured; same 1e-13 parity bound against the reference) and
     the reference's NaN tangent at f_el == 0 exactly (:318) is reproduced. "copy" brings C_tang itself back
     (bit-identical to a device call).
-    `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors carved from the context's
-    placement-calibrated output arena (Context.output_arena); pass them as `out=` to the device call.
+    `external_function.arena(n_points, d)` returns (C_tang, sigma, dp) CUDA tensors in one block of the context's
+    output arena, chosen among several candidate blocks by timing THIS kernel on each (dxo_vm_output_alloc, DESIGN.md
+    3.1); pass them as `out=` to the device call.
     state (NumPy operands only): "host" (default) is the reference's contract — sigma_n and p are re-read from the
     holders and uploaded at every call (:347-348). "resident" keeps a device mirror (dxo_vm_state, include/dxo.h): the
     holders are uploaded at the first call and from then on only `deps` (or the dof vector of a lazy operand) crosses
@@ -224,7 +225,7 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     def arena(n_points: int, d: int):
         """(C_tang, sigma, dp) as flat CUDA tensors inside the context's output arena (placement-calibrated device
         memory owned by the dxo_ctx, dxo_output_arena): the persistent coefficient buffers of a solver."""
-        return _ctx().output_tensors((n_points * d * d, n_points * d, n_points))
+        return _ctx().vm_output_tensors(n_points, d)
 
     def _need_mirror():
         if mirror is None:

@@ -131,23 +131,46 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
  * frees the rest; the block is owned by the ctx (freed by dxo_output_free or dxo_ctx_destroy). Meant for the
  * persistent coefficient buffers a solver allocates once. Options: "placement_mode" 2 = hipMalloc candidates
  * (default), 0 = plain hipMalloc; "placement_candidates"
- * (default 12, at most 32, and never more than fit 60 % of the free memory together); "placement_min_bytes"
- * (default 1 GiB: smaller blocks are plain hipMalloc, a working set that small lives in the caches). The
+ * (default 16, at most 32, and never more than fit 60 % of the free memory together); "placement_min_bytes"
+ * (default 1 GiB: smaller blocks are plain hipMalloc, a working set that small lives in the caches); "placement_vmm"
+ * (default 1: three of every four candidates are virtual ranges backed by 2 MB physical chunks, hipMemCreate / hipMemMap,
+ * which land in the fast class about twice as often as hipMalloc blocks and were the only fast ones for vm_tile on several boxes; 0 = hipMalloc candidates only, e.g. for buffers
+ * that must be shareable through hipIpcGetMemHandle); "placement_probe" (default 1: candidates are ranked with a sweep in
+ * the constitutive kernels' own pattern — three input streams read, three output streams written, 13 : 43 KiB per
+ * 64-point tile, rates in algorithmic GB/s, early exit at "placement_good_mix_GBps" = 6250; 0: one stream of stores,
+ * early exit at "placement_good_GBps"). The
  * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
 #define DXO_PLACEMENT_MAX 32
 typedef struct dxo_placement_info {
-    int32_t mode;                           /* how the block was obtained: 0 plain hipMalloc, 2 candidates         */
+    int16_t mode;                           /* how the block was obtained: 0 plain hipMalloc, 2 candidates         */
+    int16_t probe_kind;                     /* what the candidates were timed with: 0 one store stream, 1 the
+                                               kernels' six-stream read + write sweep (option "placement_probe"),
+                                               2 the von Mises kernel itself (dxo_vm_output_alloc)                 */
     int32_t candidates;                     /* ranges / allocations timed                                          */
     int32_t chosen;                         /* index of the one kept (-1: no calibration)                          */
-    int32_t _pad;
+    uint32_t vmm_mask;                      /* bit k: candidate k was built from 2 MB physical chunks (option
+                                               "placement_vmm"), not by hipMalloc                                  */
     double probe_GBps[DXO_PLACEMENT_MAX];   /* streaming-write rate of each candidate                              */
     double calibration_ms;                  /* wall time of the whole call                                         */
     double chosen_GBps;                     /* rate of the block kept, re-timed after all but the three best
                                                candidates were freed (rates read low while many coexist)           */
+    int32_t tuned_blocks_per_cu;            /* dxo_vm_output_alloc: launch shape of vm_tile that was fastest on the block
+                                               kept (0 one tile per wave, k persistent workgroups per CU); the kernel
+                                               uses it whenever it writes into this block and option "blocks_per_cu"
+                                               is 0                                                                 */
+    int32_t reserved_;
 } dxo_placement_info;
 int dxo_output_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_output_free(dxo_ctx* ctx, void* ptr);
 int dxo_output_info(dxo_ctx* ctx, const void* ptr, dxo_placement_info* info);
+/* The output arrays of dxo_von_mises for n points of Mandel length d, as ONE arena block calibrated WITH THE KERNEL
+ * ITSELF: every candidate is timed running vm_tile on synthetic inputs of the reference's distribution, in two launch
+ * shapes (one tile per wave, 32 persistent workgroups per CU), and the block that makes the kernel fastest is kept
+ * together with its shape (probe_kind 2). Generic sweeps rank blocks for ONE access pattern: blocks that topped a
+ * store-stream or six-stream ranking ran the kernel anywhere between 5.3 and 6.4 TB/s (scripts/exp/arena_eval.hip).
+ * C_tang is the base of the block (pass it to dxo_output_free / dxo_output_info); sigma and dp start on 256-byte borders
+ * behind it. Same options as dxo_output_alloc; blocks below "placement_min_bytes" are plain hipMalloc. */
+int dxo_vm_output_alloc(dxo_ctx* ctx, int d, int64_t n, double** C_tang, double** sigma, double** dp);
 
 /* ---- von Mises radial return + consistent tangent ---------------------------------------
  * Replaces return_mapping/_kernel + C_tang_impl, demo_plasticity_von_mises.py:298-352.

@@ -1,0 +1,157 @@
+// arena_eval.hip — which calibration sweep predicts the von Mises kernel's rate on a block, and which kind of block is
+// worth having? NH hipMalloc blocks and NV blocks backed by 2 MB chunks (virtual-memory API), all alive side by side;
+// for each: one store stream, the 2-stream mix (one input + one output stream), the 6-stream mix of arena.hip, and
+// dxo_von_mises itself (d = 6, 10^7 points, device pointers) through libdxo_hip.so.
+// build: hipcc --offload-arch=gfx950 -O3 -Iinclude scripts/exp/arena_eval.hip -o scripts/exp/arena_eval \
+//        -Ldolfinx_external_operator_amd -ldxo_hip -Wl,-rpath,$PWD/dolfinx_external_operator_amd
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "dxo.h"
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); fflush(stdout); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void wr(long n_tiles, f64x2* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long t = (long)blockIdx.x * 4 + wave; t < n_tiles; t += (long)gridDim.x * 4) {
+        f64x2* d = dst + t * (43 * 64);
+#pragma unroll
+        for (int k = 0; k < 43; ++k) __builtin_nontemporal_store(f64x2{(double)t, (double)k}, d + k * 64 + lane);
+    }
+}
+__global__ __launch_bounds__(256) void mix2(long n_tiles, const f64x2* __restrict__ src, f64x2* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long t = (long)blockIdx.x * 4 + wave; t < n_tiles; t += (long)gridDim.x * 4) {
+        const f64x2* s = src + t * (13 * 64);
+        f64x2 acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 13; ++k) acc += s[k * 64 + lane];
+        f64x2* d = dst + t * (43 * 64);
+#pragma unroll
+        for (int k = 0; k < 43; ++k) __builtin_nontemporal_store(acc + (double)k, d + k * 64 + lane);
+    }
+}
+__global__ __launch_bounds__(256) void mix6(long n_tiles, const f64x2* __restrict__ src, f64x2* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f64x2 *i0 = src, *i1 = src + n_tiles * (6 * 64), *i2 = src + n_tiles * (12 * 64);
+    f64x2 *o0 = dst, *o1 = dst + n_tiles * (36 * 64), *o2 = dst + n_tiles * (42 * 64);
+    for (long t = (long)blockIdx.x * 4 + wave; t < n_tiles; t += (long)gridDim.x * 4) {
+        f64x2 a = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a += i0[t * (6 * 64) + k * 64 + lane] + i1[t * (6 * 64) + k * 64 + lane];
+        a += i2[t * 64 + lane];
+        __builtin_nontemporal_store(a, o2 + t * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __builtin_nontemporal_store(a, o1 + t * (6 * 64) + k * 64 + lane);
+#pragma unroll 6
+        for (int k = 0; k < 36; ++k) __builtin_nontemporal_store(a, o0 + t * (36 * 64) + k * 64 + lane);
+    }
+}
+static hipStream_t st;
+float timeit(int launches, int reps, const std::function<void()>& fn) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<float> v;
+    fn(); fn();
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a, st)); for (int l = 0; l < launches; ++l) fn(); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); v.push_back(ms / launches);
+    }
+    std::sort(v.begin(), v.end()); CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return v[v.size() / 2];
+}
+static hipMemAllocationProp prop = {};
+static hipMemAccessDesc acc = {};
+const size_t MB = 1ull << 20;
+struct Vm { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> h; };
+static std::vector<std::pair<char*, Vm>> vms;
+char* make_vmm(size_t bytes, size_t chunk) {
+    const size_t nch = (bytes + chunk - 1) / chunk;
+    char* va = nullptr;
+    Vm v; v.bytes = nch * chunk;
+    CK(hipMemAddressReserve((void**)&va, nch * chunk, 2 * MB, nullptr, 0));
+    for (size_t i = 0; i < nch; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        CK(hipMemCreate(&h, chunk, &prop, 0));
+        CK(hipMemMap(va + i * chunk, chunk, 0, h, 0));
+        v.h.push_back(h);
+    }
+    CK(hipMemSetAccess(va, nch * chunk, &acc, 1));
+    vms.push_back({va, v});
+    return va;
+}
+void drop(char* p, char kind) {
+    if (kind == 'h') { CK(hipFree(p)); return; }
+    for (auto& e : vms)
+        if (e.first == p) {
+            CK(hipMemUnmap(p, e.second.bytes));
+            for (auto& h : e.second.h) CK(hipMemRelease(h));
+            CK(hipMemAddressFree(p, e.second.bytes));
+        }
+}
+int main(int argc, char** argv) {
+    const int NH = argc > 1 ? atoi(argv[1]) : 10, NV = argc > 2 ? atoi(argv[2]) : 10;
+    const size_t vchunk = (argc > 3 ? atoi(argv[3]) : 2) * MB;
+    const long n = 10000000, tiles = n / 64;
+    const size_t out_bytes = (size_t)tiles * 43 * 1024, in_bytes = (size_t)tiles * 13 * 1024;
+    CK(hipStreamCreate(&st));
+    int dev = 0; CK(hipGetDevice(&dev));
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    dxo_ctx* ctx = nullptr;
+    if (dxo_ctx_create(dev, &ctx) != 0) { printf("dxo_ctx_create failed\n"); return 1; }
+    dxo_ctx_set_stream(ctx, st);
+    double* in = nullptr;
+    CK(hipMalloc((void**)&in, in_bytes));
+    {   // plausible inputs: deps ~ 3e-3, sigma_n ~ 100, p ~ 1e-3 (constant fill is enough for a bandwidth measurement)
+        std::vector<double> h((size_t)n * 13);
+        for (long i = 0; i < n * 6; ++i) h[i] = 3e-3 * ((i * 2654435761u % 2001) / 1000.0 - 1.0);
+        for (long i = n * 6; i < n * 12; ++i) h[i] = 100.0 * ((i * 2654435761u % 2001) / 1000.0 - 1.0);
+        for (long i = n * 12; i < n * 13; ++i) h[i] = 1e-3 * ((i * 2654435761u % 1000) / 1000.0);
+        CK(hipMemcpy(in, h.data(), in_bytes, hipMemcpyHostToDevice));
+    }
+    const dxo_vm_params prm = {70e3, 0.3, 250.0, 70e3 * 700.0 / (70e3 - 700.0)};
+    std::vector<char*> blk; std::vector<char> kind;
+    for (int i = 0; i < NH + NV; ++i) {   // interleaved creation
+        const bool v = (i & 1) ? (int)std::count(kind.begin(), kind.end(), 'v') < NV : (int)std::count(kind.begin(), kind.end(), 'h') >= NH;
+        if (v) { blk.push_back(make_vmm(out_bytes, vchunk)); kind.push_back('v'); }
+        else { char* p = nullptr; CK(hipMalloc((void**)&p, out_bytes)); blk.push_back(p); kind.push_back('h'); }
+    }
+    printf("kind  write  mix2  mix6  vm_tile with blocks_per_cu 0 16 32 64   (GB/s; write over 3.44 GB, the others algorithmic 4.48 GB per launch)\n");
+    double best_rate = 0.0; int best_i = -1; long best_bpc = 0;
+    for (size_t i = 0; i < blk.size(); ++i) {
+        char* p = blk[i];
+        const float w = timeit(4, 3, [&] { hipLaunchKernelGGL(wr, dim3(4096), dim3(256), 0, st, tiles, (f64x2*)p); });
+        const float m2 = timeit(4, 3, [&] { hipLaunchKernelGGL(mix2, dim3(4096), dim3(256), 0, st, tiles, (const f64x2*)in, (f64x2*)p); });
+        const float m6 = timeit(4, 3, [&] { hipLaunchKernelGGL(mix6, dim3(4096), dim3(256), 0, st, tiles, (const f64x2*)in, (f64x2*)p); });
+        double* o = (double*)p;
+        printf("%c  %5.0f %5.0f %5.0f ", kind[i], out_bytes / w / 1e6, (out_bytes + in_bytes) / m2 / 1e6, (out_bytes + in_bytes) / m6 / 1e6);
+        for (long bpc : {0L, 16L, 32L, 64L}) {   // vm_tile: one tile per wave (0) or a persistent grid of bpc workgroups per CU
+            dxo_ctx_set_option(ctx, "blocks_per_cu", bpc);
+            const float vm = timeit(6, 3, [&] { dxo_von_mises(ctx, &prm, 6, n, DXO_MEM_DEVICE, in, in + n * 6, in + n * 12, o, o + n * 36, o + n * 42); });
+            const double r = 448.0 * n / vm / 1e6;
+            printf(" %5.0f", r);
+            if (r > best_rate) { best_rate = r; best_i = (int)i; best_bpc = bpc; }
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    printf("best: block %d (%c) at blocks_per_cu %ld: %.0f GB/s; freeing the others\n", best_i, kind[best_i], best_bpc, best_rate);
+    CK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < blk.size(); ++i) if ((int)i != best_i) drop(blk[i], kind[i]);
+    double* o = (double*)blk[best_i];
+    for (int rep = 0; rep < 3; ++rep) {
+        printf("survivor alone:");
+        for (long bpc : {0L, 16L, 32L, 64L}) {
+            dxo_ctx_set_option(ctx, "blocks_per_cu", bpc);
+            const float vm = timeit(10, 3, [&] { dxo_von_mises(ctx, &prm, 6, n, DXO_MEM_DEVICE, in, in + n * 6, in + n * 12, o, o + n * 36, o + n * 42); });
+            printf("  bpc %ld: %5.0f", bpc, 448.0 * n / vm / 1e6);
+        }
+        printf("\n");
+    }
+    return 0;
+}

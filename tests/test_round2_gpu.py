@@ -46,22 +46,27 @@ def test_output_arena_small_block_is_plain_and_usable(ctx):
     assert float(C.sum()) == 1.5 * C.numel() and float(s[-1]) == 2.5
 
 
-def test_output_arena_calibrates_and_kernel_results_are_unchanged(ctx, oracle, mode=2):
-    """A 1.1 GB block goes through the calibration (hipMalloc candidates side by side, the fastest kept); the kernel
-    writing into it gives the oracle's numbers; the record names the chosen candidate."""
+@pytest.mark.parametrize("vmm", [1, 0])
+def test_output_arena_calibrates_and_kernel_results_are_unchanged(ctx, oracle, vmm, mode=2):
+    """A 1.1 GB block goes through the calibration (candidates side by side — hipMalloc blocks and, with placement_vmm,
+    virtual ranges backed by 2 MB physical chunks — the fastest kept); the kernel writing into it gives the oracle's
+    numbers; the record names the chosen candidate and its kind."""
     import torch
 
     n, d = 3_200_000, 6          # 344 B/point -> 1.10 GB
-    old = {k: ctx.get_option(k) for k in ("placement_mode", "placement_candidates")}
+    old = {k: ctx.get_option(k) for k in ("placement_mode", "placement_candidates", "placement_vmm")}
     ctx.set_option("placement_mode", mode)
     ctx.set_option("placement_candidates", 4)
+    ctx.set_option("placement_vmm", vmm)
     try:
         C, s, dp = ctx.output_tensors((n * d * d, n * d, n))
     finally:
         for k, v in old.items():
             ctx.set_option(k, v)
     info = C.dxo_block.info
-    assert info["mode"] == "hipMalloc_candidates", info
+    assert info["mode"] == "candidates", info
+    want = (["hipMalloc", "2MB_chunks", "2MB_chunks", "2MB_chunks"] * 2)[: info["candidates"]] if vmm else ["hipMalloc"] * info["candidates"]
+    assert info["kinds"][:4] == want[:4] and info["chosen_kind"] == info["kinds"][info["chosen"]], info
     assert 1 <= info["candidates"] <= 5 and 0 <= info["chosen"] < info["candidates"]   # 4 + the late lone allocation
     assert all(b > 1000.0 for b in info["probe_GBps"]), info             # every candidate was really timed (GB/s)
     assert info["chosen_GBps"] > 1000.0                                   # the final round's rate of the block kept
@@ -397,3 +402,41 @@ def test_default_factory_path_reproduces_the_reference_nan_points(ctx, oracle, g
         assert np.array_equal(dpg == 0.0, dpo == 0.0) and not np.signbit(dpg[dpg == 0.0]).any()   # the mark does not leak out
     ctx.set_option("vm_rebuild_min_points", old_min)
     assert np.array_equal(outs["rebuild"][1], outs["copy"][1]) and np.array_equal(outs["rebuild"][2], outs["copy"][2])
+
+
+def test_vm_output_alloc_calibrates_with_the_kernel_itself(ctx, oracle):
+    """dxo_vm_output_alloc: candidates are timed running vm_tile; the record names the probe, the kinds and the launch
+    shape that was fastest on the block kept; a later dxo_von_mises into that block (which picks the shape up) gives the
+    oracle's numbers, bit-identical to the same call into a plain allocation."""
+    import torch
+
+    n, d = 3_300_000, 6
+    old = {k: ctx.get_option(k) for k in ("placement_candidates",)}
+    ctx.set_option("placement_candidates", 4)
+    try:
+        C, s, dp = ctx.vm_output_tensors(n, d)
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+    info = C.dxo_block.info
+    assert info["mode"] == "candidates" and info["probe"] == "vm_tile", info
+    assert info["tuned_blocks_per_cu"] in (0, 32) and 0 <= info["chosen"] < info["candidates"] <= 5
+    assert all(b > 1000.0 for b in info["probe_GBps"]) and info["chosen_GBps"] > 1000.0
+    assert C.numel() == n * d * d and s.numel() == n * d and dp.numel() == n
+    assert s.data_ptr() % 256 == 0 and dp.data_ptr() % 256 == 0 and s.data_ptr() >= C.data_ptr() + C.numel() * 8
+    g = torch.Generator(device="cuda:0").manual_seed(6)
+    deps = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 3e-3, generator=g)
+    sigma_n = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 100.0, generator=g)
+    p = torch.empty(n, dtype=torch.float64, device="cuda:0").normal_(0, 1e-3, generator=g).abs_()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C.data_ptr(), s.data_ptr(), dp.data_ptr())
+    C2, s2, dp2 = (torch.empty_like(t) for t in (C, s, dp))
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C2.data_ptr(), s2.data_ptr(), dp2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(C, C2) and torch.equal(s, s2) and torch.equal(dp, dp2)      # the launch shape changes no value
+    idx = torch.arange(0, n, 1009, device="cuda:0")
+    Co, so, dpo = oracle.von_mises(deps[idx].cpu().numpy(), sigma_n[idx].cpu().numpy(), p[idx].cpu().numpy())
+    assert_close_scaled(C.view(n, d * d)[idx].cpu().numpy(), Co, 1e-13, "C_tang in the kernel-calibrated block")
+    assert_close_scaled(dp[idx].cpu().numpy(), dpo, 1e-13, "dp")
+    small = ctx.vm_output_tensors(1000, 4)                                  # below placement_min_bytes: plain, no calibration
+    assert small[0].dxo_block.info["chosen"] == -1 and small[0].numel() == 16000
