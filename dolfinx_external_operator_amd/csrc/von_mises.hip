@@ -71,41 +71,55 @@ __global__ __launch_bounds__(DXO_BLOCK) void vm_point(VmConst c, int64_t n, cons
 }
 
 // ------------------------------------------------------------------ variant 1: wave = 64-point tile (helpers: vm_core.h)
-// one tile of `npts` points starting at point p0; FULL = (npts == 64): every guard folds away
-template <int D, bool NT, bool FULL>
-__device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int npts, int lane, double* X, double* Y,
-                                             const double* __restrict__ deps, const double* __restrict__ sigma_n,
-                                             const double* __restrict__ p, double* __restrict__ C_tang,
-                                             double* __restrict__ sigma, double* __restrict__ dp_out) {
-    using T = VmTile<D>;
-    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
-    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
-    const int nvec = npts * T::CH_VEC;                              // valid 16-byte chunks of a [npts][D] block
+// A tile of `npts` points starting at point p0 in three phases; FULL = (npts == 64): every guard folds away.
+template <int D>
+struct VmTileIn {
+    dxo_f64x2 ve[D / 2], vs[D / 2];
+    double p;
+};
 
-    // ---- A: lane-linear global loads -> LDS -> point-per-lane registers
+// ---- A1: lane-linear global loads into registers
+template <int D, bool FULL>
+__device__ __forceinline__ void vm_tile_load(VmTileIn<D>& r, int64_t p0, int npts, int lane, const double* __restrict__ deps,
+                                             const double* __restrict__ sigma_n, const double* __restrict__ p) {
+    using T = VmTile<D>;
+    const int nvec = npts * T::CH_VEC;                              // valid 16-byte chunks of a [npts][D] block
     const dxo_f64x2* g_e = reinterpret_cast<const dxo_f64x2*>(deps + p0 * D);
     const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
-    dxo_f64x2 ve[T::CH_VEC], vs[T::CH_VEC];
 #pragma unroll
     for (int k = 0; k < T::CH_VEC; ++k) {
         const int idx = k * DXO_WAVE + lane;
         const bool ok = FULL || idx < nvec;
 #if DXO_VM_NT_LOADS
-        ve[k] = ok ? __builtin_nontemporal_load(g_e + idx) : dxo_f64x2{0.0, 0.0};
-        vs[k] = ok ? __builtin_nontemporal_load(g_s + idx) : dxo_f64x2{0.0, 0.0};
+        r.ve[k] = ok ? __builtin_nontemporal_load(g_e + idx) : dxo_f64x2{0.0, 0.0};
+        r.vs[k] = ok ? __builtin_nontemporal_load(g_s + idx) : dxo_f64x2{0.0, 0.0};
 #else
-        ve[k] = ok ? g_e[idx] : dxo_f64x2{0.0, 0.0};
-        vs[k] = ok ? g_s[idx] : dxo_f64x2{0.0, 0.0};
+        r.ve[k] = ok ? g_e[idx] : dxo_f64x2{0.0, 0.0};
+        r.vs[k] = ok ? g_s[idx] : dxo_f64x2{0.0, 0.0};
 #endif
     }
-    const double p_l = (FULL || lane < npts) ? p[p0 + lane] : 0.0;
+    r.p = (FULL || lane < npts) ? p[p0 + lane] : 0.0;
+}
+
+// ---- A2: registers -> LDS (lane-linear); the transposed read-back is vm_tile_unstage
+template <int D>
+__device__ __forceinline__ void vm_tile_stage(const VmTileIn<D>& r, int lane, double* X, double* Y) {
+    using T = VmTile<D>;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
+    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
 #pragma unroll
     for (int k = 0; k < T::CH_VEC; ++k) {
-        X2[k * DXO_WAVE + lane] = ve[k];
-        Y2[k * DXO_WAVE + lane] = vs[k];
+        X2[k * DXO_WAVE + lane] = r.ve[k];
+        Y2[k * DXO_WAVE + lane] = r.vs[k];
     }
     wave_lds_fence();
-    double e[D], sn[D];
+}
+
+template <int D>
+__device__ __forceinline__ void vm_tile_unstage(int lane, double* X, double* Y, double (&e)[D], double (&sn)[D]) {
+    using T = VmTile<D>;
+    const dxo_f64x2* X2 = reinterpret_cast<const dxo_f64x2*>(X);
+    const dxo_f64x2* Y2 = reinterpret_cast<const dxo_f64x2*>(Y);
 #pragma unroll
     for (int k = 0; k < T::CH_VEC; ++k) {
         const dxo_f64x2 a2 = X2[lane * T::CH_VEC + k];
@@ -116,12 +130,20 @@ __device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int n
         sn[2 * k + 1] = b2.y;
     }
     wave_lds_fence();  // staging slices are about to be reused
+}
 
-    // ---- B: radial return of this lane's point
+// ---- B + C: radial return of this lane's point, then output-ordered coalesced stores
+template <int D, bool NT, bool FULL>
+__device__ __forceinline__ void vm_tile_finish(const VmConst& c, const double (&e)[D], const double (&sn)[D], double p_l, int64_t p0,
+                                               int npts, int lane, double* X, double* Y, double* __restrict__ C_tang,
+                                               double* __restrict__ sigma, double* __restrict__ dp_out) {
+    using T = VmTile<D>;
+    dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
+    dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
+    const int nvec = npts * T::CH_VEC;
     double sig[D], nrm[D], dp, a, b;
     vm_return_map<D>(c, e, sn, p_l, sig, dp, nrm, a, b);
-
-    // ---- C: sigma -> X (point-per-lane), state -> Y, then output-ordered coalesced stores
+    // sigma -> X (point-per-lane), state -> Y
 #pragma unroll
     for (int k = 0; k < T::CH_VEC; ++k) {
         X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
@@ -141,6 +163,19 @@ __device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int n
     wave_lds_fence();  // next tile overwrites X / Y
 }
 
+template <int D, bool NT, bool FULL>
+__device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int npts, int lane, double* X, double* Y,
+                                             const double* __restrict__ deps, const double* __restrict__ sigma_n,
+                                             const double* __restrict__ p, double* __restrict__ C_tang,
+                                             double* __restrict__ sigma, double* __restrict__ dp_out) {
+    VmTileIn<D> r;
+    vm_tile_load<D, FULL>(r, p0, npts, lane, deps, sigma_n, p);
+    vm_tile_stage<D>(r, lane, X, Y);
+    double e[D], sn[D];
+    vm_tile_unstage<D>(lane, X, Y, e, sn);
+    vm_tile_finish<D, NT, FULL>(c, e, sn, r.p, p0, npts, lane, X, Y, C_tang, sigma, dp_out);
+}
+
 template <int D, bool NT>
 __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
                                                      const double* __restrict__ sigma_n,
@@ -155,7 +190,11 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst 
 
     const int64_t n_tiles = (n + T::PTS - 1) / T::PTS;
     const int64_t tile_stride = (int64_t)gridDim.x * T::WAVES;
-    for (int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave; tile < n_tiles; tile += tile_stride) {
+    int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave;
+    // Tried and dropped (round 2): in persistent grids, requesting the wave's NEXT tile's inputs right after this tile's
+    // have been staged in LDS, so that their latency runs under the arithmetic and the stores — 0.781-0.784 against
+    // 0.778-0.787 of 8 TB/s in four interleaved bench runs each: the loads are not what the kernel waits for.
+    for (; tile < n_tiles; tile += tile_stride) {
         const int64_t p0 = tile * T::PTS;
         const int npts = (n - p0 < T::PTS) ? (int)(n - p0) : T::PTS;  // wave-uniform
 #if DXO_VM_FULL_PATH

@@ -20,8 +20,4 @@ build() {  # name, macros...
   echo built $name
 }
 build base                               # same flags as the product (sanity: must time like libdxo_hip.so)
-build nofull  -DDXO_VM_FULL_PATH=0        # vm_tile: guarded body for every tile (round-2 form before the guard-free path)
-build occ1    -DDXO_VM_MIN_BLOCKS=1       # vm_tile: scheduling under other __launch_bounds__ register budgets
-build occ2    -DDXO_VM_MIN_BLOCKS=2
-build occ3    -DDXO_VM_MIN_BLOCKS=3
-build nofull2 -DDXO_VM_FULL_PATH=0 -DDXO_VM_MIN_BLOCKS=2
+# (a variant that prefetched the next tile's inputs in persistent grids was tried this way and dropped: no difference)
