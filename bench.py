@@ -379,16 +379,15 @@ def main():
     if args.placement <= 1:
         ctx.set_option("placement_mode", 0)
     else:
-        ctx.set_option("placement_candidates", min(args.placement, 3) if gather_on else args.placement)
+        ctx.set_option("placement_candidates", args.placement)   # the library caps it so that all candidates fit 60 % of the free memory
         ctx.set_option("placement_mode", 2)
         if gather_on:
             # the gathered arrays are RCCL send / receive buffers: plain hipMalloc blocks only (a virtual range backed by
             # 2 MB chunks cannot be exported with hipIpcGetMemHandle, which RCCL may use for peer access)
             ctx.set_option("placement_vmm", 0)
-    if gather_on:
-        C_full, sigma_full, dp_full = ctx.output_tensors((N_full * d * d, N_full * d, N_full))
-    else:   # what make_von_mises(...).arena(n, d) hands out: candidates timed with the kernel itself (dxo_vm_output_alloc)
-        C_full, sigma_full, dp_full = ctx.vm_output_tensors(N_full, d)
+    # what make_von_mises(...).arena(n, d) hands out: candidates timed with the kernel itself, block and launch shape
+    # (dxo_vm_output_alloc); with the gather on, the block holds the FULL-length arrays (hipMalloc candidates only, see above)
+    C_full, sigma_full, dp_full = ctx.vm_output_tensors(N_full, d)
     placement = dict(C_full.dxo_block.info)
     C_tang = C_full[own * n * d * d:(own + 1) * n * d * d]
     sigma = sigma_full[own * n * d:(own + 1) * n * d]
