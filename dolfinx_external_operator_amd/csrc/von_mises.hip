@@ -354,7 +354,13 @@ int vm_expand_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* s
     const bool tiled = ctx->vm_variant != 0 && aligned16(sigma) && aligned16(C_tang);
     if (tiled) {
         const int64_t n_tiles = (n + DXO_WAVE - 1) / DXO_WAVE;
-        const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
+        // the tangent stores are vm_tile's: a block calibrated for vm_tile (dxo_vm_output_alloc) lends its launch shape
+        const int shape = ctx->blocks_per_cu == 0 && !ctx->arena.empty() ? dxo_arena_tuned_shape(ctx, C_tang) : -1;
+        if (shape > 0) {
+            const int64_t cap = (int64_t)ctx->compute_units * shape, full = (n_tiles + DXO_BLOCK / DXO_WAVE - 1) / (DXO_BLOCK / DXO_WAVE);
+            grid = (int)(full < cap ? full : cap);
+        }
         const bool nt = ctx->nontemporal != 0;
         if (L.d == 4) {
             if (nt) hipLaunchKernelGGL((vm_expand_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, sigma, dp, C_tang);

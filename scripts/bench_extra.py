@@ -47,9 +47,7 @@ def vm_case(n, d, label, expand=False):
     deps[:, 3:] *= 2 ** 0.5
     sig = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 100
     p = (torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 1e-3).abs()
-    C = torch.empty(n * d * d, dtype=torch.float64, device=dev)
-    s = torch.empty(n * d, dtype=torch.float64, device=dev)
-    dp = torch.empty(n, dtype=torch.float64, device=dev)
+    C, s, dp = ctx.vm_output_tensors(n, d)   # kernel-calibrated arena block (dxo_vm_output_alloc); below 1 GiB a plain allocation
     ms = ev_time(lambda: ctx.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sig.data_ptr(), p.data_ptr(),
                                        C.data_ptr(), s.data_ptr(), dp.data_ptr()))
     print(json.dumps({"case": label, "n": n, "d": d, "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
@@ -74,9 +72,7 @@ def vm_branch_case(n, d, scale, label):
     deps = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 3e-3 * scale
     sig = torch.randn(n, d, generator=g, device=dev, dtype=torch.float64) * 100 * scale
     p = (torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 1e-3).abs()
-    C = torch.empty(n * d * d, dtype=torch.float64, device=dev)
-    s = torch.empty(n * d, dtype=torch.float64, device=dev)
-    dp = torch.empty(n, dtype=torch.float64, device=dev)
+    C, s, dp = ctx.vm_output_tensors(n, d)   # kernel-calibrated arena block (dxo_vm_output_alloc); below 1 GiB a plain allocation
     ms = ev_time(lambda: ctx.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sig.data_ptr(), p.data_ptr(),
                                        C.data_ptr(), s.data_ptr(), dp.data_ptr()))
     print(json.dumps({"case": label, "n": n, "d": d, "plastic_fraction": float((dp > 0).double().mean()), "kernel_ms": ms,
