@@ -191,6 +191,9 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst 
     const int64_t n_tiles = (n + T::PTS - 1) / T::PTS;
     const int64_t tile_stride = (int64_t)gridDim.x * T::WAVES;
     int64_t tile = (int64_t)blockIdx.x * T::WAVES + wave;
+    // Persistent grids deal the tiles round-robin to the waves (consecutive workgroups = consecutive tiles, so the 8 XCDs
+    // write neighbouring tiles at any time). Tried and dropped: every XCD sweeping its own contiguous eighth (0.729-0.775 of
+    // 8 TB/s against 0.790-0.793) and runs of 4 consecutive tiles per wave (0.746-0.762), three interleaved bench runs each.
     // Tried and dropped (round 2): in persistent grids, requesting the wave's NEXT tile's inputs right after this tile's
     // have been staged in LDS, so that their latency runs under the arithmetic and the stores — 0.781-0.784 against
     // 0.778-0.787 of 8 TB/s in four interleaved bench runs each: the loads are not what the kernel waits for.

@@ -21,3 +21,4 @@ build() {  # name, macros...
 }
 build base                               # same flags as the product (sanity: must time like libdxo_hip.so)
 # (a variant that prefetched the next tile's inputs in persistent grids was tried this way and dropped: no difference)
+# (tile-walk variants of the persistent grid — XCD-contiguous eighths, runs of 4 tiles per wave — were tried this way and lost)
