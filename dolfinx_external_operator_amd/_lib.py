@@ -92,6 +92,7 @@ _SIGNATURES = {
     "dxo_output_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_output_free": (C.c_int, [_P, _P]),
     "dxo_output_info": (C.c_int, [_P, _P, C.POINTER(PlacementInfo)]),
+    "dxo_output_alloc_probed": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.POINTER(C.c_int32), C.c_int, C.POINTER(_P)]),
     "dxo_vm_output_alloc": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
@@ -491,7 +492,7 @@ class Context:
         return {"mode": {0: "hipMalloc", 2: "candidates"}[info.mode],
                 "candidates": info.candidates, "chosen": info.chosen,
                 "chosen_kind": kinds[info.chosen] if 0 <= info.chosen < len(kinds) else "hipMalloc",
-                "kinds": kinds, "probe": {0: "store_stream", 1: "six_stream_mix", 2: "vm_tile"}.get(info.probe_kind, str(info.probe_kind)),
+                "kinds": kinds, "probe": {0: "store_stream", 1: "six_stream_mix", 2: "vm_tile", 3: "caller"}.get(info.probe_kind, str(info.probe_kind)),
                 "tuned_blocks_per_cu": info.tuned_blocks_per_cu,
                 "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
                 "chosen_GBps": round(info.chosen_GBps, 1), "calibration_ms": info.calibration_ms}
@@ -515,6 +516,43 @@ class Context:
             view = _CudaArrayView(block, block.ptr + off, int(n), typestr)
             t = torch.as_tensor(view, device=torch.device("cuda", self.device)) if n else torch.empty(0, dtype=dtype, device=torch.device("cuda", self.device))
             t.dxo_block = block   # keeps the arena block alive with the tensor
+            out.append(t)
+        return out
+
+    def output_tensors_probed(self, sizes, launch, bytes_per_launch: float = 0.0, shapes=(0,), dtype=None):
+        """`output_tensors` with the caller's own consumer as the probe (dxo_output_alloc_probed): `launch(ptrs, shape)`
+        gets the device addresses the `sizes` arrays would have inside a candidate block and must enqueue one pass of the
+        kernel that will write them (e.g. `ctx.heat(..., MEM_DEVICE, ...)`) without synchronising."""
+        import torch
+
+        dtype = dtype or torch.float64
+        item = torch.empty((), dtype=dtype).element_size()
+        offs, total = [], 0
+        for m in sizes:
+            offs.append(total)
+            total += (int(m) * item + 255) // 256 * 256
+        errors = []
+
+        def _cb(block, shape, _user):
+            try:
+                launch([block + o for o in offs], shape)
+            except Exception as exc:   # noqa: BLE001 — never unwind through the C frames
+                errors.append(exc)
+
+        cb = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)(_cb)
+        sh = (C.c_int32 * len(shapes))(*[int(x) for x in shapes])
+        p = _P()
+        self.check(self.lib.dxo_output_alloc_probed(self._h, max(total, 256), C.cast(cb, _P), None, float(bytes_per_launch), sh, len(shapes),
+                                                    C.byref(p)), "dxo_output_alloc_probed")
+        block = _ArenaBlock(self, max(total, 256), ptr=p.value)
+        if errors:
+            raise errors[0]
+        typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+        out = []
+        for m, off in zip(sizes, offs):
+            view = _CudaArrayView(block, block.ptr + off, int(m), typestr)
+            t = torch.as_tensor(view, device=torch.device("cuda", self.device)) if m else torch.empty(0, dtype=dtype, device=torch.device("cuda", self.device))
+            t.dxo_block = block
             out.append(t)
         return out
 

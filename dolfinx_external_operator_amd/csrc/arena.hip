@@ -71,12 +71,20 @@ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // GB/s of `launches` back-to-back sweeps of `shape` over the block; 0 on error. The block must have been swept before:
 // the first passes over a fresh allocation run ~20 % slower than its steady state (measured: every candidate of a
 // 12-candidate search read 4.8-5.2 TB/s when timed right after hipMalloc, gpurun_out r02c).
+// (events of its own: a probe may call the library's entry points, which record the context's timing events)
+hipEvent_t cal_ev[2] = {nullptr, nullptr};
+bool cal_events() {
+    for (auto& e : cal_ev)
+        if (!e && hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return false; }
+    return true;
+}
 double time_shape(dxo_ctx* c, const dxo_arena_probe& pr, void* p, int shape, hipStream_t s, int launches) {
-    if (hipEventRecord(c->ev_start, s) != hipSuccess) return 0.0;
+    (void)c;
+    if (!cal_events() || hipEventRecord(cal_ev[0], s) != hipSuccess) return 0.0;
     for (int l = 0; l < launches; ++l) pr.launch(p, shape, s);
-    if (hipEventRecord(c->ev_stop, s) != hipSuccess || hipEventSynchronize(c->ev_stop) != hipSuccess) return 0.0;
+    if (hipEventRecord(cal_ev[1], s) != hipSuccess || hipEventSynchronize(cal_ev[1]) != hipSuccess) return 0.0;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess || ms <= 0.f) return 0.0;
+    if (hipEventElapsedTime(&ms, cal_ev[0], cal_ev[1]) != hipSuccess || ms <= 0.f) return 0.0;
     return pr.bytes_per_launch * launches / (ms * 1e-3) / 1e9;
 }
 
@@ -289,7 +297,7 @@ void dxo_arena_register(dxo_ctx* c, const dxo_arena_block& blk) { c->arena.push_
 int dxo_arena_tuned_shape(dxo_ctx* c, const void* ptr) {
     for (const auto& b : c->arena)
         if (b.ptr && (const char*)ptr >= (const char*)b.ptr && (const char*)ptr < (const char*)b.ptr + b.bytes)
-            return b.info.mode == 2 ? b.info.tuned_blocks_per_cu : -1;
+            return b.info.mode == 2 && b.info.probe_kind == 2 ? b.info.tuned_blocks_per_cu : -1;   // shapes of vm_tile only
     return -1;
 }
 
@@ -350,6 +358,47 @@ extern "C" int dxo_output_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
         blk.bytes = need;
     }
     DXO_HIP(c, hipStreamSynchronize(s));
+    blk.info.calibration_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->arena.push_back(blk);
+    *ptr = blk.ptr;
+    return DXO_OK;
+}
+
+// The caller's own consumer as the probe: `launch(block, shape, user)` enqueues ONE pass of the kernel that will write the
+// block, on the context's launch stream, and returns without synchronising — typically a call of the dxo_* entry point
+// itself with device pointers into `block` (the context's lock is recursive: the callback runs on the calling thread).
+extern "C" int dxo_output_alloc_probed(dxo_ctx* c, int64_t bytes, dxo_probe_launch launch, void* user, double bytes_per_launch,
+                                       const int32_t* shapes, int n_shapes, void** ptr) {
+    if (!c || !ptr) return DXO_E_NULL;
+    DXO_LOCK(c);
+    *ptr = nullptr;
+    if (!launch) return dxo_fail(c, DXO_E_NULL, "dxo_output_alloc_probed: launch is NULL");
+    if (bytes < 0 || n_shapes < 0 || n_shapes > 8) return dxo_fail(c, DXO_E_SIZE, "dxo_output_alloc_probed: bad size / more than 8 shapes");
+    DXO_HIP(c, hipSetDevice(c->device));
+    const size_t need = bytes > 0 ? (size_t)bytes : 1;
+    dxo_arena_block blk;
+    std::memset(&blk.info, 0, sizeof blk.info);
+    blk.info.chosen = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = dxo_launch_stream(c);   // where the caller's entry points launch
+    bool done = false;
+    if ((int64_t)need >= c->placement_min_bytes && c->placement_candidates > 1 && c->placement_mode >= 1) {
+        dxo_arena_probe pr;
+        pr.launch = [=](void* p, int shape, hipStream_t) { launch(p, shape, user); };
+        pr.shapes.assign(shapes && n_shapes > 0 ? shapes : nullptr, shapes && n_shapes > 0 ? shapes + n_shapes : nullptr);
+        if (pr.shapes.empty()) pr.shapes = {0};
+        pr.bytes_per_launch = bytes_per_launch > 0.0 ? bytes_per_launch : (double)need;
+        pr.kind = 3;
+        done = alloc_by_candidates(c, need, pr, blk, s);
+        (void)hipStreamSynchronize(s);
+    }
+    if (!done) {
+        std::memset(&blk.info, 0, sizeof blk.info);
+        blk.info.chosen = -1;
+        blk.vmm = nullptr;
+        DXO_HIP(c, hipMalloc(&blk.ptr, need));
+        blk.bytes = need;
+    }
     blk.info.calibration_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->arena.push_back(blk);
     *ptr = blk.ptr;

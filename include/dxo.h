@@ -145,7 +145,8 @@ typedef struct dxo_placement_info {
     int16_t mode;                           /* how the block was obtained: 0 plain hipMalloc, 2 candidates         */
     int16_t probe_kind;                     /* what the candidates were timed with: 0 one store stream, 1 the
                                                kernels' six-stream read + write sweep (option "placement_probe"),
-                                               2 the von Mises kernel itself (dxo_vm_output_alloc)                 */
+                                               2 the von Mises kernel itself (dxo_vm_output_alloc), 3 the caller's
+                                               launch (dxo_output_alloc_probed)                                     */
     int32_t candidates;                     /* ranges / allocations timed                                          */
     int32_t chosen;                         /* index of the one kept (-1: no calibration)                          */
     uint32_t vmm_mask;                      /* bit k: candidate k was built from 2 MB physical chunks (option
@@ -163,6 +164,15 @@ typedef struct dxo_placement_info {
 int dxo_output_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_output_free(dxo_ctx* ctx, void* ptr);
 int dxo_output_info(dxo_ctx* ctx, const void* ptr, dxo_placement_info* info);
+/* The caller's own consumer as the probe. launch(block, shape, user) must enqueue ONE pass of the kernel that will write
+ * the block — typically the dxo_* entry point itself with device pointers into `block` — on the context's launch stream
+ * (dxo_ctx_set_stream, else the library's) and return without synchronising; it runs on the calling thread with the
+ * context's (recursive) lock held. shapes: launch shapes to try (NULL / 0: one pass with shape 0); the best one is
+ * recorded in tuned_blocks_per_cu for the caller to read back. bytes_per_launch: what a pass moves (for the GB/s of the
+ * record; 0: the block size). probe_kind 3. */
+typedef void (*dxo_probe_launch)(void* block, int shape, void* user);
+int dxo_output_alloc_probed(dxo_ctx* ctx, int64_t bytes, dxo_probe_launch launch, void* user, double bytes_per_launch,
+                            const int32_t* shapes, int n_shapes, void** ptr);
 /* The output arrays of dxo_von_mises for n points of Mandel length d, as ONE arena block calibrated WITH THE KERNEL
  * ITSELF: every candidate is timed running vm_tile on synthetic inputs of the reference's distribution, in two launch
  * shapes (one tile per wave, 32 persistent workgroups per CU), and the block that makes the kernel fastest is kept

@@ -114,6 +114,14 @@ q = torch.empty(n * 2, device=dev, dtype=torch.float64); dT = torch.empty_like(q
 ms = ev_time(lambda: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr()))
 print(json.dumps({"case": "heat fused q, dq/dT, dq/dsigma, gdim=2, 5e7 points", "kernel_ms": ms, "qp_per_s": n / ms * 1e3,
                   "GBps": 88 * n / ms / 1e6}), flush=True)
+del q, dT, ds
+# the same with the outputs in an arena block chosen by timing THIS kernel on the candidates (dxo_output_alloc_probed)
+q, dT, ds = ctx.output_tensors_probed((n * 2, n * 2, n * 4), lambda ptrs, shape: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), *ptrs),
+                                      bytes_per_launch=88.0 * n)
+ms = ev_time(lambda: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr()))
+print(json.dumps({"case": "heat fused, 5e7 points, outputs in a block calibrated with the heat kernel", "kernel_ms": ms, "GBps": 88 * n / ms / 1e6,
+                  "chosen_kind": q.dxo_block.info["chosen_kind"], "calibration_GBps": q.dxo_block.info["chosen_GBps"]}), flush=True)
+del q, dT, ds
 # ICNN (BASELINE config 5): F = I + 0.1 N(0,1), det F > 0.2
 w = {k.replace("__", "."): v for k, v in np.load(ROOT / "tests" / "golden" / "icnn_isihara_weights.npz").items()}
 model = ctx.icnn_create(w)
@@ -138,4 +146,10 @@ iprm = IsiharaParams(0.5, 1.0, 1.0, 1.5)
 ms = ev_time(lambda: ctx.isihara(iprm, n, MEM_DEVICE, Ft.data_ptr(), dPt.data_ptr(), Pt.data_ptr()))
 print(json.dumps({"case": "analytic Isihara stress + tangent (dxo_isihara), fp64, 2e7 points", "n": n, "kernel_ms": ms,
                   "qp_per_s": n / ms * 1e3, "GBps": 192 * n / ms / 1e6}), flush=True)
+del dPt, Pt
+dPt, Pt = ctx.output_tensors_probed((n * 16, n * 4), lambda ptrs, shape: ctx.isihara(iprm, n, MEM_DEVICE, Ft.data_ptr(), *ptrs), bytes_per_launch=192.0 * n)
+ms = ev_time(lambda: ctx.isihara(iprm, n, MEM_DEVICE, Ft.data_ptr(), dPt.data_ptr(), Pt.data_ptr()))
+print(json.dumps({"case": "analytic Isihara, 2e7 points, outputs in a block calibrated with the Isihara kernel", "kernel_ms": ms,
+                  "GBps": 192 * n / ms / 1e6, "chosen_kind": dPt.dxo_block.info["chosen_kind"], "calibration_GBps": dPt.dxo_block.info["chosen_GBps"]}), flush=True)
+del dPt, Pt
 ctx.close()

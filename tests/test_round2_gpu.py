@@ -440,3 +440,39 @@ def test_vm_output_alloc_calibrates_with_the_kernel_itself(ctx, oracle):
     assert_close_scaled(dp[idx].cpu().numpy(), dpo, 1e-13, "dp")
     small = ctx.vm_output_tensors(1000, 4)                                  # below placement_min_bytes: plain, no calibration
     assert small[0].dxo_block.info["chosen"] == -1 and small[0].numel() == 16000
+
+
+def test_output_alloc_probed_runs_the_callers_kernel(ctx):
+    """dxo_output_alloc_probed: the candidates are exercised by the caller's own launch (here dxo_heat through the Python
+    binding, re-entering the context from the callback); the record says so; results in the block are the kernel's."""
+    import torch
+
+    n = 18_000_000                                                        # 64 B/point of outputs -> 1.15 GB (above placement_min_bytes)
+    T = torch.rand(n, device="cuda:0", dtype=torch.float64) + 0.5
+    sg = torch.randn(n, 2, device="cuda:0", dtype=torch.float64)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    calls = []
+
+    def launch(ptrs, shape):
+        calls.append(shape)
+        ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), *ptrs)
+
+    old = ctx.get_option("placement_candidates")
+    ctx.set_option("placement_candidates", 4)
+    try:
+        q, dT, ds = ctx.output_tensors_probed((n * 2, n * 2, n * 4), launch, bytes_per_launch=88.0 * n)
+    finally:
+        ctx.set_option("placement_candidates", old)
+    info = q.dxo_block.info
+    assert info["probe"] == "caller" and info["mode"] == "candidates" and len(calls) >= 4 * 5 and set(calls) == {0}, (info, len(calls))
+    assert all(b > 500.0 for b in info["probe_GBps"])
+    ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, T.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr())
+    torch.cuda.synchronize()
+    k = 1.0 / (1.0 + T)
+    assert torch.allclose(q.view(n, 2), -k[:, None] * sg, rtol=1e-14, atol=0) and torch.allclose(dT.view(n, 2), (k * k)[:, None] * sg, rtol=1e-14, atol=0)
+
+    def bad(ptrs, shape):
+        raise RuntimeError("boom")
+
+    with pytest.raises(RuntimeError, match="boom"):                       # an exception in the callback surfaces after the call
+        ctx.output_tensors_probed((n * 8,), bad)
