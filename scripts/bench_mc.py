@@ -27,6 +27,8 @@ ap.add_argument("--variant", type=int, default=1)
 ap.add_argument("--bpc", type=int, default=2)
 ap.add_argument("--wps", type=int, default=1)
 ap.add_argument("--cpu", type=int, default=0, help="also time the CPU oracle (nested dual numbers, OpenMP) on this many points")
+ap.add_argument("--arena", type=int, default=0, help="(no gain measured: the call is fp64-bound, 1.39-1.44 ms either way) 1: C_tang and sigma in an arena block chosen by timing this kernel on the candidates "
+                                                    "(dxo_output_alloc_probed); 0: plain torch.empty")
 args = ap.parse_args()
 n = args.n
 o = load_oracle()
@@ -38,8 +40,6 @@ idx = torch.randint(0, args.pool, (n,), generator=g, device=dev)
 scale = torch.rand(n, 1, generator=g, device=dev, dtype=torch.float64) * 0.5 + 0.5
 deps = (torch.from_numpy(pool_d).to(dev)[idx] * scale).contiguous()
 sn = torch.from_numpy(pool_s).to(dev)[idx].contiguous()
-Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
-s = torch.empty(n * 4, dtype=torch.float64, device=dev)
 it = torch.empty(n, dtype=torch.int32, device=dev)
 y, nr, dl = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
 prm = McParams(6778.0, 0.25, 3.45, np.pi / 6, np.pi / 6, 26 * np.pi / 180, 0.26 * 3.45 / np.tan(np.pi / 6), 1e-8, 200, 0)
@@ -50,6 +50,14 @@ ctx.set_option("mc_variant", args.variant)
 ctx.set_option("mc_blocks_per_cu", args.bpc)
 ctx.set_option("mc_waves_per_simd", args.wps)
 diag = (it.data_ptr(), y.data_ptr(), nr.data_ptr(), dl.data_ptr()) if args.diag else (None, None, None, None)
+placement = None
+if args.arena:
+    Ct, s = ctx.output_tensors_probed((n * 16, n * 4), lambda ptrs, shape: ctx.mohr_coulomb(prm, n, MEM_DEVICE, deps.data_ptr(), sn.data_ptr(), ptrs[0], ptrs[1], *diag),
+                                      bytes_per_launch=(224.0 + (28 if args.diag else 0)) * n)
+    placement = {k: Ct.dxo_block.info[k] for k in ("chosen_kind", "chosen_GBps", "candidates", "probe")}
+else:
+    Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
+    s = torch.empty(n * 4, dtype=torch.float64, device=dev)
 
 
 def run():
@@ -67,7 +75,7 @@ torch.cuda.synchronize()
 ms = statistics.median(a.elapsed_time(b) for a, b in evs)
 bpp = 224 + (28 if args.diag else 0)
 out = {"case": "Mohr-Coulomb return map + AD tangent, tracing distribution", "variant": args.variant, "bpc": args.bpc, "wps": args.wps, "n": n, "kernel_ms": ms,
-       "qp_per_s": n / ms * 1e3, "GBps_algorithmic": bpp * n / ms / 1e6, "bytes_per_qp": bpp}
+       "qp_per_s": n / ms * 1e3, "GBps_algorithmic": bpp * n / ms / 1e6, "bytes_per_qp": bpp, "output_placement": placement}
 if args.diag:
     u, c = torch.unique(it, return_counts=True)
     out["iteration_histogram"] = {int(a): int(b) for a, b in zip(u.tolist(), c.tolist())}
