@@ -71,16 +71,16 @@ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // GB/s of `launches` back-to-back sweeps of `shape` over the block; 0 on error. The block must have been swept before:
 // the first passes over a fresh allocation run ~20 % slower than its steady state (measured: every candidate of a
 // 12-candidate search read 4.8-5.2 TB/s when timed right after hipMalloc, gpurun_out r02c).
-// (events of its own: a probe may call the library's entry points, which record the context's timing events)
-hipEvent_t cal_ev[2] = {nullptr, nullptr};
-bool cal_events() {
-    for (auto& e : cal_ev)
+// (events of its own, per context = per device: a probe may call the library's entry points, which record the context's
+// timing events)
+bool cal_events(dxo_ctx* c) {
+    for (auto& e : c->cal_ev)
         if (!e && hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return false; }
     return true;
 }
 double time_shape(dxo_ctx* c, const dxo_arena_probe& pr, void* p, int shape, hipStream_t s, int launches) {
-    (void)c;
-    if (!cal_events() || hipEventRecord(cal_ev[0], s) != hipSuccess) return 0.0;
+    hipEvent_t* cal_ev = c->cal_ev;
+    if (!cal_events(c) || hipEventRecord(cal_ev[0], s) != hipSuccess) return 0.0;
     for (int l = 0; l < launches; ++l) pr.launch(p, shape, s);
     if (hipEventRecord(cal_ev[1], s) != hipSuccess || hipEventSynchronize(cal_ev[1]) != hipSuccess) return 0.0;
     float ms = 0.f;

@@ -61,6 +61,7 @@ struct dxo_ctx {
     void* slot_buf[DXO_HOST_SLOTS] = {nullptr, nullptr, nullptr};
     size_t slot_bytes = 0;              // capacity of each slot buffer
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t cal_ev[2] = {nullptr, nullptr};   // arena.hip: the calibration's own pair (a probe may call entry points that record ev_*)
     bool ev_pending = false;            // device-path events recorded, not yet read
     int compute_units = 256;
     // options

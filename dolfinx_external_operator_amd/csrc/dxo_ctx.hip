@@ -87,6 +87,8 @@ int dxo_ctx_destroy(dxo_ctx* c) {
     dxo_arena_release_all(c);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (auto& e : c->cal_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     dxo_host_pool_destroy(c->pool);
     delete c;
