@@ -152,3 +152,67 @@ def test_icnn_at_one_million_points(ctx, golden):
     assert bool(torch.isfinite(dP).all()) and bool(torch.isfinite(P).all())
     T = dP.view(n, 4, 4)
     assert float((T - T.transpose(1, 2)).abs().max()) <= 2e-5 * float(T.abs().max())   # hyperelastic tangent: major symmetry, fp32 noise
+
+
+def test_config_3_cell_blocks_at_a_hundred_million_points_on_one_gpu(ctx, oracle):
+    """BASELINE config 3 (von Mises, 12.5 * 10^6 hexahedra x 8 points = 10^8 points, cell-block sharded over 8 GPUs) with
+    the eight blocks run ONE AFTER ANOTHER on the single GPU of this box, each writing its slice of the full-length
+    arrays exactly as a rank does before the gather (sharding.CellBlockPartition gives the ranges; the compact gather's
+    tangent rebuild, dxo_vm_expand_tangent over the 'remote' ranges of rank 0, is run as well). What this pins at the
+    configuration's real size: the block offsets (34 GB of outputs, indices beyond 2^32), bit-identity of a block's slice
+    with one whole-array call, the oracle on a strided sample, and the rebuilt remote tangents against the owners'.
+    The exchange itself needs the 8-GPU node."""
+    import torch
+
+    from dolfinx_external_operator_amd.sharding import CellBlockPartition, remote_point_ranges
+
+    world, nq, d = 8, 8, 6
+    part = CellBlockPartition(12_500_000, nq, world)
+    n_rank, N = part.points_per_rank, part.padded_points
+    assert part.num_points == 100_000_000 and n_rank % 64 == 0 and 0 <= N - part.num_points < world * 64   # blocks end on wave tiles
+    dev = torch.device("cuda:0")
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 110 * 2**30:
+        pytest.skip("needs ~100 GB of free HBM")
+    g = torch.Generator(device=dev).manual_seed(100)
+    deps = torch.empty(N, d, dtype=torch.float64, device=dev).normal_(0.0, 3e-3, generator=g)
+    sigma_n = torch.empty(N, d, dtype=torch.float64, device=dev).normal_(0.0, 100.0, generator=g)
+    p = torch.empty(N, dtype=torch.float64, device=dev).normal_(0.0, 1e-3, generator=g).abs_()
+    C = torch.full((N * d * d,), float("nan"), dtype=torch.float64, device=dev)
+    s = torch.full((N * d,), float("nan"), dtype=torch.float64, device=dev)
+    dp = torch.full((N,), float("nan"), dtype=torch.float64, device=dev)
+    prm = VmParams(E, NU, SIGMA_0, H)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rank in range(world):                                          # what rank `rank` launches
+        rb, re = part.point_range(rank)                              # the rank's REAL points; its block is padded to n_rank
+        b, e = rank * n_rank, (rank + 1) * n_rank
+        assert rb == b and b < re <= e and (re == e or rank == world - 1)
+        ctx.von_mises(prm, d, e - b, MEM_DEVICE, deps[b:e].data_ptr(), sigma_n[b:e].data_ptr(), p[b:e].data_ptr(),
+                      C[b * d * d:].data_ptr(), s[b * d:].data_ptr(), dp[b:].data_ptr())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(s).all()) and bool(torch.isfinite(dp).all())           # every slice was written
+    assert bool(torch.isfinite(C[-4096 * d * d:]).all()) and bool(torch.isfinite(C[: 4096 * d * d]).all())
+    # one whole-array call gives the same bits as the eight block calls
+    s2, dp2 = torch.empty_like(s), torch.empty_like(dp)
+    C2 = torch.empty(n_rank * d * d, dtype=torch.float64, device=dev)                  # tangent of the LAST block only (memory)
+    last = (world - 1) * n_rank
+    ctx.von_mises(prm, d, n_rank, MEM_DEVICE, deps[last:].data_ptr(), sigma_n[last:].data_ptr(), p[last:].data_ptr(),
+                  C2.data_ptr(), s2[last * d:].data_ptr(), dp2[last:].data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(C2, C[last * d * d:]) and torch.equal(s2[last * d:], s[last * d:]) and torch.equal(dp2[last:], dp[last:])
+    del C2, s2, dp2
+    # oracle on a strided sample across all blocks (+ the first and last point of every block)
+    idx = torch.cat([torch.arange(0, N, 1009, device=dev), torch.arange(0, N, n_rank, device=dev), torch.arange(n_rank - 1, N, n_rank, device=dev)])
+    Co, so, dpo = oracle.von_mises(deps[idx].cpu().numpy(), sigma_n[idx].cpu().numpy(), p[idx].cpu().numpy(), nthreads=8)
+    assert_close_scaled(C.view(N, d * d)[idx].cpu().numpy(), Co, 1e-13, "C_tang sample over the eight blocks")
+    assert_close_scaled(s.view(N, d)[idx].cpu().numpy(), so, 1e-13, "sigma sample")
+    assert_close_scaled(dp[idx].cpu().numpy(), dpo, 1e-13, "dp sample")
+    # rank 0 after a compact gather: the tangents of the remote ranges rebuilt from (sigma, dp) agree with the owners'
+    for (b, e) in remote_point_ranges(0, world, n_rank):
+        owner = C[b * d * d: b * d * d + 4096 * d * d].clone()
+        tail = C[e * d * d - 4096 * d * d: e * d * d].clone()
+        ctx.vm_expand_tangent(prm, d, e - b, MEM_DEVICE, s[b * d:].data_ptr(), dp[b:].data_ptr(), C[b * d * d:].data_ptr())
+        torch.cuda.synchronize()
+        scale = float(owner.abs().max())
+        assert float((C[b * d * d: b * d * d + 4096 * d * d] - owner).abs().max()) <= 1e-13 * scale
+        assert float((C[e * d * d - 4096 * d * d: e * d * d] - tail).abs().max()) <= 1e-13 * scale
