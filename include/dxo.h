@@ -101,7 +101,8 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
 /* Integer tuning knobs: "vm_variant" (0 scalar AoS kernel, 1 LDS-staged coalesced kernel,
  * default 1), "host_chunk_points" (points per H2D/kernel/D2H pipeline chunk),
  * "nontemporal" (0/1 streaming stores), "timing" (0/1 record dxo_timing on device calls),
- * "blocks_per_cu" (0 = one tile per wave, k = grid-stride over k workgroups per CU),
+ * "blocks_per_cu" (0 = one tile per wave — except that dxo_von_mises / dxo_vm_expand_tangent writing into a block from
+ * dxo_vm_output_alloc use the launch shape its calibration found best; k = grid-stride over k workgroups per CU),
  * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
  * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 2), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
@@ -112,7 +113,8 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0
- * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the machine's), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
+ * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the CPUs the process may use: affinity mask and
+ * cgroup CPU quota, minus two; DXO_HOST_CPU_BUDGET in the environment overrides the detection), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
  * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);
