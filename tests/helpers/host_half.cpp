@@ -79,7 +79,13 @@ int main() {
     for (size_t k = (size_t)n * 36; k < C.size(); ++k) if (C[k] != -7.0) return 3;
     if (!(C[17 * 36] != C[17 * 36]) || std::signbit(dp[17])) return 4;   // NaN tangent, dp back to +0
     for (int64_t i = 0; i < n * 36; ++i) if (i / 36 != 17 && !(C[(size_t)i] == C[(size_t)i])) return 5;
-    std::printf("host half harness: ok (%ld parallel_for rounds)\n", rounds);
+    // the CPU budget the pool caps itself with: at least 1, at most the machine's threads, and overridable
+    const int budget = dxo_host_cpu_budget();
+    if (budget < 1 || (std::thread::hardware_concurrency() > 0 && budget > (int)std::thread::hardware_concurrency())) return 6;
+    setenv("DXO_HOST_CPU_BUDGET", "3", 1);
+    if (dxo_host_cpu_budget() != 3) return 7;
+    unsetenv("DXO_HOST_CPU_BUDGET");
+    std::printf("host half harness: ok (%ld parallel_for rounds, cpu budget %d)\n", rounds, budget);
     return 0;
 }
 #endif
