@@ -389,23 +389,44 @@ DXO_HD void elastic_point(const Const& k, const double* sn, const double* Ce, co
 }
 
 // State of one plastic point between Newton passes: y = (sig, dl), Y = d y / d deps (5 x 4).
-struct Lane {
+// WHERE the bulky, rarely touched part lives — the inputs (deps, sn: read once per pass, by the residual) and Y (touched
+// one column at a time at the end of a pass) — is a policy: LaneRegs keeps them in the struct (registers on the GPU;
+// the CPU build and mc_point), the Newton kernel of mohr_coulomb.hip parks them in the wave's LDS slice so that the
+// 28 doubles = 56 VGPRs are not live across the surface / Hessian / third-derivative arithmetic of a pass. The
+// arithmetic and its order are the same for every policy.
+struct LaneRegs {
     double deps[4], sn[4];
-    double sig[4], dl;
     double Y[5][4];
+    DXO_HD void set_inputs(const double* d, const double* s) {
+        for (int i = 0; i < 4; ++i) { deps[i] = d[i]; sn[i] = s[i]; }
+    }
+    DXO_HD void get_inputs(double* d, double* s) const {
+        for (int i = 0; i < 4; ++i) { d[i] = deps[i]; s[i] = sn[i]; }
+    }
+    DXO_HD void get_col(int m, double* v5) const {
+        for (int i = 0; i < 5; ++i) v5[i] = Y[i][m];
+    }
+    DXO_HD void set_col(int m, const double* v5) {
+        for (int i = 0; i < 5; ++i) Y[i][m] = v5[i];
+    }
+};
+
+template <class Store>
+struct LaneT {
+    Store st;
+    double sig[4], dl;
     double norm0, norm;   // norm_res0 (:501) and the current residual norm
     int32_t niter;
 };
+using Lane = LaneT<LaneRegs>;
 
-DXO_HD void lane_init(Lane& L, const double* deps, const double* sn) {
-    for (int i = 0; i < 4; ++i) {
-        L.deps[i] = deps[i];
-        L.sn[i] = sn[i];
-        L.sig[i] = sn[i];   // :496-498
-    }
+template <class Store>
+DXO_HD void lane_init(LaneT<Store>& L, const double* deps, const double* sn) {
+    L.st.set_inputs(deps, sn);
+    for (int i = 0; i < 4; ++i) L.sig[i] = sn[i];   // :496-498
     L.dl = 0.0;
-    for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 4; ++j) L.Y[i][j] = 0.0;
+    const double zero[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < 4; ++m) L.st.set_col(m, zero);
     L.norm0 = -1.0;  // "not evaluated yet"
     L.norm = 0.0;
     L.niter = 0;
@@ -414,12 +435,17 @@ DXO_HD void lane_init(Lane& L, const double* deps, const double* sn) {
 // One pass = evaluate the surface at the current iterate, form r and its norm, test cond_fun (:503-505);
 // if the loop continues, do body_fun (:507-522): Newton step + tangent recursion. Returns true when the
 // point is finished (converged, NaN, or niter == nitermax); L then holds the reference's outputs.
-DXO_HD bool lane_pass(const Const& k, Lane& L) {
+template <class Store>
+DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     Surf e;
     surf_eval(k, L.sig, e);
     double gradg[4], r_sig[4], r_f;
     grad_surface(k, e, 1, gradg);
-    L.norm = residual(k, e, L.sig, L.dl, L.deps, L.sn, gradg, r_sig, &r_f);   // :500 / :516-517
+    {
+        double deps[4], sn[4];
+        L.st.get_inputs(deps, sn);
+        L.norm = residual(k, e, L.sig, L.dl, deps, sn, gradg, r_sig, &r_f);   // :500 / :516-517
+    }
     if (L.norm0 < 0.0 || L.norm0 != L.norm0) L.norm0 = (L.niter == 0) ? L.norm : L.norm0;  // :501
     if (!((L.norm / L.norm0 > k.tol) && (L.niter < k.nitermax))) return true;
     // M = S + dlambda H_g (symmetric)
@@ -445,17 +471,19 @@ DXO_HD bool lane_pass(const Const& k, Lane& L) {
     const double t_l = (dot4(gradf, xh) - r_f) / cb;
     double t_s[4];
     for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
-    // tangent recursion Y <- J^-1 ([C; 0] + (D J[Y]) t)
+    // tangent recursion Y <- J^-1 ([C; 0] + (D J[Y]) t), column by column (column m of the new Y depends on column m
+    // of the old one only, so the update is done in place)
     double Ht[4], Hft[4];
     hess_apply(e, 1, t_s, Ht);
     if (k.same_angle) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
     else hess_apply(e, 0, t_s, Hft);
     Third T;
     third_setup(e, 1, t_s, T);
-    double Ynew[5][4];
     for (int m = 0; m < 4; ++m) {
-        const double v[4] = {L.Y[0][m], L.Y[1][m], L.Y[2][m], L.Y[3][m]};
-        const double dlm = L.Y[4][m];
+        double col[5];
+        L.st.get_col(m, col);
+        const double v[4] = {col[0], col[1], col[2], col[3]};
+        const double dlm = col[4];
         double Tv[4], Hv[4], rhs[4], zh[4];
         third_apply(e, 1, T, v, Tv);
         hess_apply(e, 1, v, Hv);
@@ -463,11 +491,10 @@ DXO_HD bool lane_pass(const Const& k, Lane& L) {
         const double nu_m = dot4(Hft, v);
         ldl_solve(F, rhs, zh);
         const double mu_m = (dot4(gradf, zh) - nu_m) / cb;
-        for (int i = 0; i < 4; ++i) Ynew[i][m] = zh[i] - bh[i] * mu_m;
-        Ynew[4][m] = mu_m;
+        for (int i = 0; i < 4; ++i) col[i] = zh[i] - bh[i] * mu_m;
+        col[4] = mu_m;
+        L.st.set_col(m, col);
     }
-    for (int i = 0; i < 5; ++i)
-        for (int m = 0; m < 4; ++m) L.Y[i][m] = Ynew[i][m];
     for (int i = 0; i < 4; ++i) L.sig[i] -= t_s[i];   // y <- y + solve(j, -r), :513-514
     L.dl -= t_l;
     L.niter += 1;                                      // :520
@@ -486,9 +513,11 @@ DXO_HD void return_map(const Const& k, const double* deps, const double* sn, Res
     Lane L;
     lane_init(L, deps, sn);
     while (!lane_pass(k, L)) {}
-    for (int i = 0; i < 4; ++i) {
-        R.sigma[i] = L.sig[i];
-        for (int j = 0; j < 4; ++j) R.C_tang[i * 4 + j] = L.Y[i][j];
+    for (int i = 0; i < 4; ++i) R.sigma[i] = L.sig[i];
+    for (int j = 0; j < 4; ++j) {
+        double col[5];
+        L.st.get_col(j, col);
+        for (int i = 0; i < 4; ++i) R.C_tang[i * 4 + j] = col[i];
     }
     R.niter = L.niter;
     R.norm_res = L.norm;

@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int MC_PENDING = 512;  // per-wave buffer of plastic point indices (mc_classify)
+#ifndef DXO_MC_LDS_STATE
+#define DXO_MC_LDS_STATE 1    // mc_newton: inputs and tangent iterate of a lane's point parked in LDS between their uses
+#endif
 constexpr int MC_BATCH = 256;    // list entries a wave reserves per cursor atomic (mc_newton)
 constexpr int MC_ROW = 18;  // LDS doubles per point: 16 C_tang + 2 pad (144 B stride: conflict-free b128 writes)
 
@@ -205,6 +208,29 @@ __global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n,
     if (n_pend) flush();
 }
 
+// The inputs and the tangent iterate of a lane's point in the wave's LDS slice: slot-major, lane-minor (a slot of all 64
+// lanes is 512 contiguous bytes: conflict-free ds_read/write_b64), slots 0-7 = deps, sn, slots 8 + 5 m + i = Y[i][m].
+struct LaneLds {
+    double* slots;   // wave slice + lane
+    __device__ __forceinline__ void set_inputs(const double* d, const double* s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { slots[i * DXO_WAVE] = d[i]; slots[(4 + i) * DXO_WAVE] = s[i]; }
+    }
+    __device__ __forceinline__ void get_inputs(double* d, double* s) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i] = slots[i * DXO_WAVE]; s[i] = slots[(4 + i) * DXO_WAVE]; }
+    }
+    __device__ __forceinline__ void get_col(int m, double* v5) const {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v5[i] = slots[(8 + 5 * m + i) * DXO_WAVE];
+    }
+    __device__ __forceinline__ void set_col(int m, const double* v5) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) slots[(8 + 5 * m + i) * DXO_WAVE] = v5[i];
+    }
+};
+constexpr int MC_LANE_SLOTS = 28;
+
 template <int MINW>
 __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const double* __restrict__ deps,
                                                        const double* __restrict__ sigma_n, double* __restrict__ C_tang,
@@ -213,7 +239,13 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
                                                        McScratchHeader* __restrict__ hdr, const int32_t* __restrict__ list) {
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const unsigned int total = hdr->n_plastic;   // written by mc_classify, earlier on the same stream
+#if DXO_MC_LDS_STATE
+    __shared__ double lane_state[(DXO_BLOCK / DXO_WAVE) * MC_LANE_SLOTS * DXO_WAVE];
+    mc::LaneT<LaneLds> L;
+    L.st.slots = lane_state + (threadIdx.x >> 6) * (MC_LANE_SLOTS * DXO_WAVE) + lane;
+#else
     mc::Lane L;
+#endif
     bool active = false, exhausted = false;
     int64_t idx = 0;
     unsigned int lo = 0, hi = 0;   // the wave's reserved slice of the list (wave-uniform)
@@ -248,10 +280,13 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
         if (active) {
             if (mc::lane_pass(k, L)) {
                 dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + idx * 16);
+                double Yc[4][5];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) L.st.get_col(m, Yc[m]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    gc[2 * r] = dxo_f64x2{L.Y[r][0], L.Y[r][1]};
-                    gc[2 * r + 1] = dxo_f64x2{L.Y[r][2], L.Y[r][3]};
+                    gc[2 * r] = dxo_f64x2{Yc[0][r], Yc[1][r]};
+                    gc[2 * r + 1] = dxo_f64x2{Yc[2][r], Yc[3][r]};
                 }
                 dxo_f64x2* gg = reinterpret_cast<dxo_f64x2*>(sigma + idx * 4);
                 gg[0] = dxo_f64x2{L.sig[0], L.sig[1]};

@@ -104,7 +104,7 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * "blocks_per_cu" (0 = one tile per wave — except that dxo_von_mises / dxo_vm_expand_tangent writing into a block from
  * dxo_vm_output_alloc use the launch shape its calibration found best; k = grid-stride over k workgroups per CU),
  * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
- * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 2), "mc_waves_per_simd", "mc_part_points"
+ * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
  * (0 VALU, 1 MFMA 8 waves per workgroup, 2 MFMA 4 waves), "host_small_bytes" (host batches whose inputs + outputs
  * fit this many bytes, default 1 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of

@@ -24,7 +24,7 @@ ap.add_argument("--diag", type=int, default=1)
 ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--pool", type=int, default=50_000)
 ap.add_argument("--variant", type=int, default=1)
-ap.add_argument("--bpc", type=int, default=2)
+ap.add_argument("--bpc", type=int, default=3)
 ap.add_argument("--wps", type=int, default=1)
 ap.add_argument("--cpu", type=int, default=0, help="also time the CPU oracle (nested dual numbers, OpenMP) on this many points")
 ap.add_argument("--arena", type=int, default=0, help="(no gain measured: the call is fp64-bound, 1.39-1.44 ms either way) 1: C_tang and sigma in an arena block chosen by timing this kernel on the candidates "
