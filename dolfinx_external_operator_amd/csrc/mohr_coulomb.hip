@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int MC_PENDING = 512;  // per-wave buffer of plastic point indices (mc_classify)
+#ifndef DXO_MC_SIGMA_ALL
+#define DXO_MC_SIGMA_ALL 1    // mc_classify: whole-line sigma stores for every point (mc_newton overwrites the plastic ones): 1.30 vs 1.35 ms
+#endif
 #ifndef DXO_MC_LDS_STATE
 #define DXO_MC_LDS_STATE 1    // mc_newton: inputs and tangent iterate of a lane's point parked in LDS between their uses
 #endif
@@ -170,11 +173,18 @@ __global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n,
         }
         if (live) {
             if (yielding) yielding[i] = yld;
+#if DXO_MC_SIGMA_ALL
+            // whole-line stores for every point: the plastic points' entries are placeholders that mc_newton overwrites
+            if (niter) niter[i] = R.niter;
+            if (norm_res) norm_res[i] = R.norm_res;
+            if (dlambda) dlambda[i] = 0.0;
+#else
             if (elastic) {
                 if (niter) niter[i] = R.niter;
                 if (norm_res) norm_res[i] = R.norm_res;
                 if (dlambda) dlambda[i] = 0.0;
             }
+#endif
         }
         // sigma of elastic points: point-per-lane rows -> lane-linear stores, masked by the owner's branch
         X2[lane * 2] = dxo_f64x2{R.sigma[0], R.sigma[1]};
@@ -186,7 +196,11 @@ __global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n,
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int q = it * DXO_WAVE + lane;
+#if DXO_MC_SIGMA_ALL
+            if (q < npts * 2) st16<true>(gg + q, X2[q]);   // plastic points get their trial stress here and the returned one from mc_newton
+#else
             if ((el_mask >> (q >> 1)) & 1ull) st16<true>(gg + q, X2[q]);
+#endif
         }
         // C_tang of elastic points: constants in output order (chunk q = point q/8, entries 2(q%8), 2(q%8)+1)
         dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + p0 * 16);
