@@ -83,6 +83,23 @@ int main(void) {
     CHECK(dxo_copy(ctx, sn_back, d_sn, n * d * 8, 1));
     int same = memcmp(p_back, dp, n * 8) == 0 && memcmp(sn_back, sigma, n * d * 8) == 0;   /* p was 0, so p == dp */
     printf("device state: history update %s the host result\n", same ? "reproduces" : "DIFFERS FROM");
+    /* host arrays again, but the history variables live in a device mirror (dxo_vm_state): uploaded once, every call
+     * sends deps only, and the load-step update is applied on the device while the caller applies it to its arrays */
+    dxo_vm_state* st = NULL;
+    CHECK(dxo_vm_state_create(ctx, d, n, &st));
+    CHECK(dxo_vm_state_upload(ctx, st, DXO_MEM_HOST, sigma_n, p));
+    double* C2 = malloc(n * d * d * sizeof(double));
+    double* s2 = malloc(n * d * sizeof(double));
+    double* dp2 = malloc(n * sizeof(double));
+    CHECK(dxo_von_mises_state(ctx, &prm, st, DXO_MEM_HOST, deps, C2, s2, dp2));
+    int same_state = memcmp(C2, C_tang, n * d * d * 8) == 0 && memcmp(s2, sigma, n * d * 8) == 0 && memcmp(dp2, dp, n * 8) == 0;
+    CHECK(dxo_vm_state_commit(ctx, st));                                   /* p += dp; sigma_n <- sigma, in the mirror */
+    CHECK(dxo_vm_state_download(ctx, st, DXO_MEM_HOST, sn_back, p_back));
+    same_state = same_state && memcmp(p_back, dp, n * 8) == 0 && memcmp(sn_back, sigma, n * d * 8) == 0;
+    printf("resident state: call and commit %s the plain call\n", same_state ? "reproduce" : "DIFFER FROM");
+    dxo_vm_state_destroy(ctx, st);
+    free(C2); free(s2); free(dp2);
+    same = same && same_state;
     dxo_device_free(ctx, d_deps); dxo_device_free(ctx, d_sn); dxo_device_free(ctx, d_p);
     dxo_device_free(ctx, d_C); dxo_device_free(ctx, d_s); dxo_device_free(ctx, d_dp);
     free(deps); free(sigma_n); free(p); free(C_tang); free(sigma); free(dp); free(p_back); free(sn_back);

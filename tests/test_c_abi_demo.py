@@ -37,3 +37,4 @@ def test_runs_from_c_on_the_gpu(demo):
     r = subprocess.run([str(demo)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "history update reproduces the host result" in r.stdout
+    assert "resident state: call and commit reproduce the plain call" in r.stdout
