@@ -286,6 +286,9 @@ def main():
                          "`dry_collective` and is not a measurement.")
     ap.add_argument("--no-library-gather", action="store_true",
                     help="skip the dxo_mgpu_* (RCCL inside libdxo_hip.so) cross-check that runs after the result line at N > 1")
+    ap.add_argument("--gather-vmm", type=int, default=0,
+                    help="1: let the gathered (RCCL send / receive) arrays live in a virtual range backed by 2 MB chunks too "
+                         "(experiment; default 0 = hipMalloc candidates only, see the comment at placement_vmm below)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
@@ -381,10 +384,12 @@ def main():
     else:
         ctx.set_option("placement_candidates", args.placement)   # the library caps it so that all candidates fit 60 % of the free memory
         ctx.set_option("placement_mode", 2)
-        if gather_on:
+        if gather_on and not args.gather_vmm:
             # the gathered arrays are RCCL send / receive buffers: plain hipMalloc blocks only (a virtual range backed by
             # 2 MB chunks cannot be exported with hipIpcGetMemHandle, which RCCL may use for peer access)
             ctx.set_option("placement_vmm", 0)
+        elif gather_on and args.gather_vmm >= 2:
+            ctx.set_option("placement_vmm", 2)   # chunk-backed candidates only
     # what make_von_mises(...).arena(n, d) hands out: candidates timed with the kernel itself, block and launch shape
     # (dxo_vm_output_alloc); with the gather on, the block holds the FULL-length arrays (hipMalloc candidates only, see above)
     C_full, sigma_full, dp_full = ctx.vm_output_tensors(N_full, d)

@@ -215,7 +215,7 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, const dxo_arena_probe& pr, dx
     while ((int)cand.size() < K && !good && !oom) {
         const int first = (int)cand.size();
         for (int k = first; k < K && k < first + 4; ++k)
-            if (!add(use_vmm && (k & 3) != 0)) { oom = true; break; }   // one hipMalloc block, three of 2 MB chunks, per group of four
+            if (!add(use_vmm && ((k & 3) != 0 || c->placement_vmm >= 2))) { oom = true; break; }   // one hipMalloc block, three of 2 MB chunks, per group of four (placement_vmm 2: chunks only)
         for (int k = first; k < (int)cand.size(); ++k) warm_block(pr, cand[(size_t)k].p, s);
         if (hipStreamSynchronize(s) != hipSuccess) break;
         for (int k = first; k < (int)cand.size(); ++k) {

@@ -135,7 +135,7 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
  * (default), 0 = plain hipMalloc; "placement_candidates"
  * (default 16, at most 32, and never more than fit 60 % of the free memory together); "placement_min_bytes"
  * (default 1 GiB: smaller blocks are plain hipMalloc, a working set that small lives in the caches); "placement_vmm"
- * (default 1: three of every four candidates are virtual ranges backed by 2 MB physical chunks, hipMemCreate / hipMemMap,
+ * (default 1: three of every four candidates — 2: all of them — are virtual ranges backed by 2 MB physical chunks, hipMemCreate / hipMemMap,
  * which land in the fast class about twice as often as hipMalloc blocks and were the only fast ones for vm_tile on several boxes; 0 = hipMalloc candidates only, e.g. for buffers
  * that must be shareable through hipIpcGetMemHandle); "placement_probe" (default 1: candidates are ranked with a sweep in
  * the constitutive kernels' own pattern — three input streams read, three output streams written, 13 : 43 KiB per
