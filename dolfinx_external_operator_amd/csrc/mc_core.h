@@ -139,12 +139,24 @@ struct Surf {
     T23 F[2];              // F for angle phi (f) and psi (g)
 };
 
-// theta(J2, J3) as a Taylor object, :290-295. Also hands back the clipped argument `arg` itself:
-// sin(3 theta) = sin(asin(arg)) = arg, which F_taylor uses in the rounded branch instead of composing
-// asin and sin — their derivatives grow like (1 - arg^2)^(-1/2, -3/2, -5/2) towards the compression /
-// extension meridians and cancel against cos(3 theta) -> 0; composed numerically that cancellation costs
-// up to 1e-2 of the tangent at 1 - |arg| ~ 1e-5, while arg is a smooth rational function of (J2, J3).
-DXO_HD T23 theta_taylor(double J2, double J3, T23& arg_out) {
+// The Lode argument arg(J2, J3) = -(3 sqrt3 / 2) J3 J2^(-3/2) as a Taylor object (:290-295, jnp.clip included), and
+// theta = asin(arg) / 3 as a plain number. K(theta) is then composed with arg DIRECTLY in both branches:
+//   rounded  (|theta| > theta_T):  K = A + B arg + C arg^2          (sin 3 theta = sin(asin(arg)) = arg)
+//   plain    (|theta| <= theta_T): K = cos theta - k_lin sin theta,  theta = asin(arg) / 3
+// so every point needs ONE third-order composition (Faa di Bruno) for K instead of one for theta plus two for
+// cos / sin, and the two branches differ only in four scalars (K and its first three derivatives with respect to arg).
+// In the rounded branch the derivatives of asin — which grow like (1 - arg^2)^(-1/2, -3/2, -5/2) towards the compression /
+// extension meridians and cancel against cos(3 theta) -> 0 — never appear (composing asin and sin numerically there cost
+// up to 1e-2 of the tangent at 1 - |arg| ~ 1e-5); in the plain branch |arg| <= sin(3 theta_T) < 1 keeps them tame.
+struct LodeArg {
+    T23 a;                  // arg and its partials in (J2, J3)
+    double theta;           // asin(arg) / 3
+    double sn, cs;          // sin theta, cos theta (plain branch only)
+    double t1, t2, t3;      // d theta / d arg, second, third derivative (plain branch only)
+    bool rounded;
+};
+
+DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
     const double r = sqrt(J2);
     const double iJ2 = 1.0 / J2;
     const double h0 = 1.0 / (J2 * r);   // J2^-1.5 (kept as one division: the value path must match f_value)
@@ -152,7 +164,7 @@ DXO_HD T23 theta_taylor(double J2, double J3, T23& arg_out) {
     const double h2 = -2.5 * h1 * iJ2;
     const double h3 = -3.5 * h2 * iJ2;
     const double kk = -(3.0 * sqrt(3.0)) / 2.0;
-    T23 a;
+    T23& a = o.a;
     a.c[0] = kk * J3 * h0;
     a.c[1] = kk * J3 * h1;
     a.c[2] = kk * h0;
@@ -168,30 +180,42 @@ DXO_HD T23 theta_taylor(double J2, double J3, T23& arg_out) {
         for (int i = 1; i < 10; ++i) a.c[i] = 0.0;
         a.c[0] = v;
     }
-    arg_out = a;
     const double u = a.c[0];
-    const double w = 1.0 / sqrt(1.0 - u * u);
-    const double w3 = w * w * w;
-    T23 th = t_compose(a, asin(u), w, u * w3, w3 + 3.0 * u * u * w3 * w * w);
-    return t_scale(th, 1.0 / 3.0);
+    o.theta = asin(u) * (1.0 / 3.0);
+    o.rounded = fabs(o.theta) > k.theta_T;
+    if (!o.rounded) {
+        o.sn = sin(o.theta);
+        o.cs = cos(o.theta);
+        const double w = 1.0 / sqrt(1.0 - u * u);
+        const double w3 = w * w * w;
+        o.t1 = w * (1.0 / 3.0);
+        o.t2 = u * w3 * (1.0 / 3.0);
+        o.t3 = (w3 + 3.0 * u * u * w3 * w * w) * (1.0 / 3.0);
+    } else {
+        o.sn = o.cs = o.t1 = o.t2 = o.t3 = 0.0;
+    }
 }
 
 // F(J2, J3) = sqrt(J2 K(theta)^2 + a_g^2 sin^2 a) for angle index ia, :334-345, :364-374
-DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th, const T23& arg) {
-    T23 K;
-    const double t0 = th.c[0];
-    if (fabs(t0) > k.theta_T) {
-        const int sg = t0 < 0.0 ? 0 : 1;  // sign(theta), :298-299
-        // sin(3 theta) == clip(arg) (see theta_taylor): K = A + B arg + C arg^2 is a quadratic in arg
-        const double a0 = arg.c[0];
-        K = t_compose(arg, k.A[ia][sg] + (k.B[ia][sg] + k.Cc[ia][sg] * a0) * a0, k.B[ia][sg] + 2.0 * k.Cc[ia][sg] * a0,
-                      2.0 * k.Cc[ia][sg], 0.0);
+DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const LodeArg& L) {
+    double k0, k1, k2, k3;   // K and dK/darg, d2K/darg2, d3K/darg3
+    const double u = L.a.c[0];
+    if (L.rounded) {
+        const int sg = L.theta < 0.0 ? 0 : 1;  // sign(theta), :298-299
+        k0 = k.A[ia][sg] + (k.B[ia][sg] + k.Cc[ia][sg] * u) * u;
+        k1 = k.B[ia][sg] + 2.0 * k.Cc[ia][sg] * u;
+        k2 = 2.0 * k.Cc[ia][sg];
+        k3 = 0.0;
     } else {
-        const double sn = sin(t0), cs = cos(t0);
-        const T23 Ct = t_compose(th, cs, -sn, -cs, sn);
-        const T23 St = t_compose(th, sn, cs, -sn, -cs);
-        for (int i = 0; i < 10; ++i) K.c[i] = Ct.c[i] - k.k_lin[ia] * St.c[i];
+        const double kl = k.k_lin[ia];
+        const double d1 = -L.sn - kl * L.cs;   // dK/dtheta
+        const double d2 = -L.cs + kl * L.sn;   // d2K/dtheta2;  d3K/dtheta3 = -d1
+        k0 = L.cs - kl * L.sn;
+        k1 = d1 * L.t1;
+        k2 = d2 * L.t1 * L.t1 + d1 * L.t2;
+        k3 = -d1 * L.t1 * L.t1 * L.t1 + 3.0 * d2 * L.t1 * L.t2 + d1 * L.t3;
     }
+    const T23 K = t_compose(L.a, k0, k1, k2, k3);
     const T23 KK = t_compose(K, K.c[0] * K.c[0], 2.0 * K.c[0], 2.0, 0.0);   // K^2
     T23 w;  // x * KK + const, x = J2 (dx = 1)
     w.c[0] = J2 * KK.c[0] + k.ag2s2[ia];
@@ -207,6 +231,9 @@ DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const T23& th, const T23&
     return t_sqrt(w);
 }
 
+// SAME (phi == psi, the reference's demo): f and g share every derivative, F[0] and f are never formed or read — as a
+// compile-time fact, so the ten doubles of F[0] cost no registers in the Newton kernel.
+template <bool SAME>
 DXO_HD void surf_eval(const Const& k, const double* sig, Surf& o) {
     devv(sig, o.s);
     o.I1 = sig[0] + sig[1] + sig[2];
@@ -215,15 +242,14 @@ DXO_HD void surf_eval(const Const& k, const double* sig, Surf& o) {
     const double J3 = s[2] * (s[0] * s[1] - s[3] * s[3] / 2.0);  // :282-283
     const double qs[4] = {s[1] * s[2], s[0] * s[2], s[0] * s[1] - s[3] * s[3] / 2.0, -s[2] * s[3]};
     devv(qs, o.q);
-    T23 arg;
-    const T23 th = theta_taylor(J2, J3, arg);
-    o.F[1] = F_taylor(k, 1, J2, th, arg);
+    LodeArg lode;
+    lode_arg(k, J2, J3, lode);
+    o.F[1] = F_taylor(k, 1, J2, lode);
     o.g = o.I1 / 3.0 * k.sin_a[1] + o.F[1].c[0] - k.c * k.cos_a[1];
-    if (k.same_angle) {
-        o.F[0] = o.F[1];
+    if constexpr (SAME) {
         o.f = o.g;
     } else {
-        o.F[0] = F_taylor(k, 0, J2, th, arg);
+        o.F[0] = F_taylor(k, 0, J2, lode);
         o.f = o.I1 / 3.0 * k.sin_a[0] + o.F[0].c[0] - k.c * k.cos_a[0];
     }
 }
@@ -435,10 +461,10 @@ DXO_HD void lane_init(LaneT<Store>& L, const double* deps, const double* sn) {
 // One pass = evaluate the surface at the current iterate, form r and its norm, test cond_fun (:503-505);
 // if the loop continues, do body_fun (:507-522): Newton step + tangent recursion. Returns true when the
 // point is finished (converged, NaN, or niter == nitermax); L then holds the reference's outputs.
-template <class Store>
+template <bool SAME, class Store>
 DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     Surf e;
-    surf_eval(k, L.sig, e);
+    surf_eval<SAME>(k, L.sig, e);
     double gradg[4], r_sig[4], r_f;
     grad_surface(k, e, 1, gradg);
     {
@@ -460,7 +486,7 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     Ldl F;
     ldl_factor(M, F);
     double gradf[4];
-    if (k.same_angle) { for (int i = 0; i < 4; ++i) gradf[i] = gradg[i]; }
+    if constexpr (SAME) { for (int i = 0; i < 4; ++i) gradf[i] = gradg[i]; }
     else grad_surface(k, e, 0, gradf);
     // Newton step t = J^-1 r
     double rho[4], xh[4], bh[4];
@@ -475,7 +501,7 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     // of the old one only, so the update is done in place)
     double Ht[4], Hft[4];
     hess_apply(e, 1, t_s, Ht);
-    if (k.same_angle) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
+    if constexpr (SAME) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
     else hess_apply(e, 0, t_s, Hft);
     Third T;
     third_setup(e, 1, t_s, T);
@@ -512,7 +538,8 @@ DXO_HD void return_map(const Const& k, const double* deps, const double* sn, Res
     }
     Lane L;
     lane_init(L, deps, sn);
-    while (!lane_pass(k, L)) {}
+    if (k.same_angle) { while (!lane_pass<true>(k, L)) {} }
+    else { while (!lane_pass<false>(k, L)) {} }
     for (int i = 0; i < 4; ++i) R.sigma[i] = L.sig[i];
     for (int j = 0; j < 4; ++j) {
         double col[5];

@@ -245,7 +245,7 @@ struct LaneLds {
 };
 constexpr int MC_LANE_SLOTS = 28;
 
-template <int MINW>
+template <int MINW, bool SAME>
 __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const double* __restrict__ deps,
                                                        const double* __restrict__ sigma_n, double* __restrict__ C_tang,
                                                        double* __restrict__ sigma, int32_t* __restrict__ niter,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
         if (!__ballot(active)) break;
         // ---- one Newton pass on every lane that holds a point
         if (active) {
-            if (mc::lane_pass(k, L)) {
+            if (mc::lane_pass<SAME>(k, L)) {
                 dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + idx * 16);
                 double Yc[4][5];
 #pragma unroll
@@ -355,14 +355,14 @@ int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, co
         int64_t newton_blocks = (int64_t)ctx->compute_units * ctx->mc_blocks_per_cu;
         const int64_t enough = (m + DXO_BLOCK - 1) / DXO_BLOCK;
         if (newton_blocks > enough) newton_blocks = enough;
-        if (ctx->mc_waves_per_simd >= 2)
-            hipLaunchKernelGGL(mc_newton<2>, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
-                               C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
-                               norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
-        else
-            hipLaunchKernelGGL(mc_newton<1>, dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4,
-                               C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr,
-                               norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr, hdr, list);
+#define DXO_MC_NEWTON(W_, S_)                                                                                                  \
+    hipLaunchKernelGGL((mc_newton<W_, S_>), dim3((int)newton_blocks), dim3(DXO_BLOCK), 0, s, L.k, deps + off * 4, sigma_n + off * 4, \
+                       C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr, norm_res ? norm_res + off : nullptr,  \
+                       dlambda ? dlambda + off : nullptr, hdr, list)
+        const bool same = L.k.same_angle != 0;
+        if (ctx->mc_waves_per_simd >= 2) { if (same) DXO_MC_NEWTON(2, true); else DXO_MC_NEWTON(2, false); }
+        else { if (same) DXO_MC_NEWTON(1, true); else DXO_MC_NEWTON(1, false); }
+#undef DXO_MC_NEWTON
     }
     return DXO_OK;
 }
