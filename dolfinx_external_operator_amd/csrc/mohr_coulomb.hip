@@ -25,7 +25,7 @@ constexpr int MC_PENDING = 512;  // per-wave buffer of plastic point indices (mc
 #ifndef DXO_MC_LDS_STATE
 #define DXO_MC_LDS_STATE 1    // mc_newton: inputs and tangent iterate of a lane's point parked in LDS between their uses
 #endif
-constexpr int MC_BATCH = 256;    // list entries a wave reserves per cursor atomic (mc_newton)
+constexpr int MC_BATCH = 256;    // list entries a wave reserves per cursor atomic (mc_newton); 128 and 64 were not faster
 constexpr int MC_ROW = 18;  // LDS doubles per point: 16 C_tang + 2 pad (144 B stride: conflict-free b128 writes)
 
 template <bool NT>
