@@ -120,7 +120,8 @@ def _dev_f64(t, what: str, numel: int | None = None):
 
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
-                   reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host") -> Callable:
+                   reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host",
+                   devices=None) -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -146,6 +147,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
       external_function.commit_state()   after the reference's load-step update `p += dp; sigma_n[:] = sigma`
                                          (:564-565) on the host arrays: the same update on the device, no transfer;
       external_function.state_changed()  after ANY other change of the holders: re-upload at the next call.
+    devices (NumPy operands only): a list of GPU indices, e.g. [0, 1, 2, 3] — the arrays are cut into one contiguous cell
+    block per GPU and every GPU streams its block over its own PCIe link concurrently (dxo_mgpu_von_mises_host; no
+    collective, RCCL is not loaded). The NumPy path is PCIe-bound, so this is how one process scales it. Not combined
+    with state="resident" or lazy operands.
     As a tripwire (not a guarantee) every call compares 2 048 strided samples of the holders with what they were when the
     mirror was last known to match; a difference re-uploads and warns. external_function.check_state() downloads the
     mirror and returns max |mirror - holders| (tests, debugging).
@@ -158,7 +163,9 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         raise ValueError('host_tangent must be "copy" or "rebuild"')
     if state not in ("host", "resident"):
         raise ValueError('state must be "host" or "resident"')
-    holder = {"ctx": ctx, "out": None}
+    if devices is not None and (state != "host" or len(devices) < 1):
+        raise ValueError('devices=[...] needs at least one GPU index and state="host"')
+    holder = {"ctx": ctx, "out": None, "mgpu": None}
     mirror = _StateMirror(sigma_n, p) if state == "resident" else None
 
     def _ctx() -> Context:
@@ -206,6 +213,15 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         C_tang_ = out.get("C_tang", n * d * d)
         sigma_ = out.get("sigma", n * d)
         dp_ = out.get("dp", n)
+        if devices is not None:   # one cell block per GPU, each over its own PCIe link, no collective
+            if holder["mgpu"] is None:
+                from ._lib import MultiGpu
+
+                holder["mgpu"] = MultiGpu.local(list(devices))
+            g = holder["mgpu"]
+            g.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
+            g.von_mises_host(prm, d, n, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
+            return _like(deps, C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1))
         with c._lock:   # the option is per context: set, call, restore without another thread's call in between
             c.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
             try:

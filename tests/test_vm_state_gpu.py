@@ -210,3 +210,22 @@ def test_host_arrays_sharded_over_local_pipelines(ctx, n_dev, n, rebuild):
             g.all_gather([0] * n_dev, 16)
     finally:
         g.close()
+
+
+def test_factory_over_several_local_pipelines(ctx, oracle):
+    """make_von_mises(devices=[...]): the NumPy arrays of one call cut into one cell block per listed GPU (here device 0
+    three times), results in the reference's tuple order, equal to the single-GPU factory."""
+    n, nq, d = 200_000, 8, 6
+    deps, sigma_n, p = vm_inputs(n, d, seed=14)
+    one = make_von_mises(sigma_n, p, ctx=ctx, host_tangent="copy")
+    many = make_von_mises(sigma_n, p, ctx=ctx, host_tangent="copy", devices=[0, 0, 0])
+    a = one((1,))(deps.reshape(n // nq, nq, d))
+    b = many((1,))(deps.reshape(n // nq, nq, d))
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(b[0], Co.reshape(-1), 1e-13, "C_tang over three pipelines")
+    with pytest.raises(NotImplementedError):
+        many((0,))
+    with pytest.raises(ValueError, match="devices"):
+        make_von_mises(sigma_n, p, ctx=ctx, state="resident", devices=[0])
