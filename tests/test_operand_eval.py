@@ -299,6 +299,8 @@ def test_load_stepping_example_runs():
     fr = [s["plastic_fraction"] for s in rep["steps"]]
     assert fr[0] < fr[2] and fr[3] == 0.0                     # yielding spreads under loading, unloading is elastic
     assert rep["steps"][2]["max_p"] > 0
+    res = mod.main(24, "resident")                            # history variables in the device mirror: the same trajectory, bit for bit
+    assert np.array_equal(res["final_p"], rep["final_p"]) and np.array_equal(res["final_sigma_n"], rep["final_sigma_n"])
 
 
 @pytest.mark.gpu
