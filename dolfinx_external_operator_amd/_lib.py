@@ -89,6 +89,8 @@ _SIGNATURES = {
     "dxo_last_timing": (C.c_int, [_P, C.POINTER(Timing)]),
     "dxo_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_host_free": (C.c_int, [_P, _P]),
+    "dxo_host_register": (C.c_int, [_P, _P, C.c_int64]),
+    "dxo_host_unregister": (C.c_int, [_P, _P]),
     "dxo_output_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "dxo_output_free": (C.c_int, [_P, _P]),
     "dxo_output_info": (C.c_int, [_P, _P, C.POINTER(PlacementInfo)]),
@@ -384,6 +386,18 @@ class Context:
         rc = self.lib.dxo_von_mises(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(deps), _ptr(sigma_n),
                                     _ptr(p), _ptr(C_tang), _ptr(sigma), _ptr(dp))
         self.check(rc, "dxo_von_mises")
+
+    def pin(self, array: np.ndarray) -> np.ndarray:
+        """Page-lock an array the caller owns (dxo_host_register) — typically the `x.array` of the coefficient a factory's
+        `outputs=` writes into, once, at set-up. The array must stay alive until `unpin(array)` or the end of the process."""
+        a = np.asarray(array)
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("pin: the array must be C-contiguous")
+        self.check(self.lib.dxo_host_register(self._h, _P(a.ctypes.data), int(a.nbytes)), "dxo_host_register")
+        return a
+
+    def unpin(self, array: np.ndarray) -> None:
+        self.check(self.lib.dxo_host_unregister(self._h, _P(np.asarray(array).ctypes.data)), "dxo_host_unregister")
 
     def vm_state(self, d: int, n: int) -> "VmState":
         """Device mirror of the von Mises history variables for n points (dxo_vm_state_*, include/dxo.h)."""

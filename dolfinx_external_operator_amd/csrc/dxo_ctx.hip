@@ -206,6 +206,24 @@ int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     return DXO_OK;
 }
 
+// Page-lock memory the CALLER owns (e.g. the storage of a DOLFINx coefficient the results are written into at every call):
+// DMA then goes straight to it instead of through the driver's staging buffers.
+int dxo_host_register(dxo_ctx* c, void* ptr, int64_t bytes) {
+    DXO_LOCK(c);
+    if (!ptr) return DXO_E_NULL;
+    if (bytes <= 0) return dxo_fail(c, DXO_E_SIZE, "dxo_host_register: size must be positive");
+    if (c) DXO_HIP(c, hipSetDevice(c->device));
+    DXO_HIP(c, hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return DXO_OK;
+}
+
+int dxo_host_unregister(dxo_ctx* c, void* ptr) {
+    DXO_LOCK(c);
+    if (!ptr) return DXO_OK;
+    DXO_HIP(c, hipHostUnregister(ptr));
+    return DXO_OK;
+}
+
 int dxo_host_free(dxo_ctx* c, void* ptr) {
     DXO_LOCK(c);
     if (!ptr) return DXO_OK;

@@ -75,15 +75,28 @@ class _Outputs:
     same page-locked, already-touched memory back at the next call: 7.5 ms vs 38 ms per call at 10^6 points (d = 6)
     against first-touched pageable arrays.
     reuse=True (opt-in): ONE set of buffers owned by the operator, overwritten by its next call and released by
-    Context.close() — only for callers that copy the results out before calling again."""
+    Context.close() — only for callers that copy the results out before calling again.
+    targets (factory argument `outputs=`): holders (fem.Function | ndarray | callable) of arrays the CALLER owns, by output
+    name. The kernel's results are written straight into them and the very same memory is returned — so the reference's
+    `coefficient.x.array[:] = values` (external_operator.py:289-290, :441) and the demos' copies of the extras
+    (demo_plasticity_von_mises.py:451-456) find source == destination, which NumPy skips: at 10^7 points (d = 6) that
+    assignment is a 2.9 GB single-threaded memcpy otherwise — tens of times the GPU call it follows."""
 
-    def __init__(self, ctx: Context, reuse: bool):
+    def __init__(self, ctx: Context, reuse: bool, targets: dict | None = None):
         self.ctx = ctx
         self.reuse = reuse
+        self.targets = {k: v for k, v in (targets or {}).items() if v is not None}
         self._cache: dict[tuple[str, int], np.ndarray] = {}
         self._retired: list[np.ndarray] = []   # reuse=True buffers of an earlier batch size: never freed under a live view
 
     def get(self, key: str, size: int, dtype=np.float64) -> np.ndarray:
+        if key in self.targets:
+            a = _state_array(self.targets[key])
+            if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]:
+                raise TypeError(f"outputs[{key!r}]: expected a writable C-contiguous {np.dtype(dtype)} ndarray (or a holder of one)")
+            if a.size != size:
+                raise ValueError(f"outputs[{key!r}] has {a.size} entries, the call produces {size}")
+            return a.reshape(-1)
         if not self.reuse:
             return self.ctx.pinned_recycled(size, dtype)
         buf = self._cache.get((key, size))
@@ -121,7 +134,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
                    reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host",
-                   devices=None) -> Callable:
+                   devices=None, outputs=None) -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -147,6 +160,10 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
       external_function.commit_state()   after the reference's load-step update `p += dp; sigma_n[:] = sigma`
                                          (:564-565) on the host arrays: the same update on the device, no transfer;
       external_function.state_changed()  after ANY other change of the holders: re-upload at the next call.
+    outputs (NumPy operands only): `(C_tang_holder, sigma_holder, dp_holder)`, entries may be None — arrays the caller
+    owns (typically `operator.ref_coefficient` and the Functions the demo copies the extras into, :451-456). Results are
+    written straight into them and those very arrays are returned, so the reference's `x.array[:] = values` (:441) finds
+    source == destination and NumPy skips the 36 N-double copy. `Context.pin(array)` page-locks such an array once.
     devices (NumPy operands only): a list of GPU indices, e.g. [0, 1, 2, 3] — the arrays are cut into one contiguous cell
     block per GPU and every GPU streams its block over its own PCIe link concurrently (dxo_mgpu_von_mises_host; no
     collective, RCCL is not loaded). The NumPy path is PCIe-bound, so this is how one process scales it. Not combined
@@ -163,6 +180,8 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         raise ValueError('host_tangent must be "copy" or "rebuild"')
     if state not in ("host", "resident"):
         raise ValueError('state must be "host" or "resident"')
+    if outputs is not None and len(outputs) != 3:
+        raise ValueError("outputs must be (C_tang, sigma, dp) holders (entries may be None)")
     if devices is not None and (state != "host" or len(devices) < 1):
         raise ValueError('devices=[...] needs at least one GPU index and state="host"')
     holder = {"ctx": ctx, "out": None, "mgpu": None}
@@ -172,7 +191,8 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["out"] is None:
-            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+            tg = dict(zip(("C_tang", "sigma", "dp"), outputs)) if outputs is not None else None
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, tg)
         return holder["ctx"]
 
     def C_tang_impl(deps, out=None):
@@ -456,7 +476,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
                       phi: float = 30 * np.pi / 180, psi: float = 30 * np.pi / 180, theta_T: float = 26 * np.pi / 180,
                       a: float | None = None, tol: float = 1e-8, Nitermax: int = 200, diagnostics: bool = True,
                       on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0,
-                      reuse_outputs: bool = False) -> Callable:
+                      reuse_outputs: bool = False, outputs=None) -> Callable:
     """`sigma_external` of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:604-608) on the GPU.
 
     `external_function((1,))(deps) -> (C_tang, sigma)`, flat arrays, the reference's order (:593); any other
@@ -480,7 +500,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             holder["ctx"] = default_context(device)
         cx = holder["ctx"]
         if holder["out"] is None:
-            holder["out"] = _Outputs(cx, reuse_outputs)
+            holder["out"] = _Outputs(cx, reuse_outputs, dict(zip(("C_tang", "sigma"), outputs)) if outputs is not None else None)
         if _is_device_tensor(deps):
             return _mohr_coulomb_device(cx, prm, deps, _state_array(sigma_n), diagnostics, on_summary, sigma_external)
         deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
@@ -557,7 +577,7 @@ def _P_device(cx: Context, Fvals, launch):
 
 
 def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None, device: int = 0,
-              reuse_outputs: bool = False) -> Callable:
+              reuse_outputs: bool = False, outputs=None) -> Callable:
     """`P_external` of the hyperelasticity demo (demo_hyperelasticity.py:459-466) on the GPU.
 
     `external_function((1,))(Fvals) -> (dP, P)`, flat arrays in the reference's order (:456); other
@@ -575,7 +595,7 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
             holder["ctx"] = default_context(device)
         if holder["model"] is None:
             holder["model"] = holder["ctx"].icnn_create(state_dict)
-            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), outputs)) if outputs is not None else None)
         return holder["ctx"], holder["model"]
 
     def dP_dF_impl(Fvals):
@@ -598,7 +618,7 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
 
 
 def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float = 1.5, ctx: Context | None = None,
-                 device: int = 0, reuse_outputs: bool = False) -> Callable:
+                 device: int = 0, reuse_outputs: bool = False, outputs=None) -> Callable:
     """The analytic Isihara model behind the same `P_external` contract as `make_icnn`.
 
     The reference states it in UFL only (demo_hyperelasticity.py:686-703, `P = ufl.diff(W_Isihara, F_)`) and
@@ -612,7 +632,7 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["out"] is None:
-            holder["out"] = _Outputs(holder["ctx"], reuse_outputs)
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), outputs)) if outputs is not None else None)
         if _is_device_tensor(Fvals):
             cx = holder["ctx"]
             return _P_device(cx, Fvals, lambda n, F, dP, P: cx.isihara(prm, n, MEM_DEVICE, F, dP, P))

@@ -122,6 +122,10 @@ int dxo_last_timing(dxo_ctx* ctx, dxo_timing* t);
 /* Pinned host buffers (hipHostMalloc) so DXO_MEM_HOST calls DMA without staging. ctx may be NULL for both
  * (the memory belongs to the process; a buffer may outlive the context it was first used with). */
 int dxo_host_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
+/* Page-lock / release memory the caller owns (hipHostRegister): e.g. the storage of the coefficient the results are
+ * written into at every call (x.array of a fem.Function lives as long as the simulation). ctx may be NULL. */
+int dxo_host_register(dxo_ctx* ctx, void* ptr, int64_t bytes);
+int dxo_host_unregister(dxo_ctx* ctx, void* ptr);
 int dxo_host_free(dxo_ctx* ctx, void* ptr);
 
 /* ---- output arena: device memory for OUTPUT arrays, placed by calibration -------------------------------------

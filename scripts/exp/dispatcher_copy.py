@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""What the reference's dispatcher adds after the kernel: `coefficient.x.array[:] = values` (external_operator.py:289-290)
+is a 36 N-double host copy per call. evaluate_external_operators (value-side mirror) at 10^7 points, d = 6, with
+  default   results in the factory's own page-locked arrays, the dispatcher copies C_tang into the coefficient
+  outputs=  results written straight into the coefficient's storage (pageable, then page-locked with Context.pin):
+            the dispatcher's assignment is array-to-itself, which NumPy skips."""
+import json
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+import numpy as np  # noqa: E402
+
+from dolfinx_external_operator_amd import (Context, QuadratureExternalOperator, evaluate_external_operators, evaluate_operands,  # noqa: E402
+                                           make_von_mises)
+from dolfinx_external_operator_amd.evaluation import Operand  # noqa: E402
+
+nq, d = 8, 6
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+nc = n // nq
+ctx = Context(0)
+rng = np.random.Generator(np.random.PCG64(7))
+blk = 1_000_000
+deps = np.tile(rng.normal(0.0, 3e-3, size=blk * d), n // blk).reshape(nc, nq, d)
+sigma_n = np.tile(rng.normal(0.0, 100.0, size=blk * d), n // blk)
+p = np.tile(np.abs(rng.normal(0.0, 1e-3, size=blk)), n // blk)
+operand = Operand(lambda cells: deps, "deps")
+
+
+def timed(op, label, calls=3):
+    ts = []
+    for _ in range(calls + 1):
+        ev = evaluate_operands([op])
+        t0 = time.perf_counter()
+        evaluate_external_operators([op], ev)
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    print(json.dumps({"case": label, "ms_per_call": round(t * 1e3, 2), "qp_per_s_e8": round(n / t / 1e8, 2)}), flush=True)
+
+
+for state in ("host", "resident"):
+    op = QuadratureExternalOperator(operand, num_cells=nc, num_points=nq, value_shape=(d, d), derivatives=(1,))
+    op.external_function = make_von_mises(sigma_n, p, ctx=ctx, state=state)
+    timed(op, f"default outputs, state={state}: dispatcher copies 2.9 GB into the coefficient")
+    op2 = QuadratureExternalOperator(operand, num_cells=nc, num_points=nq, value_shape=(d, d), derivatives=(1,))
+    op2.external_function = make_von_mises(sigma_n, p, ctx=ctx, state=state, outputs=(op2.ref_coefficient, None, None))
+    timed(op2, f"outputs=(coefficient, ...), pageable storage, state={state}")
+    ctx.pin(op2.ref_coefficient.x.array)
+    timed(op2, f"outputs=(coefficient, ...), storage page-locked with Context.pin, state={state}")
+    ctx.unpin(op2.ref_coefficient.x.array)

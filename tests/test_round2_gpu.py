@@ -476,3 +476,40 @@ def test_output_alloc_probed_runs_the_callers_kernel(ctx):
 
     with pytest.raises(RuntimeError, match="boom"):                       # an exception in the callback surfaces after the call
         ctx.output_tensors_probed((n * 8,), bad)
+
+
+def test_outputs_land_in_the_callers_coefficient_storage(ctx, oracle):
+    """`outputs=`: the kernel's results go straight into arrays the caller owns (the operator's coefficient, the Functions
+    the demo copies the extras into) and those very arrays come back — the reference's `x.array[:] = values`
+    (external_operator.py:289-290) then assigns an array to itself, which NumPy skips. Checked through the dispatcher
+    mirror, with pageable and with page-locked (Context.pin) targets, rebuild and copy mode."""
+    from dolfinx_external_operator_amd import QuadratureExternalOperator, evaluate_external_operators, evaluate_operands
+    from dolfinx_external_operator_amd.evaluation import Operand
+
+    nc, nq, d = 40_000, 8, 6
+    n = nc * nq                                                       # 320 000 points: above the rebuild threshold
+    deps, sigma_n, p = vm_inputs(n, d, seed=91)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    for mode in ("rebuild", "copy"):
+        for pinned in (False, True):
+            sig_store, dp_store = np.full(n * d, np.nan), np.full(n, np.nan)
+            op = QuadratureExternalOperator(Operand(lambda cells: deps.reshape(nc, nq, d)[cells], "deps"), num_cells=nc, num_points=nq,
+                                            value_shape=(d, d), derivatives=(1,))
+            coeff = op.ref_coefficient.x.array
+            if pinned:
+                ctx.pin(coeff)
+            try:
+                op.external_function = make_von_mises(sigma_n, p, ctx=ctx, host_tangent=mode, outputs=(op.ref_coefficient, sig_store, dp_store))
+                ((C, s, dp),) = evaluate_external_operators([op], evaluate_operands([op]))
+                assert np.shares_memory(C, coeff) and C.ctypes.data == coeff.ctypes.data      # the assignment was array-to-itself
+                assert s.ctypes.data == sig_store.ctypes.data and dp.ctypes.data == dp_store.ctypes.data
+                assert_close_scaled(coeff, Co.reshape(-1), 1e-13, f"coefficient storage ({mode}, pinned={pinned})")
+                assert_close_scaled(sig_store, so.reshape(-1), 1e-13, "sigma store")
+                assert_close_scaled(dp_store, dpo.reshape(-1), 1e-13, "dp store")
+            finally:
+                if pinned:
+                    ctx.unpin(coeff)
+    with pytest.raises(ValueError, match="entries"):                   # a target of the wrong size is refused, nothing is written
+        make_von_mises(sigma_n, p, ctx=ctx, outputs=(np.zeros(10), None, None))((1,))(deps.reshape(nc, nq, d))
+    with pytest.raises(TypeError, match="float64"):
+        make_von_mises(sigma_n, p, ctx=ctx, outputs=(np.zeros(n * d * d, dtype=np.float32), None, None))((1,))(deps.reshape(nc, nq, d))
