@@ -513,3 +513,24 @@ def test_outputs_land_in_the_callers_coefficient_storage(ctx, oracle):
         make_von_mises(sigma_n, p, ctx=ctx, outputs=(np.zeros(10), None, None))((1,))(deps.reshape(nc, nq, d))
     with pytest.raises(TypeError, match="float64"):
         make_von_mises(sigma_n, p, ctx=ctx, outputs=(np.zeros(n * d * d, dtype=np.float32), None, None))((1,))(deps.reshape(nc, nq, d))
+
+
+def test_outputs_targets_of_the_other_factories(ctx, oracle, golden):
+    """`outputs=` on make_mohr_coulomb, make_icnn, make_isihara: results land in the caller's arrays, same bits as the
+    default call."""
+    n = 3000
+    deps, sigma_n = mc_tracing_inputs(oracle, n, seed=23)
+    C0, s0 = make_mohr_coulomb(sigma_n, ctx=ctx, diagnostics=False)((1,))(deps)
+    C_t, s_t = np.full(n * 16, np.nan), np.full(n * 4, np.nan)
+    C1, s1 = make_mohr_coulomb(sigma_n, ctx=ctx, diagnostics=False, outputs=(C_t, s_t))((1,))(deps)
+    assert C1.ctypes.data == C_t.ctypes.data and s1.ctypes.data == s_t.ctypes.data
+    assert np.array_equal(C_t, C0) and np.array_equal(s_t, s0)
+    g, w = golden("icnn_isihara.npz"), golden("icnn_isihara_weights.npz")
+    F = np.asarray(g["F"], dtype=np.float64).reshape(-1, 2, 2)
+    m = F.shape[0]
+    for make in (lambda **kw: make_icnn({k: w[k] for k in w.files}, ctx=ctx, **kw), lambda **kw: make_isihara(ctx=ctx, **kw)):
+        dP0, P0 = make()((1,))(F)
+        dP_t, P_t = np.full(m * 16, np.nan), np.full(m * 4, np.nan)
+        dP1, P1 = make(outputs=(dP_t, None))((1,))(F)                  # only the tangent has a target; P is a fresh array
+        assert dP1.ctypes.data == dP_t.ctypes.data and P1.ctypes.data != P_t.ctypes.data
+        assert np.array_equal(dP_t, dP0) and np.array_equal(P1, P0) and np.isnan(P_t).all()
