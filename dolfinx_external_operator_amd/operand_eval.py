@@ -171,10 +171,16 @@ class DeviceMesh:
                                            C.c_void_p(out_ptr))
         self.ctx.check(rc, "dxo_eval_operand")
 
-    def operand(self, kind: str, field, bs: int | None = None, name: str | None = None, lazy: bool = False) -> "DeviceOperand":
+    def operand(self, kind: str, field, bs: int | None = None, name: str | None = None, lazy: bool = False,
+                snapshot: bool = True) -> "DeviceOperand":
         """lazy=True: `.eval()` over all cells returns a `LazyOperand` — an array-like that a fused consumer
-        (`make_von_mises`) evaluates inside its own launch and that turns into the ndarray on `np.asarray`."""
-        return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind, lazy)
+        (`make_von_mises`) evaluates inside its own launch and that turns into the ndarray on `np.asarray`.
+        snapshot (lazy only): True copies the field vector when the operand is "evaluated", so the value is the one at
+        `evaluate_operands` time exactly as with `Expression.eval` (one host copy of the dof vector per call: 25-40 ms
+        at 10^7 Q2 nodes). False keeps a reference to the live array instead — for the reference's own calling
+        sequence, where `evaluate_external_operators` follows `evaluate_operands` at once (demo_plasticity_von_mises.py:
+        445-456) and the field does not change in between."""
+        return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind, lazy, snapshot)
 
     def von_mises(self, prm, u, sigma_n, p, C_tang, sigma, dp, mem: int = MEM_HOST) -> None:
         """dxo_von_mises_field: eps(u) + radial return + tangent in one launch (all cells of the mesh)."""
@@ -233,15 +239,18 @@ class DeviceOperand:
     `Expression.eval` returns, (len(entities), nq, *shape); for "F" the trailing shape is (gdim, gdim) like the
     tensor operand of the hyperelasticity demo, for "grad" of a vector field (bs, gdim)."""
 
-    def __init__(self, mesh: DeviceMesh, kind: str, field, bs: int, name: str, lazy: bool = False):
-        self.mesh, self.kind, self.field, self.bs, self.name, self.lazy = mesh, kind, field, bs, name, lazy
+    def __init__(self, mesh: DeviceMesh, kind: str, field, bs: int, name: str, lazy: bool = False, snapshot: bool = True):
+        self.mesh, self.kind, self.field, self.bs, self.name, self.lazy, self.snapshot = mesh, kind, field, bs, name, lazy, snapshot
         self.eval_count = 0
 
     def eval(self, entities):
         self.eval_count += 1
         if self.lazy and (entities is None or (len(entities) == self.mesh.num_cells
                                                and np.array_equal(entities, np.arange(self.mesh.num_cells)))):
-            u = np.array(_state(self.field), dtype=np.float64).reshape(-1)      # snapshot, like Expression.eval's result
+            if self.snapshot:
+                u = np.array(_state(self.field), dtype=np.float64).reshape(-1)  # snapshot, like Expression.eval's result
+            else:
+                u = np.ascontiguousarray(_state(self.field), dtype=np.float64).reshape(-1)   # the live array (no copy if fp64)
             return LazyOperand(self.mesh, self.kind, self.bs, u)
         if entities is not None and np.ndim(entities) == 2:
             out = self.mesh.evaluate_facets(self.kind, self.bs, self.field, entities)    # (cell, local facet) pairs

@@ -421,3 +421,22 @@ def test_hip_on_cell_facet_pairs(ctx, cell, degree):
         assert dm.evaluate_facets("value", 1, field, np.empty((0, 2), dtype=np.int32)).shape == (0, tabs[0].shape[1], 1)
     finally:
         dm.close()
+
+
+@pytest.mark.gpu
+def test_lazy_operand_snapshot_or_live_field(ctx):
+    """`operand(..., lazy=True)` snapshots the field vector at evaluate_operands time (what Expression.eval's result is);
+    `snapshot=False` keeps the live array for the reference's back-to-back calling sequence — no copy of the dof vector."""
+    from dolfinx_external_operator_amd import DeviceMesh
+
+    m = structured_mesh("triangle", (6, 5), 2)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    u = np.linspace(0.0, 1.0, m.node_x.shape[0] * 2)
+    snap = dm.operand("eps", u, lazy=True).eval(None)
+    live = dm.operand("eps", u, lazy=True, snapshot=False).eval(None)
+    assert not np.shares_memory(snap.u, u) and np.shares_memory(live.u, u)
+    before = np.asarray(dm.operand("eps", u).eval(None))
+    u *= 2.0                                                    # the field changes after "evaluation"
+    assert np.array_equal(np.asarray(snap), before)             # the snapshot still is the old value
+    assert np.max(np.abs(np.asarray(live) - 2.0 * before)) <= 1e-14 * np.max(np.abs(before))   # the live operand follows the field
+    dm.close()
