@@ -174,10 +174,39 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
         if not (np.array_equal(sigma[: 4096 * d], ref_s) and np.array_equal(dp[:4096], ref_dp) and np.array_equal(C_tang[: 4096 * d * d], ref_C)):
             raise SystemExit("bench: the resident-state call differs from the plain host call")
         ctx.set_option("vm_host_tangent", 0)
+        if n == sizes[-1]:
+            entry["through_dispatcher"] = through_dispatcher(ctx, n, d, deps, sigma_n, p)
         for b in bufs:
             ctx.pinned_free(b)
         out["sizes"].append(entry)
     return out
+
+
+def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=2):
+    """One level above the C ABI: the factory called the way the reference calls it, through the value-side mirror of
+    evaluate_external_operators (external_operator.py:407-448), which ends with `coefficient.x.array[:] = values` (:289-290)
+    — a 36 N-double single-threaded host copy unless the factory was given the coefficient as its output (`outputs=`:
+    the assignment is then array-to-itself, which NumPy skips). ms per call, median."""
+    import numpy as np
+
+    from dolfinx_external_operator_amd import QuadratureExternalOperator, evaluate_external_operators, evaluate_operands, make_von_mises
+    from dolfinx_external_operator_amd.evaluation import Operand
+
+    nc = n // nq
+    operand = Operand(lambda cells: deps.reshape(nc, nq, d), "deps")
+    res = {"points": n, "unit": "ms per evaluate_external_operators call"}
+    for label, kw, with_out in (("default", {}, False), ("outputs_coefficient", {}, True), ("outputs_coefficient_resident_state", {"state": "resident"}, True)):
+        op = QuadratureExternalOperator(operand, num_cells=nc, num_points=nq, value_shape=(d, d), derivatives=(1,))
+        op.external_function = make_von_mises(sigma_n, p, ctx=ctx, outputs=(op.ref_coefficient, None, None) if with_out else None, **kw)
+        ts = []
+        for _ in range(calls + 1):
+            ev = evaluate_operands([op])
+            t0 = time.perf_counter()
+            evaluate_external_operators([op], ev)
+            ts.append(time.perf_counter() - t0)
+        res[label] = round(sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, 2)
+        del op
+    return res
 
 
 def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 20, steps=5):
