@@ -534,3 +534,32 @@ def test_outputs_targets_of_the_other_factories(ctx, oracle, golden):
         dP1, P1 = make(outputs=(dP_t, None))((1,))(F)                  # only the tangent has a target; P is a fresh array
         assert dP1.ctypes.data == dP_t.ctypes.data and P1.ctypes.data != P_t.ctypes.data
         assert np.array_equal(dP_t, dP0) and np.array_equal(P1, P0) and np.isnan(P_t).all()
+
+
+def test_vm_output_alloc_d4_reference_layout(ctx, oracle):
+    """The reference demo's layout (d = 4) in a kernel-calibrated block: 8*10^6 points = 1.34 GB of outputs, tuned launch
+    shape picked up by the call, oracle on a strided sample, every entry written."""
+    import torch
+
+    n, d = 8_000_000, 4
+    old = ctx.get_option("placement_candidates")
+    ctx.set_option("placement_candidates", 4)
+    try:
+        C, s, dp = ctx.vm_output_tensors(n, d)
+    finally:
+        ctx.set_option("placement_candidates", old)
+    assert C.dxo_block.info["probe"] == "vm_tile" and C.numel() == n * 16
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    deps = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 3e-3, generator=g)
+    sigma_n = torch.empty(n, d, dtype=torch.float64, device="cuda:0").normal_(0, 100.0, generator=g)
+    p = torch.empty(n, dtype=torch.float64, device="cuda:0").normal_(0, 1e-3, generator=g).abs_()
+    C.fill_(float("nan")); s.fill_(float("nan")); dp.fill_(float("nan"))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.von_mises(PRM, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C.data_ptr(), s.data_ptr(), dp.data_ptr())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(C).all()) and bool(torch.isfinite(s).all()) and bool(torch.isfinite(dp).all())
+    idx = torch.cat([torch.arange(0, n, 2003, device="cuda:0"), torch.tensor([n - 1], device="cuda:0")])
+    Co, so, dpo = oracle.von_mises(deps[idx].cpu().numpy(), sigma_n[idx].cpu().numpy(), p[idx].cpu().numpy())
+    assert_close_scaled(C.view(n, 16)[idx].cpu().numpy(), Co, 1e-13, "C_tang d=4")
+    assert_close_scaled(s.view(n, d)[idx].cpu().numpy(), so, 1e-13, "sigma d=4")
+    assert_close_scaled(dp[idx].cpu().numpy(), dpo, 1e-13, "dp d=4")
