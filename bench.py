@@ -30,6 +30,7 @@ import os
 import pathlib
 import statistics
 import sys
+import threading
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent
@@ -303,10 +304,11 @@ def main():
     ap.add_argument("--d", type=int, default=6, choices=(4, 6))
     ap.add_argument("--nq", type=int, default=8, help="points per cell (bookkeeping only)")
     ap.add_argument("--gather", type=int, default=-1, help="all-gather outputs each step: -1 auto (N>1), 0, 1")
-    ap.add_argument("--gather-mode", choices=("auto", "compact", "compact_pipelined", "full"), default="auto",
+    ap.add_argument("--gather-mode", choices=("auto", "compact", "compact_pipelined", "compact_direct", "full"), default="auto",
                     help="compact: RCCL all-gather of (sigma, dp) + local rebuild of the remote tangents "
                          "(dxo_vm_expand_tangent); compact_pipelined: the same in 4 pieces, rebuild overlapped with the "
-                         "link traffic; full: RCCL all-gather of (C_tang, sigma, dp). Every mode is timed over the same K "
+                         "link traffic; compact_direct: (sigma, dp) exchanged as one batch of RCCL sends / receives, every "
+                         "block on its own xGMI link; full: RCCL all-gather of (C_tang, sigma, dp). Every mode is timed over the same K "
                          "steps and reported under config.gather_modes; auto (default) makes the fastest of them the headline "
                          "(all three leave the same arrays on every rank) and names it in config.gather.")
     ap.add_argument("--dry-collective", action="store_true",
@@ -369,7 +371,7 @@ def main():
     from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
     from dolfinx_external_operator_amd._build import build_library
     from dolfinx_external_operator_amd.sharding import (WAVE_TILE, all_gather_in_place, gather_von_mises_compact,
-                                                        gather_von_mises_compact_pipelined)
+                                                        gather_von_mises_compact_direct, gather_von_mises_compact_pipelined)
 
     if rank == 0:
         build_library()
@@ -463,6 +465,8 @@ def main():
                 gather_von_mises_compact(C_full, sigma_full, dp_full, rank, d, expand)
             elif mode == "compact_pipelined":
                 gather_von_mises_compact_pipelined(C_full, sigma_full, dp_full, rank, d, expand, chunks=4)
+            elif mode == "compact_direct":
+                gather_von_mises_compact_direct(C_full, sigma_full, dp_full, rank, d, expand)
             else:
                 for buf in (C_full, sigma_full, dp_full):
                     all_gather_in_place(buf, rank)
@@ -489,7 +493,96 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # the other gather modes, same protocol, reported beside the headline (never as `value`)
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    total_points = n * world
+    bytes_per_launch = BYTES_PER_QP[d] * n
+    MODES = ("compact", "compact_pipelined", "compact_direct", "full")
+    emitted = threading.Lock()
+
+    def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True):
+        """Rank 0: build the result line and write it to the real stdout, once."""
+        if rank != 0 or not emitted.acquire(blocking=False):
+            return
+        # HBM traffic of this kernel is NOT measured in this run (PMC counters need rocprofv3 around the process): the
+        # stored result of the last counter pass over the same launch shape is quoted with its source, `traffic` is null.
+        traffic_from_profile = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                tj = json.loads(tfile.read_text())
+                # the counter pass records the launch's grid size in threads = points rounded up to whole workgroups
+                if 0 <= tj.get("grid_threads", -1) - n < 256 and tj.get("d") == d:
+                    traffic_from_profile = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"), "file": "profiles/traffic.json",
+                                            "measured": tj.get("measured", "earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                                           "(scripts/gpu_check.sh), not this run")}
+            except Exception:
+                traffic_from_profile = None
+        achieved = bytes_per_launch / (kernel_ms_ * 1e-3) / 1e9
+        result = {
+            "metric": "quadrature-points/sec (von Mises return-map + tangent)",
+            "value": total_points * K / elapsed_, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed_ / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            **({"dry_collective": "NOT A MEASUREMENT: all ranks on one GPU, gloo collectives (logic check of the N > 1 path)"}
+               if args.dry_collective else {}),
+            **({"note": note} if note else {}),
+            "config": {
+                "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
+                            f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
+                            + ((", cell-block sharded, RCCL exchange of (sigma, dp) + on-device rebuild of the remote "
+                                "tangents every step" if args.gather_mode.startswith("compact") else
+                                ", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step") if gather_on
+                               else (", cell-block sharded, no gather" if world > 1 else "")),
+                "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
+                "sharding": "cell-block" if world > 1 else "none",
+                "gather": f"rccl_all_gather_{args.gather_mode}" if gather_on else "none",
+                "gather_mode_selection": ("auto: the fastest of the timed modes is the headline" if auto_mode else "fixed by --gather-mode") if gather_on else None,
+                "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
+                                      "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
+                                  for m, t_m in {args.gather_mode: elapsed_, **other_}.items()} if gather_on else None),
+                "gather_modes_meaning": ({"full": "north_star's plain RCCL all-gather of all three output arrays",
+                                          "compact": "all-gather of (sigma, dp) + local rebuild of the remote tangents (to rounding; C_elas at "
+                                                     "the reference's 0/0 point f_el == 0)",
+                                          "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic",
+                                          "compact_direct": "compact with (sigma, dp) exchanged as ONE batch of point-to-point sends / receives "
+                                                            "(every block on its own xGMI link at once) instead of the library's all-gather"}
+                                         if gather_on else None),
+                "rccl_ranks": world if dist_on else 0,
+                "kernel": "vm_tile" if args.variant else "vm_point",
+                "arch": info["arch"], "compute_units": info["compute_units"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profile": traffic_from_profile,
+                "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
+                "kernel_ms_avg": kernel_ms_, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "bytes_per_qp": BYTES_PER_QP[d],
+                "output_memory": "dxo_output_alloc (library output arena, " + placement["mode"] + ")",
+                "placement": placement,
+                "achieved_plain_hipMalloc": plain_GBps,
+                "stream_probe_GBps": probe_GBps,
+            },
+            "kernel_only_value": total_points / (kernel_ms_ * 1e-3),
+        }
+        if extras and world == 1 and not args.no_e2e:
+            result["end_to_end"] = end_to_end(ctx, prm, d)
+        if extras and world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+    # the other gather modes, same protocol, reported beside the headline (never as `value`). They are comparison figures:
+    # if one of them — or the reduction of the times behind them — does not come back (a collective that hangs), rank 0
+    # prints the line with the headline mode alone, from its own clock, and every rank leaves with exit code 0.
+    compare_done = threading.Event()
+    if gather_on and world > 1:
+        def _compare_watchdog():
+            if not compare_done.wait(300.0):
+                log(f"bench rank {rank}: the comparison gather modes did not come back in 300 s — reporting the headline mode alone")
+                emit_result(elapsed, kernel_ms_avg, {}, note="comparison gather modes abandoned after 300 s; value and kernel time are rank 0's "
+                                                              "own (not the maximum over ranks)", extras=False)
+                os._exit(0)
+        threading.Thread(target=_compare_watchdog, daemon=True).start()
     other_elapsed = {}
     if gather_on:
         if world > 1:   # remote tangents rebuilt from (sigma, dp) must be usable: finite and symmetric
@@ -497,7 +590,8 @@ def main():
             chk = C_full[nb * n * d * d: nb * n * d * d + 4096 * d * d].view(-1, d, d)
             if not bool(torch.isfinite(chk).all()) or float((chk - chk.transpose(1, 2)).abs().max()) > 1e-9 * E:
                 raise SystemExit("bench: gathered/rebuilt remote C_tang block is not a finite symmetric tangent")
-        for mode in ("compact", "compact_pipelined", "full"):
+        sums = (float(sigma_full.sum()), float(dp_full.sum()))      # every mode must leave the same gathered arrays
+        for mode in MODES:
             if mode == args.gather_mode:
                 continue
             try:    # comparison figures only: they must never cost the headline line
@@ -509,18 +603,20 @@ def main():
                 for k in range(K):
                     step2()
                 fence()
+                if (float(sigma_full.sum()), float(dp_full.sum())) != sums:
+                    raise RuntimeError("gathered (sigma, dp) differ from the headline mode's")
                 other_elapsed[mode] = time.perf_counter() - t0
             except Exception as exc:   # noqa: BLE001
                 log(f"bench: gather mode '{mode}' failed and is left out: {exc!r}")
 
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     if dist_on:
-        names = ("compact", "compact_pipelined", "full")
-        t = torch.tensor([elapsed, kernel_ms_avg] + [other_elapsed.get(m, 0.0) for m in names], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kernel_ms_avg] + [other_elapsed.get(m, 0.0) for m in MODES], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # a mode that failed on ANY rank is out: its time is only meaningful if every rank ran it
+        ok = torch.tensor([1.0 if m in other_elapsed or m == args.gather_mode else 0.0 for m in MODES], dtype=torch.float64, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
-        other_elapsed = {m: float(t[2 + i]) for i, m in enumerate(names) if m in other_elapsed}
+        other_elapsed = {m: float(t[2 + i]) for i, m in enumerate(MODES) if m in other_elapsed and float(ok[i]) > 0.0}
         if auto_mode and gather_on:
             # the reduced times are identical on every rank, so every rank picks the same headline
             best = min({args.gather_mode: elapsed, **{m: v for m, v in other_elapsed.items() if v > 0.0}}.items(), key=lambda kv: kv[1])
@@ -530,6 +626,7 @@ def main():
                 del other_elapsed[args.gather_mode]
     else:
         kernel_ms_avg_max = kernel_ms_avg
+    compare_done.set()
 
     # correctness tripwire inside the bench itself (not timed): plastic points sit on the yield surface — checked on
     # the first and on the LAST 4096 points (the tail exercises the 64-bit index arithmetic of very large batches)
@@ -544,10 +641,6 @@ def main():
             raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
         if not bool(torch.isfinite(C_tang[lo * d * d:(lo + 4096) * d * d]).all()):
             raise SystemExit("bench: non-finite tangent in the kernel output — refusing to report a number")
-    total_points = n * world
-    value = total_points * K / elapsed
-    bytes_per_launch = BYTES_PER_QP[d] * n
-    achieved = bytes_per_launch / (kernel_ms_avg_max * 1e-3) / 1e9
 
     # stream probe: a no-arithmetic kernel moving the same read:write mix (13 : 43 sixteen-byte rows per tile) from the
     # input slab into the SAME output block, persistent grid of 16 workgroups per CU. A reference point beside the
@@ -569,77 +662,14 @@ def main():
         ctx.set_option("blocks_per_cu", saved_bpc)
         probe_GBps = tiles * (R + Wc) * 1024 / (e0.elapsed_time(e1) / K * 1e-3) / 1e9
 
-    result = None
     if rank == 0:
-        # HBM traffic of this kernel is NOT measured in this run (PMC counters need rocprofv3 around the process): the
-        # stored result of the last counter pass over the same launch shape is quoted with its source, `traffic` is null.
-        traffic_from_profile = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            try:
-                tj = json.loads(tfile.read_text())
-                # the counter pass records the launch's grid size in threads = points rounded up to whole workgroups
-                if 0 <= tj.get("grid_threads", -1) - n < 256 and tj.get("d") == d:
-                    traffic_from_profile = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"), "file": "profiles/traffic.json",
-                                            "measured": tj.get("measured", "earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                                                           "(scripts/gpu_check.sh), not this run")}
-            except Exception:
-                traffic_from_profile = None
-        result = {
-            "metric": "quadrature-points/sec (von Mises return-map + tangent)",
-            "value": value, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            **({"dry_collective": "NOT A MEASUREMENT: all ranks on one GPU, gloo collectives (logic check of the N > 1 path)"}
-               if args.dry_collective else {}),
-            "config": {
-                "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
-                            f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
-                            + ((", cell-block sharded, RCCL all-gather of (sigma, dp) + on-device rebuild of the remote "
-                                "tangents every step" if args.gather_mode.startswith("compact") else
-                                ", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step") if gather_on
-                               else (", cell-block sharded, no gather" if world > 1 else "")),
-                "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
-                "sharding": "cell-block" if world > 1 else "none",
-                "gather": f"rccl_all_gather_{args.gather_mode}" if gather_on else "none",
-                "gather_mode_selection": ("auto: the fastest of the timed modes is the headline" if auto_mode else "fixed by --gather-mode") if gather_on else None,
-                "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
-                                      "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
-                                  for m, t_m in {args.gather_mode: elapsed, **other_elapsed}.items()} if gather_on else None),
-                "gather_modes_meaning": ({"full": "north_star's plain RCCL all-gather of all three output arrays",
-                                          "compact": "all-gather of (sigma, dp) + local rebuild of the remote tangents (to rounding; C_elas at "
-                                                     "the reference's 0/0 point f_el == 0)",
-                                          "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic"}
-                                         if gather_on else None),
-                "rccl_ranks": world if dist_on else 0,
-                "kernel": "vm_tile" if args.variant else "vm_point",
-                "arch": info["arch"], "compute_units": info["compute_units"],
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profile": traffic_from_profile,
-                "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
-                "kernel_ms_avg": kernel_ms_avg_max, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "bytes_per_qp": BYTES_PER_QP[d],
-                "output_memory": "dxo_output_alloc (library output arena, " + placement["mode"] + ")",
-                "placement": placement,
-                "achieved_plain_hipMalloc": plain_GBps,
-                "stream_probe_GBps": probe_GBps,
-            },
-            "kernel_only_value": total_points / (kernel_ms_avg_max * 1e-3),
-        }
         if world == 1 and not args.no_e2e:
             del C_tang, sigma, dp, C_full, sigma_full, dp_full, in_slab, deps, sigma_n, p
             torch.cuda.empty_cache()
-            result["end_to_end"] = end_to_end(ctx, prm, d)
-        if world == 1 and not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        emit_result(elapsed, kernel_ms_avg_max, other_elapsed, probe_GBps)
     if dist_on:
         # nothing after the result line may cost it: whatever is still running 180 s from now (a collective of the
         # cross-check or the final barrier that does not come back) is abandoned with exit code 0
-        import threading
-
         def _leave():
             time.sleep(180.0)
             log(f"bench rank {rank}: post-result phase still running after 180 s — leaving")

@@ -222,5 +222,44 @@ def gather_von_mises_compact_pipelined(C_tang_full, sigma_full, dp_full, rank: i
             expand(sigma_full[lo * d:hi * d], dp_full[lo:hi], C_tang_full[lo * d * d:hi * d * d], hi - lo)
 
 
-__all__ = ["CellBlockPartition", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
+def exchange_blocks_direct(full, rank: int, group=None) -> None:
+    """The same result as `all_gather_in_place`, as point-to-point traffic: every rank sends its block to every peer
+    and receives each peer's block straight into place, all 2 (world - 1) operations in ONE batch (ncclGroupStart / End
+    with RCCL). On a fully connected xGMI node (one link per GPU pair) that puts each block on its own link at once —
+    the all-pairs pattern SURVEY.md 8e asks for — whatever algorithm the library's all-gather would have chosen for the
+    message size (a ring moves world - 1 blocks over every link, one after another)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if full.numel() % world:
+        raise ValueError(f"gather buffer of {full.numel()} elements does not split into {world} equal blocks")
+    if world == 1:
+        return
+    m = full.numel() // world
+    own = full[rank * m:(rank + 1) * m]
+    ops = []
+    for step in range(1, world):          # peer order staggered by rank: at every step the pairs are disjoint
+        to, frm = (rank + step) % world, (rank - step) % world
+        ops.append(dist.P2POp(dist.isend, own, to, group))
+        ops.append(dist.P2POp(dist.irecv, full[frm * m:(frm + 1) * m], frm, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None) -> None:
+    """`gather_von_mises_compact` with the exchange of (sigma, dp) as direct peer-to-peer sends / receives
+    (`exchange_blocks_direct`) instead of the backend's all-gather; the rebuild of the remote tangents is the same."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    m = dp_full.numel() // world
+    if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
+        raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    exchange_blocks_direct(sigma_full, rank, group)
+    exchange_blocks_direct(dp_full, rank, group)
+    for b, e in remote_point_ranges(rank, world, m):
+        expand(sigma_full[b * d:e * d], dp_full[b:e], C_tang_full[b * d * d:e * d * d], e - b)
+
+
+__all__ = ["CellBlockPartition", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
            "remote_point_ranges", "gather_von_mises_compact", "gather_von_mises_compact_pipelined", "WAVE_TILE"]

@@ -73,7 +73,7 @@ import pytest  # noqa: E402
 
 @pytest.mark.gpu
 def test_two_rank_path_logic_on_one_gpu():
-    """The N > 1 control flow of bench.py (cell-block offsets into full-length arena buffers, the three gather modes,
+    """The N > 1 control flow of bench.py (cell-block offsets into full-length arena buffers, the four gather modes,
     the remote-tangent rebuild and its finiteness / symmetry check, max-over-ranks timing) with two ranks sharing the
     one GPU of the test box and gloo collectives (`--dry-collective`): RCCL itself needs one device per rank and is
     exercised with a world of one (tests/test_round2_gpu.py) and by the driver's 8-GPU run."""
@@ -84,5 +84,5 @@ def test_two_rank_path_logic_on_one_gpu():
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "dry_collective" in line and line["config"]["rccl_ranks"] == 2
-    assert set(line["config"]["gather_modes"]) == {"compact", "compact_pipelined", "full"}
+    assert set(line["config"]["gather_modes"]) == {"compact", "compact_pipelined", "compact_direct", "full"}
     assert line["config"]["points_per_gpu"] % 128 == 0 and line["value"] > 0

@@ -126,7 +126,7 @@ def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from dolfinx_external_operator_amd.sharding import (CellBlockPartition, gather_von_mises_compact,
+    from dolfinx_external_operator_amd.sharding import (CellBlockPartition, gather_von_mises_compact, gather_von_mises_compact_direct,
                                                         gather_von_mises_compact_pipelined, remote_point_ranges)
     from oracle import load_oracle
 
@@ -159,7 +159,9 @@ def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
             with np.errstate(all="ignore"):
                 Cv.copy_(torch.from_numpy(numpy_expand_tangent(sv.numpy(), dv.numpy(), d).reshape(-1)))
 
-        if pipelined:
+        if pipelined < 0:       # the direct peer-to-peer form of the exchange
+            gather_von_mises_compact_direct(Cf, sf, dpf, rank, d, expand)
+        elif pipelined:
             gather_von_mises_compact_pipelined(Cf, sf, dpf, rank, d, expand, chunks=pipelined)
         else:
             gather_von_mises_compact(Cf, sf, dpf, rank, d, expand)
@@ -172,7 +174,7 @@ def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
         ok = ok and np.array_equal(gC[own_b * d * d:own_e * d * d], Cw.reshape(-1)[own_b * d * d:own_e * d * d])  # untouched
         ok = ok and np.max(np.abs(gC - Cw.reshape(-1))) <= 1e-13 * scale
         ok = ok and sum(calls) == (world - 1) * m
-        ok = ok and (pipelined or len(calls) == len(remote_point_ranges(rank, world, m)))
+        ok = ok and (pipelined > 0 or len(calls) == len(remote_point_ranges(rank, world, m)))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -189,7 +191,8 @@ def test_remote_point_ranges():
         remote_point_ranges(4, 4, 64)
 
 
-@pytest.mark.parametrize("num_cells,nq,d,world,pipelined", [(101, 8, 6, 2, 0), (50, 3, 4, 3, 0), (101, 8, 6, 2, 3), (70, 8, 4, 3, 5)])
+@pytest.mark.parametrize("num_cells,nq,d,world,pipelined", [(101, 8, 6, 2, 0), (50, 3, 4, 3, 0), (101, 8, 6, 2, 3), (70, 8, 4, 3, 5),
+                                                            (101, 8, 6, 2, -1), (50, 3, 4, 3, -1), (64, 8, 6, 4, -1)])
 def test_gloo_compact_gather_rebuilds_remote_tangents(oracle, num_cells, nq, d, world, pipelined):
     import torch.multiprocessing as mp
 
