@@ -213,8 +213,8 @@ def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=2):
 def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 20, steps=5):
     """After the result line is out: the same split + exchange through the C ABI's own RCCL path (dxo_mgpu_create_rank /
     dxo_mgpu_von_mises, csrc/mgpu.hip) on a small batch, compared with torch.distributed's all-gather of the same
-    blocks. Reported on stderr only (it must never cost the headline): a watchdog ends the process with exit code 0 if
-    a collective does not come back."""
+    blocks. Reported on stderr only; the result line is already out when it starts. A collective that does not come back
+    ends the process with exit code 3 (a rank that has touched the GPU and gives up must not report success)."""
     import threading
 
     from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_FULL, MultiGpu
@@ -223,8 +223,8 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
 
     def watchdog():
         if not done.wait(120.0):
-            log(f"bench rank {rank}: library_gather_check did not finish in 120 s — leaving (the result line is already out)")
-            os._exit(0)
+            log(f"bench rank {rank}: library_gather_check did not finish in 120 s — leaving with exit code 3 (the result line is already out)")
+            os._exit(3)
 
     threading.Thread(target=watchdog, daemon=True).start()
     uid = [MultiGpu.unique_id() if rank == 0 else None]
@@ -254,13 +254,20 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     err_s = float((out["full"]["s"] - s_ref).abs().max())
     err_cs = float((out["compact"]["s"] - s_ref).abs().max())
     scale = float(out["full"]["C"].abs().max())
-    err_C = float((out["compact"]["C"] - out["full"]["C"]).abs().max()) / scale      # rebuilt remote tangents vs gathered ones
+    err_C = float((out["compact"]["C"] - out["full"]["C"]).abs().max()) / scale      # rebuilt tangents vs gathered ones
+    # compact replicas must be the same BYTES on every rank (every rank rebuilds every block from the same gathered state)
+    chk = torch.stack([out["compact"]["C"].view(torch.int64).sum(), out["compact"]["dp"].view(torch.int64).sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    identical = bool((lo == hi).all())
     mg.close()
     done.set()
-    ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13
+    ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13 and identical
     log(json.dumps({"library_gather_check": "ok" if ok else "MISMATCH", "rank": rank, "rccl_ranks_in_libdxo": world, "points_per_rank": n,
                     "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
-                    "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C}))
+                    "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C,
+                    "compact_replicas_bit_identical": identical}))
     return ok
 
 
@@ -286,10 +293,11 @@ def launch_ranks(n_gpus: int, argv: list[str]) -> int:
     for ln in lines:
         if ln not in json_lines:
             log(ln)
+    if json_lines:
+        print(json_lines[-1], flush=True)   # also the `"degraded": true` line of a run that then gave up on a hung collective
     if res.returncode != 0 or not json_lines:
         log(f"bench: the {n_gpus}-rank run failed (exit code {res.returncode}, {len(json_lines)} result lines)")
         return res.returncode or 1
-    print(json_lines[-1], flush=True)
     return 0
 
 
@@ -429,6 +437,9 @@ def main():
     sigma = sigma_full[own * n * d:(own + 1) * n * d]
     dp = dp_full[own * n:(own + 1) * n]
 
+    def bytes_per_launch_of(d_, n_):
+        return BYTES_PER_QP[d_] * n_
+
     def time_kernel(out_ptrs, launches):
         pp = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), *out_ptrs)
         ctx.von_mises(prm, d, n, MEM_DEVICE, *pp)
@@ -452,21 +463,37 @@ def main():
     def expand(s_view, dp_view, C_view, npts):
         ctx.vm_expand_tangent(prm, d, npts, MEM_DEVICE, s_view.data_ptr(), dp_view.data_ptr(), C_view.data_ptr())
 
+    def clear_marks(dp_view, npts):
+        ctx.vm_clear_marks(npts, dp_view.data_ptr())
+
+    # the compact forms: the kernel writes (sigma, dp) only (C_tang = NULL) with the reference's 0/0 point marked in the sign
+    # bit of dp, (sigma, dp) go over the links, every rank rebuilds EVERY block's tangent (its own too: bit-identical
+    # replicas, NaN at the marked points like the reference) and clears the marks
+    ptrs_state_only = (*ptrs[:3], None, ptrs[4], ptrs[5])
+    rebuild = dict(identical=True, clear_marks=clear_marks)
+
     def make_step(mode):
+        compact = gather_on and mode.startswith("compact")
+
         def step(ev=None):
             if ev is not None:
                 ev[0].record(stream)
-            ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs)
+            if compact:
+                ctx.set_option("vm_mark_indeterminate", 1)
+                ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs_state_only)
+                ctx.set_option("vm_mark_indeterminate", 0)
+            else:
+                ctx.von_mises(prm, d, n, MEM_DEVICE, *ptrs)
             if ev is not None:
                 ev[1].record(stream)
             if not gather_on:
                 return
             if mode == "compact":
-                gather_von_mises_compact(C_full, sigma_full, dp_full, rank, d, expand)
+                gather_von_mises_compact(C_full, sigma_full, dp_full, rank, d, expand, **rebuild)
             elif mode == "compact_pipelined":
-                gather_von_mises_compact_pipelined(C_full, sigma_full, dp_full, rank, d, expand, chunks=4)
+                gather_von_mises_compact_pipelined(C_full, sigma_full, dp_full, rank, d, expand, chunks=4, **rebuild)
             elif mode == "compact_direct":
-                gather_von_mises_compact_direct(C_full, sigma_full, dp_full, rank, d, expand)
+                gather_von_mises_compact_direct(C_full, sigma_full, dp_full, rank, d, expand, **rebuild)
             else:
                 for buf in (C_full, sigma_full, dp_full):
                     all_gather_in_place(buf, rank)
@@ -495,15 +522,21 @@ def main():
 
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    if gather_on:
+        # in the compact forms the step's own launch is the (sigma, dp)-only kernel; `roofline` and `kernel_only_value` are
+        # about the FULL kernel (448 B/point), so with a gather on it is timed here, K launches back to back into this
+        # rank's slice of the same arrays (outside the timed steps; the next step overwrites the slice anyway)
+        kernel_ms_avg = bytes_per_launch_of(d, n) / time_kernel(ptrs[3:], K) / 1e6
     total_points = n * world
     bytes_per_launch = BYTES_PER_QP[d] * n
     MODES = ("compact", "compact_pipelined", "compact_direct", "full")
     emitted = threading.Lock()
 
-    def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True):
+    def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True, degraded=False, mode=None):
         """Rank 0: build the result line and write it to the real stdout, once."""
         if rank != 0 or not emitted.acquire(blocking=False):
             return
+        mode = mode or args.gather_mode
         # HBM traffic of this kernel is NOT measured in this run (PMC counters need rocprofv3 around the process): the
         # stored result of the last counter pass over the same launch shape is quoted with its source, `traffic` is null.
         traffic_from_profile = None
@@ -526,24 +559,26 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             **({"dry_collective": "NOT A MEASUREMENT: all ranks on one GPU, gloo collectives (logic check of the N > 1 path)"}
                if args.dry_collective else {}),
+            **({"degraded": True} if degraded else {}),
             **({"note": note} if note else {}),
             "config": {
                 "workload": f"von Mises radial return + consistent tangent, 3-D hex mesh, {args.nq} qp/cell, Mandel d={d}, "
                             f"{n // args.nq} cells = {n} quadrature points per GPU, fp64"
                             + ((", cell-block sharded, RCCL exchange of (sigma, dp) + on-device rebuild of the remote "
-                                "tangents every step" if args.gather_mode.startswith("compact") else
+                                "tangents every step" if mode.startswith("compact") else
                                 ", cell-block sharded, RCCL all-gather of (C_tang, sigma, dp) every step") if gather_on
                                else (", cell-block sharded, no gather" if world > 1 else "")),
                 "points_per_gpu": n, "cells_per_gpu": n // args.nq, "nq": args.nq, "d": d,
                 "sharding": "cell-block" if world > 1 else "none",
-                "gather": f"rccl_all_gather_{args.gather_mode}" if gather_on else "none",
+                "gather": f"rccl_all_gather_{mode}" if gather_on else "none",
                 "gather_mode_selection": ("auto: the fastest of the timed modes is the headline" if auto_mode else "fixed by --gather-mode") if gather_on else None,
                 "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
                                       "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
-                                  for m, t_m in {args.gather_mode: elapsed_, **other_}.items()} if gather_on else None),
+                                  for m, t_m in {mode: elapsed_, **other_}.items()} if gather_on else None),
                 "gather_modes_meaning": ({"full": "north_star's plain RCCL all-gather of all three output arrays",
-                                          "compact": "all-gather of (sigma, dp) + local rebuild of the remote tangents (to rounding; C_elas at "
-                                                     "the reference's 0/0 point f_el == 0)",
+                                          "compact": "kernel writes (sigma, dp) only; all-gather of (sigma, dp); every rank rebuilds EVERY block's "
+                                                     "tangent (replicas bit-identical across ranks, equal to the full form's to rounding; the "
+                                                     "reference's NaN tangent at f_el == 0 carried by the sign bit of dp, cleared afterwards)",
                                           "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic",
                                           "compact_direct": "compact with (sigma, dp) exchanged as ONE batch of point-to-point sends / receives "
                                                             "(every block on its own xGMI link at once) instead of the library's all-gather"}
@@ -573,15 +608,17 @@ def main():
 
     # the other gather modes, same protocol, reported beside the headline (never as `value`). They are comparison figures:
     # if one of them — or the reduction of the times behind them — does not come back (a collective that hangs), rank 0
-    # prints the line with the headline mode alone, from its own clock, and every rank leaves with exit code 0.
+    # prints the line with the headline mode alone, from its own clock, marked `"degraded": true`, and every rank leaves
+    # with exit code 3: a process that has touched the GPU and gives up on a hung collective must not report success.
     compare_done = threading.Event()
     if gather_on and world > 1:
-        def _compare_watchdog():
+        def _compare_watchdog(elapsed_=elapsed, kernel_ms_=kernel_ms_avg, mode_=args.gather_mode):
+            # headline time and mode captured by value before the comparison loop (the main thread reassigns them later)
             if not compare_done.wait(300.0):
-                log(f"bench rank {rank}: the comparison gather modes did not come back in 300 s — reporting the headline mode alone")
-                emit_result(elapsed, kernel_ms_avg, {}, note="comparison gather modes abandoned after 300 s; value and kernel time are rank 0's "
-                                                              "own (not the maximum over ranks)", extras=False)
-                os._exit(0)
+                log(f"bench rank {rank}: the comparison gather modes did not come back in 300 s — reporting the headline mode alone, exit code 3")
+                emit_result(elapsed_, kernel_ms_, {}, note="comparison gather modes abandoned after 300 s; value and kernel time are rank 0's "
+                                                            "own (not the maximum over ranks)", extras=False, degraded=True, mode=mode_)
+                os._exit(3)
         threading.Thread(target=_compare_watchdog, daemon=True).start()
     other_elapsed = {}
     if gather_on:
@@ -668,12 +705,12 @@ def main():
             torch.cuda.empty_cache()
         emit_result(elapsed, kernel_ms_avg_max, other_elapsed, probe_GBps)
     if dist_on:
-        # nothing after the result line may cost it: whatever is still running 180 s from now (a collective of the
-        # cross-check or the final barrier that does not come back) is abandoned with exit code 0
+        # the result line is out; whatever is still running 180 s from now (a collective of the cross-check or the final
+        # barrier that does not come back) is abandoned — with exit code 3, so that a hang is never recorded as success
         def _leave():
             time.sleep(180.0)
-            log(f"bench rank {rank}: post-result phase still running after 180 s — leaving")
-            os._exit(0)
+            log(f"bench rank {rank}: post-result phase still running after 180 s — leaving with exit code 3")
+            os._exit(3)
 
         threading.Thread(target=_leave, daemon=True).start()
     if dist_on and not args.dry_collective and not args.no_library_gather:

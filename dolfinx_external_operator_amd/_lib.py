@@ -5,6 +5,7 @@ can be created, the operators raise.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import pathlib
 import threading
@@ -98,6 +99,7 @@ _SIGNATURES = {
     "dxo_vm_output_alloc": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "dxo_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [_P] * 6),
     "dxo_vm_expand_tangent": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int, _P, _P, _P]),
+    "dxo_vm_clear_marks": (C.c_int, [_P, C.c_int64, _P]),
     "dxo_vm_commit_state": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "dxo_vm_state_create": (C.c_int, [_P, C.c_int, C.c_int64, C.POINTER(_P)]),
     "dxo_vm_state_destroy": (None, [_P, _P]),
@@ -228,28 +230,52 @@ def _ptr(a) -> int | None:
 class _PinnedPool:
     """Size-keyed free lists of hipHostMalloc blocks. A block handed out as an ndarray comes back through a
     weakref finalizer on the ctypes object that every NumPy view of it keeps alive (ndarray.base chain), i.e.
-    only when no view can observe a later overwrite. After close() returning blocks are freed instead."""
+    only when no view can observe a later overwrite. After close() returning blocks are freed instead.
+
+    The finalizer can run at ANY allocation point of ANY thread (a cyclic-GC pass collecting a dead result array), also
+    while that same thread is inside empty() — so `_give_back` takes no lock at all: it appends to a deque (atomic in
+    CPython), and the deque is drained into the free lists by empty() / close() under the lock. hipHostFree, which may
+    block, is never called with the lock held."""
 
     KEEP_PER_SIZE = 4
 
     def __init__(self, lib):
         self.lib = lib
         self.free: dict[int, list[int]] = {}
+        self.returned: collections.deque = collections.deque()   # (addr, cap) handed back by finalizers, not yet sorted in
         self.closed = False
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()
+
+    def _drain(self, doomed: list) -> None:
+        """Sort the returned blocks into the free lists (lock held); surplus ones go to `doomed` for the caller to free."""
+        while True:
+            try:
+                addr, cap = self.returned.popleft()
+            except IndexError:
+                return
+            lst = self.free.get(cap)
+            if lst is None:
+                lst = self.free[cap] = []
+            if self.closed or len(lst) >= self.KEEP_PER_SIZE:
+                doomed.append(addr)
+            else:
+                lst.append(addr)
 
     def empty(self, n: int, dtype: np.dtype) -> np.ndarray:
         cap = max(n * dtype.itemsize, 1)
+        doomed: list = []
         with self.lock:
             if self.closed:
                 raise DxoError("pinned pool used after Context.close()")
+            self._drain(doomed)
             lst = self.free.get(cap)
             addr = lst.pop() if lst else None
             if addr is None:
                 # the batch size changed (or first call): drop idle blocks of other sizes before growing
                 for other in [k for k in self.free if k != cap]:
-                    for a in self.free.pop(other):
-                        self.lib.dxo_host_free(None, _P(a))
+                    doomed.extend(self.free.pop(other))
+        for a in doomed:
+            self.lib.dxo_host_free(None, _P(a))
         if addr is None:
             p = _P()
             rc = self.lib.dxo_host_alloc(None, cap, C.byref(p))
@@ -262,19 +288,25 @@ class _PinnedPool:
         return np.frombuffer(buf, dtype=dtype, count=n)
 
     def _give_back(self, addr: int, cap: int) -> None:
-        with self.lock:
-            lst = self.free.setdefault(cap, [])
-            if not self.closed and len(lst) < self.KEEP_PER_SIZE:
-                lst.append(addr)
-                return
-        self.lib.dxo_host_free(None, _P(addr))
+        # lock-free on purpose (see the class docstring). After close() nobody drains any more: free right here.
+        if self.closed:
+            self.lib.dxo_host_free(None, _P(addr))
+        else:
+            self.returned.append((addr, cap))
 
     def close(self) -> None:
+        doomed: list = []
         with self.lock:
             self.closed = True
-            blocks = [a for lst in self.free.values() for a in lst]
+            self._drain(doomed)
+            for lst in self.free.values():
+                doomed.extend(lst)
             self.free.clear()
-        for a in blocks:
+        for a in doomed:
+            self.lib.dxo_host_free(None, _P(a))
+        doomed = []
+        self._drain(doomed)   # a finalizer that raced with the flag
+        for a in doomed:
             self.lib.dxo_host_free(None, _P(a))
 
 
@@ -296,6 +328,20 @@ class Context:
         self._pool = _PinnedPool(self.lib)
         self._lock = threading.RLock()   # dxo_ctx itself also serialises its entry points (include/dxo.h)
 
+    @classmethod
+    def borrow(cls, handle: int, device: int = 0) -> "Context":
+        """A Context over a dxo_ctx that something else owns (the contexts of a MultiGpu group): close() releases what
+        this wrapper allocated (pinned buffers) but does not destroy the dxo_ctx."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self._h = _P(handle)
+        self.device = int(device)
+        self._pinned = []
+        self._pool = _PinnedPool(self.lib)
+        self._lock = threading.RLock()
+        self._borrowed = True
+        return self
+
     # -- plumbing ----------------------------------------------------------------------------
     def check(self, rc: int, what: str) -> None:
         if rc == 0:
@@ -312,7 +358,8 @@ class Context:
                 self.lib.dxo_host_free(self._h, _P(addr))
             self._pinned.clear()
             self._pool.close()
-            self.lib.dxo_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.dxo_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -483,6 +530,10 @@ class Context:
         rc = self.lib.dxo_vm_expand_tangent(self._h, C.byref(prm), int(d), int(n), int(mem), _ptr(sigma), _ptr(dp),
                                             _ptr(C_tang))
         self.check(rc, "dxo_vm_expand_tangent")
+
+    def vm_clear_marks(self, n: int, dp) -> None:
+        """-0.0 -> +0.0 in a device dp array (the producer's mark of the reference's 0/0 point, option vm_mark_indeterminate)."""
+        self.check(self.lib.dxo_vm_clear_marks(self._h, int(n), _ptr(dp)), "dxo_vm_clear_marks")
 
     def vm_commit_state(self, d: int, n: int, p, dp, sigma_n, sigma) -> None:
         self.check(self.lib.dxo_vm_commit_state(self._h, int(d), int(n), _ptr(p), _ptr(dp), _ptr(sigma_n), _ptr(sigma)),
@@ -695,7 +746,12 @@ class MultiGpu:
                                                         rank 0, broadcast by the caller (128 bytes)
     MultiGpu.local(devices=[0, 1, ...])                 contexts only, no communicator, RCCL never loaded: for
                                                         `von_mises_host` (NumPy arrays sharded over the GPUs' PCIe links)
-    Pointer-list arguments take one device pointer (int or tensor with data_ptr()) per LOCAL device."""
+    Pointer-list arguments take one device pointer (int or tensor with data_ptr()) per LOCAL device.
+
+    Buffers handed to a collective (all_gather, von_mises with a gather) must be ordinary hipMalloc memory (torch tensors
+    are): an output-arena block built from 2 MB physical chunks is accessible from its own device only and cannot be
+    exported to a peer. The group's contexts therefore have "placement_vmm" = 0 (from_rank sets it on the context it is
+    given), and the collectives raise ValueError (DXO_E_MEM) for a pointer inside a chunk-backed block."""
 
     def __init__(self, devices=None, n_dev: int | None = None, _handle=None, _ctx=None):
         self.lib = load_library()
@@ -772,6 +828,16 @@ class MultiGpu:
 
     def ctx_handle(self, i: int = 0) -> int:
         return self.lib.dxo_mgpu_ctx(self._h, int(i))
+
+    def context(self, i: int = 0) -> Context:
+        """The context of local device i as a (borrowed) Context: options, output arena, single-GPU entry points. Arena
+        blocks of a group's contexts are hipMalloc memory ("placement_vmm" = 0): they may become RCCL buffers."""
+        return Context.borrow(self.ctx_handle(i))
+
+    def ctx_option(self, i: int, key: str) -> int:
+        v = C.c_int64()
+        self._check(self.lib.dxo_ctx_get_option(_P(self.ctx_handle(i)), key.encode(), C.byref(v)), f"get_option({key})")
+        return v.value
 
     def set_stream(self, i: int, stream_handle) -> None:
         """Launch stream of local device i (e.g. torch.cuda.current_stream(dev).cuda_stream)."""

@@ -301,6 +301,14 @@ int dxo_arena_tuned_shape(dxo_ctx* c, const void* ptr) {
     return -1;
 }
 
+// true when `ptr` lies in an arena block built from 2 MB physical chunks (hipMemCreate / hipMemMap): such a range is
+// accessible from the owning device only and cannot be exported with hipIpcGetMemHandle, so it must never be handed to RCCL
+bool dxo_arena_is_vmm(dxo_ctx* c, const void* ptr) {
+    for (const auto& b : c->arena)
+        if (b.ptr && (const char*)ptr >= (const char*)b.ptr && (const char*)ptr < (const char*)b.ptr + b.bytes) return b.vmm != nullptr;
+    return false;
+}
+
 void dxo_arena_release_all(dxo_ctx* c) {
     for (auto& b : c->arena)
         if (b.ptr) block_free(b);

@@ -45,6 +45,8 @@ bool dxo_arena_alloc_calibrated(dxo_ctx* ctx, size_t bytes, const dxo_arena_prob
 void dxo_arena_register(dxo_ctx* ctx, const dxo_arena_block& blk);
 // tuned launch shape of the arena block that contains `ptr`, or -1
 int dxo_arena_tuned_shape(dxo_ctx* ctx, const void* ptr);
+// does `ptr` lie in an arena block backed by 2 MB physical chunks (not shareable with peers / RCCL)?
+bool dxo_arena_is_vmm(dxo_ctx* ctx, const void* ptr);
 
 // Host worker threads of a context (dxo_ctx.hip): the host half of the DXO_MEM_HOST pipeline (tangent rebuild from
 // the returned state while later chunks are still on the PCIe link). Created on first use, joined by dxo_ctx_destroy.
@@ -77,7 +79,8 @@ struct dxo_ctx {
     int64_t operand_cell = 1;           // dxo_eval_operand, eps on the 2-D standard elements: lane = cell kernel (operand_cell.h); 0: wave-group kernel
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
-    int64_t mc_waves_per_simd = 1;      // register budget of mc_newton: 1 (512 regs/lane) or 2 (256, small spill)
+    int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and
+                                        // fits two waves per SIMD (240 VGPRs, no scratch) whatever this says
     // output arena (arena.hip)
     int64_t placement_mode = 2;         // 0 plain hipMalloc, 2 (or any value >= 1) hipMalloc candidates
     int64_t placement_candidates = 16;  // allocations / ranges tried at most (<= DXO_PLACEMENT_MAX)
@@ -87,6 +90,8 @@ struct dxo_ctx {
     int64_t placement_good_mix_GBps = 6250;   // early-exit rate of the six-stream sweep (algorithmic GB/s)
     int64_t placement_good_GBps = 6800; // stop searching at the first candidate whose write sweep reaches this
     std::vector<dxo_arena_block> arena;
+    int64_t vm_mark_indeterminate = 0;  // DEVICE-path von Mises: dp = -0.0 at f_elastic == 0 exactly (the reference's 0/0, :318), for
+                                        // consumers that rebuild the tangent from (sigma, dp); dxo_vm_clear_marks restores +0
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
     int64_t host_threads = 32;          // worker threads of the host half of the pipeline (capped by the hardware's)
     int64_t vm_rebuild_chunk_points = 1 << 17;   // pipeline chunk of the vm_host_tangent = 1 mode

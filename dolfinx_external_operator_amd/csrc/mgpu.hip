@@ -14,9 +14,16 @@
 //   dxo_mgpu_create_rank  one process per GPU (MPI ranks of a DOLFINx run, torch.distributed workers): the caller
 //                         broadcasts the 128-byte id of dxo_mgpu_unique_id, every rank joins with ncclCommInitRank.
 // Gather modes: FULL = all-gather of (C_tang, sigma, dp), (d*d+d+1) doubles per point over xGMI; COMPACT = all-gather
-// of (sigma, dp) only ((d+1) doubles, 6.1x fewer link bytes at d = 6) + rebuild of the REMOTE tangents from the
-// returned state on the device (dxo_vm_expand_tangent, HBM-bound) — xGMI (7 links x ~153 GB/s per GPU), not HBM, is
-// the roof of the reassembly.
+// of (sigma, dp) only ((d+1) doubles, 6.1x fewer link bytes at d = 6) + rebuild of EVERY block's tangent — the rank's
+// own included — from the gathered state on the device (dxo_vm_expand_tangent, HBM-bound): xGMI (7 links x ~153 GB/s
+// per GPU), not HBM, is the roof of the reassembly. Because every rank runs the same rebuild on the same gathered
+// (sigma, dp), the replicas of the coefficient vector are BIT-IDENTICAL across ranks, and the reference's 0/0 point
+// (f_elastic == 0, demo_plasticity_von_mises.py:318) travels as the sign bit of dp and comes out as the reference's NaN
+// tangent on every rank (the marks are cleared afterwards: dp is +0 there, as in the reference).
+//
+// Buffers handed to RCCL must be ordinary hipMalloc memory: the group's contexts get "placement_vmm" = 0, and the
+// collectives refuse (DXO_E_MEM) a pointer inside an arena block built from 2 MB physical chunks (accessible from its
+// own device only, not exportable through hipIpcGetMemHandle).
 //
 // RCCL is resolved lazily (dlopen "librccl.so.1" at the first dxo_mgpu_* call): libdxo_hip.so has no link-time
 // dependency on it, single-GPU users never load it, and inside a PyTorch process the copy PyTorch has already
@@ -175,6 +182,7 @@ int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out) {
             dxo_mgpu_destroy(g);
             return rc;
         }
+        c->placement_vmm = 0;   // arena blocks of this context may become RCCL buffers: hipMalloc candidates only
         g->ctx.push_back(c);
         g->own_ctx.push_back(true);
         g->rank.push_back(i);
@@ -285,6 +293,7 @@ int dxo_mgpu_create_rank(dxo_ctx* ctx, const void* id128, int rank, int world, d
     std::memcpy(&id, id128, sizeof id);
     dxo_mgpu* g = new dxo_mgpu();
     g->world = world;
+    ctx->placement_vmm = 0;   // from here on this context's arena hands out hipMalloc blocks only (RCCL buffers)
     g->ctx.push_back(ctx);
     g->own_ctx.push_back(false);
     g->rank.push_back(rank);
@@ -325,6 +334,11 @@ int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank)
             (void)R->GroupEnd();
             return mg_fail(g, DXO_E_NULL, "dxo_mgpu_all_gather: NULL buffer");
         }
+        if (dxo_arena_is_vmm(g->ctx[i], buf[i])) {
+            (void)R->GroupEnd();
+            return mg_fail(g, DXO_E_MEM, "dxo_mgpu_all_gather: the buffer lies in an arena block backed by 2 MB physical chunks, which peers "
+                                         "cannot access; allocate it with option placement_vmm = 0 (the group's contexts have it set)");
+        }
         const ncclResult_t r = R->AllGather(buf[i] + (size_t)g->rank[i] * (size_t)count_per_rank, buf[i], (size_t)count_per_rank, ncclDouble,
                                             g->comm[i], dxo_launch_stream(g->ctx[i]));
         if (r != ncclSuccess) {
@@ -346,30 +360,37 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
     if (gather < DXO_GATHER_NONE || gather > DXO_GATHER_COMPACT) return mg_fail(g, DXO_E_MEM, "dxo_mgpu_von_mises: bad gather mode");
     if (gather != DXO_GATHER_NONE && (n_per_rank % 2)) return mg_fail(g, DXO_E_ALIGN, "dxo_mgpu_von_mises: with a gather n_per_rank must be even (16-byte aligned blocks)");
     const size_t n = (size_t)n_per_rank, L = g->ctx.size();
-    // 1. every local device: return map of its own cell block, written into its slice of the full-length outputs
+    const bool compact = gather == DXO_GATHER_COMPACT;
+    // 1. every local device: return map of its own cell block, written into its slice of the full-length outputs. COMPACT:
+    //    (sigma, dp) only, with the 0/0 point marked in the sign bit of dp — every tangent is rebuilt in step 3
     for (size_t i = 0; i < L; ++i) {
         const size_t off = gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n;
+        if (compact && (!C_tang[i] || !sigma[i] || !dp[i])) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL output array");
+        const int64_t saved_mark = g->ctx[i]->vm_mark_indeterminate;
+        if (compact) g->ctx[i]->vm_mark_indeterminate = 1;
         const int rc = dxo_von_mises(g->ctx[i], prm, d, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], p[i],
-                                     C_tang[i] ? C_tang[i] + off * d * d : nullptr, sigma[i] ? sigma[i] + off * d : nullptr,
-                                     dp[i] ? dp[i] + off : nullptr);
+                                     compact ? nullptr : (C_tang[i] ? C_tang[i] + off * d * d : nullptr),
+                                     sigma[i] ? sigma[i] + off * d : nullptr, dp[i] ? dp[i] + off : nullptr);
+        g->ctx[i]->vm_mark_indeterminate = saved_mark;
         if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
     }
-    if (gather == DXO_GATHER_NONE || g->world == 1 || n == 0) return DXO_OK;
-    // 2. the exchange step
-    int rc = dxo_mgpu_all_gather(g, sigma, n_per_rank * d);
-    if (rc == DXO_OK) rc = dxo_mgpu_all_gather(g, dp, n_per_rank);
-    if (rc != DXO_OK) return rc;
-    if (gather == DXO_GATHER_FULL) return dxo_mgpu_all_gather(g, C_tang, n_per_rank * d * d);
-    // 3. COMPACT: tangents of the remote blocks from the gathered state, on each device's stream behind its gathers
+    // 2. the exchange step (a world of one has none; COMPACT still owes the tangent of its only block)
+    if (gather == DXO_GATHER_NONE || n == 0) return DXO_OK;
+    int rc = DXO_OK;
+    if (g->world > 1) {
+        rc = dxo_mgpu_all_gather(g, sigma, n_per_rank * d);
+        if (rc == DXO_OK) rc = dxo_mgpu_all_gather(g, dp, n_per_rank);
+        if (rc != DXO_OK) return rc;
+        if (gather == DXO_GATHER_FULL) return dxo_mgpu_all_gather(g, C_tang, n_per_rank * d * d);
+    }
+    if (!compact) return DXO_OK;
+    // 3. COMPACT: the tangent of EVERY block (own block included) from the gathered state, on each device's stream
+    //    behind its gathers: one launch over the full range, then the marks are cleared
     for (size_t i = 0; i < L; ++i) {
-        const size_t r = (size_t)g->rank[i], W = (size_t)g->world;
-        const size_t runs[2][2] = {{0, r * n}, {(r + 1) * n, W * n}};
-        for (const auto& run : runs) {
-            if (run[1] <= run[0]) continue;
-            rc = dxo_vm_expand_tangent(g->ctx[i], prm, d, (int64_t)(run[1] - run[0]), DXO_MEM_DEVICE, sigma[i] + run[0] * d, dp[i] + run[0],
-                                       C_tang[i] + run[0] * d * d);
-            if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
-        }
+        const int64_t all = (int64_t)((size_t)g->world * n);
+        rc = dxo_vm_expand_tangent(g->ctx[i], prm, d, all, DXO_MEM_DEVICE, sigma[i], dp[i], C_tang[i]);
+        if (rc == DXO_OK) rc = dxo_vm_clear_marks(g->ctx[i], all, dp[i]);
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
     }
     return DXO_OK;
 }

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void vm_point(VmConst c, int64_t n, cons
 #pragma unroll
         for (int k = 0; k < D; ++k) sigma[i * D + k] = sig[k];
         dp_out[i] = dp;
+        if (!C_tang) continue;   // (sigma, dp) only: the compact multi-GPU gather rebuilds every tangent from them
         double* Ct = C_tang + i * (D * D);
 #pragma unroll
         for (int r = 0; r < D; ++r)
@@ -133,7 +134,8 @@ __device__ __forceinline__ void vm_tile_unstage(int lane, double* X, double* Y, 
 }
 
 // ---- B + C: radial return of this lane's point, then output-ordered coalesced stores
-template <int D, bool NT, bool FULL>
+// WT = false: the tangent is not written (C_tang == NULL: a caller that rebuilds it from (sigma, dp), dxo_vm_expand_tangent)
+template <int D, bool NT, bool FULL, bool WT = true>
 __device__ __forceinline__ void vm_tile_finish(const VmConst& c, const double (&e)[D], const double (&sn)[D], double p_l, int64_t p0,
                                                int npts, int lane, double* X, double* Y, double* __restrict__ C_tang,
                                                double* __restrict__ sigma, double* __restrict__ dp_out) {
@@ -147,9 +149,9 @@ __device__ __forceinline__ void vm_tile_finish(const VmConst& c, const double (&
 #pragma unroll
     for (int k = 0; k < T::CH_VEC; ++k) {
         X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
-        Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+        if constexpr (WT) Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
     }
-    Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+    if constexpr (WT) Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
     wave_lds_fence();
 
     if (FULL || lane < npts) store8<NT>(dp_out + p0 + lane, dp);
@@ -159,11 +161,11 @@ __device__ __forceinline__ void vm_tile_finish(const VmConst& c, const double (&
         const int idx = k * DXO_WAVE + lane;
         if (FULL || idx < nvec) store16<NT>(g_o + idx, X2[idx]);
     }
-    vm_store_tangent<D, NT, FULL>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
+    if constexpr (WT) vm_store_tangent<D, NT, FULL>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
     wave_lds_fence();  // next tile overwrites X / Y
 }
 
-template <int D, bool NT, bool FULL>
+template <int D, bool NT, bool FULL, bool WT = true>
 __device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int npts, int lane, double* X, double* Y,
                                              const double* __restrict__ deps, const double* __restrict__ sigma_n,
                                              const double* __restrict__ p, double* __restrict__ C_tang,
@@ -173,10 +175,10 @@ __device__ __forceinline__ void vm_tile_body(const VmConst& c, int64_t p0, int n
     vm_tile_stage<D>(r, lane, X, Y);
     double e[D], sn[D];
     vm_tile_unstage<D>(lane, X, Y, e, sn);
-    vm_tile_finish<D, NT, FULL>(c, e, sn, r.p, p0, npts, lane, X, Y, C_tang, sigma, dp_out);
+    vm_tile_finish<D, NT, FULL, WT>(c, e, sn, r.p, p0, npts, lane, X, Y, C_tang, sigma, dp_out);
 }
 
-template <int D, bool NT>
+template <int D, bool NT, bool WT = true>
 __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst c, int64_t n, const double* __restrict__ deps,
                                                      const double* __restrict__ sigma_n,
                                                      const double* __restrict__ p, double* __restrict__ C_tang,
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VM_MIN_BLOCKS) void vm_tile(VmConst 
         const int64_t p0 = tile * T::PTS;
         const int npts = (n - p0 < T::PTS) ? (int)(n - p0) : T::PTS;  // wave-uniform
 #if DXO_VM_FULL_PATH
-        if (npts == T::PTS) vm_tile_body<D, NT, true>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
+        if (npts == T::PTS) vm_tile_body<D, NT, true, WT>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
         else
 #endif
-            vm_tile_body<D, NT, false>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
+            vm_tile_body<D, NT, false, WT>(c, p0, npts, lane, X, Y, deps, sigma_n, p, C_tang, sigma, dp_out);
     }
 }
 
@@ -231,7 +233,7 @@ int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, co
         // launch shape: the option when set; else the shape a calibration found best for the arena block written to
         // (dxo_vm_output_alloc); else one tile per wave
         int shape = L.shape;
-        if (shape < 0 && ctx->blocks_per_cu == 0 && !ctx->arena.empty()) shape = dxo_arena_tuned_shape(ctx, C_tang);
+        if (shape < 0 && ctx->blocks_per_cu == 0 && !ctx->arena.empty()) shape = dxo_arena_tuned_shape(ctx, C_tang ? (const void*)C_tang : (const void*)sigma);
         if (shape > 0) {
             const int64_t cap = (int64_t)ctx->compute_units * shape;
             const int64_t full = (n_tiles + DXO_BLOCK / DXO_WAVE - 1) / (DXO_BLOCK / DXO_WAVE);
@@ -241,7 +243,10 @@ int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, co
             grid = (int)(full > 0x7fffffff ? 0x7fffffff : full);
         }
         const bool nt = ctx->nontemporal != 0;
-        if (L.d == 4) {
+        if (!C_tang) {   // (sigma, dp) only
+            if (L.d == 4) hipLaunchKernelGGL((vm_tile<4, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            else          hipLaunchKernelGGL((vm_tile<6, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+        } else if (L.d == 4) {
             if (nt) hipLaunchKernelGGL((vm_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
             else    hipLaunchKernelGGL((vm_tile<4, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
         } else {
@@ -269,8 +274,10 @@ int vm_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const
 // and C_tang = C_elas - 3mu(3mu/(3mu+H) - beta) n(x)n - 2 mu beta dev as in demo_plasticity_von_mises.py:318-324.
 // Used by the multi-GPU gather (sharding.py): ranks exchange (sigma, dp) = (d+1) doubles per point over xGMI
 // instead of (d*d+d+1) and rebuild the tangent of the REMOTE blocks here at HBM speed. NaN propagates as in the
-// reference (sigma NaN or 0/0 -> every entry NaN); the one difference is the reference's 0/0 at f_el == 0
-// EXACTLY (:318), which leaves no trace in (sigma, dp) and comes out as C_elas.
+// reference (sigma NaN or 0/0 -> every entry NaN). The reference's 0/0 at f_el == 0 EXACTLY (:318) leaves no trace in the
+// VALUES of (sigma, dp): a producer run with option "vm_mark_indeterminate" (every compact gather sets it) returns
+// dp = -0.0 there, and the mark comes out as the reference's all-NaN tangent here, exactly as in vm_host.h. Without the
+// mark such a point is rebuilt as C_elas.
 template <int D>
 __device__ __forceinline__ void vm_tangent_state(const VmConst& c, const double (&sig)[D], double dp,
                                                  double (&nrm)[D], double& a, double& b) {
@@ -284,9 +291,10 @@ __device__ __forceinline__ void vm_tangent_state(const VmConst& c, const double 
     const double sigma_eq = sqrt(3.0 / 2.0 * ss);
     const double beta = c.mu3 * dp / (sigma_eq + c.mu3 * dp);
     const double ind = dp > 0.0 ? 1.0 : 0.0;
+    const bool marked = dp == 0.0 && __builtin_signbit(dp);   // the producer's mark for f_elastic == 0 (vm_core.h)
 #pragma unroll
     for (int i = 0; i < D; ++i) nrm[i] = s[i] / sigma_eq * ind;
-    a = c.mu3 * (c.ratio - beta);
+    a = marked ? __builtin_nan("") : c.mu3 * (c.ratio - beta);   // NaN * (n_i n_j) = NaN in every entry, as in the reference
     b = c.mu2 * beta;
 }
 
@@ -444,7 +452,8 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
     if (d != 4 && d != 6) return dxo_fail(ctx, DXO_E_DIM, "dxo_von_mises: d must be 4 or 6");
     if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises: n < 0");
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises: bad mem");
-    if (n > 0 && (!deps || !sigma_n || !p || !C_tang || !sigma || !dp))
+    // C_tang may be NULL on the device path: (sigma, dp) only, for callers that rebuild the tangent (dxo_vm_expand_tangent)
+    if (n > 0 && (!deps || !sigma_n || !p || (!C_tang && mem != DXO_MEM_DEVICE) || !sigma || !dp))
         return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises: NULL array");
     const uintptr_t all = (uintptr_t)deps | (uintptr_t)sigma_n | (uintptr_t)p | (uintptr_t)C_tang |
                           (uintptr_t)sigma | (uintptr_t)dp;
@@ -454,6 +463,7 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
         hipStream_t s = dxo_launch_stream(ctx);
         int rc = dxo_device_begin(ctx, s);
         if (rc != DXO_OK) return rc;
+        L.c.mark_indeterminate = ctx->vm_mark_indeterminate != 0;
         rc = vm_launch(ctx, L, n, deps, sigma_n, p, C_tang, sigma, dp, s);
         if (rc != DXO_OK) return rc;
         return dxo_device_end(ctx, s);
@@ -733,10 +743,38 @@ extern "C" int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, co
     return dxo_device_end(ctx, s);
 }
 
+// -0.0 -> +0.0 in dp: the producer's mark for the reference's 0/0 point (option "vm_mark_indeterminate") is consumed by
+// dxo_vm_expand_tangent; afterwards dp is the reference's +0 again. Reads 8 B/point, writes only marked points.
+__global__ __launch_bounds__(DXO_BLOCK) void vm_clear_marks(int64_t n, double* __restrict__ dp) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = dp[i];
+        if (v == 0.0 && __builtin_signbit(v)) dp[i] = 0.0;
+    }
+}
+
+extern "C" int dxo_vm_clear_marks(dxo_ctx* ctx, int64_t n, double* dp) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_clear_marks: n < 0");
+    if (n == 0) return DXO_OK;
+    if (!dp) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_clear_marks: dp is NULL");
+    if ((uintptr_t)dp & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_vm_clear_marks: dp must be 8-byte aligned");
+    hipStream_t s = dxo_launch_stream(ctx);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(vm_clear_marks, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, dp);
+    return dxo_device_end(ctx, s);
+}
+
 extern "C" int dxo_vm_state_commit(dxo_ctx* ctx, dxo_vm_state* st) {
     if (!ctx) return DXO_E_NULL;
     DXO_LOCK(ctx);
     if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_vm_state_commit: state is NULL");
+    if (st->n == 0) return DXO_OK;   // an empty partition (a rank without cells) has nothing to update: not an error
     if (!st->has_result)
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_vm_state_commit: no call since the last upload / commit — nothing to commit");
     int rc = dxo_vm_commit_state(ctx, st->d, st->n, st->p, st->dp, st->sigma_n, st->sigma);

@@ -22,9 +22,9 @@ def get_unrolled_dofmap(dofmap_list: np.ndarray, bs: int) -> np.ndarray:
     dofmap_list = np.asarray(dofmap_list)
     if dofmap_list.shape[0] == 0:
         return np.empty((0,), dtype=dofmap_list.dtype)
-    return (
-        np.repeat(dofmap_list, bs).reshape(dofmap_list.shape[0], -1) * bs + np.tile(np.arange(bs), dofmap_list.shape[1])
-    ).flatten()
+    # blocked node k owns the scalar dofs k*bs .. k*bs + bs - 1, in the node's position in its cell
+    components = np.arange(bs, dtype=dofmap_list.dtype)
+    return (dofmap_list[:, :, None] * bs + components).reshape(-1)
 
 
 class _Vector:

@@ -159,46 +159,65 @@ def remote_point_ranges(rank: int, world: int, points_per_rank: int) -> list[tup
     return [(b, e) for b, e in runs if e > b]
 
 
-def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None) -> None:
+def _check_full(C_tang_full, sigma_full, dp_full, world: int, d: int) -> int:
+    m = dp_full.numel() // world
+    if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
+        raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    return m
+
+
+def _rebuild_ranges(rank: int, world: int, m: int, identical: bool) -> list[tuple[int, int]]:
+    return [(0, world * m)] if identical and m > 0 else remote_point_ranges(rank, world, m)
+
+
+def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None, *, identical: bool = True,
+                             clear_marks=None) -> None:
     """Reassemble (C_tang, sigma, dp) on every rank while moving only (sigma, dp) over the links.
 
     xGMI, not HBM, bounds the reassembly: the full outputs are (d*d+d+1) doubles per point (344 B at d = 6), of
     which the tangent is d*d. The tangent is a function of the returned state (see dxo_vm_expand_tangent), so
     the ranks all-gather sigma and dp in place ((d+1) doubles, 56 B at d = 6: 6.1x fewer link bytes) and rebuild
-    the tangent of the remote blocks locally — read 56 B + write 288 B per remote point at HBM speed, ~4 ms for
-    7*10^7 points, against ~50 ms saved on the links at 8 GPUs.
+    the tangents locally — read 56 B + write 288 B per point at HBM speed, ~5 ms for 8*10^7 points, against ~50 ms
+    saved on the links at 8 GPUs.
 
-    The owner's block of `C_tang_full` (written by dxo_von_mises) is left untouched; remote blocks agree with what
-    their owners hold to rounding (tests/test_von_mises_gpu.py::test_expand_tangent_*).
+    `identical=True` (default): EVERY block's tangent is rebuilt, the rank's own included, in one launch over the whole
+    range — all ranks run the same arithmetic on the same gathered values, so the replicas of the coefficient vector are
+    bit-identical across ranks; the owner's kernel then need not write a tangent at all (dxo_von_mises with
+    C_tang = NULL). `identical=False`: only the remote blocks are rebuilt and the owner keeps the tangent its kernel
+    wrote (the replicas then agree to rounding, <= 1e-14 of the scale, not bit for bit).
+
+    The reference's 0/0 point (f_elastic == 0 exactly, demo_plasticity_von_mises.py:318: NaN tangent) leaves no trace in
+    the VALUES of (sigma, dp); a producer run with option "vm_mark_indeterminate" returns dp = -0.0 there, the rebuild
+    turns the mark into the reference's NaN tangent, and `clear_marks(dp_view, n_points)` (Context.vm_clear_marks) —
+    called on the whole dp array at the end when given — restores the reference's +0.
+
     `expand(sigma_view, dp_view, C_tang_view, n_points)` launches the rebuild for one contiguous run."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    m = dp_full.numel() // world
-    if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
-        raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    m = _check_full(C_tang_full, sigma_full, dp_full, world, d)
     all_gather_in_place(sigma_full, rank, group)
     all_gather_in_place(dp_full, rank, group)
-    for b, e in remote_point_ranges(rank, world, m):
+    for b, e in _rebuild_ranges(rank, world, m, identical):
         expand(sigma_full[b * d:e * d], dp_full[b:e], C_tang_full[b * d * d:e * d * d], e - b)
+    if clear_marks is not None and m > 0:
+        clear_marks(dp_full, world * m)
 
 
 def gather_von_mises_compact_pipelined(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, chunks: int = 4,
-                                       group=None) -> None:
+                                       group=None, *, identical: bool = True, clear_marks=None) -> None:
     """`gather_von_mises_compact` with the tangent rebuild overlapped with the link traffic (SURVEY.md 8e iii).
 
     Every rank's block of m points is cut into `chunks` pieces on 64-point borders. All pieces are put on the wire
     at once as asynchronous all-gathers (they queue on the collective stream in order); as soon as piece k of
-    (sigma, dp) has arrived from every rank, the remote tangents of piece k are rebuilt on the compute stream while
-    pieces k+1.. are still in flight. The rebuild (~4 ms per step at 8 GPUs) disappears behind the gather; the cost
+    (sigma, dp) has arrived from every rank, the tangents of piece k are rebuilt on the compute stream while
+    pieces k+1.. are still in flight. The rebuild (~5 ms per step at 8 GPUs) disappears behind the gather; the cost
     is `chunks` smaller collectives instead of one and, with the list form of all_gather, a staging copy inside the
-    backend. Same result as the unpipelined form, bit for bit."""
+    backend. Same result as the unpipelined form, bit for bit (`identical`, `clear_marks`: as there)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    m = dp_full.numel() // world
-    if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
-        raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    m = _check_full(C_tang_full, sigma_full, dp_full, world, d)
     if chunks < 1:
         raise ValueError("chunks >= 1 required")
     step = -(-m // chunks)
@@ -216,10 +235,12 @@ def gather_von_mises_compact_pipelined(C_tang_full, sigma_full, dp_full, rank: i
         ws.wait()
         wp.wait()
         for r in range(world):
-            if r == rank:
+            if r == rank and not identical:
                 continue
             lo, hi = r * m + b, r * m + e
             expand(sigma_full[lo * d:hi * d], dp_full[lo:hi], C_tang_full[lo * d * d:hi * d * d], hi - lo)
+    if clear_marks is not None and m > 0:
+        clear_marks(dp_full, world * m)
 
 
 def exchange_blocks_direct(full, rank: int, group=None) -> None:
@@ -246,19 +267,20 @@ def exchange_blocks_direct(full, rank: int, group=None) -> None:
         req.wait()
 
 
-def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None) -> None:
+def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None, *,
+                                    identical: bool = True, clear_marks=None) -> None:
     """`gather_von_mises_compact` with the exchange of (sigma, dp) as direct peer-to-peer sends / receives
-    (`exchange_blocks_direct`) instead of the backend's all-gather; the rebuild of the remote tangents is the same."""
+    (`exchange_blocks_direct`) instead of the backend's all-gather; the rebuild of the tangents is the same."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    m = dp_full.numel() // world
-    if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
-        raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    m = _check_full(C_tang_full, sigma_full, dp_full, world, d)
     exchange_blocks_direct(sigma_full, rank, group)
     exchange_blocks_direct(dp_full, rank, group)
-    for b, e in remote_point_ranges(rank, world, m):
+    for b, e in _rebuild_ranges(rank, world, m, identical):
         expand(sigma_full[b * d:e * d], dp_full[b:e], C_tang_full[b * d * d:e * d * d], e - b)
+    if clear_marks is not None and m > 0:
+        clear_marks(dp_full, world * m)
 
 
 __all__ = ["CellBlockPartition", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",

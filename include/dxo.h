@@ -113,7 +113,11 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0
- * point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode), "host_threads" (worker threads of that host half, default 32, capped by the CPUs the process may use: affinity mask and
+ *  point at f_el == 0 exactly is carried across in the sign bit of dp and comes out as NaN like in the copy mode),
+ * "vm_mark_indeterminate" (default 0; 1 = DXO_MEM_DEVICE von Mises calls return dp = -0.0 — numerically 0 — at a point
+ * with f_elastic == 0 EXACTLY, where the reference's n_elas is 0/0 and its tangent all NaN, demo_plasticity_von_mises.py:318,
+ * so that dxo_vm_expand_tangent can reproduce that NaN from (sigma, dp); dxo_vm_clear_marks turns the marks back into +0;
+ * the compact multi-GPU gathers set it themselves), "host_threads" (worker threads of that host half, default 32, capped by the CPUs the process may use: affinity mask and
  * cgroup CPU quota, minus two; DXO_HOST_CPU_BUDGET in the environment overrides the detection), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
  * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
@@ -195,7 +199,9 @@ int dxo_vm_output_alloc(dxo_ctx* ctx, int d, int64_t n, double** C_tang, double*
  *   deps     [n][d]   strain increment operand            (in)
  *   sigma_n  [n][d]   stress at the previous load step    (in; closure state, :347)
  *   p        [n]      cumulative plastic strain           (in; closure state, :348)
- *   C_tang   [n][d][d] consistent tangent                 (out)
+ *   C_tang   [n][d][d] consistent tangent                 (out; with DXO_MEM_DEVICE it may be NULL: only (sigma, dp)
+ *                                                          are written, 160 instead of 448 B/point at d = 6, for callers
+ *                                                          that rebuild the tangent with dxo_vm_expand_tangent)
  *   sigma    [n][d]   new stress                          (out)
  *   dp       [n]      plastic strain increment            (out)
  */
@@ -205,9 +211,14 @@ int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int 
 
 /* Consistent tangent rebuilt from the RETURNED state: C_tang[n][d][d] from sigma[n][d], dp[n] (same formulas,
  * demo_plasticity_von_mises.py:318-324, with s = dev sigma). The multi-GPU gather exchanges (sigma, dp) and rebuilds
- * the tangent of remote cell blocks with this entry point. Agrees with dxo_von_mises' C_tang to rounding. */
+ * every tangent with this entry point. Agrees with dxo_von_mises' C_tang to rounding (<= 1e-14 of its scale; elastic points
+ * bit for bit). A point whose dp is -0.0 (the producer's mark for the reference's 0/0 at f_elastic == 0, option
+ * "vm_mark_indeterminate") comes out all NaN like the reference's tangent; without the mark such a point is C_elas. */
 int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
                           const double* sigma, const double* dp, double* C_tang);
+/* dp[n] in DEVICE memory: every -0.0 (mark, see above) becomes +0.0, the value the reference holds there. Asynchronous on
+ * the ctx stream. */
+int dxo_vm_clear_marks(dxo_ctx* ctx, int64_t n, double* dp);
 
 /* History update at the end of a load step, DEVICE memory only (demo_plasticity_von_mises.py:564-565):
  *   p[n] += dp[n];  sigma_n[n][d] = sigma[n][d].   One fused pass, asynchronous on the ctx stream. */
@@ -456,10 +467,14 @@ int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, co
  * RCCL is loaded at the first dxo_mgpu_* call (dlopen librccl.so.1): DXO_E_NODEVICE if it is absent; RCCL errors are
  * returned as 10000 + ncclResult_t with the text in dxo_mgpu_last_error.
  * gather: DXO_GATHER_NONE (outputs are block-length arrays, no exchange), DXO_GATHER_FULL (all-gather of C_tang,
- * sigma, dp: (d*d+d+1) doubles per point per peer), DXO_GATHER_COMPACT (all-gather of sigma and dp only, then the
- * tangents of the REMOTE blocks are rebuilt on each GPU with dxo_vm_expand_tangent: 6.1x fewer link bytes at d = 6;
- * remote tangents agree with the owner's to rounding, see dxo_vm_expand_tangent). n_per_rank must be even with a
- * gather (16-byte aligned blocks); pad the last block as sharding.CellBlockPartition does. */
+ * sigma, dp: (d*d+d+1) doubles per point per peer), DXO_GATHER_COMPACT (the kernel writes (sigma, dp) only, those are
+ * all-gathered, and EVERY block's tangent — the rank's own too — is rebuilt on each GPU with dxo_vm_expand_tangent:
+ * 6.1x fewer link bytes at d = 6; all ranks run the same rebuild on the same gathered values, so the replicas are
+ * bit-identical across ranks; they agree with DXO_GATHER_FULL's tangents to rounding, see dxo_vm_expand_tangent, and the
+ * reference's NaN tangent at f_elastic == 0 is reproduced on every rank through the dp = -0.0 mark, which is cleared
+ * before the call returns). n_per_rank must be even with a gather (16-byte aligned blocks); pad the last block as
+ * sharding.CellBlockPartition does. Buffers handed to a collective must be hipMalloc memory: the group's contexts have
+ * "placement_vmm" = 0 and the collectives return DXO_E_MEM for a pointer inside a chunk-backed arena block. */
 #define DXO_MGPU_ID_BYTES 128
 #define DXO_GATHER_NONE 0
 #define DXO_GATHER_FULL 1

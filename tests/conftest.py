@@ -62,6 +62,28 @@ def vm_inputs(n, d, seed, plastic_scale=1.0):
     return deps, sigma_n, p
 
 
+def vm_indeterminate_sigma0(evaluate, d, a=384.0, span=16):
+    """A yield stress that puts the uniaxial state sigma_n = (a, 0, ...), deps = 0, p = 0 EXACTLY on the yield surface in
+    the arithmetic of `evaluate`: f_elastic = sigma_eq - sigma_0 == 0, where the reference's n_elas is 0/0 and its
+    tangent all NaN (demo_plasticity_von_mises.py:318). sigma_eq is |a| up to a few roundings that depend on the
+    operation order (dense mat-vecs in the oracle, sparse + FMA in the kernel), so the neighbours of |a| are tried.
+    `evaluate(deps, sigma_n, p, sigma_0) -> (C_tang, sigma, dp)` on (1, d) inputs. Returns (sigma_0, sigma_n_row)."""
+    sn = np.zeros((1, d))
+    sn[0, 0] = a
+    cand = [a]
+    lo = hi = a
+    for _ in range(span):
+        lo, hi = np.nextafter(lo, -np.inf), np.nextafter(hi, np.inf)
+        cand += [lo, hi]
+    for s0 in cand:
+        with np.errstate(all="ignore"):
+            C, s, dp = evaluate(np.zeros((1, d)), sn, np.zeros(1), float(s0))
+        C, s, dp = np.asarray(C).reshape(-1), np.asarray(s).reshape(-1), np.asarray(dp).reshape(-1)
+        if np.isnan(C).all() and np.isfinite(s).all() and dp[0] == 0.0:
+            return float(s0), sn[0].copy()
+    raise AssertionError("no yield stress within the searched neighbourhood makes f_elastic == 0 exactly")
+
+
 def assert_close_scaled(actual, expected, rtol, what=""):
     """max |a-b| <= rtol * max|b| over finite entries, and identical NaN pattern."""
     actual = np.asarray(actual).reshape(-1)

@@ -1,0 +1,191 @@
+"""Round-3 additions on the GPU: the reference's 0/0 point carried through the compact (sigma, dp) exchange, the
+(sigma, dp)-only form of the von Mises kernel, bit-identical replicas of the compact gather, RCCL buffers refused when
+they lie in chunk-backed arena blocks, empty partitions in the resident-state update."""
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, vm_indeterminate_sigma0, vm_inputs
+from dolfinx_external_operator_amd import MEM_DEVICE, VmParams
+from dolfinx_external_operator_amd._lib import DxoError
+
+pytestmark = pytest.mark.gpu
+
+E, NU = 70e3, 0.3
+H = E * (E / 100.0) / (E - E / 100.0)
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _kernel_eval(ctx, d):
+    """(deps, sigma_n, p, sigma_0) -> (C_tang, sigma, dp) through dxo_von_mises on device memory."""
+    import torch
+
+    def run(deps, sigma_n, p, sigma_0, C_null=False):
+        n = len(p)
+        t = [_dev(a) for a in (deps, sigma_n, p)]
+        C = torch.full((n * d * d,), 7.0, dtype=torch.float64, device="cuda:0")
+        s = torch.empty(n * d, dtype=torch.float64, device="cuda:0")
+        dp = torch.empty(n, dtype=torch.float64, device="cuda:0")
+        ctx.von_mises(VmParams(E, NU, sigma_0, H), d, n, MEM_DEVICE, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                      None if C_null else C.data_ptr(), s.data_ptr(), dp.data_ptr())
+        ctx.synchronize()
+        return C.cpu().numpy().reshape(n, d, d), s.cpu().numpy().reshape(n, d), dp.cpu().numpy()
+
+    return run
+
+
+def _batch_with_indeterminate_points(ctx, d, n, seed, where):
+    run = _kernel_eval(ctx, d)
+    sigma_0, sn_row = vm_indeterminate_sigma0(run, d)
+    deps, sigma_n, p = vm_inputs(n, d, seed=seed)
+    for i in where:
+        deps[i], sigma_n[i], p[i] = 0.0, sn_row, 0.0
+    return run, sigma_0, deps, sigma_n, p
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_indeterminate_point_is_marked_rebuilt_as_nan_and_cleared(ctx, d):
+    """f_elastic == 0 exactly: the reference's n_elas is 0/0 and its tangent NaN (demo_plasticity_von_mises.py:318). The
+    kernel's own tangent is NaN there; with option vm_mark_indeterminate the point's dp is -0.0, dxo_vm_expand_tangent
+    turns the mark into the same NaN tangent, dxo_vm_clear_marks restores +0."""
+    import torch
+
+    n, where = 1000, (0, 63, 64, 517, 999)
+    run, sigma_0, deps, sigma_n, p = _batch_with_indeterminate_points(ctx, d, n, 31, where)
+    prm = VmParams(E, NU, sigma_0, H)
+    C0, s0, dp0 = run(deps, sigma_n, p, sigma_0)
+    for i in where:
+        assert np.isnan(C0[i]).all() and np.isfinite(s0[i]).all() and dp0[i] == 0.0 and not np.signbit(dp0[i])
+    assert not np.signbit(dp0).any()
+    ctx.set_option("vm_mark_indeterminate", 1)
+    try:
+        C1, s1, dp1 = run(deps, sigma_n, p, sigma_0)
+        _, s2, dp2 = run(deps, sigma_n, p, sigma_0, C_null=True)      # the (sigma, dp)-only kernel carries the same mark
+    finally:
+        ctx.set_option("vm_mark_indeterminate", 0)
+    assert np.array_equal(C1, C0, equal_nan=True) and np.array_equal(s1, s0) and np.array_equal(dp1, dp0)   # -0.0 == 0.0
+    assert sorted(np.flatnonzero(np.signbit(dp1))) == sorted(where)
+    assert np.array_equal(s2, s0) and np.array_equal(dp2, dp1) and np.array_equal(np.signbit(dp2), np.signbit(dp1))
+    # rebuild from the marked state: NaN exactly where the kernel's own tangent is NaN, equal to rounding elsewhere
+    for variant in (1, 0):
+        ctx.set_option("vm_variant", variant)
+        try:
+            ts, tdp = _dev(s1.reshape(-1)), _dev(dp1)
+            Cx = torch.zeros(n * d * d, dtype=torch.float64, device="cuda:0")
+            ctx.vm_expand_tangent(prm, d, n, MEM_DEVICE, ts.data_ptr(), tdp.data_ptr(), Cx.data_ptr())
+            ctx.vm_clear_marks(n, tdp.data_ptr())
+            ctx.synchronize()
+        finally:
+            ctx.set_option("vm_variant", 1)
+        assert_close_scaled(Cx.cpu().numpy(), C0, 1e-13, f"rebuilt tangent, variant {variant}")
+        back = tdp.cpu().numpy()
+        assert not np.signbit(back).any() and np.array_equal(back, dp0)
+    # without the mark the point leaves no trace in (sigma, dp): it is rebuilt as C_elas (documented)
+    ts, tdp = _dev(s0.reshape(-1)), _dev(dp0)
+    Cx = torch.zeros(n * d * d, dtype=torch.float64, device="cuda:0")
+    ctx.vm_expand_tangent(prm, d, n, MEM_DEVICE, ts.data_ptr(), tdp.data_ptr(), Cx.data_ptr())
+    ctx.synchronize()
+    assert np.isfinite(Cx.cpu().numpy().reshape(n, d, d)[list(where)]).all()
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 100_001])
+def test_state_only_kernel_matches_the_full_kernel(ctx, n, d=6):
+    """C_tang = NULL on the device path: (sigma, dp) bit-identical to the full call, the tangent array is never touched;
+    on the host path a NULL tangent stays an error."""
+    run = _kernel_eval(ctx, d)
+    deps, sigma_n, p = vm_inputs(n, d, seed=5)
+    C, s, dp = run(deps, sigma_n, p, 250.0)
+    Cn, sn, dpn = run(deps, sigma_n, p, 250.0, C_null=True)
+    assert np.array_equal(s, sn) and np.array_equal(dp, dpn)
+    assert np.all(Cn == 7.0) and not np.all(C == 7.0)
+    for variant in (0,):
+        ctx.set_option("vm_variant", variant)
+        try:
+            _, s0, dp0 = run(deps, sigma_n, p, 250.0, C_null=True)
+        finally:
+            ctx.set_option("vm_variant", 1)
+        assert_close_scaled(s0, s, 1e-13, "sigma, lane-per-point kernel")
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    out_s, out_dp = np.empty(n * d), np.empty(n)
+    with pytest.raises((DxoError, ValueError)):
+        ctx.von_mises(VmParams(E, NU, 250.0, H), d, n, MEM_HOST, deps, sigma_n, p, None, out_s, out_dp)
+
+
+@pytest.mark.parametrize("form", ["single_process", "rank"])
+def test_mgpu_compact_reproduces_the_nan_tangent_and_clears_the_marks(ctx, form, d=6):
+    """dxo_mgpu_von_mises, world of one: COMPACT = (sigma, dp)-only kernel + rebuild of every block (here: the only one) +
+    clear marks. Its result equals FULL's to rounding with the same NaN pattern, dp is +0 at the marked points."""
+    import torch
+
+    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_FULL, MultiGpu
+
+    n, where = 6400, (5, 64, 6399)
+    _, sigma_0, deps, sigma_n, p = _batch_with_indeterminate_points(ctx, d, n, 32, where)
+    prm = VmParams(E, NU, sigma_0, H)
+    g = MultiGpu(devices=[0]) if form == "single_process" else MultiGpu.from_rank(ctx, MultiGpu.unique_id(), 0, 1)
+    try:
+        g.set_stream(0, torch.cuda.current_stream().cuda_stream)
+        t_in = [_dev(a) for a in (deps, sigma_n, p)]
+        res = {}
+        for gather in (GATHER_FULL, GATHER_COMPACT):
+            C = torch.full((n * d * d,), 3.0, dtype=torch.float64, device="cuda:0")
+            s = torch.full((n * d,), float("nan"), dtype=torch.float64, device="cuda:0")
+            dp = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda:0")
+            g.von_mises(prm, d, n, gather, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s], [dp])
+            g.synchronize()
+            res[gather] = (C.cpu().numpy().reshape(n, d, d), s.cpu().numpy(), dp.cpu().numpy())
+        Cf, sf, dpf = res[GATHER_FULL]
+        Cc, sc, dpc = res[GATHER_COMPACT]
+        for i in where:
+            assert np.isnan(Cf[i]).all() and np.isnan(Cc[i]).all()
+        assert_close_scaled(Cc, Cf, 1e-13, "compact vs full tangent (NaN pattern included)")
+        assert np.array_equal(sc, sf) and np.array_equal(dpc, dpf)
+        assert not np.signbit(dpc).any() and not np.signbit(dpf).any()
+        assert int(g.ctx_option(0, "vm_mark_indeterminate")) == 0          # the call restores the caller's option
+        assert int(g.ctx_option(0, "placement_vmm")) == 0                  # arena blocks of a group are hipMalloc memory
+    finally:
+        g.close()
+
+
+def test_collectives_refuse_chunk_backed_arena_blocks(hip_library):
+    """A virtual range backed by 2 MB physical chunks is accessible from its own device only and cannot be exported to a
+    peer: dxo_mgpu_all_gather returns DXO_E_MEM for a pointer inside such an arena block instead of handing it to RCCL."""
+    import torch
+
+    from dolfinx_external_operator_amd import MultiGpu
+
+    g = MultiGpu(devices=[0])
+    try:
+        g.set_stream(0, torch.cuda.current_stream().cuda_stream)
+        g.set_option("placement_vmm", 2)            # the user overrides the group's default: chunk-backed candidates only
+        g.set_option("placement_candidates", 2)
+        g.set_option("placement_min_bytes", 1 << 22)
+        c = g.context(0)
+        (buf,) = c.output_tensors([1 << 20])         # 8 MiB > placement_min_bytes: calibrated, chunk-backed
+        info = buf.dxo_block.info
+        assert info["mode"] == 2 and info["vmm_mask"] != 0 and (info["vmm_mask"] >> info["chosen"]) & 1
+        with pytest.raises(ValueError, match="chunk"):
+            g.all_gather([buf], 1 << 20)
+        plain = torch.zeros(1024, dtype=torch.float64, device="cuda:0")
+        g.all_gather([plain], 1024)
+        g.synchronize()
+        del buf
+    finally:
+        g.close()
+
+
+def test_resident_state_commit_on_an_empty_partition(ctx):
+    """A rank without cells (the reference handles an empty partition, external_operator.py:365-371): upload, call and
+    the load-step update are no-ops, not errors."""
+    st = ctx.vm_state(6, 0)
+    empty = np.empty(0)
+    st.upload(empty, empty)
+    st.call(VmParams(E, NU, 250.0, H), MEM_DEVICE, None, None)
+    st.commit()
+    st.commit()
+    st.close()

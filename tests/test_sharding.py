@@ -89,8 +89,9 @@ def test_two_rank_gloo_gather_reassembles_the_flat_coefficient_vectors(oracle, n
 
 
 def numpy_expand_tangent(sigma, dp, d, E=70e3, nu=0.3):
-    """NumPy statement of the tangent-from-state formulas (dxo_vm_expand_tangent): stand-in for the HIP rebuild
-    kernel in the CPU-only gather test, itself checked against the oracle's tangent below."""
+    """NumPy statement of the tangent-from-state formulas (dxo_vm_expand_tangent), the dp = -0.0 mark of the reference's
+    0/0 point included: stand-in for the HIP rebuild kernel in the CPU-only gather test, itself checked against the
+    oracle's tangent below."""
     lmbda, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
     Et = E / 100.0
     H = E * Et / (E - Et)
@@ -105,6 +106,7 @@ def numpy_expand_tangent(sigma, dp, d, E=70e3, nu=0.3):
         beta = 3 * mu * dp / (seq + 3 * mu * dp)
         n = s / seq[:, None] * (dp > 0)[:, None]
     a = 3 * mu * (3 * mu / (3 * mu + H) - beta)
+    a = np.where((dp == 0.0) & np.signbit(dp), np.nan, a)     # the producer's mark -> the reference's NaN tangent
     return C_el[None] - a[:, None, None] * n[:, :, None] * n[:, None, :] - (2 * mu * beta)[:, None, None] * dev[None]
 
 
@@ -120,12 +122,15 @@ def test_numpy_expand_matches_oracle_tangent(oracle):
         assert_close_scaled(numpy_expand_tangent(s, dp, d), C, 1e-13, f"tangent from state d={d}")
 
 
-def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
+def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0, identical=True):
+    import hashlib
+
     import torch
     import torch.distributed as dist
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import vm_indeterminate_sigma0
     from dolfinx_external_operator_amd.sharding import (CellBlockPartition, gather_von_mises_compact, gather_von_mises_compact_direct,
                                                         gather_von_mises_compact_pipelined, remote_point_ranges)
     from oracle import load_oracle
@@ -134,22 +139,33 @@ def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        o = load_oracle()
         rng = np.random.Generator(np.random.PCG64(6))
         n = num_cells * nq
         deps = rng.normal(0, 3e-3, (n, d))
         sigma_n = rng.normal(0, 100.0, (n, d))
         p = np.abs(rng.normal(0, 1e-3, n))
+        # one point per rank block sits EXACTLY on the yield surface (f_elastic == 0): the reference's 0/0, NaN tangent (:318)
+        sigma_0, sn_row = vm_indeterminate_sigma0(lambda e, s_, p_, s0: o.von_mises(e, s_, p_, sigma_0=s0), d)
         part = CellBlockPartition(num_cells, nq, world)
         m = part.points_per_rank
-        o = load_oracle()
+        special = [b + 3 for b, e in (part.point_range(r) for r in range(world)) if e - b > 3]
+        for i in special:
+            deps[i], sigma_n[i], p[i] = 0.0, sn_row, 0.0
         with np.errstate(all="ignore"):
             C, s, dp = o.von_mises(part.local_input(deps, rank, d).reshape(-1, d),
-                                   part.local_input(sigma_n, rank, d).reshape(-1, d), part.local_input(p, rank, 1))
-        # the owner writes its block straight into the full-length buffers, as bench.py does on the GPU
+                                   part.local_input(sigma_n, rank, d).reshape(-1, d), part.local_input(p, rank, 1), sigma_0=sigma_0)
+        # what the kernel does with option vm_mark_indeterminate = 1 (vm_core.h): dp = -0.0 where f_elastic == 0 exactly
+        # (seen here as: tangent NaN, stress finite, dp == 0)
+        marked = np.isnan(C.reshape(len(dp), -1)).all(axis=1) & np.isfinite(s.reshape(len(dp), -1)).all(axis=1) & (dp == 0.0)
+        dp = np.where(marked, -0.0, dp)
+        # the owner writes its block straight into the full-length buffers, as bench.py does on the GPU; with `identical`
+        # its kernel writes no tangent at all (dxo_von_mises with C_tang = NULL)
         Cf = torch.full((world * m * d * d,), float("nan"), dtype=torch.float64)
         sf = torch.full((world * m * d,), float("nan"), dtype=torch.float64)
         dpf = torch.full((world * m,), float("nan"), dtype=torch.float64)
-        Cf[rank * m * d * d:(rank + 1) * m * d * d] = torch.from_numpy(C.reshape(-1))
+        if not identical:
+            Cf[rank * m * d * d:(rank + 1) * m * d * d] = torch.from_numpy(C.reshape(-1))
         sf[rank * m * d:(rank + 1) * m * d] = torch.from_numpy(s.reshape(-1))
         dpf[rank * m:(rank + 1) * m] = torch.from_numpy(dp)
         calls = []
@@ -159,23 +175,36 @@ def _worker_compact(rank, world, port, num_cells, nq, d, ret, pipelined=0):
             with np.errstate(all="ignore"):
                 Cv.copy_(torch.from_numpy(numpy_expand_tangent(sv.numpy(), dv.numpy(), d).reshape(-1)))
 
+        def clear_marks(dv, npts):
+            a = dv.numpy()[:npts]
+            a[(a == 0.0) & np.signbit(a)] = 0.0
+
+        kw = dict(identical=identical, clear_marks=clear_marks)
         if pipelined < 0:       # the direct peer-to-peer form of the exchange
-            gather_von_mises_compact_direct(Cf, sf, dpf, rank, d, expand)
+            gather_von_mises_compact_direct(Cf, sf, dpf, rank, d, expand, **kw)
         elif pipelined:
-            gather_von_mises_compact_pipelined(Cf, sf, dpf, rank, d, expand, chunks=pipelined)
+            gather_von_mises_compact_pipelined(Cf, sf, dpf, rank, d, expand, chunks=pipelined, **kw)
         else:
-            gather_von_mises_compact(Cf, sf, dpf, rank, d, expand)
+            gather_von_mises_compact(Cf, sf, dpf, rank, d, expand, **kw)
         with np.errstate(all="ignore"):
-            Cw, sw, dpw = o.von_mises(deps, sigma_n, p)
-        scale = np.abs(Cw).max()
+            Cw, sw, dpw = o.von_mises(deps, sigma_n, p, sigma_0=sigma_0)
+        scale = np.nanmax(np.abs(Cw))
         gC = part.trim(Cf, d * d).numpy()
+        gdp = part.trim(dpf, 1).numpy()
         own_b, own_e = part.point_range(rank)
-        ok = np.array_equal(part.trim(sf, d).numpy(), sw.reshape(-1)) and np.array_equal(part.trim(dpf, 1).numpy(), dpw)
-        ok = ok and np.array_equal(gC[own_b * d * d:own_e * d * d], Cw.reshape(-1)[own_b * d * d:own_e * d * d])  # untouched
-        ok = ok and np.max(np.abs(gC - Cw.reshape(-1))) <= 1e-13 * scale
-        ok = ok and sum(calls) == (world - 1) * m
-        ok = ok and (pipelined > 0 or len(calls) == len(remote_point_ranges(rank, world, m)))
-        ret[rank] = bool(ok)
+        ok = np.array_equal(part.trim(sf, d).numpy(), sw.reshape(-1)) and np.array_equal(gdp, dpw)
+        ok = ok and not np.signbit(gdp).any()                                      # marks cleared: the reference holds +0 there
+        if not identical:   # the owner's block is the kernel's own tangent, untouched
+            ok = ok and np.array_equal(gC[own_b * d * d:own_e * d * d], Cw.reshape(-1)[own_b * d * d:own_e * d * d], equal_nan=True)
+        # NaN pattern of the whole gathered tangent == the reference's (the f_elastic == 0 points of EVERY block, remote ones included)
+        nan_ref = np.isnan(Cw.reshape(-1))
+        ok = ok and len(special) > 0 and all(np.isnan(Cw[i]).all() for i in special)
+        ok = ok and np.array_equal(np.isnan(gC), nan_ref)
+        ok = ok and np.max(np.abs(gC[~nan_ref] - Cw.reshape(-1)[~nan_ref])) <= 1e-13 * scale
+        ok = ok and sum(calls) == (world if identical else world - 1) * m
+        ok = ok and (pipelined > 0 or len(calls) == (1 if identical else len(remote_point_ranges(rank, world, m))))
+        digest = hashlib.sha256(Cf.numpy().tobytes() + sf.numpy().tobytes() + dpf.numpy().tobytes()).hexdigest()
+        ret[rank] = (bool(ok), digest)
     finally:
         dist.destroy_process_group()
 
@@ -191,9 +220,14 @@ def test_remote_point_ranges():
         remote_point_ranges(4, 4, 64)
 
 
-@pytest.mark.parametrize("num_cells,nq,d,world,pipelined", [(101, 8, 6, 2, 0), (50, 3, 4, 3, 0), (101, 8, 6, 2, 3), (70, 8, 4, 3, 5),
-                                                            (101, 8, 6, 2, -1), (50, 3, 4, 3, -1), (64, 8, 6, 4, -1)])
-def test_gloo_compact_gather_rebuilds_remote_tangents(oracle, num_cells, nq, d, world, pipelined):
+@pytest.mark.parametrize("num_cells,nq,d,world,pipelined,identical", [
+    (101, 8, 6, 2, 0, True), (50, 3, 4, 3, 0, True), (101, 8, 6, 2, 3, True), (70, 8, 4, 3, 5, True),
+    (101, 8, 6, 2, -1, True), (50, 3, 4, 3, -1, True), (64, 8, 6, 4, -1, True),
+    (101, 8, 6, 2, 0, False), (70, 8, 4, 3, 5, False), (50, 3, 4, 3, -1, False)])
+def test_gloo_compact_gather_rebuilds_tangents_nan_exact_and_replica_identical(oracle, num_cells, nq, d, world, pipelined, identical):
+    """(sigma, dp) over the wire, tangents rebuilt locally: every rank must end with the reference's whole-range result —
+    the NaN tangent at the f_elastic == 0 point of every block included (carried by the dp = -0.0 mark) — and, with
+    `identical`, with the same BYTES on every rank."""
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
@@ -201,10 +235,13 @@ def test_gloo_compact_gather_rebuilds_remote_tangents(oracle, num_cells, nq, d, 
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker_compact, args=(r, world, port, num_cells, nq, d, ret, pipelined)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_compact, args=(r, world, port, num_cells, nq, d, ret, pipelined, identical)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
         pr.join(timeout=180)
         assert pr.exitcode == 0
-    assert dict(ret) == {r: True for r in range(world)}
+    got = dict(ret)
+    assert {r: v[0] for r, v in got.items()} == {r: True for r in range(world)}
+    if identical:
+        assert len({v[1] for v in got.values()}) == 1, "replicas differ between ranks"
