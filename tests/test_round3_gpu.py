@@ -168,7 +168,7 @@ def test_collectives_refuse_chunk_backed_arena_blocks(hip_library):
         c = g.context(0)
         (buf,) = c.output_tensors([1 << 20])         # 8 MiB > placement_min_bytes: calibrated, chunk-backed
         info = buf.dxo_block.info
-        assert info["mode"] == 2 and info["vmm_mask"] != 0 and (info["vmm_mask"] >> info["chosen"]) & 1
+        assert info["mode"] == "candidates" and info["chosen_kind"] == "2MB_chunks"
         with pytest.raises(ValueError, match="chunk"):
             g.all_gather([buf], 1 << 20)
         plain = torch.zeros(1024, dtype=torch.float64, device="cuda:0")
