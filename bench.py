@@ -331,6 +331,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (BASELINE configs 4 and 5, the reference's d = 4 layout, the fused operand + "
+                         "return-map kernel: tools/bench_secondary.py)")
+    ap.add_argument("--secondary-points", type=int, default=10_000_000)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
@@ -604,6 +608,11 @@ def main():
             result["end_to_end"] = end_to_end(ctx, prm, d)
         if extras and world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
+        if extras and world == 1 and not args.no_secondary:
+            # the other BASELINE configs, each with its own roofline and cpu_baseline (never `value`)
+            from tools.bench_secondary import secondary_block
+
+            result["secondary"] = secondary_block(torch, ctx, stream, prm, n=args.secondary_points, cpu=not args.no_cpu)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
 
     # the other gather modes, same protocol, reported beside the headline (never as `value`). They are comparison figures:

@@ -14,7 +14,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from conftest import mc_tracing_inputs  # noqa: E402
+from tools.mc_inputs import mc_tracing_inputs  # noqa: E402
 from dolfinx_external_operator_amd import MEM_DEVICE, Context, McParams  # noqa: E402
 from oracle import load_oracle  # noqa: E402  (input generation only: states after k tracing loads)
 

@@ -1,0 +1,46 @@
+#!/bin/bash
+# One gpurun call that produces every file profiles/ needs for a round (GPU box, repo root):
+#   bash scripts/profile_round.sh <tag> [quick]
+#     bench.json                 the default `python3 bench.py` line (headline + end_to_end + cpu_baseline + secondary)
+#     stats/                     rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-probe --no-e2e` (headline AND
+#                                secondary kernels: vm_tile, mc_classify / mc_newton, icnn_mfma, vm_field, ...)
+#     prof_fetch/, prof_write/   HBM counters of the headline kernel, separate --pmc passes (--no-secondary)
+#     mc_*/ icnn_*/ field_*/     counter passes of the secondary kernels (skipped with `quick`)
+# then scripts/summarize_round.py writes the text / JSON summaries next to them; copy those into profiles/.
+set -u
+TAG=${1:-r03}
+QUICK=${2:-}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1 || { echo BUILD FAILED; tail -30 "$OUT/build.log"; exit 1; }
+timeout 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
+if [ -z "$QUICK" ]; then
+  pass() {  # dir, script + args..., -- counters...
+    local name=$1; shift
+    local cmd=(); while [ "$1" != "--" ]; do cmd+=("$1"); shift; done; shift
+    timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o k -- python3 "${cmd[@]}" > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
+  }
+  MC="scripts/bench_mc.py --launches 2"
+  pass mc_valu $MC -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES
+  pass mc_wave $MC -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+  pass mc_fetch $MC -- FETCH_SIZE
+  pass mc_write $MC -- WRITE_SIZE
+  IC="scripts/bench_icnn.py --launches 2"
+  pass icnn_p1 $IC -- SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_VALU
+  pass icnn_p2 $IC -- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
+  pass icnn_p3 $IC -- SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
+  OP="scripts/bench_operand.py --launches 2 --case 0 --operand-cell 0"
+  pass field_fetch $OP -- FETCH_SIZE
+  pass field_write $OP -- WRITE_SIZE
+  pass field_sq1 $OP -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES
+  pass field_sq2 $OP -- SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE
+  pass field_tcc $OP -- TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+fi
+python3 scripts/summarize_round.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"
+find "$OUT" -name "*.db" -delete
+find "$OUT" -name "*_agent_info.csv" -delete
+du -sh "$OUT"

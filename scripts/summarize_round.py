@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Turn the raw output of scripts/profile_round.sh into the small files that go under profiles/:
+  <tag>_bench_n1.json            the default bench line
+  <tag>_kernel_stats.csv         rocprofv3 --stats rows of the library's kernels (name, calls, total / average / min / max ns)
+  <tag>_pmc_summary.txt          HBM counters of the headline kernel + traffic.json
+  <tag>_mc_pmc.json, mc_flop.json   Mohr-Coulomb counters; flop per plastic point for bench.py's secondary roofline
+  <tag>_icnn_pmc.json, <tag>_field_pmc.json
+usage: summarize_round.py gpurun_out/<tag> <tag>"""
+import collections
+import csv
+import json
+import pathlib
+import subprocess
+import sys
+
+out, tag = pathlib.Path(sys.argv[1]), sys.argv[2]
+ours = ("vm_", "mc_", "icnn_", "isihara", "heat_", "operand_", "adjoint", "node_sum", "assign", "stream_probe", "cond_", "sweep")
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "")
+
+
+# ---- kernel stats
+rows = []
+for f in (out / "stats").rglob("*kernel_stats.csv"):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            n = short(r["Name"])
+            if any(k in n for k in ours):
+                rows.append((n[:100], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"])))
+rows.sort(key=lambda r: -r[2])
+if rows:
+    with open(out / f"{tag}_kernel_stats.csv", "w") as fh:
+        fh.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
+        for r in rows:
+            fh.write(f"\"{r[0]}\",{r[1]},{r[2]:.0f},{r[3]:.1f},{r[4]:.0f},{r[5]:.0f}\n")
+    print("== kernel stats (rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-probe --no-e2e`)")
+    for r in rows[:14]:
+        print(f"  {r[0][:70]:70s} calls {r[1]:4d}  avg {r[3] / 1e3:9.1f} us")
+bj = out / "bench.json"
+if bj.exists() and bj.read_text().strip():
+    (out / f"{tag}_bench_n1.json").write_text(bj.read_text())
+    b = json.loads(bj.read_text())
+    print(f"== bench: value {b['value']:.4g} qp/s, ms/step {b['ms_per_step']:.4f}, frac {b['roofline']['frac']:.4f}, kernel_ms_avg {b['roofline']['kernel_ms_avg']:.4f}")
+
+# ---- headline HBM counters (the round-1 script does the arithmetic)
+res = subprocess.run([sys.executable, str(pathlib.Path(__file__).with_name("summarize_pmc.py")), str(out), "--json", str(out / "traffic.json")],
+                     capture_output=True, text=True)
+(out / f"{tag}_pmc_summary.txt").write_text(res.stdout + res.stderr)
+print("== headline HBM counters\n" + res.stdout)
+
+
+def counters(dirs, match):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in (out / d).rglob("*counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    key = match(short(r["Kernel_Name"]))
+                    if key:
+                        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+# ---- Mohr-Coulomb
+mc = counters(["mc_valu", "mc_wave", "mc_fetch", "mc_write"],
+              lambda n: "mc_newton" if "mc_newton" in n else "mc_classify" if "mc_classify" in n else None)
+if mc:
+    bench = None
+    log = out / "mc_valu.log"
+    for line in (log.read_text().splitlines() if log.exists() else []):
+        if line.startswith("{"):
+            bench = json.loads(line)
+    derived = {}
+    for k, c in mc.items():
+        if "SQ_INSTS_VALU_FMA_F64" in c:
+            derived[k + "_fp64_flop_per_launch"] = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"])
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            derived[k + "_hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+    rec = {"counters": mc, "derived": derived, "bench_under_profiler": bench,
+           "note": "flop = (ADD + MUL + 2 FMA wave-instructions) x 64 lanes, masked lanes counted; FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+    (out / f"{tag}_mc_pmc.json").write_text(json.dumps(rec, indent=1))
+    if bench and "mc_newton_fp64_flop_per_launch" in derived:
+        n, pl = bench["n"], bench["plastic_fraction"]
+        flop = {"flop_per_plastic_point": derived["mc_newton_fp64_flop_per_launch"] / (n * pl),
+                "flop_per_point_classify": derived.get("mc_classify_fp64_flop_per_launch", 0.0) / n,
+                "measured": f"{tag}: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 around scripts/bench_mc.py, {n} points, plastic fraction {pl:.4f}; "
+                            "masked lanes counted (upper bound on useful flop)"}
+        (out / "mc_flop.json").write_text(json.dumps(flop, indent=1))
+        print("== Mohr-Coulomb:", json.dumps(derived), json.dumps(flop))
+
+# ---- ICNN
+ic = counters(["icnn_p1", "icnn_p2", "icnn_p3"], lambda n: "icnn_mfma" if "icnn_mfma" in n else None)
+if ic:
+    c = ic["icnn_mfma"]
+    d = {}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        d["mfma_busy_cycles_per_mfma"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("SQ_INSTS_MFMA", 1.0), 1.0)
+    if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c:
+        d["valu_per_mfma"] = (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"]
+    if "SQ_WAIT_INST_ANY" in c:
+        d["wait_inst_any_frac_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    (out / f"{tag}_icnn_pmc.json").write_text(json.dumps({"counters": ic, "derived": d}, indent=1))
+    print("== ICNN:", json.dumps(d))
+
+# ---- operand / fused field kernel
+fd = counters(["field_fetch", "field_write", "field_sq1", "field_sq2", "field_tcc"],
+              lambda n: "vm_field" if "vm_field" in n else "operand_eval" if "operand_eval" in n else "vm_tile" if "vm_tile" in n else None)
+if fd:
+    d = {}
+    for k, c in fd.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            d[k + "_hbm_MB_per_launch"] = (c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024) / 1e6
+        if "TCC_MISS_sum" in c:
+            d[k + "_tcc_miss_MB"] = c["TCC_MISS_sum"] * 128 / 1e6
+    (out / f"{tag}_field_pmc.json").write_text(json.dumps({"counters": fd, "derived": d}, indent=1))
+    print("== operand / vm_field:", json.dumps(d))
