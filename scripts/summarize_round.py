@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 out, tag = pathlib.Path(sys.argv[1]), sys.argv[2]
-ours = ("vm_", "mc_", "icnn_", "isihara", "heat_", "operand_", "adjoint", "node_sum", "assign", "stream_probe", "cond_", "sweep")
+ours = ("vm_", "mc_", "icnn_", "isihara", "heat_", "operand_", "adjoint", "node_sum", "assign", "stream_probe", "cond_", "arena_sweep")
 
 
 def short(name):
@@ -27,7 +27,7 @@ for f in (out / "stats").rglob("*kernel_stats.csv"):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             n = short(r["Name"])
-            if any(k in n for k in ours):
+            if n.startswith(ours):
                 rows.append((n[:100], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"])))
 rows.sort(key=lambda r: -r[2])
 if rows:
@@ -38,6 +38,52 @@ if rows:
     print("== kernel stats (rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-probe --no-e2e`)")
     for r in rows[:14]:
         print(f"  {r[0][:70]:70s} calls {r[1]:4d}  avg {r[3] / 1e3:9.1f} us")
+# ---- kernel trace: the stats file averages ALL dispatches of a kernel (calibration launches, small input-generation
+# launches); here the timed ones are separated: the last K dispatches of the headline kernel, and for every other kernel
+# the dispatches of its LARGEST grid
+trace = list((out / "stats").rglob("*kernel_trace.csv"))
+if trace:
+    disp = collections.defaultdict(list)
+    with open(trace[0]) as fh:
+        for r in csv.DictReader(fh):
+            n = short(r["Kernel_Name"])
+            if n.startswith(ours):
+                disp[n.split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]),
+                                               int(r["VGPR_Count"]), int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"]), int(r["Scratch_Size"])))
+    prof = {}
+    pj = out / "bench_profiled.json"
+    if pj.exists() and pj.read_text().strip().startswith("{"):
+        prof = json.loads(pj.read_text().strip().splitlines()[-1])
+    lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-probe --no-e2e   (scripts/profile_round.sh {tag})",
+             "# <tag>_kernel_stats.csv averages ALL dispatches of a kernel; this file separates the timed ones."]
+    K = int(prof.get("steps", 20))
+    for name, ds in sorted(disp.items(), key=lambda kv: -sum(d[1] for d in kv[1])):
+        ds.sort()
+        big = max(d[2] for d in ds)
+        sel = [d for d in ds if d[2] == big]
+        if name.startswith("vm_tile<6, true, true>"):
+            # in start order: calibration (dxo_vm_output_alloc), the plain-allocation leg, warm-up, the K timed steps; the headline
+            # block's launches are the last W + K of that grid group before the secondary legs start -> take the K before the
+            # first dispatch of any secondary kernel
+            first_secondary = min((dd[0][0] for nn, dd in disp.items() if nn.startswith(("mc_", "icnn_", "vm_field", "vm_tile<4"))), default=1 << 62)
+            head = [d for d in ds if d[0] < first_secondary]
+            timed = head[-K:]
+            lines.append(f"{name}: {len(ds)} dispatches; the K = {K} timed steps (last {K} before the secondary legs): mean {sum(d[1] for d in timed) / len(timed) / 1e3:.1f} us "
+                         f"(min {min(d[1] for d in timed) / 1e3:.1f}, max {max(d[1] for d in timed) / 1e3:.1f}); all others (calibration, plain-allocation leg, warm-up): "
+                         f"mean {sum(d[1] for d in head[:-K]) / max(len(head) - K, 1) / 1e3:.1f} us; VGPR {timed[0][3]}+{timed[0][4]} LDS {timed[0][5]} scratch {timed[0][6]}")
+            lines.append("  timed steps, us: " + " ".join(f"{d[1] / 1e3:.0f}" for d in timed))
+        else:
+            lines.append(f"{name}: {len(ds)} dispatches, {len(sel)} at the largest grid ({big} threads): mean {sum(d[1] for d in sel) / len(sel) / 1e3:.1f} us "
+                         f"(min {min(d[1] for d in sel) / 1e3:.1f}); VGPR {sel[0][3]}+{sel[0][4]} LDS {sel[0][5]} scratch {sel[0][6]}")
+    if prof:
+        lines.append(f"# the bench line printed by the SAME (profiled) process: roofline.kernel_ms_avg = {prof['roofline']['kernel_ms_avg'] * 1e3:.1f} us, "
+                     f"frac {prof['roofline']['frac']:.4f}, ms_per_step {prof['ms_per_step'] * 1e3:.1f} us")
+        sec = prof.get("secondary", {})
+        for k, v in sec.items():
+            if "ms_per_launch" in v:
+                lines.append(f"#   secondary.{k}.ms_per_launch (HIP events, median) = {v['ms_per_launch'] * 1e3:.1f} us")
+    (out / f"{tag}_kernel_trace_summary.txt").write_text("\n".join(lines) + "\n")
+    print("== kernel trace summary\n" + "\n".join(lines))
 bj = out / "bench.json"
 if bj.exists() and bj.read_text().strip():
     (out / f"{tag}_bench_n1.json").write_text(bj.read_text())
