@@ -19,8 +19,9 @@
 // Roofline: compute (fp32 VALU). 192 B/point of HBM traffic against ~45 kflop/point: > 200 flop/B.
 // Weights are wave-uniform: they are read through the scalar path (s_load into SGPRs) and enter the FMAs
 // as scalar operands; the per-point vectors h1, phi'(a1), beta live in VGPRs (3 x 64 floats per lane).
-// The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here);
-// gfx950's fp32-input MFMA runs at the fp32 VALU rate, so round 1 keeps the VALU form.
+// The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here): the default fp32
+// kernel is icnn_mfma2 below (five 64x64x64 GEMMs per 64-point wave tile on v_mfma_f32_32x32x2_f32); icnn_point is the
+// fp64-network path of the tolerance study and the cross-check of the MFMA kernel (option icnn_variant = 0).
 #include <cmath>
 
 #include "dxo_common.h"
@@ -37,6 +38,8 @@ struct IcnnDev {
     const T* W2;    // [64][64]: W2p[j][i] (dense, the MFMA kernel's operand source)
     const T* S2;    // [64][4]: S2[j][0..2], c2[j]
     const T* w3;    // [64]: w3p
+    const T* T1;    // [64][16]: A1_i0 A1_i1 A1_i2 d1_i | 2 A1_i0, 2 A1_i1, 2 A1_i2, 0 | the six products A1_ik A1_il / 6, 0, 0   (icnn_mfma2)
+    const T* T2;    // [64][8]:  S2_j0 S2_j1 S2_j2 c2_j | w3p_j / 6, 0 0 0                                                         (icnn_mfma2)
     T s3[3];        // s3p
     double H[4];    // H_flat (:371)
 };
@@ -224,21 +227,20 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(const T* __restrict__ wA
     }
 }
 
-// ------------------------------------------------------------------ fp32 MFMA kernel (variant 1)
-// One wave = 64 points. The three mat-vec shaped products with W2p become five 64x64x64 GEMMs per wave on
-// v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf chain), everything else runs on the VALU meanwhile:
-//   [a2 | g0 | g1 | g2](j, pt) = W2p(j, i) @ [h1 | u A1_0 | u A1_1 | u A1_2](i, pt)      4 GEMMs
-//   beta(i, pt)                = W2p^T(i, j) @ delta(j, pt)                                1 GEMM
-// Lane l = (h = l >> 5, p = l & 31). Points are processed in two tiles of 32 (pt = 32 t + p).
-//   A operand (lane: row = l & 31, k = l >> 5):  A[jt][r]      = W2p[32 jt + p][r + 32 h]        K-step r covers i in {r, r + 32}
-//                                                AT[it][jt][q] = W2p[jlo(jt,q) + 4 h][32 it + p]  K-step (jt,q) covers j in {jlo, jlo + 4}
-//     — 128 weight registers, loaded ONCE per wave and kept resident across the grid-stride loop.
-//   B operand (lane: k = l >> 5, col = l & 31): the lane evaluates layer-1 neuron i = r + 32 h for point 32 t + p
-//     itself (softplus on the VALU while the matrix pipe works), so B never has to be shuffled into place.
-//   C/D (lane: col = l & 31, row = (q & 3) + 8 (q >> 2) + 4 h): delta is produced in exactly the layout the
-//     beta GEMM wants as its B operand (k = h selects row jlo + 4 h), again without a shuffle.
-// The only cross-lane traffic is x of the partner half (3 values) and the final 9-value half-wave sums.
+// ------------------------------------------------------------------ fp32 MFMA kernel: helpers
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// icnn_mfma2 is fully unrolled straight-line code; these keep the compiler from re-ordering it across neurons (it would
+// hoist every LDS read and sink every accumulation of a phase, and spill hundreds of registers): a scheduling barrier per
+// neuron, and the running sums pinned in registers at the end of each neuron
+#ifndef DXO_ICNN_SCHED1
+#define DXO_ICNN_SCHED1 __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef DXO_ICNN_SCHED2
+#define DXO_ICNN_SCHED2 __builtin_amdgcn_sched_barrier(0);
+#endif
+#define DXO_ICNN_PIN9(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
+#define DXO_ICNN_PIN6(r) asm volatile("" : "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only the compiler needs ordering
@@ -247,60 +249,115 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ------------------------------------------------------------------ fp32 MFMA kernel, round 3 (variant 1, default)
+// Same five GEMMs per 64-point wave tile as icnn_mfma above, restructured so that NOTHING is parked in LDS and no
+// softplus is evaluated twice. Per half-tile of 32 points (lane l = (h = l >> 5, p = l & 31), both halves work on
+// the same 32 points, each on half of the neurons):
+//   phase 1  K-step s = (it, q) of the four forward GEMMs covers the layer-1 neurons i_h(s) = 32 it + (q & 3) + 8 (q >> 2)
+//            + 4 h, h = 0, 1 — i.e. lane (h, p) evaluates exactly the neurons whose beta it will later find in ITS OWN
+//            accumulator registers (C layout of the beta GEMM): phi''(a1_i) is kept in a register (cph[s]) and the
+//            second Hessian term needs neither a second softplus nor a shuffle. A operand sA[jt][s][lane] =
+//            W2p[32 jt + p][i_h(s)].
+//   phase 2  the layer-2 neurons straight out of the accumulator registers (compile-time indices: everything is
+//            unrolled), and every delta_j is fed to the beta GEMM the moment it exists — C layout of the forward GEMMs is
+//            the B layout of the beta GEMM — so the 64 beta MFMAs run under the softplus arithmetic of this phase.
+//   phase 3  hess += beta_i phi''(a1_i) A1_i A1_i^T from bacc registers x cph registers x a table of the six products.
+// LDS per workgroup: A operands 32 KiB + two small tables 6 KiB (rows addressed base(h) + immediate) + 55 KiB of
+// lane-private slots for what is only needed after both half-tiles; no accumulator parking, no fences. Round 2's kernel
+// spent 36 % of a wave's cycles in vector-only phases (accumulator parking, 128 + 128 LDS accesses per lane and half-tile,
+// 32 repeated softplus) and ran at 0.46 of the fp32 MFMA peak; this one issues 7.2 instead of 11.7 vector instructions per
+// MFMA and runs at 0.60. What bounds it (scripts/exp/mfma32_valu_probe.hip, profiles/r03_mfma32_valu_probe.txt): on gfx950
+// the fp32-input MFMA does NOT run beside vector work — every v_fma_f32 placed between two v_mfma_f32_32x32x2_f32 adds
+// ~3 cycles to the 64 of the MFMA, every v_exp / v_log / v_rcp ~12.5, with one or two waves per SIMD alike — so the time of a
+// half-tile is the SUM of its 320 MFMAs (20.5 k cycles) and of its vector instructions, not the maximum; see DESIGN.md 8.
+__device__ __forceinline__ constexpr int icnn_row(int t, int q) { return 32 * t + (q & 3) + 8 * (q >> 2); }   // + 4 h
+
+// softplus with first and second derivative for icnn_mfma2: the exponent is clamped at 80 (e^80 is finite in fp32), so that
+// e r = e / (1 + e) and e r r need no select above torch's threshold of 20 — they are 1 and < 2e-9 there, which is what the
+// reference's branch returns to fp32 rounding; softplus itself is max(log(1 + e), a): log(1 + e) >= a holds below the
+// threshold, and above it the reference returns a.
+__device__ __forceinline__ void softplus3_mfma(float a, float& sp, float& s1, float& s2) {
+    const float e = __builtin_amdgcn_exp2f(fminf(a, 80.0f) * 1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const float l = __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    sp = fmaxf(l, a);   // below the threshold softplus > a; above it l is a to rounding (or the clamp) and torch returns a
+    s1 = e * r;
+    s2 = s1 * r;
+}
+
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* __restrict__ wA1, const float* __restrict__ wW2,
-                                                       const float* __restrict__ wS2, const float* __restrict__ ww3,
-                                                       IcnnSmall<float> small, int64_t n, const double* __restrict__ F,
-                                                       double* __restrict__ dP, double* __restrict__ P) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma2(const float* __restrict__ wT1, const float* __restrict__ wW2,
+                                                        const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
+                                                        const double* __restrict__ F, double* __restrict__ dP,
+                                                        double* __restrict__ P) {
     constexpr int BLOCK = WAVES * 64;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = threadIdx.x >> 6;
-    const float4* A1v = reinterpret_cast<const float4*>(wA1);   // A1[i] = (A1_i0, A1_i1, A1_i2, d1_i)
-    const float4* S2v = reinterpret_cast<const float4*>(wS2);   // S2[j] = (S2_j0, S2_j1, S2_j2, c2_j)
-    // The A operands of all five GEMMs, pre-arranged in MFMA lane order, live in LDS (32 KiB per workgroup,
-    // filled once): sA[jt][r][lane], sAT[it][jt][q][lane]. Keeping them in registers instead (128 VGPRs)
-    // forced the K loop to be fully unrolled and spilled 2.3 KB per lane.
-    __shared__ float sA[2 * 32 * 64];
-    __shared__ float sAT[2 * 2 * 16 * 64];
-    // per wave: 8 KiB to park 4 accumulator tiles, 8 of their 16 registers at a time (later the 32 beta values),
-    // and 8 KiB for delta in C layout = B operand of the beta GEMM. With WAVES = 8 the workgroup uses exactly the
-    // CU's 160 KiB and runs 2 waves per SIMD, so one wave's softplus passes overlap the other's MFMAs.
-    __shared__ float sStage[WAVES * 32 * 64];
-    __shared__ float sDelta[WAVES * 32 * 64];
-    float* stage = sStage + wave * (32 * 64);
-    float* sdlt = sDelta + wave * (32 * 64);
+    __shared__ float sA[2 * 32 * 64];                                      // [jt][s][lane], W2p / 12
+    __shared__ float sAT[2 * 32 * 64];                                     // [it][(jt, q)][lane], W2p
+    __shared__ __attribute__((aligned(16))) float sT1[NH * 16];            // A1x A1y A1z d1 | 2A1x 2A1y 2A1z 0 | xx xy xz yy | yz zz 0 0  (products / 6)
+    __shared__ __attribute__((aligned(16))) float sT2[NH * 8];             // S2x S2y S2z c2 | w3 / 6, 0 0 0
+    // per wave, lane-private slots: what is only needed again AFTER the two half-tiles (the fp64 feature derivatives of the
+    // lane's own point, 9 doubles) and the finished sums of the half-tile the lane owns (9 floats) wait here instead of
+    // occupying 27 registers through the GEMM phases (128 accumulator + 32 beta + 32 phi'' registers are live there)
+    __shared__ double sKeep[WAVES * 9 * 64];
+    __shared__ float sMine[WAVES * 9 * 64];
+    double* keep = sKeep + wave * (9 * 64) + lane;
+    float* minep = sMine + wave * (9 * 64) + lane;
     for (int e = threadIdx.x; e < 2 * 32 * 64; e += BLOCK) {
-        const int l = e & 63, r = (e >> 6) & 31, jt = e >> 11;
-        sA[e] = wW2[(32 * jt + (l & 31)) * NH + r + 32 * (l >> 5)];
+        const int l = e & 63, sq = (e >> 6) & 31, t = e >> 11;
+        // the forward GEMMs' A operand carries phi's 1/12: h1 = softplus^2 and u = 2 softplus softplus' enter unscaled
+        sA[e] = wW2[(32 * t + (l & 31)) * NH + icnn_row(sq >> 4, sq & 15) + 4 * (l >> 5)] * (1.0f / 12.0f);
+        sAT[e] = wW2[(icnn_row(sq >> 4, sq & 15) + 4 * (l >> 5)) * NH + 32 * t + (l & 31)];
     }
-    for (int e = threadIdx.x; e < 2 * 2 * 16 * 64; e += BLOCK) {
-        const int l = e & 63, q = (e >> 6) & 15, jt = (e >> 10) & 1, it = e >> 11;
-        sAT[e] = wW2[(32 * jt + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5)) * NH + 32 * it + (l & 31)];
-    }
+    for (int e = threadIdx.x; e < NH * 16; e += BLOCK) sT1[e] = wT1[e];
+    for (int e = threadIdx.x; e < NH * 8; e += BLOCK) sT2[e] = wT2[e];
     __syncthreads();
+    const float* A_l = sA + lane;
+    const float* AT_l = sAT + lane;
+    const float* T1_h = sT1 + 4 * h * 16;
+    const float* T2_h = sT2 + 4 * h * 8;
 
     const int64_t n_tiles = (n + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t tile_step = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    // the lane's own point of the NEXT tile is requested one tile ahead: its latency runs under this tile's GEMMs
+    dxo_f64x2 f01n{1.0, 0.0}, f23n{0.0, 1.0};
+    if (tile < n_tiles) {
+        const int64_t pl0 = tile * 64 + lane < n ? tile * 64 + lane : n - 1;
+        f01n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[0];
+        f23n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[1];
+    }
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t pidx = tile * 64 + lane;
-        const int64_t pl = pidx < n ? pidx : n - 1;   // tail lanes recompute the last point, never store
-        const dxo_f64x2 f01 = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[0];
-        const dxo_f64x2 f23 = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[1];
-        const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};
-        const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
-        const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
-        const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
-        const double m = pow(aD, -2.0 / 3.0), nn = m * m;
-        const float x0 = (float)((t + 1.0) * m - 3.0), x1 = (float)((t + D * D) * nn - 3.0), x2 = (float)((aD - 1.0) * (aD - 1.0));
+        float x0, x1, x2;
+        {
+            const double Fv[4] = {f01n.x, f01n.y, f23n.x, f23n.y};   // tail lanes recompute the last point, never store
+            const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+            const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+            const double aD = fabs(D), iD = 1.0 / D;
+            const double m = pow(aD, -2.0 / 3.0), nn = m * m;
+            x0 = (float)((t + 1.0) * m - 3.0); x1 = (float)((t + D * D) * nn - 3.0); x2 = (float)((aD - 1.0) * (aD - 1.0));
+            keep[0 * 64] = Fv[0]; keep[1 * 64] = Fv[1]; keep[2 * 64] = Fv[2]; keep[3 * 64] = Fv[3];
+            keep[4 * 64] = t; keep[5 * 64] = D; keep[6 * 64] = m; keep[7 * 64] = nn; keep[8 * 64] = iD;
+            asm volatile("" ::: "memory");   // the values are re-read from LDS below, not carried in registers
+        }
+        if (tile + tile_step < n_tiles) {
+            const int64_t pn = (tile + tile_step) * 64 + lane;
+            const int64_t pln = pn < n ? pn : n - 1;
+            f01n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[0];
+            f23n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[1];
+        }
         const float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
-        float mine[9];
 #pragma unroll 1
         for (int tt = 0; tt < 2; ++tt) {
             const bool own = (tt == h);
             const float xs0 = own ? x0 : xp0, xs1 = own ? x1 : xp1, xs2 = own ? x2 : xp2;
-            // Everything below runs in ROLLED loops: the MFMA results are parked in a wave-private LDS slice
-            // (lane-linear, each lane re-reads only its own column) purely so that the softplus passes can
-            // index them dynamically. Fully unrolled they were scheduled for ILP and spilled > 300 VGPRs.
+            // the table and A-operand reads below are loop-invariant: without this the compiler hoists hundreds of them out of the
+            // half-tile loop into registers (and spills them)
+            asm volatile("" ::: "memory");
             float res[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float cph[32];
             f32x16 acc[2][4];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
@@ -308,109 +365,99 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* 
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[jt][c][q] = 0.f;
-            // the small tables (A1, S2, w3) come from global memory through L1; every rolled loop below fetches the
-            // NEXT iteration's row before working on the current one, otherwise each iteration eats an L1 round trip
-            float4 a1n = A1v[32 * h];
-#pragma unroll 2
-            for (int r = 0; r < 32; ++r) {
-                const float4 a1 = a1n;
-                a1n = A1v[((r + 1) & 31) + 32 * h];
-                const float Ar0 = sA[(0 * 32 + r) * 64 + lane], Ar1 = sA[(1 * 32 + r) * 64 + lane];
-                const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
+            __builtin_amdgcn_s_setprio(1);   // the MFMA-dense phase goes first on the SIMD's issue port (-3 % measured)
+            // ---- phase 1: [a2 | g0 | g1 | g2] = (W2p / 12) @ [sp^2 | u 2A1_0 | u 2A1_1 | u 2A1_2],  u = sp sp'
+            // One K-step's B operands (this lane's layer-1 neuron) and A operands:
+            struct Ops { float Ar0, Ar1, hv, B1, B2, B3; };
+            auto step_ops = [&](int s, float& cph_s) -> Ops {
+                const float4 a1 = *reinterpret_cast<const float4*>(T1_h + icnn_row(s >> 4, s & 15) * 16);
+                const float4 b1 = *reinterpret_cast<const float4*>(T1_h + icnn_row(s >> 4, s & 15) * 16 + 4);
+                Ops o;
+                o.Ar0 = A_l[(0 * 32 + s) * 64];
+                o.Ar1 = A_l[(1 * 32 + s) * 64];
+                const float a = fmaf(a1.x, xs0, fmaf(a1.y, xs1, fmaf(a1.z, xs2, a1.w)));
                 float sp, s1, s2;
-                softplus3_fast(a, sp, s1, s2);
-                const float hv = sp * sp * (1.0f / 12.0f);
-                const float uv = sp * s1 * (1.0f / 6.0f);
-                const float B1 = uv * a1.x, B2 = uv * a1.y, B3 = uv * a1.z;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, hv, acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, hv, acc[1][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B1, acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B1, acc[1][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B2, acc[0][2], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B2, acc[1][2], 0, 0, 0);
-                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar0, B3, acc[0][3], 0, 0, 0);
-                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ar1, B3, acc[1][3], 0, 0, 0);
+                softplus3_mfma(a, sp, s1, s2);
+                o.hv = sp * sp;
+                const float uv = sp * s1;
+                cph_s = fmaf(sp, s2, s1 * s1);     // phi''(a1) * 6: the 1/6 sits in the table of products (phase 3)
+                asm volatile("" : "+v"(cph_s));    // materialise it HERE: otherwise its computation is sunk into phase 3 and its four inputs spilled
+                o.B1 = uv * b1.x; o.B2 = uv * b1.y; o.B3 = uv * b1.z;
+                return o;
+            };
+            auto step_mfma = [&](const Ops& o) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar0, o.hv, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar1, o.hv, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar0, o.B1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar1, o.B1, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar0, o.B2, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar1, o.B2, acc[1][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar0, o.B3, acc[0][3], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.Ar1, o.B3, acc[1][3], 0, 0, 0);
+            };
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const Ops o = step_ops(s, cph[s]);
+                step_mfma(o);
+                DXO_ICNN_SCHED1
             }
-#pragma unroll 1
-            for (int part = 0; part < 4; ++part) {   // (jt, half): 8 accumulator registers of 4 tiles at a time
-                const int jt = part >> 1, q0 = (part & 1) * 8;
-#define DXO_PARK(JT, Q0)                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                          \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) stage[(c * 8 + q) * 64 + lane] = acc[JT][c][Q0 + q];
-                if (part == 0) { DXO_PARK(0, 0) } else if (part == 1) { DXO_PARK(0, 8) } else if (part == 2) { DXO_PARK(1, 0) } else { DXO_PARK(1, 8) }
-#undef DXO_PARK
-                icnn_lds_fence();
-                // ---- neurons of layer 2 (C layout: q -> j): skip connection, softplus, grad / hess contributions
-                const int jbase = 32 * jt + 4 * h;
-                float4 s2n = S2v[jbase + (q0 & 3) + 8 * (q0 >> 2)];
-                float w3n = ww3[jbase + (q0 & 3) + 8 * (q0 >> 2)];
-#pragma unroll 2
-                for (int qq = 0; qq < 8; ++qq) {
-                    const int q = q0 + qq;
-                    const float4 s2r = s2n;
-                    const float w3 = w3n;
-                    {
-                        const int qn = q0 + ((qq + 1) & 7);
-                        s2n = S2v[jbase + (qn & 3) + 8 * (qn >> 2)];
-                        w3n = ww3[jbase + (qn & 3) + 8 * (qn >> 2)];
-                    }
-                    const float a2 = stage[(0 * 8 + qq) * 64 + lane] + s2r.x * xs0 + s2r.y * xs1 + s2r.z * xs2 + s2r.w;
-                    const float g0 = stage[(1 * 8 + qq) * 64 + lane] + s2r.x;
-                    const float g1 = stage[(2 * 8 + qq) * 64 + lane] + s2r.y;
-                    const float g2 = stage[(3 * 8 + qq) * 64 + lane] + s2r.z;
-                    float sp, s1, s2;
-                    softplus3_fast(a2, sp, s1, s2);
-                    const float delta = w3 * sp * s1 * (1.0f / 6.0f);
-                    const float curv = w3 * (s1 * s1 + sp * s2) * (1.0f / 6.0f);
-                    res[0] += delta * g0; res[1] += delta * g1; res[2] += delta * g2;
-                    res[3] += curv * g0 * g0; res[4] += curv * g0 * g1; res[5] += curv * g0 * g2;
-                    res[6] += curv * g1 * g1; res[7] += curv * g1 * g2; res[8] += curv * g2 * g2;
-                    sdlt[(jt * 16 + q) * 64 + lane] = delta;   // already the beta GEMM's B operand layout
-                }
-                icnn_lds_fence();
-            }
-            // ---- beta = W2p^T delta (K-step jq = (jt, q) covers j in {jlo, jlo + 4})
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 2: layer-2 neurons from the accumulators; delta feeds beta = W2p^T delta at once
             f32x16 bacc[2];
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
-#pragma unroll 4
+#pragma unroll
             for (int jq = 0; jq < 32; ++jq) {
-                const float Bd = sdlt[jq * 64 + lane];
-                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sAT[(0 * 32 + jq) * 64 + lane], Bd, bacc[0], 0, 0, 0);
-                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sAT[(1 * 32 + jq) * 64 + lane], Bd, bacc[1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) stage[(it * 16 + q) * 64 + lane] = bacc[it][q];
-            icnn_lds_fence();
-            // ---- second Hessian term: sum_i beta_i phi''(a1_i) A1_i A1_i^T (C layout: iq -> i)
-            float4 b1n = A1v[4 * h];
-#pragma unroll 2
-            for (int iq = 0; iq < 32; ++iq) {
-                const float4 a1 = b1n;
-                {
-                    const int in_ = (iq + 1) & 31, qn = in_ & 15;
-                    b1n = A1v[32 * (in_ >> 4) + (qn & 3) + 8 * (qn >> 2) + 4 * h];
-                }
-                const float a = a1.x * xs0 + a1.y * xs1 + a1.z * xs2 + a1.w;
+                const int jt = jq >> 4, q = jq & 15;
+                const float4 s2r = *reinterpret_cast<const float4*>(T2_h + icnn_row(jt, q) * 8);
+                const float w6 = T2_h[icnn_row(jt, q) * 8 + 4];
+                const float At0 = AT_l[(0 * 32 + jq) * 64], At1 = AT_l[(1 * 32 + jq) * 64];
+                const float a2 = acc[jt][0][q] + fmaf(s2r.x, xs0, fmaf(s2r.y, xs1, fmaf(s2r.z, xs2, s2r.w)));
+                const float g0 = acc[jt][1][q] + s2r.x, g1 = acc[jt][2][q] + s2r.y, g2 = acc[jt][3][q] + s2r.z;
                 float sp, s1, s2;
-                softplus3_fast(a, sp, s1, s2);
-                const float c = stage[iq * 64 + lane] * (s1 * s1 + sp * s2) * (1.0f / 6.0f);
-                res[3] += c * a1.x * a1.x; res[4] += c * a1.x * a1.y; res[5] += c * a1.x * a1.z;
-                res[6] += c * a1.y * a1.y; res[7] += c * a1.y * a1.z; res[8] += c * a1.z * a1.z;
+                softplus3_mfma(a2, sp, s1, s2);
+                const float delta = w6 * sp * s1;
+                const float curv = w6 * fmaf(sp, s2, s1 * s1);
+                bacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(At0, delta, bacc[0], 0, 0, 0);
+                bacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(At1, delta, bacc[1], 0, 0, 0);
+                const float cg0 = curv * g0, cg1 = curv * g1, cg2 = curv * g2;
+                res[0] = fmaf(delta, g0, res[0]); res[1] = fmaf(delta, g1, res[1]); res[2] = fmaf(delta, g2, res[2]);
+                res[3] = fmaf(cg0, g0, res[3]); res[4] = fmaf(cg0, g1, res[4]); res[5] = fmaf(cg0, g2, res[5]);
+                res[6] = fmaf(cg1, g1, res[6]); res[7] = fmaf(cg1, g2, res[7]); res[8] = fmaf(cg2, g2, res[8]);
+                // the nine sums are finished HERE (otherwise their updates are sunk below the whole unrolled phase and g, curv,
+                // delta of every neuron stay live: hundreds of spilled registers)
+                DXO_ICNN_PIN9(res)
+                DXO_ICNN_SCHED2
             }
-            icnn_lds_fence();
+            // ---- phase 3: second Hessian term, beta_i (accumulator registers) x phi''(a1_i) (cph) x A1_i A1_i^T / 6 (table)
+#pragma unroll
+            for (int iq = 0; iq < 32; ++iq) {
+                const int it = iq >> 4, q = iq & 15;
+                const float4 pa = *reinterpret_cast<const float4*>(T1_h + icnn_row(it, q) * 16 + 8);
+                const float2 pb = *reinterpret_cast<const float2*>(T1_h + icnn_row(it, q) * 16 + 12);
+                const float c = bacc[it][q] * cph[iq];
+                res[3] = fmaf(c, pa.x, res[3]); res[4] = fmaf(c, pa.y, res[4]); res[5] = fmaf(c, pa.z, res[5]);
+                res[6] = fmaf(c, pa.w, res[6]); res[7] = fmaf(c, pb.x, res[7]); res[8] = fmaf(c, pb.y, res[8]);
+                DXO_ICNN_PIN6(res)
+                DXO_ICNN_SCHED2
+            }
             // both half-waves hold partial sums of the SAME 32 points: add them, keep the tile this lane owns
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 const float tot = res[q] + xor32(res[q]);
-                if (own) mine[q] = tot;
+                if (own) minep[q * 64] = tot;
             }
         }
+        asm volatile("" ::: "memory");
         if (pidx < n) {
+            const double Fk[4] = {keep[0 * 64], keep[1 * 64], keep[2 * 64], keep[3 * 64]};
+            const double t = keep[4 * 64], D = keep[5 * 64], m = keep[6 * 64], nn = keep[7 * 64], iD = keep[8 * 64];
+            const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0;
+            float mine[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mine[q] = minep[q * 64];
             const double kt[3] = {m, nn, 0.0};
             const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
                                   2.0 * (aD - 1.0) * sg};
@@ -418,7 +465,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma(const float* 
             const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
                                    -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
             const float y1f[3] = {mine[0] + small.s3[0], mine[1] + small.s3[1], mine[2] + small.s3[2]};
-            icnn_chain(Fv, kt, kD, ktD, kDD, y1f, mine + 3, small.H, dP + pidx * 16, P + pidx * 4);
+            icnn_chain(Fk, kt, kD, ktD, kDD, y1f, mine + 3, small.H, dP + pidx * 16, P + pidx * 4);
         }
     }
 }
@@ -444,20 +491,14 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     if (L.precision == 0 && ctx->icnn_variant != 0) {
-        // MFMA kernel: one wave = 64 points, weights resident in registers -> persistent grid, 1 wave per SIMD
+        // MFMA kernel: one wave = 64 points, persistent grid of one 8-wave workgroup per CU (two waves per SIMD: the register
+        // budget of 256 per lane is what the 128 + 32 accumulator registers need)
         IcnnSmall<float> small;
         for (int k = 0; k < 3; ++k) small.s3[k] = L.m->f32.s3[k];
         for (int k = 0; k < 4; ++k) small.H[k] = L.m->f32.H[k];
-        // one workgroup per CU: 4 waves (1 per SIMD) or, default, 8 waves (2 per SIMD, all 160 KiB of LDS)
-        const int waves = ctx->icnn_variant == 2 ? 4 : 8;
-        int64_t mb = (n + waves * 64 - 1) / (waves * 64);
+        int64_t mb = (n + 8 * 64 - 1) / (8 * 64);
         if (mb > ctx->compute_units) mb = ctx->compute_units;
-        if (waves == 8)
-            hipLaunchKernelGGL(icnn_mfma<8>, dim3((int)mb), dim3(512), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
-                               small, n, F, dP, P);
-        else
-            hipLaunchKernelGGL(icnn_mfma<4>, dim3((int)mb), dim3(256), 0, s, L.m->f32.A1, L.m->f32.W2, L.m->f32.S2, L.m->f32.w3,
-                               small, n, F, dP, P);
+        hipLaunchKernelGGL((icnn_mfma2<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
         return DXO_OK;
     }
     if (L.precision == 0) launch_icnn<float>(L.m->f32, (int)blocks, s, n, F, dP, P);
@@ -616,7 +657,17 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
         S2[j * 4 + 3] = w->skip2_bias[j];
         w3[j] = softplus_host(w->layers3_weights[j]);
     }
-    const size_t cnt = A1.size() + W2B.size() + W2.size() + S2.size() + w3.size();
+    // tables of the round-3 MFMA kernel (products of the fp32-rounded A1, as the kernel would form them)
+    std::vector<double> T1(NH * 16, 0.0), T2(NH * 8, 0.0);
+    for (int i = 0; i < NH; ++i) {
+        const double ax = (double)(float)A1[i * 4 + 0], ay = (double)(float)A1[i * 4 + 1], az = (double)(float)A1[i * 4 + 2];
+        const double row[14] = {A1[i * 4 + 0], A1[i * 4 + 1], A1[i * 4 + 2], A1[i * 4 + 3], 2 * ax, 2 * ay, 2 * az, 0.0,
+                                ax * ax / 6, ax * ay / 6, ax * az / 6, ay * ay / 6, ay * az / 6, az * az / 6};
+        for (int k = 0; k < 14; ++k) T1[i * 16 + k] = row[k];
+        for (int k = 0; k < 4; ++k) T2[i * 8 + k] = S2[i * 4 + k];
+        T2[i * 8 + 4] = w3[i] / 6;
+    }
+    const size_t cnt = A1.size() + W2B.size() + W2.size() + S2.size() + w3.size() + T1.size() + T2.size();
     std::vector<float> h32(cnt);
     std::vector<double> h64(cnt);
     size_t o = 0;
@@ -625,6 +676,8 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
     const size_t oW2 = o; for (double v : W2) { h64[o] = v; h32[o++] = (float)v; }
     const size_t oS2 = o; for (double v : S2) { h64[o] = v; h32[o++] = (float)v; }
     const size_t ow3 = o; for (double v : w3) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t oT1 = o; for (double v : T1) { h64[o] = v; h32[o++] = (float)v; }
+    const size_t oT2 = o; for (double v : T2) { h64[o] = v; h32[o++] = (float)v; }
     dxo_icnn* m = new dxo_icnn();
     hipError_t e = hipSetDevice(ctx->device);
     const size_t bytes64 = cnt * sizeof(double), bytes32 = (cnt * sizeof(float) + 255) / 256 * 256;
@@ -638,8 +691,8 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
     }
     const double* d64 = (const double*)m->dev;
     const float* d32 = (const float*)((char*)m->dev + bytes64);
-    m->f64 = {d64 + oA1, d64 + oW, d64 + oW2, d64 + oS2, d64 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
-    m->f32 = {d32 + oA1, d32 + oW, d32 + oW2, d32 + oS2, d32 + ow3, {0, 0, 0}, {0, 0, 0, 0}};
+    m->f64 = {d64 + oA1, d64 + oW, d64 + oW2, d64 + oS2, d64 + ow3, d64 + oT1, d64 + oT2, {0, 0, 0}, {0, 0, 0, 0}};
+    m->f32 = {d32 + oA1, d32 + oW, d32 + oW2, d32 + oS2, d32 + ow3, d32 + oT1, d32 + oT2, {0, 0, 0}, {0, 0, 0, 0}};
     for (int k = 0; k < 3; ++k) {
         const double s3 = softplus_host(w->skip3_weights[k]);
         m->f64.s3[k] = s3;

@@ -106,7 +106,7 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
  * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
- * (0 VALU, 1 MFMA 8 waves per workgroup, 2 MFMA 4 waves), "host_small_bytes" (host batches whose inputs + outputs
+ * (0 lane-per-point VALU kernel, 1 MFMA kernel — the default), "host_small_bytes" (host batches whose inputs + outputs
  * fit this many bytes, default 1 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
  * the chunked pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase
  * dxo_timing is recorded on it only with "timing" = 1), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes

@@ -35,7 +35,7 @@ ms = statistics.median(x.elapsed_time(y) for x, y in ev)
 mfma_flop = 5 * 2 * 64 ** 3 / 64 * a.n
 out = {"case": "ICNN", "variant": a.variant, "precision": a.precision, "n": a.n, "kernel_ms": ms, "qp_per_s": a.n / ms * 1e3,
        "GBps_algorithmic": 192 * a.n / ms / 1e6}
-if a.variant in (1, 2) and a.precision == 0:
+if a.variant == 1 and a.precision == 0:
     out["roofline"] = {"bound": "mfma", "achieved": mfma_flop / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
                        "frac": mfma_flop / ms / 1e9 / 157.3,
                        "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak; flop = the five 64^3 GEMMs per 64-point tile only"}

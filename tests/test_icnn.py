@@ -96,7 +96,8 @@ def test_hip_against_oracle_sizes(ctx, weights, n):
 
 @pytest.mark.gpu
 def test_mfma_and_valu_kernels_agree(ctx, weights):
-    """fp32 network: the MFMA kernel (variant 1, default) against the lane-per-point VALU kernel (variant 0)."""
+    """fp32 network: the MFMA kernel (variant 1, default) against the lane-per-point VALU kernel (variant 0) and the oracle.
+    Summation orders differ between the kernels, so they agree to fp32 rounding, not bit for bit."""
     from dolfinx_external_operator_amd import MEM_HOST
 
     rng = np.random.default_rng(11)
@@ -105,7 +106,7 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
     model = ctx.icnn_create(state_dict(weights))
     out = {}
     try:
-        for variant in (0, 1, 2):
+        for variant in (0, 1):
             ctx.set_option("icnn_variant", variant)
             dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
             ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
@@ -115,10 +116,9 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
         ctx.set_option("icnn_variant", 1)
         ctx.icnn_destroy(model)
     dPo, Po = icnn_stress_tangent(F, weights)
-    for variant in (1, 2):   # 8-wave (2 per SIMD) and 4-wave MFMA workgroups
-        assert relerr(out[variant][0], out[0][0]) <= RTOL_FP32 and relerr(out[variant][1], out[0][1]) <= RTOL_FP32
+    assert relerr(out[1][0], out[0][0]) <= RTOL_FP32 and relerr(out[1][1], out[0][1]) <= RTOL_FP32
+    for variant in (0, 1):
         assert relerr(out[variant][0], dPo) <= RTOL_FP32 and relerr(out[variant][1], Po) <= RTOL_FP32
-    assert np.array_equal(out[1][0], out[2][0])    # same per-wave arithmetic in both workgroup shapes
 
 
 @pytest.mark.gpu
