@@ -15,13 +15,13 @@ from .evaluation import (
     get_unrolled_dofmap,
 )
 from .operand_eval import DeviceMesh, DeviceOperand, LazyOperand
-from .operators import make_heat, make_icnn, make_isihara, make_mohr_coulomb, make_von_mises, von_mises_commit_state
+from .operators import make_conductivity, make_heat, make_icnn, make_isihara, make_mohr_coulomb, make_von_mises, von_mises_commit_state
 
 __version__ = "0.1.0"
 
 __all__ = [
     "Context", "DxoError", "VmParams", "MEM_HOST", "MEM_DEVICE", "default_context", "load_library",
-    "make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn", "make_isihara", "McParams", "IsiharaParams", "von_mises_commit_state",
+    "make_von_mises", "make_heat", "make_conductivity", "make_mohr_coulomb", "make_icnn", "make_isihara", "McParams", "IsiharaParams", "von_mises_commit_state",
     "QuadratureExternalOperator", "MixedExternalOperator", "Operand", "Coefficient",
     "evaluate_operands", "evaluate_external_operators", "get_unrolled_dofmap", "DeviceMesh", "DeviceOperand", "LazyOperand", "AssignDesc",
     "MultiGpu", "GATHER_NONE", "GATHER_FULL", "GATHER_COMPACT",

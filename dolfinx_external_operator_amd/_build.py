@@ -18,7 +18,7 @@ INCLUDE = ROOT / "include"
 LIB = PKG / "libdxo_hip.so"
 ARCH = "gfx950"
 
-HIP_SOURCES = ["dxo_ctx.hip", "von_mises.hip", "heat.hip", "probe.hip", "mohr_coulomb.hip", "icnn.hip", "operand.hip", "vm_field.hip", "assign.hip", "heat_field.hip", "adjoint.hip", "arena.hip", "mgpu.hip", "operand_facet.hip"]
+HIP_SOURCES = ["dxo_ctx.hip", "von_mises.hip", "heat.hip", "probe.hip", "mohr_coulomb.hip", "icnn.hip", "operand.hip", "vm_field.hip", "assign.hip", "heat_field.hip", "adjoint.hip", "arena.hip", "mgpu.hip", "operand_facet.hip", "field_ops.hip"]
 
 
 def _hipcc() -> str:

@@ -114,6 +114,17 @@ _SIGNATURES = {
     "dxo_copy": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int]),
     "dxo_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [_P] * 5),
     "dxo_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [_P] * 8),
+    "dxo_mc_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "dxo_mc_state_destroy": (None, [_P, _P]),
+    "dxo_mc_state_upload": (C.c_int, [_P, _P, C.c_int, _P]),
+    "dxo_mc_state_download": (C.c_int, [_P, _P, C.c_int, _P]),
+    "dxo_mc_state_commit": (C.c_int, [_P, _P]),
+    "dxo_mc_state_pointers": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "dxo_mohr_coulomb_state": (C.c_int, [_P, C.POINTER(McParams), _P, C.c_int] + [_P] * 7),
+    "dxo_mohr_coulomb_field": (C.c_int, [_P, C.POINTER(McParams), _P, C.c_int] + [_P] * 8),
+    "dxo_icnn_field": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "dxo_isihara_field": (C.c_int, [_P, C.POINTER(IsiharaParams), _P, C.c_int, _P, _P, _P]),
+    "dxo_conductivity": (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, C.c_int, _P, _P, _P]),
     "dxo_mc_summary": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_icnn_create": (C.c_int, [_P, C.POINTER(IcnnWeights), C.POINTER(_P)]),
     "dxo_icnn_destroy": (C.c_int, [_P, _P]),
@@ -456,6 +467,28 @@ class Context:
                                        _ptr(sigma), _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
         self.check(rc, "dxo_mohr_coulomb")
 
+    def mc_state(self, n: int) -> "McState":
+        """Device mirror of the Mohr-Coulomb history variable sigma_n for n points (dxo_mc_state, include/dxo.h)."""
+        return McState(self, n)
+
+    def mohr_coulomb_field(self, prm: McParams, mesh_handle, mem: int, u, sigma_n, C_tang, sigma, niter=None, yielding=None,
+                           norm_res=None, dlambda=None) -> None:
+        rc = self.lib.dxo_mohr_coulomb_field(self._h, C.byref(prm), mesh_handle, int(mem), _ptr(u), _ptr(sigma_n), _ptr(C_tang),
+                                             _ptr(sigma), _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
+        self.check(rc, "dxo_mohr_coulomb_field")
+
+    def icnn_field(self, model: int, precision: int, mesh_handle, mem: int, u, dP, P) -> None:
+        self.check(self.lib.dxo_icnn_field(self._h, _P(model), int(precision), mesh_handle, int(mem), _ptr(u), _ptr(dP), _ptr(P)),
+                   "dxo_icnn_field")
+
+    def isihara_field(self, prm: "IsiharaParams", mesh_handle, mem: int, u, dP, P) -> None:
+        self.check(self.lib.dxo_isihara_field(self._h, C.byref(prm), mesh_handle, int(mem), _ptr(u), _ptr(dP), _ptr(P)),
+                   "dxo_isihara_field")
+
+    def conductivity(self, A: float, B: float, n: int, mem: int, T, k, dkdT) -> None:
+        self.check(self.lib.dxo_conductivity(self._h, float(A), float(B), int(n), int(mem), _ptr(T), _ptr(k), _ptr(dkdT)),
+                   "dxo_conductivity")
+
     def mc_summary(self, n: int, niter, yielding=None, norm_res=None, nbins: int = 201) -> dict:
         """Device-side inner-Newton summary (the reference's printout, demo_plasticity_mohr_coulomb.py:584-591).
         niter / yielding / norm_res are DEVICE pointers (or objects with data_ptr())."""
@@ -736,6 +769,46 @@ class VmState:
         rc = self.ctx.lib.dxo_von_mises_field_state(self.ctx._h, C.byref(prm), mesh_handle, self._h, int(mem), _ptr(u), _ptr(C_tang),
                                                     _ptr(sigma), _ptr(dp))
         self.ctx.check(rc, "dxo_von_mises_field_state")
+
+
+class McState:
+    """dxo_mc_state: device mirror of the Mohr-Coulomb history variable sigma_n plus the stress of the last call."""
+
+    def __init__(self, ctx: "Context", n: int):
+        self.ctx, self.n = ctx, int(n)
+        h = _P()
+        ctx.check(ctx.lib.dxo_mc_state_create(ctx._h, self.n, C.byref(h)), "dxo_mc_state_create")
+        self._h = h
+        self._fin = weakref.finalize(self, McState._destroy, ctx, h)
+
+    @staticmethod
+    def _destroy(ctx, h):
+        ctx.lib.dxo_mc_state_destroy(ctx._h, h)   # with a closed context (NULL) the library still frees the device block
+
+    def close(self) -> None:
+        self._fin()
+
+    def upload(self, sigma_n, mem: int = MEM_HOST) -> None:
+        self.ctx.check(self.ctx.lib.dxo_mc_state_upload(self.ctx._h, self._h, int(mem), _ptr(sigma_n)), "dxo_mc_state_upload")
+
+    def download(self, sigma_n=None, mem: int = MEM_HOST):
+        if mem == MEM_HOST and sigma_n is None:
+            sigma_n = np.empty(self.n * 4)
+        self.ctx.check(self.ctx.lib.dxo_mc_state_download(self.ctx._h, self._h, int(mem), _ptr(sigma_n)), "dxo_mc_state_download")
+        return sigma_n
+
+    def commit(self) -> None:
+        self.ctx.check(self.ctx.lib.dxo_mc_state_commit(self.ctx._h, self._h), "dxo_mc_state_commit")
+
+    def pointers(self) -> dict:
+        out = [C.c_void_p() for _ in range(2)]
+        self.ctx.check(self.ctx.lib.dxo_mc_state_pointers(self.ctx._h, self._h, *(C.byref(o) for o in out)), "dxo_mc_state_pointers")
+        return dict(zip(("sigma_n", "sigma"), (o.value for o in out)))
+
+    def call(self, prm: McParams, mem: int, deps, C_tang, sigma=None, niter=None, yielding=None, norm_res=None, dlambda=None) -> None:
+        rc = self.ctx.lib.dxo_mohr_coulomb_state(self.ctx._h, C.byref(prm), self._h, int(mem), _ptr(deps), _ptr(C_tang), _ptr(sigma),
+                                                 _ptr(niter), _ptr(yielding), _ptr(norm_res), _ptr(dlambda))
+        self.ctx.check(rc, "dxo_mohr_coulomb_state")
 
 
 class MultiGpu:

@@ -103,6 +103,8 @@ struct dxo_ctx {
     int64_t host_small_bytes = 1 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
+    void* stage[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};   // dxo_stage: operand values in front of a pointwise kernel
+    size_t stage_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     hipStream_t scratch_stream = nullptr;   // stream of the last DEVICE-path launch that used scratch[DXO_HOST_SLOTS]
     bool scratch_stream_set = false;
     int64_t assign_validate = 1;        // dxo_assign: check flat_dofs against coeff_size on the device (one sync per call)
@@ -191,3 +193,28 @@ int dxo_grid_for_tiles(const dxo_ctx* ctx, int64_t n_tiles, int tiles_per_block)
 // launches. The device-path buffer is shared by every caller stream, so when the launch stream changes the previous
 // stream is drained first (two user streams must not race on it). nullptr on allocation failure.
 void* dxo_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes);
+// A second family of the same kind: the `*_field` entry points of the Newton / network kernels stage the operand values of
+// a chunk here while the kernel behind them uses dxo_scratch for its own lists (field_ops.hip).
+void* dxo_stage(dxo_ctx* ctx, hipStream_t s, size_t bytes);
+
+// Internal launchers shared between translation units (device pointers, explicit stream, no locking, no event bracket):
+struct dxo_mesh;
+struct dxo_icnn;
+int dxo_operand_launch_range(dxo_ctx* ctx, const dxo_mesh* mesh, int kind, int bs, const double* u_dev, int64_t cell0,
+                             int64_t n_cells, double* out_dev, hipStream_t s);
+int dxo_mc_launch_device(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, const double* deps, const double* sigma_n,
+                         double* C_tang, double* sigma, int32_t* niter, double* yielding, double* norm_res, double* dlambda,
+                         hipStream_t s);
+int dxo_icnn_launch_device(dxo_ctx* ctx, const dxo_icnn* m, int precision, int64_t n, const double* F, double* dP, double* P,
+                           hipStream_t s);
+int dxo_isihara_launch_device(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, const double* F, double* dP, double* P,
+                              hipStream_t s);
+
+// Device mirror of the Mohr-Coulomb history variable plus the stress of the last call (include/dxo.h, dxo_mc_state_*):
+// ONE allocation, [sigma_n n*4 | sigma n*4] doubles.
+struct dxo_mc_state {
+    int64_t n = 0;
+    void* blob = nullptr;
+    double *sigma_n = nullptr, *sigma = nullptr;
+    bool uploaded = false, has_result = false;
+};

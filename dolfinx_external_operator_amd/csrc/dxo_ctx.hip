@@ -83,7 +83,10 @@ int dxo_ctx_destroy(dxo_ctx* c) {
         }
     }
     for (int i = 0; i <= DXO_HOST_SLOTS; ++i)
+    {
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+        if (c->stage[i]) (void)hipFree(c->stage[i]);
+    }
     dxo_arena_release_all(c);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -306,6 +309,29 @@ void* dxo_scratch(dxo_ctx* ctx, hipStream_t s, size_t bytes) {
         ctx->scratch_bytes[slot] = want;
     }
     return ctx->scratch[slot];
+}
+
+void* dxo_stage(dxo_ctx* ctx, hipStream_t s, size_t bytes) {
+    int slot = DXO_HOST_SLOTS;
+    for (int i = 0; i < DXO_HOST_SLOTS; ++i)
+        if (ctx->slot_stream[i] == s) slot = i;
+    if (slot == DXO_HOST_SLOTS) {   // device-path buffer: same hand-over between caller streams as dxo_scratch
+        if (ctx->scratch_stream_set && ctx->scratch_stream != s && hipStreamSynchronize(ctx->scratch_stream) != hipSuccess) (void)hipGetLastError();
+        ctx->scratch_stream = s;
+        ctx->scratch_stream_set = true;
+    }
+    if (ctx->stage_bytes[slot] < bytes) {
+        if (ctx->stage[slot]) {
+            if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+            (void)hipFree(ctx->stage[slot]);
+            ctx->stage[slot] = nullptr;
+            ctx->stage_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&ctx->stage[slot], want) != hipSuccess) return nullptr;
+        ctx->stage_bytes[slot] = want;
+    }
+    return ctx->stage[slot];
 }
 
 int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {

@@ -127,3 +127,72 @@ extern "C" int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, i
     if (dqdsigma) out.push_back({nullptr, dqdsigma, (size_t)gdim * gdim * sd});
     return dxo_run_host_pipeline(ctx, n, in, out, heat_chunk, &L);
 }
+
+// ------------------------------------------------------------------ scalar conductivity of the part-1 demo
+// k(T) = 1 / (A + B T) and dk/dT = -B k^2: k_impl / dkdT_impl, demo_nonlinear_heat_equation_part1.py:251-271. The operator
+// lives on a CG space there (its values go through the dofmap assigner, external_operator.py:286-287 = dxo_assign). One
+// fused pass fills whichever of the two outputs are requested: 8 B read + 8 or 16 B written per value, HBM-bound.
+namespace {
+
+__global__ __launch_bounds__(DXO_BLOCK) void conductivity_kernel(double A, double B, int64_t n, const double* __restrict__ T,
+                                                                 double* __restrict__ k_out, double* __restrict__ dk_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
+        if (i + 1 < n && (((uintptr_t)(T + i) | (uintptr_t)(k_out ? k_out + i : nullptr) | (uintptr_t)(dk_out ? dk_out + i : nullptr)) & 15u) == 0) {
+            const dxo_f64x2 t = *reinterpret_cast<const dxo_f64x2*>(T + i);
+            const dxo_f64x2 k = {1.0 / (A + B * t.x), 1.0 / (A + B * t.y)};                       // :254
+            if (k_out) __builtin_nontemporal_store(k, reinterpret_cast<dxo_f64x2*>(k_out + i));
+            if (dk_out) __builtin_nontemporal_store(dxo_f64x2{-B * (k.x * k.x), -B * (k.y * k.y)}, reinterpret_cast<dxo_f64x2*>(dk_out + i));   // :271
+        } else {
+            for (int64_t j = i; j < n && j < i + 2; ++j) {
+                const double k = 1.0 / (A + B * T[j]);
+                if (k_out) k_out[j] = k;
+                if (dk_out) dk_out[j] = -B * (k * k);
+            }
+        }
+    }
+}
+
+struct CondLaunch { double A, B; bool want_k, want_dk; };
+
+int cond_launch(dxo_ctx* ctx, const CondLaunch& L, int64_t n, const double* T, double* k, double* dk, hipStream_t s) {
+    if (n == 0) return DXO_OK;
+    const int grid = dxo_grid_for_tiles(ctx, (n / 2 + DXO_BLOCK) / DXO_BLOCK, 1);
+    hipLaunchKernelGGL(conductivity_kernel, dim3(grid), dim3(DXO_BLOCK), 0, s, L.A, L.B, n, T, k, dk);
+    return DXO_OK;
+}
+
+int cond_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
+    const CondLaunch& L = *static_cast<const CondLaunch*>(user);
+    int o = 0;
+    double* k = L.want_k ? (double*)d_out[o++] : nullptr;
+    double* dk = L.want_dk ? (double*)d_out[o++] : nullptr;
+    return cond_launch(ctx, L, m, (const double*)d_in[0], k, dk, s);
+}
+
+}  // namespace
+
+extern "C" int dxo_conductivity(dxo_ctx* ctx, double A, double B, int64_t n, int mem, const double* T, double* k, double* dkdT) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_conductivity: n < 0");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_conductivity: bad mem");
+    if (n == 0 || (!k && !dkdT)) return DXO_OK;
+    if (!T) return dxo_fail(ctx, DXO_E_NULL, "dxo_conductivity: T is NULL");
+    if (((uintptr_t)T | (uintptr_t)k | (uintptr_t)dkdT) & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_conductivity: arrays must be 8-byte aligned");
+    CondLaunch L{A, B, k != nullptr, dkdT != nullptr};
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = cond_launch(ctx, L, n, T, k, dkdT, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    const size_t sd = sizeof(double);
+    std::vector<dxo_span> in = {{T, nullptr, sd}};
+    std::vector<dxo_span> out;
+    if (k) out.push_back({nullptr, k, sd});
+    if (dkdT) out.push_back({nullptr, dkdT, sd});
+    return dxo_run_host_pipeline(ctx, n, in, out, cond_chunk, &L);
+}

@@ -727,6 +727,18 @@ extern "C" int dxo_icnn_create(dxo_ctx* ctx, const dxo_icnn_weights* w, dxo_icnn
     return DXO_OK;
 }
 
+// internal: the kernels on device pointers and an explicit stream (field_ops.hip)
+int dxo_icnn_launch_device(dxo_ctx* ctx, const dxo_icnn* m, int precision, int64_t n, const double* F, double* dP, double* P,
+                           hipStream_t s) {
+    IcnnLaunch L{m, precision};
+    return icnn_launch(ctx, L, n, F, dP, P, s);
+}
+
+int dxo_isihara_launch_device(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, const double* F, double* dP, double* P,
+                              hipStream_t s) {
+    return isihara_launch(ctx, IsiPrm{prm->c1, prm->c2, prm->c3, prm->c4}, n, F, dP, P, s);
+}
+
 extern "C" int dxo_icnn_destroy(dxo_ctx* ctx, dxo_icnn* m) {
     if (!ctx) return DXO_E_NULL;
     DXO_LOCK(ctx);

@@ -466,6 +466,155 @@ extern "C" int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t 
     return dxo_run_host_pipeline(ctx, n, in, out, mc_chunk, &L);
 }
 
+// internal: the kernels on device pointers and an explicit stream (field_ops.hip)
+int dxo_mc_launch_device(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, const double* deps, const double* sigma_n,
+                         double* C_tang, double* sigma, int32_t* niter, double* yielding, double* norm_res, double* dlambda,
+                         hipStream_t s) {
+    McLaunch L{mc::make_const(prm->E, prm->nu, prm->c, prm->phi, prm->psi, prm->theta_T, prm->a, prm->tol, prm->nitermax),
+               niter != nullptr, yielding != nullptr, norm_res != nullptr, dlambda != nullptr};
+    return mc_launch(ctx, L, n, deps, sigma_n, C_tang, sigma, niter, yielding, norm_res, dlambda, s);
+}
+
+// ------------------------------------------------------------------ history variable resident on the device
+// The reference's callback re-reads sigma_n from a closure-captured host array at every call
+// (demo_plasticity_mohr_coulomb.py:579) although it changes only at the end of a load step (:728,
+// `sigma_n.x.array[:] = sigma.ref_coefficient.x.array`). A dxo_mc_state is its device mirror plus the stress of the last
+// call; the commit is that assignment on the device.
+extern "C" int dxo_mc_state_create(dxo_ctx* ctx, int64_t n, dxo_mc_state** out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!out) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_create: out is NULL");
+    *out = nullptr;
+    if (n < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_state_create: n < 0");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bs = ((size_t)n * 4 * sizeof(double) + 255) / 256 * 256;
+    void* blob = nullptr;
+    DXO_HIP(ctx, hipMalloc(&blob, 2 * bs + 256));
+    dxo_mc_state* st = new dxo_mc_state;
+    st->n = n;
+    st->blob = blob;
+    st->sigma_n = reinterpret_cast<double*>(blob);
+    st->sigma = reinterpret_cast<double*>(static_cast<char*>(blob) + bs);
+    *out = st;
+    return DXO_OK;
+}
+
+extern "C" void dxo_mc_state_destroy(dxo_ctx* ctx, dxo_mc_state* st) {
+    if (!st) return;
+    if (ctx) {
+        DXO_LOCK(ctx);
+        (void)hipSetDevice(ctx->device);
+        (void)dxo_ctx_synchronize(ctx);
+        if (st->blob) (void)hipFree(st->blob);
+    } else if (st->blob) {
+        (void)hipFree(st->blob);
+    }
+    delete st;
+}
+
+extern "C" int dxo_mc_state_upload(dxo_ctx* ctx, dxo_mc_state* st, int mem, const double* sigma_n) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_upload: state is NULL");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_mc_state_upload: bad mem");
+    if (st->n > 0 && !sigma_n) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_upload: NULL array");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    if (st->n > 0) {
+        DXO_HIP(ctx, hipMemcpyAsync(st->sigma_n, sigma_n, (size_t)st->n * 4 * sizeof(double),
+                                    mem == DXO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));   // the next call may read the mirror from any of the pipeline's streams
+    }
+    st->uploaded = true;
+    st->has_result = false;
+    return DXO_OK;
+}
+
+extern "C" int dxo_mc_state_download(dxo_ctx* ctx, dxo_mc_state* st, int mem, double* sigma_n) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_download: state is NULL");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_mc_state_download: bad mem");
+    if (!st->uploaded) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_state_download: nothing has been uploaded");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    if (st->n > 0 && sigma_n) {
+        DXO_HIP(ctx, hipMemcpyAsync(sigma_n, st->sigma_n, (size_t)st->n * 4 * sizeof(double),
+                                    mem == DXO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return DXO_OK;
+}
+
+extern "C" int dxo_mc_state_pointers(dxo_ctx* ctx, dxo_mc_state* st, double** sigma_n, double** sigma) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_pointers: state is NULL");
+    if (sigma_n) *sigma_n = st->sigma_n;
+    if (sigma) *sigma = st->sigma;
+    return DXO_OK;
+}
+
+extern "C" int dxo_mc_state_commit(dxo_ctx* ctx, dxo_mc_state* st) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!st) return dxo_fail(ctx, DXO_E_NULL, "dxo_mc_state_commit: state is NULL");
+    if (st->n == 0) return DXO_OK;   // an empty partition has nothing to update
+    if (!st->has_result)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_mc_state_commit: no call since the last upload / commit — nothing to commit");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = dxo_launch_stream(ctx);
+    // sigma_n <- sigma (:728): a device-to-device copy at HBM speed (64 B per point)
+    DXO_HIP(ctx, hipMemcpyAsync(st->sigma_n, st->sigma, (size_t)st->n * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    DXO_HIP(ctx, hipStreamSynchronize(s));   // the pipeline's streams read the mirror next
+    st->has_result = false;
+    return DXO_OK;
+}
+
+extern "C" int dxo_mohr_coulomb_state(dxo_ctx* ctx, const dxo_mc_params* prm, dxo_mc_state* st, int mem, const double* deps,
+                                      double* C_tang, double* sigma, int32_t* niter, double* yielding, double* norm_res,
+                                      double* dlambda) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!prm || !st) return dxo_fail(ctx, DXO_E_NULL, "dxo_mohr_coulomb_state: NULL params or state");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_mohr_coulomb_state: bad mem");
+    if (!st->uploaded) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mohr_coulomb_state: dxo_mc_state_upload has not been called");
+    if (prm->nitermax < 0) return dxo_fail(ctx, DXO_E_SIZE, "dxo_mohr_coulomb_state: nitermax < 0");
+    const int64_t n = st->n;
+    if (n == 0) return DXO_OK;
+    if (!deps || !C_tang) return dxo_fail(ctx, DXO_E_NULL, "dxo_mohr_coulomb_state: NULL array");
+    const uintptr_t a16 = (uintptr_t)deps | (uintptr_t)C_tang | (uintptr_t)sigma;
+    const uintptr_t a8 = (uintptr_t)yielding | (uintptr_t)norm_res | (uintptr_t)dlambda;
+    if (mem == DXO_MEM_DEVICE && (a16 & 15u)) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_mohr_coulomb_state: deps/C_tang/sigma must be 16-byte aligned");
+    if ((a16 & 7u) || (a8 & 7u) || ((uintptr_t)niter & 3u)) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_mohr_coulomb_state: misaligned array");
+    McLaunch L{mc::make_const(prm->E, prm->nu, prm->c, prm->phi, prm->psi, prm->theta_T, prm->a, prm->tol, prm->nitermax),
+               niter != nullptr, yielding != nullptr, norm_res != nullptr, dlambda != nullptr};
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    st->has_result = false;
+    const size_t sd = sizeof(double);
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = mc_launch(ctx, L, n, deps, st->sigma_n, C_tang, st->sigma, niter, yielding, norm_res, dlambda, s);
+        if (rc != DXO_OK) return rc;
+        if (sigma) DXO_HIP(ctx, hipMemcpyAsync(sigma, st->sigma, (size_t)n * 4 * sd, hipMemcpyDeviceToDevice, s));
+        rc = dxo_device_end(ctx, s);
+        if (rc == DXO_OK) st->has_result = true;
+        return rc;
+    }
+    if (!sigma) return dxo_fail(ctx, DXO_E_NULL, "dxo_mohr_coulomb_state: host sigma is required");
+    std::vector<dxo_span> in = {{deps, nullptr, 4 * sd}, {nullptr, nullptr, 4 * sd, st->sigma_n}};
+    std::vector<dxo_span> out = {{nullptr, C_tang, 16 * sd}, {nullptr, sigma, 4 * sd, st->sigma}};
+    if (niter) out.push_back({nullptr, niter, sizeof(int32_t)});
+    if (yielding) out.push_back({nullptr, yielding, sd});
+    if (norm_res) out.push_back({nullptr, norm_res, sd});
+    if (dlambda) out.push_back({nullptr, dlambda, sd});
+    const int rc = dxo_run_host_pipeline(ctx, n, in, out, mc_chunk, &L);
+    if (rc == DXO_OK) st->has_result = true;
+    return rc;
+}
+
 extern "C" int dxo_mc_summary(dxo_ctx* ctx, int64_t n, const int32_t* niter, const double* yielding, const double* norm_res,
                               int nbins, int64_t* hist, double* max_yielding, double* max_norm_res, int64_t* nan_counts) {
     if (!ctx) return DXO_E_NULL;

@@ -87,6 +87,18 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval(OperandDev m, const do
 namespace {
 
 template <int G, int BS, int KIND>
+void launch_operand_dev(const dxo_ctx* ctx, const OperandDev& dev, const double* u, const int32_t* cells, int64_t n_cells,
+                        double* out, hipStream_t s) {
+    const int64_t n_groups = (n_cells + dev.cells_per_wave - 1) / dev.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
+    const size_t shm = (size_t)(dev.table_doubles + 4 * dev.wave_doubles) * sizeof(double);
+    hipLaunchKernelGGL((operand_eval<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, dev, u, cells, n_cells, out);
+}
+
+template <int G, int BS, int KIND>
 void launch_operand(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, const int32_t* cells, int64_t n_cells,
                     double* out, hipStream_t s) {
     const int64_t n_groups = (n_cells + m->dev.cells_per_wave - 1) / m->dev.cells_per_wave;
@@ -131,6 +143,29 @@ int ensure(dxo_ctx* ctx, void** p, size_t* cap, size_t bytes) {
 }
 
 }  // namespace
+
+// Cells [cell0, cell0 + n_cells) of the mesh into out_dev[0 .. n_cells*nq*D): the mesh's dofmaps are simply entered at cell0
+// (the kernel sees a mesh of n_cells cells), wave-group kernel. Used by the *_field entry points of field_ops.hip.
+int dxo_operand_launch_range(dxo_ctx* ctx, const dxo_mesh* mesh, int kind, int bs, const double* u_dev, int64_t cell0,
+                             int64_t n_cells, double* out_dev, hipStream_t s) {
+    if (n_cells <= 0) return DXO_OK;
+    OperandDev dev = mesh->dev;
+    dev.dofmap += cell0 * dev.ndofs;
+    dev.geom_dofmap += cell0 * dev.ngeom;
+    const int G = mesh->gdim;
+    if (bs != G) return DXO_E_DIM;
+    if (kind == DXO_OPERAND_EPS_MANDEL) {
+        if (G == 2) launch_operand_dev<2, 2, DXO_OPERAND_EPS_MANDEL>(ctx, dev, u_dev, nullptr, n_cells, out_dev, s);
+        else launch_operand_dev<3, 3, DXO_OPERAND_EPS_MANDEL>(ctx, dev, u_dev, nullptr, n_cells, out_dev, s);
+        return DXO_OK;
+    }
+    if (kind == DXO_OPERAND_DEFGRAD) {
+        if (G == 2) launch_operand_dev<2, 2, DXO_OPERAND_DEFGRAD>(ctx, dev, u_dev, nullptr, n_cells, out_dev, s);
+        else launch_operand_dev<3, 3, DXO_OPERAND_DEFGRAD>(ctx, dev, u_dev, nullptr, n_cells, out_dev, s);
+        return DXO_OK;
+    }
+    return DXO_E_OPTION;
+}
 
 extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
     if (gdim != 2 && gdim != 3) return DXO_E_DIM;

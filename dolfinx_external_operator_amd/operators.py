@@ -472,11 +472,54 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     return q_external
 
 
+def make_conductivity(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, device: int = 0) -> Callable:
+    """`k_external` of the part-1 heat demo (demo_nonlinear_heat_equation_part1.py:277-296) on the GPU.
+
+    external_function((0,))(T) -> k = 1 / (A + B T)   flat (:251-256)
+    external_function((1,))(T) -> dk/dT = -B k^2      flat (:270-271)
+    Any other multi-index raises NotImplementedError (:295-296). `T` holds the operand at the interpolation points of the
+    operator's (CG) space, any shape; NumPy arrays go through the chunked pipeline, torch CUDA tensors stay on the device.
+    The operator lives on a continuous space there, so the flat result reaches the coefficient through the dofmap assigner
+    (`evaluation._assign_non_mixed`, external_operator.py:286-287; on the device: dxo_assign)."""
+    holder = {"ctx": ctx}
+
+    def _eval(T, which: int):
+        if holder["ctx"] is None:
+            holder["ctx"] = default_context(device)
+        cx = holder["ctx"]
+        if _is_device_tensor(T):
+            torch = _torch_stream(cx, T)
+            T_d = _dev_f64(T, "T").reshape(-1)
+            out = torch.empty(T_d.numel(), dtype=torch.float64, device=T_d.device)
+            cx.conductivity(A, B, T_d.numel(), MEM_DEVICE, T_d.data_ptr(), out.data_ptr() if which == 0 else None,
+                            out.data_ptr() if which == 1 else None)
+            return out
+        T_ = _as_f64_host(T, "T").reshape(-1)
+        out = np.empty(T_.size)
+        cx.conductivity(A, B, T_.size, MEM_HOST, T_, out if which == 0 else None, out if which == 1 else None)
+        return _like(T, out)[0]
+
+    def k_impl(T):
+        return _eval(T, 0)
+
+    def dkdT_impl(T):
+        return _eval(T, 1)
+
+    def k_external(derivatives):
+        if derivatives == (0,):
+            return k_impl
+        elif derivatives == (1,):
+            return dkdT_impl
+        raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
+
+    return k_external
+
+
 def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float = 3.45,
                       phi: float = 30 * np.pi / 180, psi: float = 30 * np.pi / 180, theta_T: float = 26 * np.pi / 180,
                       a: float | None = None, tol: float = 1e-8, Nitermax: int = 200, diagnostics: bool = True,
                       on_summary: Callable | None = None, ctx: Context | None = None, device: int = 0,
-                      reuse_outputs: bool = False, outputs=None) -> Callable:
+                      reuse_outputs: bool = False, outputs=None, state: str = "host") -> Callable:
     """`sigma_external` of the Mohr-Coulomb demo (demo_plasticity_mohr_coulomb.py:604-608) on the GPU.
 
     `external_function((1,))(deps) -> (C_tang, sigma)`, flat arrays, the reference's order (:593); any other
@@ -488,12 +531,25 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
     arrays (niter, yielding, norm_res, dlambda; :533) are kept on `external_function.last_state` when
     `diagnostics=True`, and `on_summary(dict)` — if given — receives the same numbers the reference prints:
     unique iteration counts, their multiplicities, max f, max residual.
+
+    A lazy operand (`DeviceMesh.operand("eps", Du, lazy=True)`, 2-D mesh) is not evaluated on the host: the dof vector
+    goes up and the strain is formed on the device in front of the Newton kernels (dxo_mohr_coulomb_field).
+    state (NumPy operands only): "host" (default) is the reference's contract — sigma_n is re-read from its holder and
+    uploaded at every call (:579). "resident" keeps a device mirror (dxo_mc_state): the holder is uploaded at the first
+    call and from then on only `deps` crosses the link on the way up (32 instead of 64 B/point);
+      external_function.commit_state()   after the reference's load-step update `sigma_n[:] = sigma` (:728) on the host
+                                         array: the same assignment on the device, no transfer;
+      external_function.state_changed()  after ANY other change of the holder: re-upload at the next call;
+      external_function.check_state()    max |mirror - holder| (tests, debugging).
     """
     if a is None:
         a = 0.26 * c / np.tan(phi)   # :116
     prm = McParams(float(E), float(nu), float(c), float(phi), float(psi), float(theta_T), float(a), float(tol),
                    int(Nitermax), 0)
+    if state not in ("host", "resident"):
+        raise ValueError('state must be "host" or "resident"')
     holder = {"ctx": ctx, "out": None}
+    mirror = _McMirror(sigma_n) if state == "resident" else None
 
     def C_tang_impl(deps):
         if holder["ctx"] is None:
@@ -503,9 +559,13 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             holder["out"] = _Outputs(cx, reuse_outputs, dict(zip(("C_tang", "sigma"), outputs)) if outputs is not None else None)
         if _is_device_tensor(deps):
             return _mohr_coulomb_device(cx, prm, deps, _state_array(sigma_n), diagnostics, on_summary, sigma_external)
-        deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
+        lazy = isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is cx and deps.mesh.gdim == 2 and mirror is None
+        if lazy:
+            n = deps.shape[0] * deps.shape[1]
+        else:
+            deps_ = _as_f64_host(deps, "deps").reshape((-1, 4))            # :578
+            n = deps_.shape[0]
         sigma_n_ = _as_f64_host(_state_array(sigma_n), "sigma_n").reshape((-1, 4))   # :579
-        n = deps_.shape[0]
         if sigma_n_.shape[0] != n:
             raise ValueError(f"state size mismatch: sigma_n has {sigma_n_.shape[0]} points, deps {n}")
         C_tang = holder["out"].get("C_tang", n * 16)
@@ -515,7 +575,12 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             yielding, norm_res, dlambda = np.empty(n), np.empty(n), np.empty(n)
         else:
             niter = yielding = norm_res = dlambda = None
-        cx.mohr_coulomb(prm, n, MEM_HOST, deps_, sigma_n_, C_tang, sigma, niter, yielding, norm_res, dlambda)
+        if lazy:      # operand still unevaluated: eps(Du) on the device in front of the Newton kernels
+            cx.mohr_coulomb_field(prm, deps.mesh._h, MEM_HOST, deps.u, sigma_n_, C_tang, sigma, niter, yielding, norm_res, dlambda)
+        elif mirror is not None:
+            mirror.sync(cx, n, sigma_n_).call(prm, MEM_HOST, deps_, C_tang, sigma, niter, yielding, norm_res, dlambda)
+        else:
+            cx.mohr_coulomb(prm, n, MEM_HOST, deps_, sigma_n_, C_tang, sigma, niter, yielding, norm_res, dlambda)
         sigma_external.last_state = (niter, yielding, norm_res, dlambda)
         if on_summary is not None and n > 0:
             unique_iters, counts = np.unique(niter, return_counts=True)   # :584
@@ -528,9 +593,69 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             return C_tang_impl
         raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
 
+    def _need_mirror():
+        if mirror is None:
+            raise RuntimeError('make_mohr_coulomb(..., state="resident") keeps a device mirror; this operator re-reads its state at every call')
+        return mirror
+
     sigma_external.params = prm
     sigma_external.last_state = None
+    sigma_external.commit_state = lambda: _need_mirror().commit()
+    sigma_external.state_changed = lambda: _need_mirror().invalidate()
+    sigma_external.check_state = lambda: _need_mirror().check()
     return sigma_external
+
+
+class _McMirror:
+    """Host-side bookkeeping of a dxo_mc_state for make_mohr_coulomb(state="resident"): same protocol and the same
+    sampled tripwire as _StateMirror."""
+
+    SAMPLES = 2048
+
+    def __init__(self, sigma_n_holder):
+        self.holder = sigma_n_holder
+        self.state = None            # _lib.McState
+        self.fresh = False
+        self.samples = None
+        self.resample = False
+
+    def _take(self, sigma_n_):
+        flat = sigma_n_.reshape(-1)
+        return flat[::max(flat.size // self.SAMPLES, 1)].copy()
+
+    def sync(self, cx: Context, n: int, sigma_n_):
+        if self.state is None or self.state.ctx is not cx or self.state.n != n:
+            if self.state is not None:
+                self.state.close()
+            self.state, self.fresh = cx.mc_state(n), False
+        if self.fresh and not self.resample and not np.array_equal(self._take(sigma_n_), self.samples, equal_nan=True):
+            import warnings
+
+            warnings.warn("make_mohr_coulomb(state='resident'): sigma_n changed without commit_state() / state_changed(); "
+                          "re-uploading it", RuntimeWarning, stacklevel=4)
+            self.fresh = False
+        if not self.fresh:
+            self.state.upload(sigma_n_)
+            self.fresh, self.resample = True, True
+        if self.resample:
+            self.samples, self.resample = self._take(sigma_n_), False
+        return self.state
+
+    def commit(self):
+        if self.state is None or not self.fresh:
+            return
+        self.state.commit()
+        self.resample = True
+
+    def invalidate(self):
+        self.fresh = False
+
+    def check(self) -> float:
+        if self.state is None:
+            raise RuntimeError("no call has been made yet")
+        sn = self.state.download()
+        hs = _as_f64_host(_state_array(self.holder), "sigma_n").reshape(-1)
+        return float(np.max(np.abs(sn - hs), initial=0.0))
 
 
 def _mohr_coulomb_device(cx: Context, prm: McParams, deps, sigma_n, diagnostics: bool, on_summary, fn):
@@ -602,6 +727,12 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
         cx, model = _model()
         if _is_device_tensor(Fvals):
             return _P_device(cx, Fvals, lambda n, F, dP, P: cx.icnn_eval(model, prec, n, MEM_DEVICE, F, dP, P))
+        if isinstance(Fvals, LazyOperand) and Fvals.kind == "F" and Fvals.mesh.ctx is cx and Fvals.mesh.gdim == 2:
+            # operand still unevaluated: F = I + grad u on the device in front of the network kernel (dxo_icnn_field)
+            n = Fvals.shape[0] * Fvals.shape[1]
+            dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
+            cx.icnn_field(model, prec, Fvals.mesh._h, MEM_HOST, Fvals.u, dP, P)
+            return dP.reshape(-1), P.reshape(-1)
         F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)      # :452
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
@@ -636,6 +767,11 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
         if _is_device_tensor(Fvals):
             cx = holder["ctx"]
             return _P_device(cx, Fvals, lambda n, F, dP, P: cx.isihara(prm, n, MEM_DEVICE, F, dP, P))
+        if isinstance(Fvals, LazyOperand) and Fvals.kind == "F" and Fvals.mesh.ctx is holder["ctx"] and Fvals.mesh.gdim == 2:
+            n = Fvals.shape[0] * Fvals.shape[1]      # F = I + grad u formed on the device (dxo_isihara_field)
+            dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
+            holder["ctx"].isihara_field(prm, Fvals.mesh._h, MEM_HOST, Fvals.u, dP, P)
+            return dP.reshape(-1), P.reshape(-1)
         F = _as_f64_host(Fvals, "Fvals").reshape(-1, 4)
         n = F.shape[0]
         dP, P = holder["out"].get("dP", n * 16), holder["out"].get("P", n * 4)
@@ -651,4 +787,4 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
     return P_external
 
 
-__all__ = ["make_von_mises", "make_heat", "make_mohr_coulomb", "make_icnn", "make_isihara", "von_mises_commit_state"]
+__all__ = ["make_von_mises", "make_heat", "make_conductivity", "make_mohr_coulomb", "make_icnn", "make_isihara", "von_mises_commit_state"]

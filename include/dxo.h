@@ -269,6 +269,11 @@ int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, int mem,
              const double* T, const double* sigma,
              double* q, double* dqdT, double* dqdsigma);
 
+/* Scalar conductivity of the part-1 heat demo: k[n] = 1 / (A + B T[n]) and dkdT[n] = -B k^2 (k_impl / dkdT_impl,
+ * demo_nonlinear_heat_equation_part1.py:251-271). Either output may be NULL; one fused pass. The operator lives on a CG
+ * space in the demo: its values reach the coefficient through the dofmap assigner (dxo_assign below). */
+int dxo_conductivity(dxo_ctx* ctx, double A, double B, int64_t n, int mem, const double* T, double* k, double* dkdT);
+
 /* ---- Mohr-Coulomb (Abbo-Sloan) return mapping + AD-through-Newton tangent ----------------------
  * Replaces return_mapping / dsigma_ddeps_vec / C_tang_impl,
  * demo_plasticity_mohr_coulomb.py:282-391, 405-462, 469-533, 555, 574-593.
@@ -284,6 +289,30 @@ int dxo_mohr_coulomb(dxo_ctx* ctx, const dxo_mc_params* prm, int64_t n, int mem,
                      const double* deps, const double* sigma_n,
                      double* C_tang, double* sigma,
                      int32_t* niter, double* yielding, double* norm_res, double* dlambda);
+
+/* History variable resident on the device, the Mohr-Coulomb counterpart of dxo_vm_state: the
+ * reference's callback re-reads sigma_n from a closure-captured host array at every call
+ * (demo_plasticity_mohr_coulomb.py:579) although it changes only at the end of a load step
+ * (:728, `sigma_n.x.array[:] = sigma.ref_coefficient.x.array`). A dxo_mc_state mirrors sigma_n[n][4] and keeps the
+ * stress of the last call:
+ *   dxo_mc_state_upload     caller's array -> mirror; blocking. Once, and again after any change other than the commit.
+ *   dxo_mohr_coulomb_state  dxo_mohr_coulomb with sigma_n read from the mirror; `mem` says where deps and the outputs live
+ *                           (DXO_MEM_HOST: only deps goes up, 32 of 64 B/point; DXO_MEM_DEVICE: sigma may be NULL, the
+ *                           result stays in the mirror, see dxo_mc_state_pointers).
+ *   dxo_mc_state_commit     sigma_n <- sigma of the LAST call inside the mirror (:728). Blocking. DXO_E_SIZE if there was
+ *                           no call since the last upload / commit; a state of n = 0 points commits trivially.
+ *   dxo_mc_state_download   mirror -> caller's array (checks, checkpoints);  dxo_mc_state_pointers: the device arrays.
+ * Results are bit-identical to dxo_mohr_coulomb on the same values. One state belongs to one ctx. */
+typedef struct dxo_mc_state dxo_mc_state;
+int dxo_mc_state_create(dxo_ctx* ctx, int64_t n, dxo_mc_state** out);
+void dxo_mc_state_destroy(dxo_ctx* ctx, dxo_mc_state* state);
+int dxo_mc_state_upload(dxo_ctx* ctx, dxo_mc_state* state, int mem, const double* sigma_n);
+int dxo_mc_state_download(dxo_ctx* ctx, dxo_mc_state* state, int mem, double* sigma_n);
+int dxo_mc_state_commit(dxo_ctx* ctx, dxo_mc_state* state);
+int dxo_mc_state_pointers(dxo_ctx* ctx, dxo_mc_state* state, double** sigma_n, double** sigma);
+int dxo_mohr_coulomb_state(dxo_ctx* ctx, const dxo_mc_params* prm, dxo_mc_state* state, int mem, const double* deps,
+                           double* C_tang, double* sigma, int32_t* niter, double* yielding, double* norm_res,
+                           double* dlambda);
 
 /* Inner-Newton summary of a dxo_mohr_coulomb call whose diagnostics live in DEVICE memory: the numbers the
  * reference prints at every call (unique iteration counts and their multiplicities, max f, max residual,
@@ -451,6 +480,25 @@ int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_do
  * all cells: q[n][gdim], dqdT[n][gdim], dqdsigma[n][gdim][gdim], n = num_cells*nq; any output may be NULL. */
 int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, const double* T_dofs,
                    double* q, double* dqdT, double* dqdsigma);
+
+/* The Newton / network / analytic hyperelastic operators with the operand formed on the device from the dof vector of
+ * the displacement field on `mesh` (gdim = 2): the reference's pair evaluate_operands + evaluate_external_operators
+ * (demo_plasticity_mohr_coulomb.py:679-688, demo_hyperelasticity.py:548-557) behind one call.
+ *   dxo_mohr_coulomb_field   operand eps(Du) in Mandel notation (:163-165), then dxo_mohr_coulomb's kernels; sigma_n and
+ *                            the outputs cover all cells, n = num_cells*nq points, diagnostics as in dxo_mohr_coulomb
+ *   dxo_icnn_field           operand F = I + grad u (demo_hyperelasticity.py:479), then dxo_icnn_eval's kernel
+ *   dxo_isihara_field        the same operand in front of dxo_isihara
+ * u: num_field_nodes*2 doubles (blocked, as fem.Function.x.array). A host caller uploads the dof vector instead of the
+ * operand array; the operand values pass through a staging buffer of the context in HBM (they are not fused into the
+ * registers of these kernels: two of the three are compute-bound, csrc/field_ops.hip). Results are bit-identical to
+ * dxo_eval_operand followed by the plain entry point. */
+int dxo_mohr_coulomb_field(dxo_ctx* ctx, const dxo_mc_params* prm, dxo_mesh* mesh, int mem, const double* u,
+                           const double* sigma_n, double* C_tang, double* sigma, int32_t* niter, double* yielding,
+                           double* norm_res, double* dlambda);
+int dxo_icnn_field(dxo_ctx* ctx, const dxo_icnn* model, int precision, dxo_mesh* mesh, int mem, const double* u,
+                   double* dP, double* P);
+int dxo_isihara_field(dxo_ctx* ctx, const dxo_isihara_params* prm, dxo_mesh* mesh, int mem, const double* u,
+                      double* dP, double* P);
 
 /* ---- multi-GPU: cell-block sharding + RCCL all-gather inside the library (BASELINE north_star) ----
  * The reference splits only by MPI mesh partition and never gathers quadrature data

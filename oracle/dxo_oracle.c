@@ -13,6 +13,9 @@
  *   heat      : PINNED — checked against tests/golden/heat_c1.npz produced by executing the reference's
  *               q_impl / dqdT_impl / dqdsigma_impl (doc/demo/demo_nonlinear_heat_equation_part2.py:215-261)
  *               (tests/golden/make_golden_heat.py).
+ *   conductivity : PINNED — checked against tests/golden/conductivity_p1.npz produced by executing the reference's
+ *               k_impl / dkdT_impl (doc/demo/demo_nonlinear_heat_equation_part1.py:251-271)
+ *               (tests/golden/make_golden_conductivity.py).
  *
  * The arithmetic follows the reference statement by statement (dense C_elas and `deviatoric`
  * mat-vecs, np.dot, np.outer), compiled with -ffp-contract=off so no FMA is introduced that NumPy
@@ -113,6 +116,16 @@ int oracle_heat(double A, double B, int gdim, int64_t n, const double* T, const 
             if (dqdsigma)
                 for (int b = 0; b < gdim; ++b) dqdsigma[(i * gdim + a) * gdim + b] = -k * (a == b ? 1.0 : 0.0); /* :260 */
         }
+    }
+    return 0;
+}
+
+/* Scalar conductivity of the part-1 heat demo, demo_nonlinear_heat_equation_part1.py:251-271. Outputs may be NULL. */
+int oracle_conductivity(double A, double B, int64_t n, const double* T, double* k_out, double* dkdT) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double k = 1.0 / (A + B * T[i]);   /* :254 */
+        if (k_out) k_out[i] = k;
+        if (dkdT) dkdT[i] = -B * (k * k);        /* :271  -B * k_impl(T) ** 2 */
     }
     return 0;
 }

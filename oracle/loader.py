@@ -49,6 +49,8 @@ class OracleLib:
         P = C.c_void_p
         self.lib.oracle_von_mises.restype = C.c_int
         self.lib.oracle_von_mises.argtypes = [P, C.c_int, C.c_int64, P, P, P, P, P, P, C.c_int]
+        self.lib.oracle_conductivity.restype = C.c_int
+        self.lib.oracle_conductivity.argtypes = [C.c_double, C.c_double, C.c_int64, P, P, P]
         self.lib.oracle_heat.restype = C.c_int
         self.lib.oracle_heat.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int64, P, P, P, P, P, C.c_int]
         self.lib.oracle_max_threads.restype = C.c_int
@@ -100,6 +102,15 @@ class OracleLib:
             raise ValueError(f"oracle_heat rc={rc}")
         return q, dqdT, dqds
 
+
+    def conductivity(self, T, *, A=1.0, B=1.0):
+        """k = 1 / (A + B T), dk/dT = -B k^2 (demo_nonlinear_heat_equation_part1.py:251-271); flat arrays."""
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1)
+        k, dk = np.empty(T.size), np.empty(T.size)
+        rc = self.lib.oracle_conductivity(A, B, T.size, _dp(T), _dp(k), _dp(dk))
+        if rc != 0:
+            raise ValueError(f"oracle_conductivity rc={rc}")
+        return k, dk
 
     def mohr_coulomb(self, deps, sigma_n, *, nthreads=1, tangent=True, **params):
         """deps (N,4), sigma_n (N,4) -> C_tang (N,4,4) [None if tangent=False], sigma (N,4), niter (N,) int32,

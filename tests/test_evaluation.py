@@ -204,3 +204,29 @@ def test_mixed_space_assigners_scalar_and_padded_vector():
     assert M._assign_func == M._assign_mixed_3d and M._comp_size == 2
     with pytest.raises(ValueError):      # wrong size, as in the reference (:440-444)
         M._assign_func(np.zeros(7))
+
+
+def test_conductivity_operator_on_a_cg_space_goes_through_the_dofmap_assigner(golden):
+    """Part 1 of the heat demo (demo_nonlinear_heat_equation_part1.py:212-303): the operator k lives on the SAME P2 space as
+    T, its operand is T at the interpolation points, (num_cells, 6), and its flat values reach the coefficient through the
+    unrolled dofmap (external_operator.py:203-209 picks `_assign_non_mixed`, :286-287), last writer wins. The golden holds
+    the reference's k_impl / dkdT_impl outputs on a 10 x 10 P2 mesh and the coefficient they leave. Value-side mirror only
+    (no GPU): the kernel's twin test is tests/test_round3_fields_gpu.py."""
+    g = golden("conductivity_p1.npz")
+    A, B = float(g["A"]), float(g["B"])
+    dofmap = g["dofmap"]
+
+    def k_external(derivatives):      # NumPy stand-in with the reference's multi-index rule (:277-296)
+        if derivatives == (0,):
+            return lambda T: (1.0 / (A + B * T)).reshape(-1)
+        if derivatives == (1,):
+            return lambda T: (-B * (1.0 / (A + B * T)) ** 2).reshape(-1)
+        raise NotImplementedError
+
+    T = Operand(lambda cells: g["T"][cells], "T")
+    ops = [QuadratureExternalOperator(T, num_cells=dofmap.shape[0], num_points=6, unrolled_dofmap=get_unrolled_dofmap(dofmap, 1),
+                                      coefficient_size=int(dofmap.max()) + 1, external_function=k_external, derivatives=d)
+           for d in ((0,), (1,))]
+    res = evaluate_external_operators(ops, evaluate_operands(ops))
+    assert np.array_equal(res[0], g["k"]) and np.array_equal(res[1], g["dkdT"])
+    assert np.array_equal(ops[0].ref_coefficient.x.array, g["coeff_k"])

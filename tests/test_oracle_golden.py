@@ -89,3 +89,14 @@ def test_von_mises_load_history_golden(oracle, golden):
         sigma_n = s.reshape(-1, d).copy()
         assert_close_scaled(p, g[f"p_after_{k}"], 1e-13, f"p after step {k}")
     assert (g["dp_2"] > 0).mean() > 0.5 and (g["dp_3"] > 0).sum() == 0       # loading, then elastic unloading
+
+
+def test_conductivity_oracle_matches_reference_golden(oracle, golden):
+    """k_impl / dkdT_impl of the part-1 heat demo executed by the generator (demo_nonlinear_heat_equation_part1.py:251-271):
+    the C restatement is bit-identical, including the pole A + B T = 0 (inf) and huge |T|."""
+    g = golden("conductivity_p1.npz")
+    k, dk = oracle.conductivity(g["T"], A=float(g["A"]), B=float(g["B"]))
+    assert np.array_equal(k, g["k"]) and np.array_equal(dk, g["dkdT"])
+    with np.errstate(all="ignore"):
+        k, dk = oracle.conductivity(g["T_rand"], A=float(g["A"]), B=float(g["B"]))
+    assert np.array_equal(k, g["k_rand"], equal_nan=True) and np.array_equal(dk, g["dkdT_rand"], equal_nan=True)

@@ -1,0 +1,252 @@
+"""Round-3 widening on the GPU: the part-1 conductivity operator (through the dofmap assigner), the Mohr-Coulomb history
+variable resident on the device, and the `*_field` entry points that form the operand of the Mohr-Coulomb / ICNN /
+analytic Isihara operators on the device."""
+import numpy as np
+import pytest
+
+from conftest import mc_compare_all, mc_tracing_inputs
+from dolfinx_external_operator_amd import (MEM_DEVICE, MEM_HOST, AssignDesc, DeviceMesh, QuadratureExternalOperator,
+                                           evaluate_external_operators, evaluate_operands, get_unrolled_dofmap, make_conductivity,
+                                           make_icnn, make_isihara, make_mohr_coulomb)
+from dolfinx_external_operator_amd.evaluation import Operand
+from tools.mc_inputs import mc_default_params
+from tools.synthetic import structured_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------- conductivity (a7, part 1)
+def test_conductivity_matches_the_reference_golden_through_the_dispatcher(ctx, oracle, golden):
+    """k_external of demo_nonlinear_heat_equation_part1.py:277-296 on the GPU, called the way the reference calls it:
+    operand T at the interpolation points of a P2 space, values assigned through the unrolled dofmap (:286-287)."""
+    g = golden("conductivity_p1.npz")
+    A, B = float(g["A"]), float(g["B"])
+    dofmap = g["dofmap"]
+    ext = make_conductivity(A=A, B=B, ctx=ctx)
+    with pytest.raises(NotImplementedError):
+        ext((2,))
+    T = Operand(lambda cells: g["T"][cells], "T")
+    ops = [QuadratureExternalOperator(T, num_cells=dofmap.shape[0], num_points=6, unrolled_dofmap=get_unrolled_dofmap(dofmap, 1),
+                                      coefficient_size=int(dofmap.max()) + 1, external_function=ext, derivatives=d)
+           for d in ((0,), (1,))]
+    res = evaluate_external_operators(ops, evaluate_operands(ops))
+    # one division and two products per value: the kernel forms them like the reference, bit for bit
+    assert np.array_equal(res[0], g["k"]) and np.array_equal(res[1], g["dkdT"])
+    assert np.array_equal(ops[0].ref_coefficient.x.array, g["coeff_k"])
+    with np.errstate(all="ignore"):
+        k = ext((0,))(g["T_rand"])
+        dk = ext((1,))(g["T_rand"])
+    assert np.array_equal(k, g["k_rand"], equal_nan=True) and np.array_equal(dk, g["dkdT_rand"], equal_nan=True)   # pole -> inf
+    assert ext((0,))(np.empty((0, 6))).size == 0
+    assert ext((0,))(g["T"].astype(np.float32)).dtype == np.float32
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1001, 2_000_003])
+def test_conductivity_device_path_and_device_assign(ctx, oracle, n):
+    """CUDA tensors in / out (odd sizes: the kernel moves 16-byte pairs), then the device assigner into a CG coefficient:
+    the whole part-1 operator without the values ever leaving the GPU."""
+    import torch
+
+    rng = np.random.Generator(np.random.PCG64(n))
+    T = rng.normal(0.5, 0.3, n)
+    ko, dko = oracle.conductivity(T, A=1.0, B=2.0)
+    ext = make_conductivity(A=1.0, B=2.0, ctx=ctx)
+    Td = torch.from_numpy(T).cuda()
+    k = ext((0,))(Td)
+    dk = ext((1,))(Td)
+    assert np.array_equal(k.cpu().numpy(), ko) and np.array_equal(dk.cpu().numpy(), dko)
+    if n >= 6 and n % 6 == 0 or n == 1001:
+        n_pts = 7 if n == 1001 else 6
+        nc = n // n_pts
+        dofmap = np.stack([(np.arange(nc) * 3 + j) % (nc + 5) for j in range(n_pts)], axis=1).astype(np.int32)   # shared dofs
+        un = get_unrolled_dofmap(dofmap, 1)
+        coeff = torch.full((nc + 5,), -1.0, dtype=torch.float64, device="cuda:0")
+        ctx.assign(AssignDesc(nc, n_pts, 1, 0, n_pts, 1, 0), torch.from_numpy(un).cuda().data_ptr(), k.data_ptr(), coeff.data_ptr(), nc + 5)
+        ctx.synchronize()
+        expect = np.full(nc + 5, -1.0)
+        expect[un] = ko[: nc * n_pts]
+        assert np.array_equal(coeff.cpu().numpy(), expect)
+
+
+# ------------------------------------------------------------------------------------------------- Mohr-Coulomb resident state (f2)
+def test_mohr_coulomb_state_is_bit_identical_and_follows_the_load_steps(ctx, oracle):
+    """dxo_mc_state: sigma_n uploaded once, every call reads it from HBM, the load-step update sigma_n <- sigma
+    (demo_plasticity_mohr_coulomb.py:728) happens on the device. Three load steps against the plain call that re-uploads
+    its state, bit for bit, host and device operands; commit without a call is an error, an empty state commits."""
+    import torch
+
+    prm = mc_default_params()
+    n = 20_000
+    deps, sn0 = mc_tracing_inputs(oracle, n, seed=21)
+    st = ctx.mc_state(n)
+    with pytest.raises(ValueError):
+        st.call(prm, MEM_HOST, deps, np.empty(n * 16), np.empty(n * 4))      # nothing uploaded yet
+    st.upload(sn0)
+    with pytest.raises(ValueError):
+        st.commit()                                                           # no call since the upload
+    sn = sn0.copy()
+    for step in range(3):
+        de = deps * (0.6 + 0.3 * step)
+        C_ref, s_ref = np.empty(n * 16), np.empty(n * 4)
+        it_ref = np.empty(n, dtype=np.int32)
+        ctx.mohr_coulomb(prm, n, MEM_HOST, de, sn, C_ref, s_ref, it_ref)
+        C, s = np.empty(n * 16), np.empty(n * 4)
+        it = np.empty(n, dtype=np.int32)
+        if step == 1:     # device operands, stress left in the mirror
+            de_d = torch.from_numpy(de).cuda()
+            C_d = torch.empty(n * 16, dtype=torch.float64, device="cuda:0")
+            it_d = torch.empty(n, dtype=torch.int32, device="cuda:0")
+            st.call(prm, MEM_DEVICE, de_d.data_ptr(), C_d.data_ptr(), None, it_d.data_ptr())
+            ctx.synchronize()
+            C, it = C_d.cpu().numpy(), it_d.cpu().numpy()
+            s_dev = torch.empty(n * 4, dtype=torch.float64, device="cuda:0")
+            ctx.copy(s_dev.data_ptr(), st.pointers()["sigma"], n * 32, 2)
+            s = s_dev.cpu().numpy()
+        else:
+            st.call(prm, MEM_HOST, de, C, s, it)
+        assert np.array_equal(C, C_ref) and np.array_equal(s, s_ref) and np.array_equal(it, it_ref)
+        st.commit()
+        sn = s_ref.reshape(n, 4).copy()                                       # :728 on the host side
+        assert np.array_equal(st.download().reshape(n, 4), sn)
+    st.close()
+    empty = ctx.mc_state(0)
+    empty.upload(np.empty(0))
+    empty.call(prm, MEM_HOST, None, None, None)
+    empty.commit()
+    empty.close()
+
+
+def test_mohr_coulomb_factory_resident_state(ctx, oracle):
+    """make_mohr_coulomb(state="resident"): same results as the default factory over two load steps with the caller's
+    `sigma_n[:] = sigma` + commit_state(); an unannounced change of the holder is caught by the tripwire."""
+    n = 6000
+    deps, sn0 = mc_tracing_inputs(oracle, n, seed=22)
+    sn_a, sn_b = sn0.copy(), sn0.copy()
+    plain = make_mohr_coulomb(sn_a, ctx=ctx)
+    res = make_mohr_coulomb(sn_b, ctx=ctx, state="resident")
+    with pytest.raises(RuntimeError):
+        plain.commit_state()
+    for step in range(2):
+        de = (deps * (0.7 + 0.3 * step)).reshape(n // 3, 3, 4)
+        Ca, sa = plain((1,))(de)
+        Cb, sb = res((1,))(de)
+        assert np.array_equal(Ca, Cb) and np.array_equal(sa, sb)
+        assert all(np.array_equal(x, y) for x, y in zip(plain.last_state, res.last_state))
+        sn_a[:] = sa.reshape(n, 4)
+        sn_b[:] = sb.reshape(n, 4)          # :728
+        res.commit_state()
+        assert res.check_state() == 0.0
+    res((1,))(deps.reshape(n // 3, 3, 4))     # the call after a commit samples the holder (it carries the committed update)
+    sn_b[:] = sn0                            # a change the operator was not told about
+    sn_a[:] = sn0
+    with pytest.warns(RuntimeWarning, match="re-uploading"):
+        Cb, sb = res((1,))(deps.reshape(n // 3, 3, 4))
+    Ca, sa = plain((1,))(deps.reshape(n // 3, 3, 4))
+    assert np.array_equal(Ca, Cb) and np.array_equal(sa, sb)
+    # parity of the whole thing with the oracle, iteration counts included
+    ref = oracle.mohr_coulomb(deps, sn0, nthreads=8)
+    mc_compare_all((Cb.reshape(n, 4, 4), sb.reshape(n, 4), *res.last_state), ref, "resident-state factory", sn0)
+
+
+# ------------------------------------------------------------------------------------------------- operand formed on the device (f1)
+def _p2_mesh(ctx, n=40):
+    m = structured_mesh("triangle", (n, n), 2, distort=0.2, seed=3)
+    return m, DeviceMesh.from_synthetic(m, ctx=ctx)
+
+
+def _smooth_field(m, amplitude, seed):
+    """A smooth displacement field (plus a little nodal noise) sampled at the field nodes: gradients of O(amplitude)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x, y = m.node_x[:, 0], m.node_x[:, 1]
+    u = np.stack([np.sin(3 * x) * np.cos(2 * y) + 0.3 * x * y, np.cos(2 * x) * y - 0.5 * x * x], axis=1)
+    return (amplitude * (u + 1e-3 * rng.normal(size=u.shape))).reshape(-1)
+
+
+def test_mohr_coulomb_field_equals_operand_then_kernel(ctx, oracle):
+    """dxo_mohr_coulomb_field: eps(Du) formed on the device in front of the Newton kernels — bit-identical to
+    dxo_eval_operand followed by dxo_mohr_coulomb, host arrays (chunk borders inside the mesh) and device pointers; through
+    the factory a lazy operand takes this path; parity with the oracle on the operand the oracle-side evaluation gives."""
+    import torch
+
+    m, dm = _p2_mesh(ctx)
+    try:
+        rng = np.random.Generator(np.random.PCG64(9))
+        n = m.num_cells * m.nq
+        u = _smooth_field(m, 4e-4, 9)
+        _, pool_s = mc_tracing_inputs(oracle, 4000, seed=23)
+        sigma_n = pool_s[rng.integers(0, 4000, n)]
+        prm = mc_default_params()
+        deps = dm.evaluate("eps", 2, u)                                      # (num_cells, nq, 4) through dxo_eval_operand
+        outs = {}
+        for name in ("two_calls", "field_host", "field_host_chunked", "field_device"):
+            C, s = np.empty(n * 16), np.empty(n * 4)
+            it = np.empty(n, dtype=np.int32)
+            y, nr, dl = np.empty(n), np.empty(n), np.empty(n)
+            if name == "two_calls":
+                ctx.mohr_coulomb(prm, n, MEM_HOST, deps, sigma_n, C, s, it, y, nr, dl)
+            elif name.startswith("field_host"):
+                saved = ctx.get_option("host_chunk_points")
+                if name.endswith("chunked"):
+                    ctx.set_option("host_chunk_points", 1000)                 # many chunks, borders inside wave groups
+                try:
+                    ctx.mohr_coulomb_field(prm, dm._h, MEM_HOST, u, sigma_n, C, s, it, y, nr, dl)
+                finally:
+                    ctx.set_option("host_chunk_points", saved)
+            else:
+                t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in (("u", u), ("sn", sigma_n))}
+                o = [torch.empty(sz, dtype=dt, device="cuda:0") for sz, dt in ((n * 16, torch.float64), (n * 4, torch.float64), (n, torch.int32),
+                                                                               (n, torch.float64), (n, torch.float64), (n, torch.float64))]
+                ctx.mohr_coulomb_field(prm, dm._h, MEM_DEVICE, t["u"].data_ptr(), t["sn"].data_ptr(), *(x.data_ptr() for x in o))
+                ctx.synchronize()
+                C, s, it, y, nr, dl = (x.cpu().numpy() for x in o)
+            outs[name] = (C, s, it, y, nr, dl)
+        for name in ("field_host", "field_host_chunked", "field_device"):
+            for a, b in zip(outs[name], outs["two_calls"]):
+                assert np.array_equal(a, b, equal_nan=True), name
+        # the factory: a lazy operand is routed to the field entry point and the host never sees the strain
+        ext = make_mohr_coulomb(sigma_n, ctx=ctx)
+        lazy = dm.operand("eps", u, lazy=True).eval(None)
+        C, s = ext((1,))(lazy)
+        assert lazy._value is None
+        assert np.array_equal(C, outs["two_calls"][0]) and np.array_equal(s, outs["two_calls"][1])
+        ref = oracle.mohr_coulomb(deps.reshape(n, 4), sigma_n, nthreads=8)
+        C2, s2, it2, y2, nr2, dl2 = outs["field_host"]
+        mc_compare_all((C2.reshape(n, 4, 4), s2.reshape(n, 4), it2, y2, nr2, dl2), ref, "Mohr-Coulomb field", sigma_n)
+    finally:
+        dm.close()
+
+
+def test_icnn_and_isihara_field_equal_operand_then_kernel(ctx, golden):
+    """dxo_icnn_field / dxo_isihara_field: F = I + grad u formed on the device (demo_hyperelasticity.py:479) in front of
+    the network / analytic kernels — bit-identical to the two-call sequence, lazy operands are routed there."""
+    m, dm = _p2_mesh(ctx, 32)
+    try:
+        rng = np.random.Generator(np.random.PCG64(10))
+        n = m.num_cells * m.nq
+        u = _smooth_field(m, 0.08, 10)
+        w = golden("icnn_isihara_weights.npz")
+        icnn = make_icnn({k: w[k] for k in w.files}, ctx=ctx)
+        isi = make_isihara(ctx=ctx)
+        Fvals = dm.operand("F", u).eval(None)                                # (num_cells, nq, 2, 2)
+        assert Fvals.shape == (m.num_cells, m.nq, 2, 2)
+        for ext in (icnn, isi):
+            dP0, P0 = ext((1,))(Fvals)
+            lazy = dm.operand("F", u, lazy=True).eval(None)
+            saved = ctx.get_option("host_chunk_points")
+            ctx.set_option("host_chunk_points", 700)
+            try:
+                dP1, P1 = ext((1,))(lazy)
+            finally:
+                ctx.set_option("host_chunk_points", saved)
+            assert lazy._value is None
+            assert np.isfinite(dP0).all() and 0.05 < np.abs(P0).max() < 1e3     # a deformation the models are meant for
+            assert dP1.shape == (n * 16,) and np.array_equal(dP1, dP0) and np.array_equal(P1, P0)
+        with pytest.raises(ValueError):      # a 3-D mesh has no 2x2 deformation gradient
+            m3 = structured_mesh("tetrahedron", (2, 2, 2), 1, distort=0.0, seed=0)
+            dm3 = DeviceMesh.from_synthetic(m3, ctx=ctx)
+            try:
+                ctx.isihara_field(isi.params, dm3._h, MEM_HOST, np.zeros(m3.node_x.shape[0] * 3), np.empty(8), np.empty(8))
+            finally:
+                dm3.close()
+    finally:
+        dm.close()
