@@ -108,6 +108,19 @@ class _Outputs:
         return buf
 
 
+def _coefficient_of(x):
+    """An operator's coefficient (FEMExternalOperator.ref_coefficient, external_operator.py:108-126) or the holder itself."""
+    return getattr(x, "ref_coefficient", x)
+
+
+def _bind_targets(names, operator, extras):
+    """(holder of the operator's coefficient, *extras) as the `outputs=` tuple of a factory: what `bind` installs."""
+    if len(extras) > len(names) - 1:
+        raise ValueError(f"bind takes at most {len(names) - 1} holders after the operator ({', '.join(names[1:])})")
+    tg = [None if operator is None else _coefficient_of(operator)] + [None if e is None else _coefficient_of(e) for e in extras]
+    return tuple(tg + [None] * (len(names) - len(tg)))
+
+
 def _torch_stream(c: Context, t):
     """Launch on torch's current stream of the tensor's device; refuse tensors of another GPU."""
     import torch
@@ -134,7 +147,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
                    reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host",
-                   devices=None, outputs=None) -> Callable:
+                   devices=None, outputs=None, device_outputs: str = "arena") -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -164,6 +177,17 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     owns (typically `operator.ref_coefficient` and the Functions the demo copies the extras into, :451-456). Results are
     written straight into them and those very arrays are returned, so the reference's `x.array[:] = values` (:441) finds
     source == destination and NumPy skips the 36 N-double copy. `Context.pin(array)` page-locks such an array once.
+    `external_function.bind(operator, sigma_holder=None, dp_holder=None)` is the one-line form of `outputs=`: it takes the
+    operator whose coefficient receives element 0 of the result — in the demo `J_external_operators[0]`, :441 — and the
+    Functions of the extras, installs `(operator.ref_coefficient, sigma_holder, dp_holder)` as the output targets and
+    returns the external_function, so a script needs one extra statement after its operators exist:
+        sigma.external_function.bind(J_external_operators[0], sigma_new, dp)
+    device_outputs (CUDA-tensor operands only): "arena" (default) — batches whose outputs exceed the arena's threshold
+    (option placement_min_bytes, 1 GiB: about 3*10^6 points at d = 6) are written into ONE persistent block of the
+    context's output arena, placed and launch-shaped by timing this kernel on candidate blocks (dxo_vm_output_alloc; 2-4 s
+    once per batch size): 0.77-0.81 of the HBM peak on a normal board instead of 0.66 into a fresh allocation. The tensors
+    returned are views of that block and are OVERWRITTEN by the operator's next device call (copy what must survive, or
+    pass `out=`); smaller batches and "fresh" return new tensors at every call.
     devices (NumPy operands only): a list of GPU indices, e.g. [0, 1, 2, 3] — the arrays are cut into one contiguous cell
     block per GPU and every GPU streams its block over its own PCIe link concurrently (dxo_mgpu_von_mises_host; no
     collective, RCCL is not loaded). The NumPy path is PCIe-bound, so this is how one process scales it. Not combined
@@ -184,20 +208,24 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         raise ValueError("outputs must be (C_tang, sigma, dp) holders (entries may be None)")
     if devices is not None and (state != "host" or len(devices) < 1):
         raise ValueError('devices=[...] needs at least one GPU index and state="host"')
-    holder = {"ctx": ctx, "out": None, "mgpu": None}
+    if device_outputs not in ("arena", "fresh"):
+        raise ValueError('device_outputs must be "arena" or "fresh"')
+    holder = {"ctx": ctx, "out": None, "mgpu": None, "targets": outputs, "dev_out": None}
     mirror = _StateMirror(sigma_n, p) if state == "resident" else None
 
     def _ctx() -> Context:
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["out"] is None:
-            tg = dict(zip(("C_tang", "sigma", "dp"), outputs)) if outputs is not None else None
+            tg = dict(zip(("C_tang", "sigma", "dp"), holder["targets"])) if holder["targets"] is not None else None
             holder["out"] = _Outputs(holder["ctx"], reuse_outputs, tg)
         return holder["ctx"]
 
     def C_tang_impl(deps, out=None):
         c = _ctx()
         if _is_device_tensor(deps):
+            if out is None and device_outputs == "arena":
+                out = _persistent_device_outputs(c, holder, deps)
             return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p), out)
         if isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is c:
             # operand still unevaluated: strain + return map + tangent in ONE launch (dxo_von_mises_field)
@@ -268,6 +296,12 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
             raise RuntimeError('make_von_mises(..., state="resident") keeps a device mirror; this operator re-reads its state at every call')
         return mirror
 
+    def bind(operator=None, *extras):
+        holder["targets"] = _bind_targets(("C_tang", "sigma", "dp"), operator, extras)
+        holder["out"] = None          # rebuilt with the new targets at the next call
+        return sigma_external
+
+    sigma_external.bind = bind
     sigma_external.params = prm
     sigma_external.context = _ctx
     sigma_external.arena = arena
@@ -331,6 +365,20 @@ class _StateMirror:
         hs = _as_f64_host(_state_array(self.holders[0]), "sigma_n").reshape(-1)
         hp = _as_f64_host(_state_array(self.holders[1]), "p").reshape(-1)
         return float(max(np.max(np.abs(sn - hs), initial=0.0), np.max(np.abs(pp - hp), initial=0.0)))
+
+
+def _persistent_device_outputs(c: Context, holder: dict, deps):
+    """The operator's persistent (C_tang, sigma, dp) block in the output arena for this batch size, or None for batches
+    below the arena's threshold (they get fresh tensors). Made at the first large call, replaced when the batch size
+    changes; the tensors alias across calls by design (make_von_mises, `device_outputs`)."""
+    n, d = deps.shape[0] * deps.shape[1], deps.shape[2]
+    if d not in (4, 6) or n * (d * d + d + 1) * 8 < c.get_option("placement_min_bytes"):
+        return None
+    key = (n, d, deps.device.index)
+    if holder["dev_out"] is None or holder["dev_out"][0] != key:
+        holder["dev_out"] = None      # give the old block back before the new one is calibrated
+        holder["dev_out"] = (key, c.vm_output_tensors(n, d))
+    return holder["dev_out"][1]
 
 
 def _von_mises_device(c: Context, prm: VmParams, deps, sigma_n, p, out=None):
@@ -548,7 +596,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
                    int(Nitermax), 0)
     if state not in ("host", "resident"):
         raise ValueError('state must be "host" or "resident"')
-    holder = {"ctx": ctx, "out": None}
+    holder = {"ctx": ctx, "out": None, "targets": outputs}
     mirror = _McMirror(sigma_n) if state == "resident" else None
 
     def C_tang_impl(deps):
@@ -556,7 +604,7 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             holder["ctx"] = default_context(device)
         cx = holder["ctx"]
         if holder["out"] is None:
-            holder["out"] = _Outputs(cx, reuse_outputs, dict(zip(("C_tang", "sigma"), outputs)) if outputs is not None else None)
+            holder["out"] = _Outputs(cx, reuse_outputs, dict(zip(("C_tang", "sigma"), holder["targets"])) if holder["targets"] is not None else None)
         if _is_device_tensor(deps):
             return _mohr_coulomb_device(cx, prm, deps, _state_array(sigma_n), diagnostics, on_summary, sigma_external)
         lazy = isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is cx and deps.mesh.gdim == 2 and mirror is None
@@ -598,6 +646,14 @@ def make_mohr_coulomb(sigma_n, *, E: float = 6778.0, nu: float = 0.25, c: float 
             raise RuntimeError('make_mohr_coulomb(..., state="resident") keeps a device mirror; this operator re-reads its state at every call')
         return mirror
 
+    def bind(operator=None, *extras):
+        """One-line form of `outputs=`: element 0 of the result lands in `operator.ref_coefficient`'s storage (the
+        reference's assignment, external_operator.py:441, then finds source == destination), sigma in the holder given."""
+        holder["targets"] = _bind_targets(("C_tang", "sigma"), operator, extras)
+        holder["out"] = None
+        return sigma_external
+
+    sigma_external.bind = bind
     sigma_external.params = prm
     sigma_external.last_state = None
     sigma_external.commit_state = lambda: _need_mirror().commit()
@@ -713,14 +769,15 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
     variant (BASELINE config 5). The stress correction H (:362-381) is computed once at creation.
     """
     prec = {"fp32": 0, "fp64": 1}[precision]
-    holder = {"ctx": ctx, "model": None, "out": None}
+    holder = {"ctx": ctx, "model": None, "out": None, "targets": outputs}
 
     def _model():
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["model"] is None:
             holder["model"] = holder["ctx"].icnn_create(state_dict)
-            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), outputs)) if outputs is not None else None)
+        if holder["out"] is None:
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), holder["targets"])) if holder["targets"] is not None else None)
         return holder["ctx"], holder["model"]
 
     def dP_dF_impl(Fvals):
@@ -744,6 +801,13 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
             return dP_dF_impl
         raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
 
+    def bind(operator=None, *extras):
+        """One-line form of `outputs=`: dP lands in `operator.ref_coefficient`'s storage, P in the holder given."""
+        holder["targets"] = _bind_targets(("dP", "P"), operator, extras)
+        holder["out"] = None
+        return P_external
+
+    P_external.bind = bind
     P_external.correction = lambda: _model()[0].icnn_correction(_model()[1])
     return P_external
 
@@ -757,13 +821,13 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
     operand `F = I + grad u` exactly like the network: `external_function((1,))(Fvals) -> (dP, P)`.
     W = c1 (I1bar-3) + c2 (I2bar-3) + c3 (I1bar-3)^2 + c4 (J-1)^2; defaults are the reference's (:700)."""
     prm = IsiharaParams(float(c1), float(c2), float(c3), float(c4))
-    holder = {"ctx": ctx, "out": None}
+    holder = {"ctx": ctx, "out": None, "targets": outputs}
 
     def dP_dF_impl(Fvals):
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         if holder["out"] is None:
-            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), outputs)) if outputs is not None else None)
+            holder["out"] = _Outputs(holder["ctx"], reuse_outputs, dict(zip(("dP", "P"), holder["targets"])) if holder["targets"] is not None else None)
         if _is_device_tensor(Fvals):
             cx = holder["ctx"]
             return _P_device(cx, Fvals, lambda n, F, dP, P: cx.isihara(prm, n, MEM_DEVICE, F, dP, P))
@@ -783,6 +847,13 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
             return dP_dF_impl
         raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
 
+    def bind(operator=None, *extras):
+        """One-line form of `outputs=`: dP lands in `operator.ref_coefficient`'s storage, P in the holder given."""
+        holder["targets"] = _bind_targets(("dP", "P"), operator, extras)
+        holder["out"] = None
+        return P_external
+
+    P_external.bind = bind
     P_external.params = prm
     return P_external
 

@@ -189,3 +189,76 @@ def test_resident_state_commit_on_an_empty_partition(ctx):
     st.commit()
     st.commit()
     st.close()
+
+
+def test_bind_puts_the_results_into_the_operators_coefficient(ctx, oracle):
+    """`external_function.bind(operator, sigma_holder, dp_holder)`: the one-line form of `outputs=`. Element 0 of the result
+    IS the operator's coefficient storage, so the reference's `coefficient.x.array[:] = values` (external_operator.py:441)
+    is an assignment of an array to itself; the extras land in the holders the demo copies them into
+    (demo_plasticity_von_mises.py:451-456)."""
+    from dolfinx_external_operator_amd import (Coefficient, QuadratureExternalOperator, evaluate_external_operators, evaluate_operands,
+                                               make_mohr_coulomb, make_von_mises)
+    from dolfinx_external_operator_amd.evaluation import Operand
+
+    nc, nq, d = 500, 8, 6
+    n = nc * nq
+    deps, sigma_n, p = vm_inputs(n, d, seed=41)
+    op = QuadratureExternalOperator(Operand(lambda cells: deps.reshape(nc, nq, d)[cells], "deps"), num_cells=nc, num_points=nq,
+                                    value_shape=(d, d), derivatives=(1,))
+    sigma_new, dp_new = Coefficient(n * d), Coefficient(n)
+    op.external_function = make_von_mises(sigma_n, p, ctx=ctx)
+    assert op.external_function.bind(op, sigma_new, dp_new) is op.external_function
+    ((C, s, dpv),) = evaluate_external_operators([op], evaluate_operands([op]))
+    assert np.shares_memory(C, op.ref_coefficient.x.array) and np.shares_memory(s, sigma_new.x.array) and np.shares_memory(dpv, dp_new.x.array)
+    Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+    assert_close_scaled(op.ref_coefficient.x.array, Co, 1e-13, "coefficient")
+    assert_close_scaled(sigma_new.x.array, so, 1e-13, "sigma")
+    assert_close_scaled(dp_new.x.array, dpo, 1e-13, "dp")
+    with pytest.raises(ValueError):
+        op.external_function.bind(op, sigma_new, dp_new, dp_new)
+    op.external_function.bind()                   # unbound again: fresh arrays
+    ((C2, _, _),) = evaluate_external_operators([op], evaluate_operands([op]))
+    assert not np.shares_memory(C2, op.ref_coefficient.x.array) and np.array_equal(C2, C)
+    mc = make_mohr_coulomb(np.zeros((10, 4)), ctx=ctx)
+    tgt = Coefficient(160)
+    mc.bind(tgt)
+    Cm, _ = mc((1,))(np.zeros((10, 4)))
+    assert np.shares_memory(Cm, tgt.x.array)
+
+
+def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle):
+    """CUDA-tensor operands, default factory: above the arena threshold the outputs live in ONE calibrated block that the
+    next call overwrites (documented aliasing); below it, and with device_outputs="fresh", every call returns new tensors."""
+    import torch
+
+    from dolfinx_external_operator_amd import make_von_mises
+
+    d, nq = 6, 8
+    saved = ctx.get_option("placement_min_bytes"), ctx.get_option("placement_candidates")
+    ctx.set_option("placement_min_bytes", 1 << 22)     # 4 MiB so that a test-sized batch is "large"
+    ctx.set_option("placement_candidates", 3)
+    try:
+        n = 64_000
+        deps, sigma_n, p = vm_inputs(n, d, seed=42)
+        t = [_dev(a) for a in (deps.reshape(n // nq, nq, d), sigma_n.reshape(-1), p)]
+        ext = make_von_mises(t[1], t[2], ctx=ctx)
+        C1, s1, dp1 = ext((1,))(t[0])
+        ptr = C1.data_ptr()
+        assert C1.dxo_block.info["mode"] == "candidates"
+        Co, so, dpo = oracle.von_mises(deps, sigma_n, p)
+        assert_close_scaled(C1.cpu().numpy(), Co, 1e-13, "arena-backed device call")
+        C2, _, _ = ext((1,))(t[0] * 0.5)
+        assert C2.data_ptr() == ptr                                  # the same block: the first result has been overwritten
+        assert_close_scaled(C1.cpu().numpy(), oracle.von_mises(deps * 0.5, sigma_n, p)[0], 1e-13, "aliased view sees the new call")
+        small = [_dev(a) for a in (deps[:800].reshape(100, nq, d), sigma_n[:800].reshape(-1), p[:800])]
+        ext_s = make_von_mises(small[1], small[2], ctx=ctx)
+        a = ext_s((1,))(small[0])[0]
+        b = ext_s((1,))(small[0])[0]
+        assert a.data_ptr() != b.data_ptr()                          # below the threshold: fresh tensors
+        fresh = make_von_mises(t[1], t[2], ctx=ctx, device_outputs="fresh")
+        x = fresh((1,))(t[0])[0]
+        y = fresh((1,))(t[0])[0]
+        assert x.data_ptr() != y.data_ptr() and torch.equal(x, y)
+    finally:
+        ctx.set_option("placement_min_bytes", saved[0])
+        ctx.set_option("placement_candidates", saved[1])
