@@ -119,7 +119,10 @@ struct McScratchHeader {
     unsigned int pad[62];
 };
 
-__global__ __launch_bounds__(DXO_BLOCK) void mc_classify(mc::Const k, int64_t n, const double* __restrict__ deps,
+#ifndef DXO_MC_CLASSIFY_MINW
+#define DXO_MC_CLASSIFY_MINW 1
+#endif
+__global__ __launch_bounds__(DXO_BLOCK, DXO_MC_CLASSIFY_MINW) void mc_classify(mc::Const k, int64_t n, const double* __restrict__ deps,
                                                          const double* __restrict__ sigma_n, double* __restrict__ C_tang,
                                                          double* __restrict__ sigma, int32_t* __restrict__ niter,
                                                          double* __restrict__ yielding, double* __restrict__ norm_res,

@@ -25,6 +25,15 @@ namespace {
 #ifndef DXO_OP_CT
 #define DXO_OP_CT 1
 #endif
+#ifndef DXO_VMF_PRELOAD
+#define DXO_VMF_PRELOAD 0   // request sigma_n / p before the strain is formed: no gain (0.844 vs 0.844 ms with two waves per SIMD, 1.00 with three: spills)
+#endif
+#ifndef DXO_VMF_FULL
+#define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
+#endif
+#ifndef DXO_VMF_BLOCKS_PER_CU
+#define DXO_VMF_BLOCKS_PER_CU 16
+#endif
 template <int G, bool NT, int ND_CT = 0, int NG_CT = 0>
 __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
@@ -69,6 +78,19 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         const int64_t p0 = c0 * m.nq;                 // first point, relative to the state/output arrays passed in
         const int nvec = npts * T::CH_VEC;
 
+#if DXO_VMF_PRELOAD
+        // the state of this group is requested BEFORE the strain is formed: its HBM latency runs under the contraction
+        dxo_f64x2 sreg[T::CH_VEC];
+        {
+            const dxo_f64x2* g_s0 = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
+#pragma unroll
+            for (int k = 0; k < T::CH_VEC; ++k) {
+                const int idx = k * DXO_WAVE + lane;
+                sreg[k] = idx < nvec ? g_s0[idx] : dxo_f64x2{0.0, 0.0};
+            }
+        }
+        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
+#endif
         // ---- A1: strain increment of this lane's point from the displacement dofs
         double e[D];
         bool active;
@@ -85,6 +107,10 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
             for (int k = 0; k < D; ++k) e[k] = 0.0;
         }
         // ---- A2: sigma_n lane-linear -> LDS -> point-per-lane
+#if DXO_VMF_PRELOAD
+#pragma unroll
+        for (int k = 0; k < T::CH_VEC; ++k) Y2[k * DXO_WAVE + lane] = sreg[k];
+#else
         const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
@@ -92,6 +118,7 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
             Y2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{0.0, 0.0};
         }
         const double p_l = lane < npts ? p[p0 + lane] : 0.0;
+#endif
         wave_lds_fence();
         double sn[D];
 #pragma unroll
@@ -121,6 +148,11 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
             const int idx = k * DXO_WAVE + lane;
             if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
         }
+#if DXO_VMF_FULL
+        // a full group of 64 points (8 cells x 8 points on hexahedra): guard-free tangent stores, as in vm_tile
+        if (npts == DXO_WAVE) vm_store_tangent<D, NT, true>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
+        else
+#endif
         vm_store_tangent<D, NT>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
         wave_lds_fence();
     }
@@ -150,7 +182,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");
     const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    const int64_t cap = (int64_t)ctx->compute_units * DXO_VMF_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;

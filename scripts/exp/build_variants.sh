@@ -22,4 +22,8 @@ build() {  # name, macros...
 build base                               # same flags as the product (sanity: must time like libdxo_hip.so)
 # (a variant that prefetched the next tile's inputs in persistent grids was tried this way and dropped: no difference)
 # (tile-walk variants of the persistent grid — XCD-contiguous eighths, runs of 4 tiles per wave — were tried this way and lost)
-build mcmask  -DDXO_MC_SIGMA_ALL=0         # mc_classify: sigma stores masked to the elastic points (the form before: 1.35 vs 1.30 ms)
+# round 3, tried this way and dropped (scripts/exp/vmfield_ab.py on ONE shared output block; scripts/bench_mc.py):
+#   -DDXO_VMF_PRELOAD=1 (sigma_n / p requested before the strain is formed)      0.844 vs 0.844 ms (2 waves/SIMD), 1.00 with 3 (spills)
+#   -DDXO_VMF_WAVES=2 / 4                                                         0.847 / 1.30 ms (3: 0.844)
+#   -DDXO_VMF_BLOCKS_PER_CU=8 / 32 / 64                                           0.819 / 0.827 / 0.867 ms (16: 0.816)
+#   -DDXO_MC_CLASSIFY_MINW=4 / 5 (mc_classify at <= 128 / <= 96 registers)        1.28-1.31 / 1.46 ms (1: 1.18-1.26)
