@@ -10,15 +10,100 @@
 // PCIe for the network operators), and there is no `Expression.eval` on the CPU. Unlike dxo_von_mises_field (vm_field.hip)
 // the operand is not formed in the registers of the consuming kernel: the Newton and the network kernels are
 // compute-bound (fp64 vector pipe / fp32 MFMA), the 64 B per point that pass through HBM between the two
-// launches are a few per cent of their time. The analytic Isihara kernel IS HBM-bound: for it the staging costs 64 of
-// 256 B per point (noted in DESIGN.md 10 as the one place where in-register fusion would still pay).
+// launches are a few per cent of their time. The analytic Isihara kernel IS HBM-bound (192 B per point): there F is formed
+// in the registers of the kernel that evaluates the model (isihara_field below) and never reaches memory.
 //
 // Host arrays: the field vector goes up whole, cells stream through the chunked pipeline (units of CELLS), every chunk
 // = operand launch + constitutive launch on the chunk's stream.
 #include "dxo_common.h"
+#include "hyper_core.h"
 #include "operand_core.h"
 
 namespace {
+
+// ---- analytic Isihara model with the operand in registers: a wave owns floor(64 / nq) consecutive cells, each lane forms
+// F = I + grad u of its own quadrature point (operand_core.h), evaluates P and dP/dF (hyper_core.h) into the wave's LDS
+// slice — the gather buffer, free again after the contraction — and the wave stores its points in output order.
+template <bool NT>
+__global__ __launch_bounds__(DXO_BLOCK) void isihara_field(IsiPrm prm, OperandDev m, int wave_doubles, int64_t cell0, int64_t n_cells,
+                                                           const double* __restrict__ u, double* __restrict__ dP,
+                                                           double* __restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tab = lds;
+    operand_load_tables<2>(m, tab);
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + m.table_doubles + wave * wave_doubles;
+    double* Xd = W;                        // [64][16] tangent rows
+    double* Xp = W + DXO_WAVE * 16;        // [64][4]  stresses
+    const dxo_f64x2* Xd2 = reinterpret_cast<const dxo_f64x2*>(Xd);
+    const dxo_f64x2* Xp2 = reinterpret_cast<const dxo_f64x2*>(Xp);
+    const int cpw = m.cells_per_wave;
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
+        const int npts = ncell * m.nq;
+        const int64_t p0 = c0 * m.nq;
+        double Fv[4];
+        const bool active = operand_point<2, 2, DXO_OPERAND_DEFGRAD>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, Fv);
+        if (active) isihara_point(prm, Fv, Xd + lane * 16, Xp + lane * 4);
+        op_fence();
+        dxo_f64x2* g_d = reinterpret_cast<dxo_f64x2*>(dP + p0 * 16);
+        dxo_f64x2* g_p = reinterpret_cast<dxo_f64x2*>(P + p0 * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            if (idx < npts * 8) {
+                if constexpr (NT) __builtin_nontemporal_store(Xd2[idx], g_d + idx);
+                else g_d[idx] = Xd2[idx];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = k * DXO_WAVE + lane;
+            if (idx < npts * 2) {
+                if constexpr (NT) __builtin_nontemporal_store(Xp2[idx], g_p + idx);
+                else g_p[idx] = Xp2[idx];
+            }
+        }
+        op_fence();
+    }
+}
+
+struct IsiFieldLaunch {
+    IsiPrm prm;
+    dxo_mesh* mesh;
+    const double* d_u;
+    int64_t next_cell = 0;
+};
+
+int isi_field_launch(dxo_ctx* ctx, const IsiFieldLaunch& L, int64_t cell0, int64_t n_cells, double* dP, double* P, hipStream_t s) {
+    if (n_cells == 0) return DXO_OK;
+    const OperandDev& m = L.mesh->dev;
+    int wd = m.wave_doubles;
+    if (wd < DXO_WAVE * 20) wd = DXO_WAVE * 20;
+    wd = (wd + 1) & ~1;
+    const size_t shm = (size_t)(m.table_doubles + 4 * wd) * sizeof(double);
+    if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_isihara_field: element too large for the LDS budget");
+    const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;
+    if (ctx->nontemporal != 0) hipLaunchKernelGGL(isihara_field<true>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.prm, m, wd, cell0, n_cells, L.d_u, dP, P);
+    else hipLaunchKernelGGL(isihara_field<false>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.prm, m, wd, cell0, n_cells, L.d_u, dP, P);
+    return DXO_OK;
+}
+
+int isi_field_chunk(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const*, void* const* d_out, hipStream_t s) {
+    IsiFieldLaunch& L = *static_cast<IsiFieldLaunch*>(user);
+    const int64_t cell0 = L.next_cell;
+    L.next_cell += n_chunk;
+    return isi_field_launch(ctx, L, cell0, n_chunk, (double*)d_out[0], (double*)d_out[1], s);
+}
 
 int upload_u(dxo_ctx* ctx, dxo_mesh* mesh, const double* u) {
     const size_t ub = (size_t)mesh->num_field_nodes * mesh->gdim * sizeof(double);
@@ -162,14 +247,21 @@ extern "C" int dxo_isihara_field(dxo_ctx* ctx, const dxo_isihara_params* prm, dx
     const uintptr_t all = (uintptr_t)u | (uintptr_t)dP | (uintptr_t)P;
     if (all & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_isihara_field: arrays must be 8-byte aligned");
     if (mem == DXO_MEM_DEVICE && (((uintptr_t)dP | (uintptr_t)P) & 15u)) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_isihara_field: device dP, P must be 16-byte aligned");
-    const dxo_isihara_params K = *prm;
-    FieldOp L{mesh, nullptr, DXO_OPERAND_DEFGRAD};
-    L.consume = [K](dxo_ctx* c, const double* F, int64_t n, void* const*, void* const* d_out, hipStream_t s) {
-        return dxo_isihara_launch_device(c, &K, n, F, (double*)d_out[0], (double*)d_out[1], s);
-    };
+    IsiFieldLaunch L{IsiPrm{prm->c1, prm->c2, prm->c3, prm->c4}, mesh, u, 0};
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem == DXO_MEM_DEVICE) {
+        hipStream_t s = dxo_launch_stream(ctx);
+        int rc = dxo_device_begin(ctx, s);
+        if (rc != DXO_OK) return rc;
+        rc = isi_field_launch(ctx, L, 0, mesh->num_cells, dP, P, s);
+        if (rc != DXO_OK) return rc;
+        return dxo_device_end(ctx, s);
+    }
+    int rc = upload_u(ctx, mesh, u);
+    if (rc != DXO_OK) return rc;
+    L.d_u = mesh->d_u;
     const size_t sd = sizeof(double) * (size_t)mesh->dev.nq;
     std::vector<dxo_span> in;
     std::vector<dxo_span> out = {{nullptr, dP, 16 * sd}, {nullptr, P, 4 * sd}};
-    void* dout[2] = {dP, P};
-    return run_field_op(ctx, L, mem, u, in, out, nullptr, dout);
+    return dxo_run_host_pipeline(ctx, mesh->num_cells, in, out, isi_field_chunk, &L, mesh->dev.nq);
 }

@@ -489,9 +489,10 @@ int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, int mem, co
  *   dxo_icnn_field           operand F = I + grad u (demo_hyperelasticity.py:479), then dxo_icnn_eval's kernel
  *   dxo_isihara_field        the same operand in front of dxo_isihara
  * u: num_field_nodes*2 doubles (blocked, as fem.Function.x.array). A host caller uploads the dof vector instead of the
- * operand array; the operand values pass through a staging buffer of the context in HBM (they are not fused into the
- * registers of these kernels: two of the three are compute-bound, csrc/field_ops.hip). Results are bit-identical to
- * dxo_eval_operand followed by the plain entry point. */
+ * operand array. dxo_isihara_field (HBM-bound) forms F in the registers of the kernel that evaluates the model, F never
+ * reaches memory; for the two compute-bound operators (fp64 Newton, fp32 MFMA network) the operand values pass through a
+ * staging buffer of the context in HBM between the operand kernel and theirs (csrc/field_ops.hip). Results are
+ * bit-identical to dxo_eval_operand followed by the plain entry point. */
 int dxo_mohr_coulomb_field(dxo_ctx* ctx, const dxo_mc_params* prm, dxo_mesh* mesh, int mem, const double* u,
                            const double* sigma_n, double* C_tang, double* sigma, int32_t* niter, double* yielding,
                            double* norm_res, double* dlambda);

@@ -4,7 +4,7 @@ analytic Isihara operators on the device."""
 import numpy as np
 import pytest
 
-from conftest import mc_compare_all, mc_tracing_inputs
+from conftest import assert_close_scaled, mc_compare_all, mc_tracing_inputs
 from dolfinx_external_operator_amd import (MEM_DEVICE, MEM_HOST, AssignDesc, DeviceMesh, QuadratureExternalOperator,
                                            evaluate_external_operators, evaluate_operands, get_unrolled_dofmap, make_conductivity,
                                            make_icnn, make_isihara, make_mohr_coulomb)
@@ -218,7 +218,8 @@ def test_mohr_coulomb_field_equals_operand_then_kernel(ctx, oracle):
 
 def test_icnn_and_isihara_field_equal_operand_then_kernel(ctx, golden):
     """dxo_icnn_field / dxo_isihara_field: F = I + grad u formed on the device (demo_hyperelasticity.py:479) in front of
-    the network / analytic kernels — bit-identical to the two-call sequence, lazy operands are routed there."""
+    the network kernel (through a staging buffer: bit-identical to the two-call sequence) / inside the analytic kernel (in
+    registers: equal to rounding); lazy operands are routed there."""
     m, dm = _p2_mesh(ctx, 32)
     try:
         rng = np.random.Generator(np.random.PCG64(10))
@@ -240,7 +241,12 @@ def test_icnn_and_isihara_field_equal_operand_then_kernel(ctx, golden):
                 ctx.set_option("host_chunk_points", saved)
             assert lazy._value is None
             assert np.isfinite(dP0).all() and 0.05 < np.abs(P0).max() < 1e3     # a deformation the models are meant for
-            assert dP1.shape == (n * 16,) and np.array_equal(dP1, dP0) and np.array_equal(P1, P0)
+            assert dP1.shape == (n * 16,)
+            if ext is icnn:      # operand kernel -> staging buffer -> the same network kernel: bit for bit
+                assert np.array_equal(dP1, dP0) and np.array_equal(P1, P0)
+            else:                # F formed in the registers of the fused kernel: the same statements compiled in another kernel, so
+                assert_close_scaled(dP1, dP0, 1e-13, "isihara_field dP")      # products may be fused differently: rounding only
+                assert_close_scaled(P1, P0, 1e-13, "isihara_field P")
         with pytest.raises(ValueError):      # a 3-D mesh has no 2x2 deformation gradient
             m3 = structured_mesh("tetrahedron", (2, 2, 2), 1, distort=0.0, seed=0)
             dm3 = DeviceMesh.from_synthetic(m3, ctx=ctx)
