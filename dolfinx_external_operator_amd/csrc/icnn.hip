@@ -217,7 +217,7 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
 // LDS per workgroup: A operands 32 KiB + two small tables 6 KiB (rows addressed base(h) + immediate) + 55 KiB of
 // lane-private slots for what is only needed after both half-tiles; no accumulator parking, no fences. Round 2's kernel
 // spent 36 % of a wave's cycles in vector-only phases (accumulator parking, 128 + 128 LDS accesses per lane and half-tile,
-// 32 repeated softplus) and ran at 0.46 of the fp32 MFMA peak; this one issues 7.2 instead of 11.7 vector instructions per
+// 32 repeated softplus) and ran at 0.46 of the fp32 MFMA peak; this one issues 6.8 instead of 11.7 vector instructions per
 // MFMA and runs at 0.60. What bounds it (scripts/exp/mfma32_valu_probe.hip, profiles/r03_mfma32_valu_probe.txt): on gfx950
 // the fp32-input MFMA does NOT run beside vector work — every v_fma_f32 placed between two v_mfma_f32_32x32x2_f32 adds
 // ~3 cycles to the 64 of the MFMA, every v_exp / v_log / v_rcp ~12.5, with one or two waves per SIMD alike — so the time of a
