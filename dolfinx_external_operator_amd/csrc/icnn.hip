@@ -219,9 +219,10 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
 // spent 36 % of a wave's cycles in vector-only phases (accumulator parking, 128 + 128 LDS accesses per lane and half-tile,
 // 32 repeated softplus) and ran at 0.46 of the fp32 MFMA peak; this one issues 6.8 instead of 11.7 vector instructions per
 // MFMA and runs at 0.60. What bounds it (scripts/exp/mfma32_valu_probe.hip, profiles/r03_mfma32_valu_probe.txt): on gfx950
-// the fp32-input MFMA does NOT run beside vector work — every v_fma_f32 placed between two v_mfma_f32_32x32x2_f32 adds
-// ~3 cycles to the 64 of the MFMA, every v_exp / v_log / v_rcp ~12.5, with one or two waves per SIMD alike — so the time of a
-// half-tile is the SUM of its 320 MFMAs (20.5 k cycles) and of its vector instructions, not the maximum; see DESIGN.md 8.
+// vector work placed between MFMAs does not hide under them at this density — every v_fma_f32 between two
+// v_mfma_f32_32x32x2_f32 adds ~2.5-3 cycles to the 64 of the MFMA, every v_exp / v_log / v_rcp ~12.5, with one or two waves
+// per SIMD alike (the bf16 pipe behaves the same way) — so the time of a half-tile is the SUM of its 320 MFMAs (20.5 k
+// cycles) and of its vector instructions, not the maximum; see DESIGN.md 8.
 __device__ __forceinline__ constexpr int icnn_row(int t, int q) { return 32 * t + (q & 3) + 8 * (q >> 2); }   // + 4 h
 
 // softplus with first and second derivative for icnn_mfma2: the exponent is clamped at 80 (e^80 is finite in fp32), so that
