@@ -158,6 +158,10 @@ _SIGNATURES = {
     "dxo_mgpu_synchronize": (C.c_int, [_P]),
     "dxo_mgpu_all_gather": (C.c_int, [_P, C.POINTER(_P), C.c_int64]),
     "dxo_mgpu_von_mises": (C.c_int, [_P, C.POINTER(VmParams), C.c_int, C.c_int64, C.c_int] + [C.POINTER(_P)] * 6),
+    "dxo_mgpu_mohr_coulomb": (C.c_int, [_P, C.POINTER(McParams), C.c_int64, C.c_int] + [C.POINTER(_P)] * 8),
+    "dxo_mgpu_icnn": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int64, C.c_int] + [C.POINTER(_P)] * 3),
+    "dxo_mgpu_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int] + [C.POINTER(_P)] * 3),
+    "dxo_mgpu_heat": (C.c_int, [_P, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int] + [C.POINTER(_P)] * 5),
     "dxo_stream_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
 }
 
@@ -928,6 +932,35 @@ class MultiGpu:
             if len(a) != self.local_count:
                 raise ValueError(f"every pointer list needs {self.local_count} entries (one per local device)")
         self._check(self.lib.dxo_mgpu_von_mises(self._h, C.byref(prm), int(d), int(n_per_rank), int(gather), *args), "dxo_mgpu_von_mises")
+
+    def _opt_ptrs(self, seq):
+        """A pointer list, or NULL for an output that is not requested (None)."""
+        if seq is None:
+            return None
+        a = self._ptrs(seq)
+        if len(a) != self.local_count:
+            raise ValueError(f"every pointer list needs {self.local_count} entries (one per local device)")
+        return a
+
+    def mohr_coulomb(self, prm: McParams, n_per_rank: int, gather: int, deps, sigma_n, C_tang, sigma, niter=None, yielding=None,
+                     norm_res=None, dlambda=None) -> None:
+        """dxo_mgpu_mohr_coulomb: every local device's cell block + (gather = GATHER_FULL) one all-gather per output."""
+        args = [self._opt_ptrs(a) for a in (deps, sigma_n, C_tang, sigma, niter, yielding, norm_res, dlambda)]
+        self._check(self.lib.dxo_mgpu_mohr_coulomb(self._h, C.byref(prm), int(n_per_rank), int(gather), *args), "dxo_mgpu_mohr_coulomb")
+
+    def icnn(self, models, precision: int, n_per_rank: int, gather: int, F, dP, P) -> None:
+        """dxo_mgpu_icnn; models: one dxo_icnn handle per local device (created on that device's context)."""
+        m = (_P * len(models))(*[_P(x) for x in models])
+        args = [self._opt_ptrs(a) for a in (F, dP, P)]
+        self._check(self.lib.dxo_mgpu_icnn(self._h, m, int(precision), int(n_per_rank), int(gather), *args), "dxo_mgpu_icnn")
+
+    def isihara(self, prm: "IsiharaParams", n_per_rank: int, gather: int, F, dP, P) -> None:
+        args = [self._opt_ptrs(a) for a in (F, dP, P)]
+        self._check(self.lib.dxo_mgpu_isihara(self._h, C.byref(prm), int(n_per_rank), int(gather), *args), "dxo_mgpu_isihara")
+
+    def heat(self, A: float, B: float, gdim: int, n_per_rank: int, gather: int, T, sigma, q=None, dqdT=None, dqdsigma=None) -> None:
+        args = [self._opt_ptrs(a) for a in (T, sigma, q, dqdT, dqdsigma)]
+        self._check(self.lib.dxo_mgpu_heat(self._h, float(A), float(B), int(gdim), int(n_per_rank), int(gather), *args), "dxo_mgpu_heat")
 
     def all_gather(self, bufs, count_per_rank: int) -> None:
         a = self._ptrs(bufs)

@@ -319,14 +319,12 @@ int dxo_mgpu_synchronize(dxo_mgpu* g) {
     return DXO_OK;
 }
 
-// In-place all-gather of `count_per_rank` doubles per rank on every local device: buf[i] is the FULL-length array of
-// local device i, whose own block already sits at offset rank * count_per_rank.
-int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank) {
-    if (!g || !buf) return DXO_E_NULL;
-    if (count_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_all_gather: negative count");
+// In-place all-gather of `bytes_per_rank` bytes per rank on every local device: buf[i] is the FULL-length array of local
+// device i, whose own block already sits at offset rank * bytes_per_rank.
+static int mg_all_gather_bytes(dxo_mgpu* g, void* const* buf, size_t bytes_per_rank) {
     const int rc0 = need_rccl(g);
     if (rc0 != DXO_OK) return rc0;
-    if (count_per_rank == 0) return DXO_OK;
+    if (bytes_per_rank == 0) return DXO_OK;
     Rccl* R = rccl();
     DXO_NCCL(g, R->GroupStart());
     for (size_t i = 0; i < g->ctx.size(); ++i) {
@@ -339,8 +337,9 @@ int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank)
             return mg_fail(g, DXO_E_MEM, "dxo_mgpu_all_gather: the buffer lies in an arena block backed by 2 MB physical chunks, which peers "
                                          "cannot access; allocate it with option placement_vmm = 0 (the group's contexts have it set)");
         }
-        const ncclResult_t r = R->AllGather(buf[i] + (size_t)g->rank[i] * (size_t)count_per_rank, buf[i], (size_t)count_per_rank, ncclDouble,
-                                            g->comm[i], dxo_launch_stream(g->ctx[i]));
+        char* b = static_cast<char*>(buf[i]);
+        const ncclResult_t r = R->AllGather(b + (size_t)g->rank[i] * bytes_per_rank, b, bytes_per_rank, ncclChar, g->comm[i],
+                                            dxo_launch_stream(g->ctx[i]));
         if (r != ncclSuccess) {
             (void)R->GroupEnd();
             return nccl_fail(g, r, "ncclAllGather");
@@ -348,6 +347,122 @@ int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank)
     }
     DXO_NCCL(g, R->GroupEnd());
     return DXO_OK;
+}
+
+int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank) {
+    if (!g || !buf) return DXO_E_NULL;
+    if (count_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_all_gather: negative count");
+    return mg_all_gather_bytes(g, reinterpret_cast<void* const*>(buf), (size_t)count_per_rank * sizeof(double));
+}
+
+// ---- the other pointwise operators, sharded the same way: every local device evaluates its cell block into its slice of
+// the FULL-length outputs, then one in-place all-gather per output array (DXO_GATHER_FULL) or none (DXO_GATHER_NONE,
+// block-length outputs). There is no compact form for them (no output is a function of the others): DXO_GATHER_COMPACT
+// is refused with DXO_E_OPTION. A NULL pointer ARRAY means "this output is not requested" (on every device).
+}  // extern "C"
+
+namespace {
+
+struct MgOut {
+    void* const* arr;       // per local device: full-length (gather) or block-length array; may be NULL = skip
+    size_t bytes_pp;        // bytes per point
+};
+
+int mg_check(dxo_mgpu* g, int64_t n_per_rank, int gather, const char* who) {
+    if (n_per_rank < 0) return mg_fail(g, DXO_E_SIZE, std::string(who) + ": n_per_rank < 0");
+    if (gather == DXO_GATHER_COMPACT) return mg_fail(g, DXO_E_OPTION, std::string(who) + ": DXO_GATHER_COMPACT exists for von Mises only (its tangent is a function of (sigma, dp))");
+    if (gather != DXO_GATHER_NONE && gather != DXO_GATHER_FULL) return mg_fail(g, DXO_E_OPTION, std::string(who) + ": bad gather mode");
+    if (gather != DXO_GATHER_NONE && (n_per_rank % 4)) return mg_fail(g, DXO_E_ALIGN, std::string(who) + ": with a gather n_per_rank must be a multiple of 4 (16-byte aligned blocks of every array)");
+    return DXO_OK;
+}
+
+// slice of local device i inside output k (NULL stays NULL)
+template <class T>
+T* mg_slice(const dxo_mgpu* g, const MgOut& o, size_t i, int gather, size_t n) {
+    if (!o.arr || !o.arr[i]) return nullptr;
+    const size_t off = gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n * o.bytes_pp;
+    return reinterpret_cast<T*>(static_cast<char*>(o.arr[i]) + off);
+}
+
+int mg_gather_outputs(dxo_mgpu* g, int gather, size_t n, std::initializer_list<MgOut> outs) {
+    if (gather == DXO_GATHER_NONE || g->world == 1 || n == 0) return DXO_OK;
+    for (const MgOut& o : outs) {
+        if (!o.arr) continue;
+        const int rc = mg_all_gather_bytes(g, o.arr, n * o.bytes_pp);
+        if (rc != DXO_OK) return rc;
+    }
+    return DXO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dxo_mgpu_mohr_coulomb(dxo_mgpu* g, const dxo_mc_params* prm, int64_t n_per_rank, int gather, const double* const* deps,
+                          const double* const* sigma_n, double* const* C_tang, double* const* sigma, int32_t* const* niter,
+                          double* const* yielding, double* const* norm_res, double* const* dlambda) {
+    if (!g) return DXO_E_NULL;
+    if (!prm || !deps || !sigma_n || !C_tang || !sigma) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_mohr_coulomb: NULL argument");
+    int rc = mg_check(g, n_per_rank, gather, "dxo_mgpu_mohr_coulomb");
+    if (rc != DXO_OK) return rc;
+    const size_t n = (size_t)n_per_rank, sd = sizeof(double);
+    const MgOut oC{(void* const*)C_tang, 16 * sd}, oS{(void* const*)sigma, 4 * sd}, oI{(void* const*)niter, sizeof(int32_t)},
+        oY{(void* const*)yielding, sd}, oR{(void* const*)norm_res, sd}, oL{(void* const*)dlambda, sd};
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        rc = dxo_mohr_coulomb(g->ctx[i], prm, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], mg_slice<double>(g, oC, i, gather, n),
+                              mg_slice<double>(g, oS, i, gather, n), mg_slice<int32_t>(g, oI, i, gather, n), mg_slice<double>(g, oY, i, gather, n),
+                              mg_slice<double>(g, oR, i, gather, n), mg_slice<double>(g, oL, i, gather, n));
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+    }
+    return mg_gather_outputs(g, gather, n, {oC, oS, oI, oY, oR, oL});
+}
+
+int dxo_mgpu_icnn(dxo_mgpu* g, dxo_icnn* const* models, int precision, int64_t n_per_rank, int gather, const double* const* F,
+                  double* const* dP, double* const* P) {
+    if (!g) return DXO_E_NULL;
+    if (!models || !F || !dP || !P) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_icnn: NULL argument");
+    int rc = mg_check(g, n_per_rank, gather, "dxo_mgpu_icnn");
+    if (rc != DXO_OK) return rc;
+    const size_t n = (size_t)n_per_rank, sd = sizeof(double);
+    const MgOut oD{(void* const*)dP, 16 * sd}, oP{(void* const*)P, 4 * sd};
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        rc = dxo_icnn_eval(g->ctx[i], models[i], precision, n_per_rank, DXO_MEM_DEVICE, F[i], mg_slice<double>(g, oD, i, gather, n),
+                           mg_slice<double>(g, oP, i, gather, n));
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+    }
+    return mg_gather_outputs(g, gather, n, {oD, oP});
+}
+
+int dxo_mgpu_isihara(dxo_mgpu* g, const dxo_isihara_params* prm, int64_t n_per_rank, int gather, const double* const* F,
+                     double* const* dP, double* const* P) {
+    if (!g) return DXO_E_NULL;
+    if (!prm || !F || !dP || !P) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_isihara: NULL argument");
+    int rc = mg_check(g, n_per_rank, gather, "dxo_mgpu_isihara");
+    if (rc != DXO_OK) return rc;
+    const size_t n = (size_t)n_per_rank, sd = sizeof(double);
+    const MgOut oD{(void* const*)dP, 16 * sd}, oP{(void* const*)P, 4 * sd};
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        rc = dxo_isihara(g->ctx[i], prm, n_per_rank, DXO_MEM_DEVICE, F[i], mg_slice<double>(g, oD, i, gather, n), mg_slice<double>(g, oP, i, gather, n));
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+    }
+    return mg_gather_outputs(g, gather, n, {oD, oP});
+}
+
+int dxo_mgpu_heat(dxo_mgpu* g, double A, double B, int gdim, int64_t n_per_rank, int gather, const double* const* T,
+                  const double* const* sigma, double* const* q, double* const* dqdT, double* const* dqdsigma) {
+    if (!g) return DXO_E_NULL;
+    if (!T || !sigma) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_heat: NULL argument");
+    if (gdim < 1 || gdim > 3) return mg_fail(g, DXO_E_DIM, "dxo_mgpu_heat: gdim must be 1, 2 or 3");
+    int rc = mg_check(g, n_per_rank, gather, "dxo_mgpu_heat");
+    if (rc != DXO_OK) return rc;
+    const size_t n = (size_t)n_per_rank, sd = sizeof(double);
+    const MgOut oQ{(void* const*)q, gdim * sd}, oT{(void* const*)dqdT, gdim * sd}, oS{(void* const*)dqdsigma, (size_t)gdim * gdim * sd};
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        rc = dxo_heat(g->ctx[i], A, B, gdim, n_per_rank, DXO_MEM_DEVICE, T[i], sigma[i], mg_slice<double>(g, oQ, i, gather, n),
+                      mg_slice<double>(g, oT, i, gather, n), mg_slice<double>(g, oS, i, gather, n));
+        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+    }
+    return mg_gather_outputs(g, gather, n, {oQ, oT, oS});
 }
 
 int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_per_rank, int gather,

@@ -551,6 +551,22 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
                        const double* const* deps, const double* const* sigma_n, const double* const* p,
                        double* const* C_tang, double* const* sigma, double* const* dp);
 
+/* The other pointwise operators sharded the same way (every kernel of the path is a pointwise map): each
+ * local device evaluates its cell block (n_per_rank points, the single-GPU entry point on device memory) into its slice of
+ * the FULL-length outputs, then one in-place all-gather per requested output array. gather: DXO_GATHER_NONE (block-length
+ * outputs, no exchange) or DXO_GATHER_FULL; DXO_GATHER_COMPACT is refused (DXO_E_OPTION): only the von Mises tangent is a
+ * function of the other outputs. With a gather n_per_rank must be a multiple of 4. A NULL pointer ARRAY (niter, yielding,
+ * ..., q, dqdT, dqdsigma) means the output is not requested. models[i] is the dxo_icnn created on dxo_mgpu_ctx(g, i). */
+int dxo_mgpu_mohr_coulomb(dxo_mgpu* g, const dxo_mc_params* prm, int64_t n_per_rank, int gather, const double* const* deps,
+                          const double* const* sigma_n, double* const* C_tang, double* const* sigma, int32_t* const* niter,
+                          double* const* yielding, double* const* norm_res, double* const* dlambda);
+int dxo_mgpu_icnn(dxo_mgpu* g, dxo_icnn* const* models, int precision, int64_t n_per_rank, int gather, const double* const* F,
+                  double* const* dP, double* const* P);
+int dxo_mgpu_isihara(dxo_mgpu* g, const dxo_isihara_params* prm, int64_t n_per_rank, int gather, const double* const* F,
+                     double* const* dP, double* const* P);
+int dxo_mgpu_heat(dxo_mgpu* g, double A, double B, int gdim, int64_t n_per_rank, int gather, const double* const* T,
+                  const double* const* sigma, double* const* q, double* const* dqdT, double* const* dqdsigma);
+
 /* HOST arrays of all n points sharded over the local devices, no collective: contiguous blocks (borders on 64-point
  * tiles), one dxo_von_mises(DXO_MEM_HOST) per device, concurrently, each over its own PCIe link; results land in the
  * caller's arrays. The NumPy path is PCIe-bound, so the links are what scales it. Works on any group (create,

@@ -262,3 +262,66 @@ def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle
     finally:
         ctx.set_option("placement_min_bytes", saved[0])
         ctx.set_option("placement_candidates", saved[1])
+
+
+@pytest.mark.parametrize("form", ["single_process", "rank"])
+def test_mgpu_sharded_entry_points_of_the_other_operators(ctx, oracle, golden, form):
+    """dxo_mgpu_mohr_coulomb / _icnn / _isihara / _heat with a world of one: the communicator comes up, every operator
+    writes its block into the full-length outputs, DXO_GATHER_FULL is the in-place collective, results are those of the
+    single-GPU entry points bit for bit; optional outputs may be left out; DXO_GATHER_COMPACT is refused (it exists for
+    von Mises only). World > 1 differs by block offsets only (tests/test_sharding.py covers that arithmetic)."""
+    import torch
+
+    from conftest import mc_tracing_inputs
+    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_FULL, GATHER_NONE, IsiharaParams, MultiGpu
+    from tools.mc_inputs import mc_default_params
+
+    g = MultiGpu(devices=[0]) if form == "single_process" else MultiGpu.from_rank(ctx, MultiGpu.unique_id(), 0, 1)
+    c = g.context(0)
+    model = None
+    try:
+        g.set_stream(0, torch.cuda.current_stream().cuda_stream)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        f64 = dict(dtype=torch.float64, device="cuda:0")
+        n = 4096
+        # ---- Mohr-Coulomb
+        prm = mc_default_params()
+        deps, sn = mc_tracing_inputs(oracle, n, seed=51)
+        td, ts = _dev(deps), _dev(sn)
+        ref = [torch.empty(n * 16, **f64), torch.empty(n * 4, **f64), torch.empty(n, dtype=torch.int32, device="cuda:0"), torch.empty(n, **f64)]
+        c.mohr_coulomb(prm, n, MEM_DEVICE, td.data_ptr(), ts.data_ptr(), ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), ref[3].data_ptr())
+        for gather in (GATHER_NONE, GATHER_FULL):
+            out = [torch.zeros_like(t) for t in ref]
+            g.mohr_coulomb(prm, n, gather, [td], [ts], [out[0]], [out[1]], niter=[out[2]], yielding=[out[3]])
+            g.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(out, ref))
+        with pytest.raises(ValueError, match="von Mises only"):
+            g.mohr_coulomb(prm, n, GATHER_COMPACT, [td], [ts], [out[0]], [out[1]])
+        with pytest.raises(ValueError):
+            g.mohr_coulomb(prm, n - 2, GATHER_FULL, [td], [ts], [out[0]], [out[1]])         # blocks must stay 16-byte aligned
+        # ---- ICNN + analytic Isihara
+        gd, w = golden("icnn_isihara.npz"), golden("icnn_isihara_weights.npz")
+        F = _dev(np.tile(gd["F"].reshape(-1, 4), (3, 1))[:n])
+        model = c.icnn_create({k.replace("__", "."): w[k] for k in w.files})
+        r_dP, r_P = torch.empty(n * 16, **f64), torch.empty(n * 4, **f64)
+        c.icnn_eval(model, 0, n, MEM_DEVICE, F.data_ptr(), r_dP.data_ptr(), r_P.data_ptr())
+        dP, P = torch.zeros(n * 16, **f64), torch.zeros(n * 4, **f64)
+        g.icnn([model], 0, n, GATHER_FULL, [F], [dP], [P])
+        g.synchronize()
+        assert torch.equal(dP, r_dP) and torch.equal(P, r_P)
+        ip = IsiharaParams(0.5, 1.0, 1.0, 1.5)
+        c.isihara(ip, n, MEM_DEVICE, F.data_ptr(), r_dP.data_ptr(), r_P.data_ptr())
+        g.isihara(ip, n, GATHER_FULL, [F], [dP], [P])
+        g.synchronize()
+        assert torch.equal(dP, r_dP) and torch.equal(P, r_P)
+        # ---- heat (only two of the three outputs requested)
+        h = golden("heat_c1.npz")
+        T, sg = _dev(h["T"].reshape(-1)[:n]), _dev(h["sigma"].reshape(-1, 2)[:n])
+        q, ds = torch.zeros(n * 2, **f64), torch.zeros(n * 4, **f64)
+        g.heat(1.0, 1.0, 2, n, GATHER_FULL, [T], [sg], q=[q], dqdsigma=[ds])
+        g.synchronize()
+        assert np.array_equal(q.cpu().numpy(), h["q"][: n * 2]) and np.array_equal(ds.cpu().numpy(), h["dqdsigma"][: n * 4])
+    finally:
+        if model is not None:
+            c.icnn_destroy(model)
+        g.close()
