@@ -256,3 +256,53 @@ def test_icnn_and_isihara_field_equal_operand_then_kernel(ctx, golden):
                 dm3.close()
     finally:
         dm.close()
+
+
+def test_yield_surface_tracing_known_answers_with_resident_state(ctx, oracle):
+    """The demo's yield-surface tracing (demo_plasticity_mohr_coulomb.py:854-957) through the drop-in factory with the
+    history variable on the device: after every loading the plastic paths sit on f = 0 (the demo prints `max f`, :928),
+    elastic paths are untouched, and the traced locus follows the standard Mohr-Coulomb surface (:933-954) away from the
+    corners the Abbo-Sloan form rounds (|theta| > theta_T = 26 deg)."""
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location("mc_tracing", pathlib.Path(__file__).resolve().parents[1] / "examples" / "mohr_coulomb_tracing.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    theta, rows, rho_mc = mod.trace(ctx)
+    assert len(rows) == 9
+    tr0 = np.array([1.0, 1.0, 1.0, 0.0])
+    c, phi = 3.45, 30 * np.pi / 180
+    saw_plastic = 0
+    for r in rows:
+        assert r["max_niter"] <= 6
+        ret, plastic = r["sigma_returned"], r["yielding"] > 0
+        saw_plastic += int(plastic.sum())
+        f_ret = oracle.mc_surface(ret)[0]
+        assert np.all(np.abs(f_ret[plastic]) < 1e-7)               # the returned stress sits on f = 0 (:928 prints max f of the trial state)
+        if not plastic.any():
+            continue
+        # Haigh-Westergaard coordinates of the returned stress (:886-898) against the standard Mohr-Coulomb surface (:947-952)
+        pr = ret @ tr0 / 3.0
+        dev = ret - np.outer(pr, tr0)
+        J2 = 0.5 * np.sum(dev * dev, axis=1)
+        J3 = dev[:, 2] * (dev[:, 0] * dev[:, 1] - dev[:, 3] ** 2 / 2.0)
+        th = np.arcsin(np.clip(-(3.0 * np.sqrt(3.0) * J3) / (2.0 * np.sqrt(J2 ** 3)), -1.0, 1.0)) / 3.0
+        # (stresses are tension-positive here, :334-349: the mean stress enters the surface as + I1/3 sin(phi))
+        rho_mc_ret = (np.sqrt(2) * (c * np.cos(phi) - pr * np.sin(phi))) / (np.cos(th) - np.sin(phi) * np.sin(th) / np.sqrt(3))
+        side = plastic & (np.abs(th) < 20 * np.pi / 180)            # away from the corners the Abbo-Sloan form rounds (theta_T = 26 deg)
+        if side.any():                                              # the tension cut-off a = 0.26 c / tan(phi) pulls the surface in by a few per cent
+            rel = np.sqrt(2.0 * J2[side]) / rho_mc_ret[side] - 1.0
+            assert np.all(rel < 1e-9) and np.all(rel > -0.08), (rel.min(), rel.max())
+    assert saw_plastic > 100
+    # and the whole sequence equals the oracle-driven tracing (state by state)
+    from tools.mc_inputs import mc_elastic_matrices, mc_path_increment
+    _, S = mc_elastic_matrices()
+    tr = np.array([1.0, 1.0, 1.0, 0.0])
+    sn = np.zeros((50, 4))
+    sn[:, :3] = 0.1
+    d = mc_path_increment(theta, 0.7)
+    for r in rows:
+        _, s, *_ = oracle.mohr_coulomb(d @ S.T, sn, tangent=False)
+        sn = s - np.outer(s @ tr / 3.0 - 0.1, tr)
+        assert np.max(np.abs(r["sigma"] - sn)) <= 1e-10 * max(np.max(np.abs(sn)), 1.0)
