@@ -306,3 +306,33 @@ def test_yield_surface_tracing_known_answers_with_resident_state(ctx, oracle):
         _, s, *_ = oracle.mohr_coulomb(d @ S.T, sn, tangent=False)
         sn = s - np.outer(s @ tr / 3.0 - 0.1, tr)
         assert np.max(np.abs(r["sigma"] - sn)) <= 1e-10 * max(np.max(np.abs(sn)), 1.0)
+
+
+@pytest.mark.parametrize("cells", [(1, 1), (3, 4), (5, 9)])
+def test_field_entry_points_on_tiny_and_ragged_meshes(ctx, oracle, golden, cells):
+    """2, 24 and 90 cells (6, 72, 270 points: fewer than one wave group, partial groups): the three field entry points
+    against operand + plain call, host arrays."""
+    m = structured_mesh("triangle", cells, 2, distort=0.1, seed=5)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        n = m.num_cells * m.nq
+        u = _smooth_field(m, 0.05, 12)
+        F = dm.evaluate("F", 2, u).reshape(n, 4)
+        w = golden("icnn_isihara_weights.npz")
+        icnn = make_icnn({k: w[k] for k in w.files}, ctx=ctx)
+        isi = make_isihara(ctx=ctx)
+        for ext, exact in ((icnn, True), (isi, False)):
+            dP0, P0 = ext((1,))(F.reshape(m.num_cells, m.nq, 2, 2))
+            dP1, P1 = ext((1,))(dm.operand("F", u, lazy=True).eval(None))
+            if exact:
+                assert np.array_equal(dP1, dP0) and np.array_equal(P1, P0)
+            else:
+                assert_close_scaled(dP1, dP0, 1e-13, "dP") and assert_close_scaled(P1, P0, 1e-13, "P")
+        um = _smooth_field(m, 4e-4, 13)
+        sn = np.tile(np.array([0.1, 0.1, 0.1, 0.0]), (n, 1))
+        mc = make_mohr_coulomb(sn, ctx=ctx)
+        C0, s0 = mc((1,))(dm.evaluate("eps", 2, um))
+        C1, s1 = mc((1,))(dm.operand("eps", um, lazy=True).eval(None))
+        assert np.array_equal(C0, C1) and np.array_equal(s0, s1)
+    finally:
+        dm.close()

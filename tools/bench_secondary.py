@@ -4,6 +4,9 @@ Every leg runs a few launches on `cuda:0` with inputs resident in HBM, HIP event
 own `roofline` (and, where a CPU restatement exists, its own bounded `cpu_baseline`). A leg that fails is reported as
 {"error": ...}; nothing here can cost the headline line. Only the cpu_baseline parts touch oracle/.
 
+  heat_cfg1           BASELINE config 1: the nonlinear heat flux on the 32 x 32 unit square (6 144 points): call latency through
+                      the drop-in factory beside the reference's NumPy statements; the kernel's HBM roofline at 5*10^7 points
+  isihara             the analytic model behind config 5's network, HBM-bound
   mohr_coulomb_cfg4   BASELINE config 4: Mohr-Coulomb return map + AD-through-the-loop tangent, 10^7 points of the demo's
                       yield-surface tracing distribution (demo_plasticity_mohr_coulomb.py:854-929)
   icnn_cfg5           BASELINE config 5: ICNN hyperelastic surrogate (fp32 network, fp64 I/O), 10^7 points
@@ -225,9 +228,82 @@ def vm_field_q2(torch, ctx, stream, cells_per_side, prm):
         dm.close()
 
 
+def heat_cfg1(torch, ctx, stream, cpu):
+    """BASELINE config 1 is the reference's own CPU-runnable case: q(T, grad T) on a 32 x 32 unit square = 6 144 points
+    (demo_nonlinear_heat_equation_part2.py). At that size a call is latency, not bandwidth: reported as microseconds per
+    call through the drop-in factory (NumPy in, NumPy out, all three operators of the demo: q, dq/dT, dq/dsigma) beside the
+    reference's own NumPy statements on the same host; the kernel's roofline is quoted at 5*10^7 points."""
+    from dolfinx_external_operator_amd import MEM_DEVICE, make_heat
+
+    g = np.load(ROOT / "tests" / "golden" / "heat_c1.npz")
+    T, sigma = np.ascontiguousarray(g["T"]), np.ascontiguousarray(g["sigma"].reshape(g["T"].shape[0], -1))
+    ext = make_heat(ctx=ctx)
+    fns = [ext(d) for d in ((0, 0), (1, 0), (0, 1))]
+    for f in fns:
+        f(T, sigma)
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for f in fns:
+            f(T, sigma)
+    us = (time.perf_counter() - t0) / reps * 1e6
+    out = {"workload": "nonlinear heat flux q, dq/dT, dq/dsigma on the 32 x 32 unit square of BASELINE config 1: 6 144 points, three "
+                       "evaluate_external_operators-style calls (NumPy in, NumPy out) per step", "points": int(T.size),
+           "us_per_step_three_calls": us, "value": T.size / (us * 1e-6), "unit": "qp/s", "dtype": "f64"}
+    n = 50_000_000
+    dev = torch.device("cuda", ctx.device)
+    Td = torch.rand(n, dtype=torch.float64, device=dev)
+    sg = torch.randn(n * 2, dtype=torch.float64, device=dev)
+    q, dT, ds = (torch.empty(n * k, dtype=torch.float64, device=dev) for k in (2, 2, 4))
+    ms, _ = _time(torch, stream, lambda: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, Td.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr()), 10)
+    out["roofline"] = {**_hbm(88 * n, ms), "bytes_per_qp": 88, "kernel": "heat_g2", "points": n, "ms_per_launch": ms,
+                       "note": "fused q, dq/dT, dq/dsigma at 5*10^7 points (config 1 itself is 540 KB: cache-resident, latency-bound)"}
+    if cpu:   # the reference's statements (part2.py:215-261) in NumPy on this host, same arrays
+        A = B = 1.0
+        Id = np.eye(2)
+        nc, nq = T.shape
+
+        def ref_step():
+            k = 1.0 / (A + B * T)
+            s3 = sigma.reshape(nc, nq, 2)
+            q_ = (-k[..., None] * s3).reshape(-1)
+            dT_ = (B * (k ** 2)[..., None] * s3).reshape(-1)
+            ds_ = (-k[..., None, None] * Id).reshape(-1)
+            return q_, dT_, ds_
+
+        ref_step()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref_step()
+        us_ref = (time.perf_counter() - t0) / reps * 1e6
+        out["cpu_baseline"] = {"value": T.size / (us_ref * 1e-6), "unit": "qp/s", "cores": 1, "kind": "port", "us_per_step": us_ref,
+                               "sample": f"{reps} steps of the same 6 144 points, the reference's NumPy statements (part2.py:215-261) restated"}
+    return out
+
+
+def isihara_leg(torch, ctx, stream, n):
+    from dolfinx_external_operator_amd import MEM_DEVICE, IsiharaParams
+
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    eye = torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
+    F = torch.randn(n, 4, device=dev, dtype=torch.float64, generator=g) * 0.1 + eye
+    F[(F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2]) <= 0.2] = eye
+    dP = torch.empty(n * 16, device=dev, dtype=torch.float64)
+    P = torch.empty(n * 4, device=dev, dtype=torch.float64)
+    prm = IsiharaParams(0.5, 1.0, 1.0, 1.5)
+    ms, _ = _time(torch, stream, lambda: ctx.isihara(prm, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr()), 10, warm=3)
+    return {"workload": f"analytic Isihara stress + tangent (the model the network of config 5 was trained on), {n} points, fp64",
+            "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms, "dtype": "f64",
+            "roofline": {**_hbm(192 * n, ms), "bytes_per_qp": 192, "kernel": "isihara_tile"}}
+
+
 def secondary_block(torch, ctx, stream, prm, n=10_000_000, cpu=True, field_cells=108, legs=None):
-    legs = legs or ("mohr_coulomb_cfg4", "icnn_cfg5", "von_mises_d4_nq3", "vm_field_q2")
-    fns = {"mohr_coulomb_cfg4": lambda: mohr_coulomb_cfg4(torch, ctx, stream, n, cpu),
+    legs = legs or ("heat_cfg1", "mohr_coulomb_cfg4", "icnn_cfg5", "isihara", "von_mises_d4_nq3", "vm_field_q2")
+    fns = {"heat_cfg1": lambda: heat_cfg1(torch, ctx, stream, cpu),
+           "isihara": lambda: isihara_leg(torch, ctx, stream, 2 * n),
+           "mohr_coulomb_cfg4": lambda: mohr_coulomb_cfg4(torch, ctx, stream, n, cpu),
            "icnn_cfg5": lambda: icnn_cfg5(torch, ctx, stream, n, cpu),
            "von_mises_d4_nq3": lambda: von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu),
            "vm_field_q2": lambda: vm_field_q2(torch, ctx, stream, field_cells, prm)}
