@@ -59,6 +59,8 @@ class OracleLib:
             self.lib.oracle_mohr_coulomb.argtypes = [P, C.c_int64] + [P] * 8 + [C.c_int]
             self.lib.oracle_mohr_coulomb_sigma.restype = C.c_int
             self.lib.oracle_mohr_coulomb_sigma.argtypes = [P, C.c_int64] + [P] * 7 + [C.c_int]
+            self.lib.oracle_mohr_coulomb_ld.restype = C.c_int
+            self.lib.oracle_mohr_coulomb_ld.argtypes = [P, C.c_int64] + [P] * 5 + [C.c_int]
             self.lib.oracle_mc_surface.restype = C.c_int
             self.lib.oracle_mc_surface.argtypes = [P, C.c_int64, P, P, P, P]
 
@@ -132,6 +134,19 @@ class OracleLib:
         if rc != 0:
             raise ValueError(f"oracle_mohr_coulomb rc={rc}")
         return C_tang, sigma, niter, yielding, norm_res, dlambda
+
+    def mohr_coulomb_long_double(self, deps, sigma_n, *, nthreads=1, **params):
+        """The same return map + AD tangent with 80-bit long double under the dual numbers (an accuracy referee, not the
+        reference's arithmetic): C_tang (N,4,4), sigma (N,4), niter (N,)."""
+        prm = mc_params(**params)
+        deps = np.ascontiguousarray(deps, dtype=np.float64).reshape(-1, 4)
+        sigma_n = np.ascontiguousarray(sigma_n, dtype=np.float64).reshape(-1, 4)
+        n = deps.shape[0]
+        C_tang, sigma, niter = np.empty((n, 4, 4)), np.empty((n, 4)), np.empty(n, dtype=np.int32)
+        rc = self.lib.oracle_mohr_coulomb_ld(C.byref(prm), n, _dp(deps), _dp(sigma_n), _dp(C_tang), _dp(sigma), _dp(niter), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_mohr_coulomb_ld rc={rc}")
+        return C_tang, sigma, niter
 
     def mc_surface(self, sigma, **params):
         """f(sigma), g(sigma), dg/dsigma for sigma (N,4)."""

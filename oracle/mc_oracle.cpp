@@ -34,10 +34,10 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // forward-mode scalars
-template <int N>
-struct DualN {  // value + N tangents (the deps directions)
-    double v;
-    double d[N];
+template <int N, class R = double>
+struct DualN {  // value + N tangents (the deps directions); R = double is the oracle, R = long double the accuracy referee
+    R v;
+    R d[N];
     DualN() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
     DualN(double c) : v(c) { for (int i = 0; i < N; ++i) d[i] = 0.0; }  // NOLINT: implicit lift of constants
 };
@@ -51,19 +51,19 @@ struct Dual {  // one jvp level on top of scalar type T
 };
 
 inline double primal(double x) { return x; }
-template <int N> inline double primal(const DualN<N>& x) { return x.v; }
+template <int N, class R> inline double primal(const DualN<N, R>& x) { return (double)x.v; }
 template <class T> inline double primal(const Dual<T>& x) { return primal(x.v); }
 
 // ---- DualN algebra
-template <int N> inline DualN<N> operator+(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int N> inline DualN<N> operator-(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-template <int N> inline DualN<N> operator-(const DualN<N>& a) { DualN<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
-template <int N> inline DualN<N> operator*(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-template <int N> inline DualN<N> operator/(const DualN<N>& a, const DualN<N>& b) { DualN<N> r; r.v = a.v / b.v; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
-template <int N> inline DualN<N> sqrt(const DualN<N>& a) { DualN<N> r; r.v = std::sqrt(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / (2.0 * r.v); return r; }
-template <int N> inline DualN<N> asin(const DualN<N>& a) { DualN<N> r; r.v = std::asin(a.v); const double g = 1.0 / std::sqrt(1.0 - a.v * a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
-template <int N> inline DualN<N> sin(const DualN<N>& a) { DualN<N> r; r.v = std::sin(a.v); const double g = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
-template <int N> inline DualN<N> cos(const DualN<N>& a) { DualN<N> r; r.v = std::cos(a.v); const double g = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
+template <int N, class R> inline DualN<N, R> operator+(const DualN<N, R>& a, const DualN<N, R>& b) { DualN<N, R> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N, class R> inline DualN<N, R> operator-(const DualN<N, R>& a, const DualN<N, R>& b) { DualN<N, R> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N, class R> inline DualN<N, R> operator-(const DualN<N, R>& a) { DualN<N, R> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N, class R> inline DualN<N, R> operator*(const DualN<N, R>& a, const DualN<N, R>& b) { DualN<N, R> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N, class R> inline DualN<N, R> operator/(const DualN<N, R>& a, const DualN<N, R>& b) { DualN<N, R> r; r.v = a.v / b.v; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
+template <int N, class R> inline DualN<N, R> sqrt(const DualN<N, R>& a) { DualN<N, R> r; r.v = std::sqrt(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / (R(2.0) * r.v); return r; }
+template <int N, class R> inline DualN<N, R> asin(const DualN<N, R>& a) { DualN<N, R> r; r.v = std::asin(a.v); const R g = R(1.0) / std::sqrt(R(1.0) - a.v * a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
+template <int N, class R> inline DualN<N, R> sin(const DualN<N, R>& a) { DualN<N, R> r; r.v = std::sin(a.v); const R g = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
+template <int N, class R> inline DualN<N, R> cos(const DualN<N, R>& a) { DualN<N, R> r; r.v = std::cos(a.v); const R g = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g; return r; }
 
 // ---- Dual<T> algebra (recursive)
 template <class T> inline Dual<T> operator+(const Dual<T>& a, const Dual<T>& b) { return Dual<T>(a.v + b.v, a.d + b.d); }
@@ -82,8 +82,8 @@ template <class T> inline Dual<T> cos(const Dual<T>& a) { return Dual<T>(cos(a.v
 
 // mixed with double constants (works for DualN and Dual<T> alike)
 #define DXO_MIXED(OP)                                                                                   \
-    template <int N> inline DualN<N> operator OP(const DualN<N>& a, double b) { return a OP DualN<N>(b); } \
-    template <int N> inline DualN<N> operator OP(double a, const DualN<N>& b) { return DualN<N>(a) OP b; } \
+    template <int N, class R> inline DualN<N, R> operator OP(const DualN<N, R>& a, double b) { return a OP DualN<N, R>(b); } \
+    template <int N, class R> inline DualN<N, R> operator OP(double a, const DualN<N, R>& b) { return DualN<N, R>(a) OP b; } \
     template <class T> inline Dual<T> operator OP(const Dual<T>& a, double b) { return a OP Dual<T>(b); }   \
     template <class T> inline Dual<T> operator OP(double a, const Dual<T>& b) { return Dual<T>(a) OP b; }
 DXO_MIXED(+)
@@ -319,6 +319,40 @@ int oracle_mohr_coulomb(const void* prm, int64_t n, const double* deps, const do
         if (yielding) yielding[i] = yl;
         if (norm_res) norm_res[i] = nr;
         if (dlambda) dlambda[i] = y[4].v;
+    }
+    return 0;
+}
+
+/* The same algorithm with 80-bit long double under the dual numbers: NOT the reference's arithmetic (JAX runs in fp64,
+ * :103) but a referee for it — where the fp64 restatement and the HIP lane math disagree (they do, up to 1e-9 of the
+ * tangent's scale, at the compression / extension meridians where the reference's sin(3 asin(arg)/3) chain cancels terms of
+ * size (1 - arg^2)^(-5/2)), this tells which side carries the rounding error. Inputs and outputs are doubles. The Newton
+ * loop's exit test uses the same tol on the long-double residual, so iteration counts can differ from the fp64 run for
+ * residuals sitting at the tolerance; niter is returned so that the test can select points with equal counts. */
+int oracle_mohr_coulomb_ld(const void* prm, int64_t n, const double* deps, const double* sigma_n, double* C_tang, double* sigma,
+                           int32_t* niter, int nthreads) {
+    McParams p;
+    std::memcpy(&p, prm, sizeof p);
+    const McModel M(p);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        typedef DualN<4, long double> S;
+        S e[4], s0[4], y[5];
+        for (int k = 0; k < 4; ++k) {
+            e[k] = S(deps[i * 4 + k]);
+            e[k].d[k] = 1.0L;
+            s0[k] = S(sigma_n[i * 4 + k]);
+        }
+        int it;
+        double yl, nr;
+        return_mapping<S>(M, e, s0, y, &it, &yl, &nr);
+        for (int a = 0; a < 4; ++a) {
+            sigma[i * 4 + a] = (double)y[a].v;
+            for (int b = 0; b < 4; ++b) C_tang[i * 16 + a * 4 + b] = (double)y[a].d[b];
+        }
+        if (niter) niter[i] = it;
     }
     return 0;
 }

@@ -187,3 +187,34 @@ def test_tangent_is_the_derivative_of_the_K_th_newton_iterate(oracle):
         worst = max(worst, err)
         assert err < 2e-8, (i, K, err)     # measured: max 8e-10 (differencing noise); the implicit-function tangent is off by up to 1.3e-7
     assert worst > 0.0
+
+
+def test_near_the_meridians_the_lane_math_is_the_more_accurate_side(oracle, mc_core):
+    """Why the tangent's parity bound is 1e-9 (not 1e-12) where 1 - |arg| < 1e-3 (conftest.mc_compare): there the REFERENCE's
+    own derivative chain sin(3 asin(arg) / 3) cancels terms of size (1 - arg^2)^(-5/2) in fp64, while the lane math composes K
+    with the Lode argument directly (csrc/mc_core.h). The referee is the reference's algorithm with 80-bit long double
+    under the dual numbers (oracle_mohr_coulomb_ld): against it the fp64 restatement of the reference loses up to ~1e-10
+    of the tangent's scale at the meridians, the lane math stays at rounding level — so the disagreement allowed there is
+    the reference's rounding error, not the kernel's."""
+    from conftest import lode_arg
+
+    deps, sn = mc_tracing_inputs(oracle, 20000, seed=3)
+    Co, so, ito, y, *_ = oracle.mohr_coulomb(deps, sn, nthreads=8)
+    Cl, sl, itl = oracle.mohr_coulomb_long_double(deps, sn, nthreads=8)
+    Ck, sk, itk, *_ = mc_core(deps, sn)
+    plastic = y > 0
+    sel = plastic & (ito == itl) & (itk == itl)                    # the tangent differentiates the iterates: compare equal counts only
+    assert sel.sum() > 0.95 * plastic.sum()
+    scale = np.max(np.abs(Cl))
+    err_o = np.max(np.abs(Co - Cl).reshape(len(Co), -1), axis=1) / scale
+    err_k = np.max(np.abs(Ck - Cl).reshape(len(Ck), -1), axis=1) / scale
+    with np.errstate(all="ignore"):
+        margin = np.minimum(1.0 - np.abs(lode_arg(sn)), 1.0 - np.abs(lode_arg(so)))
+    margin = np.where(np.isfinite(margin), margin, 1.0)
+    near = sel & (margin < 1e-3)
+    far = sel & (margin >= 1e-3)
+    assert near.sum() > 100 and far.sum() > 1000
+    assert err_k[far].max() < 1e-12 and err_o[far].max() < 1e-12   # away from the meridians both sides are at rounding level
+    assert err_k[near].max() < 1e-12                               # the lane math stays there at the meridians ...
+    assert err_o[near].max() > 10 * err_k[near].max()              # ... the reference's fp64 chain does not
+    assert np.max(np.abs(sk - sl)[sel]) < 1e-12 * max(np.max(np.abs(sl)), 1.0)
