@@ -100,7 +100,8 @@ struct dxo_ctx {
     void* small_pinned = nullptr;
     size_t small_pinned_bytes = 0;
     hipEvent_t small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int64_t host_small_bytes = 1 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
+    int64_t host_small_bytes = 2 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
+    int64_t host_zero_copy_bytes = 2 << 20;   // ... and below this many bytes the kernel reads / writes the pinned staging block itself (no DMA)
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     void* stage[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};   // dxo_stage: operand values in front of a pointwise kernel

@@ -107,9 +107,13 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
  * (0 lane-per-point VALU kernel, 1 MFMA kernel — the default), "host_small_bytes" (host batches whose inputs + outputs
- * fit this many bytes, default 1 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
+ * fit this many bytes, default 2 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
  * the chunked pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase
- * dxo_timing is recorded on it only with "timing" = 1), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
+ * dxo_timing is recorded on it only with "timing" = 1), "host_zero_copy_bytes" (default 2 MiB: on that path, batches up
+ * to this size are not copied by DMA at all — the kernel reads its inputs from and writes its outputs to the page-locked,
+ * device-mapped staging block over PCIe directly, which removes the two copy launches from the call: 49 -> 34 us at 600
+ * points, 153 -> 86 us at 6 144 points (von Mises d = 4), 39 -> 24 us for the heat flux of config 1; results are
+ * bit-identical; 0 = off; with "timing" = 1 the copy form is used so that the phases can be timed), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0

@@ -325,3 +325,29 @@ def test_mgpu_sharded_entry_points_of_the_other_operators(ctx, oracle, golden, f
         if model is not None:
             c.icnn_destroy(model)
         g.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 600, 6144])
+def test_tiny_host_batches_without_dma_are_bit_identical(ctx, n, d=4):
+    """At the reference's demo sizes a host call no longer copies by DMA: the kernel reads / writes the page-locked staging
+    block over PCIe itself (option host_zero_copy_bytes). Same bytes as the copy form, the chunked pipeline and a device
+    call; guard words behind the outputs stay untouched."""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    deps, sigma_n, p = vm_inputs(n, d, seed=60 + n)
+    prm = VmParams(E, NU, 250.0, H)
+    res = {}
+    saved = ctx.get_option("host_zero_copy_bytes"), ctx.get_option("host_small_bytes")
+    try:
+        for name, zc, small in (("zero_copy", 1 << 22, 1 << 22), ("copy", 0, 1 << 22), ("chunked", 0, 0)):
+            ctx.set_option("host_zero_copy_bytes", zc)
+            ctx.set_option("host_small_bytes", small)
+            C, s, dp = np.full(n * d * d + 3, -7.0), np.full(n * d + 3, -7.0), np.full(n + 3, -7.0)
+            ctx.von_mises(prm, d, n, MEM_HOST, deps, sigma_n, p, C, s, dp)
+            assert np.all(C[n * d * d:] == -7.0) and np.all(s[n * d:] == -7.0) and np.all(dp[n:] == -7.0)
+            res[name] = (C.copy(), s.copy(), dp.copy())
+    finally:
+        ctx.set_option("host_zero_copy_bytes", saved[0])
+        ctx.set_option("host_small_bytes", saved[1])
+    for name in ("copy", "chunked"):
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res["zero_copy"], res[name])), name
