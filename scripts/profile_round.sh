@@ -15,9 +15,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1 || { echo BUILD FAILED; tail -30 "$OUT/build.log"; exit 1; }
 timeout 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e --no-traffic > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
 if [ -z "$QUICK" ]; then
   pass() {  # dir, script + args..., -- counters...
     local name=$1; shift
