@@ -20,7 +20,7 @@
 // Weights are wave-uniform: they are read through the scalar path (s_load into SGPRs) and enter the FMAs
 // as scalar operands; the per-point vectors h1, phi'(a1), beta live in VGPRs (3 x 64 floats per lane).
 // The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here): the default fp32
-// kernel is icnn_mfma2 below (five 64x64x64 GEMMs per 64-point wave tile on v_mfma_f32_32x32x2_f32); icnn_point is the
+// kernel is icnn_mfma_f32 below (five 64x64x64 GEMMs per 64-point wave tile on v_mfma_f32_32x32x2_f32); icnn_point is the
 // fp64-network path of the tolerance study and the cross-check of the MFMA kernel (option icnn_variant = 0).
 #include <cmath>
 
@@ -39,8 +39,8 @@ struct IcnnDev {
     const T* W2;    // [64][64]: W2p[j][i] (dense, the MFMA kernel's operand source)
     const T* S2;    // [64][4]: S2[j][0..2], c2[j]
     const T* w3;    // [64]: w3p
-    const T* T1;    // [64][16]: A1_i0 A1_i1 A1_i2 d1_i | 2 A1_i0, 2 A1_i1, 2 A1_i2, 0 | the six products A1_ik A1_il / 6, 0, 0   (icnn_mfma2)
-    const T* T2;    // [64][8]:  S2_j0 S2_j1 S2_j2 c2_j | w3p_j / 6, 0 0 0                                                         (icnn_mfma2)
+    const T* T1;    // [64][16]: A1_i0 A1_i1 A1_i2 d1_i | 2 A1_i0, 2 A1_i1, 2 A1_i2, 0 | the six products A1_ik A1_il / 6, 0, 0   (icnn_mfma_f32)
+    const T* T2;    // [64][8]:  S2_j0 S2_j1 S2_j2 c2_j | w3p_j / 6, 0 0 0                                                         (icnn_mfma_f32)
     T s3[3];        // s3p
     double H[4];    // H_flat (:371)
 };
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void icnn_point(const T* __restrict__ wA
 // ------------------------------------------------------------------ fp32 MFMA kernel: helpers
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// icnn_mfma2 is fully unrolled straight-line code; these keep the compiler from re-ordering it across neurons (it would
+// icnn_mfma_f32 is fully unrolled straight-line code; these keep the compiler from re-ordering it across neurons (it would
 // hoist every LDS read and sink every accumulation of a phase, and spill hundreds of registers): a scheduling barrier per
 // neuron, and the running sums pinned in registers at the end of each neuron
 #ifndef DXO_ICNN_SCHED1
@@ -225,7 +225,7 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
 // cycles) and of its vector instructions, not the maximum; see DESIGN.md 8.
 __device__ __forceinline__ constexpr int icnn_row(int t, int q) { return 32 * t + (q & 3) + 8 * (q >> 2); }   // + 4 h
 
-// softplus with first and second derivative for icnn_mfma2: the exponent is clamped at 80 (e^80 is finite in fp32), so that
+// softplus with first and second derivative for icnn_mfma_f32: the exponent is clamped at 80 (e^80 is finite in fp32), so that
 // e r = e / (1 + e) and e r r need no select above torch's threshold of 20 — they are 1 and < 2e-9 there, which is what the
 // reference's branch returns to fp32 rounding; softplus itself is max(log(1 + e), a): log(1 + e) >= a holds below the
 // threshold, and above it the reference returns a.
@@ -239,7 +239,7 @@ __device__ __forceinline__ void softplus3_mfma(float a, float& sp, float& s1, fl
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma2(const float* __restrict__ wT1, const float* __restrict__ wW2,
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_f32(const float* __restrict__ wT1, const float* __restrict__ wW2,
                                                         const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
                                                         const double* __restrict__ F, double* __restrict__ dP,
                                                         double* __restrict__ P) {
@@ -423,6 +423,319 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma2(const float*
     }
 }
 
+// ------------------------------------------------------------------ fp32-equivalent MFMA kernel on the bf16 pipe (icnn_variant = 2, the default)
+// The same five GEMMs with every fp32 operand split EXACTLY into three bf16 numbers (8 + 8 + 8 mantissa bits by
+// truncation: v = h + m + l) and the product formed as h h' + h m' + m h' + h l' + l h' + m m' on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate): the dropped terms are below 2^-24 of the product, i.e. at fp32 rounding
+// level, while six bf16 MFMAs (16 x the fp32-input rate each) cost 3/8 of the matrix-pipe time of the fp32 form.
+// K-step s of the forward GEMMs covers 16 layer-1 neurons: lane (h, p) evaluates the eight neurons
+// icnn_row(s >> 1, 8 (s & 1) + i) + 4 h, i = 0..7, of ITS point and packs their split parts as the B fragment (k = 8 h + i);
+// the enumeration over s is again the C layout of the beta GEMM, so beta_i meets phi''(a1_i) in the same lane. A fragments
+// (the split weights, eight bf16 per lane) are prepared once per workgroup in LDS.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 icnn_bf16x8;
+typedef unsigned int icnn_u32x4 __attribute__((ext_vector_type(4)));
+
+struct IcnnSplit { icnn_u32x4 h, m, l; };
+struct IcnnSplitW { unsigned h[4], m[4], l[4]; };   // the same, dword-addressable while it is being filled
+
+__device__ __forceinline__ void icnn_split1(float v, unsigned& hb, unsigned& mb, unsigned& lb) {
+    hb = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(hb);
+    mb = __float_as_uint(r1) & 0xffff0000u;
+    lb = __float_as_uint(r1 - __uint_as_float(mb));   // at most 8 significant bits left: a bf16 number, low half zero
+}
+
+__device__ __forceinline__ f32x16 icnn_mfma_bf16(icnn_u32x4 a, icnn_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(icnn_bf16x8, a), __builtin_bit_cast(icnn_bf16x8, b), c, 0, 0, 0);
+}
+
+typedef float icnn_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ IcnnSplit icnn_pack(const IcnnSplitW& w) {
+    IcnnSplit o;
+    o.h = icnn_u32x4{w.h[0], w.h[1], w.h[2], w.h[3]};
+    o.m = icnn_u32x4{w.m[0], w.m[1], w.m[2], w.m[3]};
+    o.l = icnn_u32x4{w.l[0], w.l[1], w.l[2], w.l[3]};
+    return o;
+}
+
+// one B-fragment dword (two consecutive k: the neuron pair) of each part from a pair of fp32 values
+__device__ __forceinline__ void icnn_split_pair(icnn_f2 v, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned vx = __float_as_uint(v.x), vy = __float_as_uint(v.y);
+    h = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    const icnn_f2 vh = {__uint_as_float(vx & 0xffff0000u), __uint_as_float(vy & 0xffff0000u)};
+    const icnn_f2 r = v - vh;
+    const unsigned rx = __float_as_uint(r.x), ry = __float_as_uint(r.y);
+    m = __builtin_amdgcn_perm(ry, rx, 0x07060302u);
+    const icnn_f2 rh = {__uint_as_float(rx & 0xffff0000u), __uint_as_float(ry & 0xffff0000u)};
+    const icnn_f2 q = r - rh;
+    l = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
+}
+
+// softplus, softplus', softplus'' of two pre-activations: softplus3_mfma's operations, the multiplies and adds as packed fp32
+__device__ __forceinline__ void softplus3_pk(icnn_f2 a, icnn_f2& sp, icnn_f2& s1, icnn_f2& s2) {
+    const icnn_f2 am = {fminf(a.x, 80.0f), fminf(a.y, 80.0f)};
+    const icnn_f2 t = am * 1.4426950408889634f;
+    const icnn_f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const icnn_f2 ope = e + 1.0f;
+    const icnn_f2 r = {__builtin_amdgcn_rcpf(ope.x), __builtin_amdgcn_rcpf(ope.y)};
+    const icnn_f2 l = icnn_f2{__builtin_amdgcn_logf(ope.x), __builtin_amdgcn_logf(ope.y)} * 0.6931471805599453f;
+    sp = icnn_f2{fmaxf(l.x, a.x), fmaxf(l.y, a.y)};
+    s1 = e * r;
+    s2 = s1 * r;
+}
+
+__device__ __forceinline__ icnn_f2 icnn_fma2(icnn_f2 a, icnn_f2 b, icnn_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// c0, c1 += A[jt] (split) x B (split): the six products with a weight above 2^-24, smallest first, accumulators alternating
+__device__ __forceinline__ void icnn_mma6(const IcnnSplit (&A)[2], const IcnnSplit& B, f32x16& c0, f32x16& c1) {
+    c0 = icnn_mfma_bf16(A[0].l, B.h, c0); c1 = icnn_mfma_bf16(A[1].l, B.h, c1);
+    c0 = icnn_mfma_bf16(A[0].h, B.l, c0); c1 = icnn_mfma_bf16(A[1].h, B.l, c1);
+    c0 = icnn_mfma_bf16(A[0].m, B.m, c0); c1 = icnn_mfma_bf16(A[1].m, B.m, c1);
+    c0 = icnn_mfma_bf16(A[0].m, B.h, c0); c1 = icnn_mfma_bf16(A[1].m, B.h, c1);
+    c0 = icnn_mfma_bf16(A[0].h, B.m, c0); c1 = icnn_mfma_bf16(A[1].h, B.m, c1);
+    c0 = icnn_mfma_bf16(A[0].h, B.h, c0); c1 = icnn_mfma_bf16(A[1].h, B.h, c1);
+}
+
+#define DXO_ICNN_PIN2(x) asm volatile("" : "+v"(x));
+
+// |D|^(-2/3) for icnn_mfma_bf16x3: an fp32 seed (v_log_f32 / v_exp_f32) and two Newton steps on y^-3 = D^2 in fp64 (the error squares
+// twice: 1e-6 -> 1e-12 -> fp64 rounding) instead of the library pow (about 120 fp64 instructions and a table of constants)
+__device__ __forceinline__ double icnn_pow_m23(double aD) {
+    const double c = aD * aD;
+    const float y0 = __builtin_amdgcn_exp2f(-0.6666666666666666f * __builtin_amdgcn_logf((float)aD));
+    double y = (double)y0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double r = fma(-(c * (y * y)), y, 1.0);   // 1 - D^2 y^3
+        y = fma(y * (1.0 / 3.0), r, y);
+    }
+    return y == y ? y : (double)y0;   // D = 0 or not finite: the seed's inf / nan, as pow returns
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const float* __restrict__ wT1, const float* __restrict__ wW2,
+                                                        const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
+                                                        const double* __restrict__ F, double* __restrict__ dP,
+                                                        double* __restrict__ P) {
+    constexpr int BLOCK = WAVES * 64;
+    constexpr int FRAG = 64 * 8;   // bf16 per fragment (64 lanes x 8)
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    // A fragments, [matrix][t][step][part][lane] x 8 bf16 (one 16-byte read per lane and fragment). Forward matrices:
+    //   c = 0: W2p / 12 (meets h1 = softplus^2);  c = 1..3: W2p[j][i] / 12 * 2 A1[i][c - 1] (meets u = softplus softplus'):
+    // the layer-1 input weights ride in the A operand, so all three gradient GEMMs share ONE B operand.
+    __shared__ __attribute__((aligned(16))) unsigned short sA3[4 * 2 * 4 * 3 * FRAG];
+    __shared__ __attribute__((aligned(16))) unsigned short sAT3[2 * 4 * 3 * FRAG];   // beta GEMM: W2p transposed
+    // per neuron PAIR (rows 2 r, 2 r + 1; the two values of a quantity adjacent: operands of the packed fp32 instructions)
+    __shared__ __attribute__((aligned(16))) float sP1[32 * 8];    // A1x A1y A1z d1
+    __shared__ __attribute__((aligned(16))) float sP3[32 * 12];   // the six products A1_k A1_l / 6
+    __shared__ __attribute__((aligned(16))) float sP2[32 * 12];   // S2x S2y S2z c2 w3/6, 0
+    __shared__ float sMine[WAVES * 9 * 64];
+    float* minep = sMine + wave * (9 * 64) + lane;
+    for (int e = threadIdx.x; e < 2 * 4 * 64 * 8; e += BLOCK) {
+        const int i = e & 7, l = (e >> 3) & 63, st = (e >> 9) & 3, t = e >> 11;
+        const int row = icnn_row(st >> 1, 8 * (st & 1) + i) + 4 * (l >> 5);
+        const float wf = wW2[(32 * t + (l & 31)) * NH + row] * (1.0f / 12.0f);   // forward GEMMs: A[j = 32 t + p][k -> neuron row]
+        const float wb = wW2[row * NH + 32 * t + (l & 31)];                      // beta GEMM:     A[i = 32 t + p][k -> neuron row (a j)]
+        const int base = ((t * 4 + st) * 3) * FRAG + l * 8 + i;
+        unsigned hb, mb, lb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            icnn_split1(c == 0 ? wf : wf * wT1[row * 16 + 3 + c], hb, mb, lb);
+            unsigned short* d = sA3 + c * (2 * 4 * 3 * FRAG) + base;
+            d[0] = (unsigned short)(hb >> 16); d[FRAG] = (unsigned short)(mb >> 16); d[2 * FRAG] = (unsigned short)(lb >> 16);
+        }
+        icnn_split1(wb, hb, mb, lb);
+        sAT3[base] = (unsigned short)(hb >> 16); sAT3[base + FRAG] = (unsigned short)(mb >> 16); sAT3[base + 2 * FRAG] = (unsigned short)(lb >> 16);
+    }
+    for (int e = threadIdx.x; e < NH * 4; e += BLOCK) {
+        const int row = e >> 2, k = e & 3;
+        sP1[(row >> 1) * 8 + 2 * k + (row & 1)] = wT1[row * 16 + k];
+    }
+    for (int e = threadIdx.x; e < NH * 6; e += BLOCK) {
+        const int row = e / 6, k = e % 6;
+        sP3[(row >> 1) * 12 + 2 * k + (row & 1)] = wT1[row * 16 + 8 + k];
+        sP2[(row >> 1) * 12 + 2 * k + (row & 1)] = k < 5 ? wT2[row * 8 + k] : 0.0f;
+    }
+    __syncthreads();
+    const icnn_u32x4* A_l = reinterpret_cast<const icnn_u32x4*>(sA3) + lane;     // fragment (c, t, st, part) at (((c*2+t)*4+st)*3+part)*64
+    const icnn_u32x4* AT_l = reinterpret_cast<const icnn_u32x4*>(sAT3) + lane;
+    // the lane's neurons are rows icnn_row(t, q) + 4 h: pair index (icnn_row(t, q) >> 1) + 2 h for even q
+    const float* P1_h = sP1 + 2 * h * 8;
+    const float* P3_h = sP3 + 2 * h * 12;
+    const float* P2_h = sP2 + 2 * h * 12;
+
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t tile_step = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    dxo_f64x2 f01n{1.0, 0.0}, f23n{0.0, 1.0};
+    if (tile < n_tiles) {
+        const int64_t pl0 = tile * 64 + lane < n ? tile * 64 + lane : n - 1;
+        f01n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[0];
+        f23n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[1];
+    }
+    for (; tile < n_tiles; tile += tile_step) {
+        const int64_t pidx = tile * 64 + lane;
+        const dxo_f64x2 f01 = f01n, f23 = f23n;
+        float x0, x1, x2;
+        {
+            const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};   // tail lanes recompute the last point, never store
+            const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+            const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+            const double aD = fabs(D);
+            const double m = icnn_pow_m23(aD), nn = m * m;
+            x0 = (float)((t + 1.0) * m - 3.0); x1 = (float)((t + D * D) * nn - 3.0); x2 = (float)((aD - 1.0) * (aD - 1.0));
+        }
+        if (tile + tile_step < n_tiles) {
+            const int64_t pn = (tile + tile_step) * 64 + lane;
+            const int64_t pln = pn < n ? pn : n - 1;
+            f01n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[0];
+            f23n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[1];
+        }
+        const float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
+#pragma unroll 1
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool own = (tt == h);
+            const float xs0 = own ? x0 : xp0, xs1 = own ? x1 : xp1, xs2 = own ? x2 : xp2;
+            asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads inside the loop (see icnn_mfma_f32)
+            icnn_f2 res[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) res[q] = icnn_f2{0.f, 0.f};
+            icnn_f2 cph[16];
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[jt][c][q] = 0.f;
+            // ---- phase 1: four K-steps of 16 layer-1 neurons (eight per lane, as four pairs)
+            //      [a2 | g0 | g1 | g2] += [A_0 h1 | A_1 u | A_2 u | A_3 u]
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                IcnnSplitW Bhw, Buw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pr = icnn_row(st >> 1, 8 * (st & 1) + 2 * k) >> 1;
+                    const float4 ta = *reinterpret_cast<const float4*>(P1_h + pr * 8);       // A1x pair, A1y pair
+                    const float4 tb = *reinterpret_cast<const float4*>(P1_h + pr * 8 + 4);   // A1z pair, d1 pair
+                    const icnn_f2 a = icnn_fma2(icnn_f2{ta.x, ta.y}, icnn_f2{xs0, xs0},
+                                                icnn_fma2(icnn_f2{ta.z, ta.w}, icnn_f2{xs1, xs1},
+                                                          icnn_fma2(icnn_f2{tb.x, tb.y}, icnn_f2{xs2, xs2}, icnn_f2{tb.z, tb.w})));
+                    icnn_f2 sp, s1, s2;
+                    softplus3_pk(a, sp, s1, s2);
+                    const icnn_f2 hv = sp * sp, uv = sp * s1;
+                    cph[st * 4 + k] = icnn_fma2(sp, s2, s1 * s1);   // phi''(a1) * 6: the 1/6 sits in the table of products (phase 3)
+                    DXO_ICNN_PIN2(cph[st * 4 + k])
+                    icnn_split_pair(hv, Bhw.h[k], Bhw.m[k], Bhw.l[k]);
+                    icnn_split_pair(uv, Buw.h[k], Buw.m[k], Buw.l[k]);
+                }
+                const IcnnSplit Bh = icnn_pack(Bhw), Bu = icnn_pack(Buw);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    IcnnSplit A[2];
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt) {
+                        A[jt].h = A_l[(((c * 2 + jt) * 4 + st) * 3 + 0) * 64];
+                        A[jt].m = A_l[(((c * 2 + jt) * 4 + st) * 3 + 1) * 64];
+                        A[jt].l = A_l[(((c * 2 + jt) * 4 + st) * 3 + 2) * 64];
+                    }
+                    icnn_mma6(A, c == 0 ? Bh : Bu, acc[0][c], acc[1][c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase 2: layer-2 neurons in groups of eight (four pairs); each group's deltas are one B fragment of the beta GEMM
+            f32x16 bacc[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jt = g >> 1;
+                IcnnSplitW Bdw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = 8 * (g & 1) + 2 * k;
+                    const int pr = icnn_row(jt, q) >> 1;
+                    const float4 ta = *reinterpret_cast<const float4*>(P2_h + pr * 12);       // S2x pair, S2y pair
+                    const float4 tb = *reinterpret_cast<const float4*>(P2_h + pr * 12 + 4);   // S2z pair, c2 pair
+                    const float2 tw = *reinterpret_cast<const float2*>(P2_h + pr * 12 + 8);   // w3 / 6 pair
+                    const icnn_f2 S2x = {ta.x, ta.y}, S2y = {ta.z, ta.w}, S2z = {tb.x, tb.y}, w6 = {tw.x, tw.y};
+                    const icnn_f2 a2 = icnn_f2{acc[jt][0][q], acc[jt][0][q + 1]} +
+                                       icnn_fma2(S2x, icnn_f2{xs0, xs0}, icnn_fma2(S2y, icnn_f2{xs1, xs1}, icnn_fma2(S2z, icnn_f2{xs2, xs2}, icnn_f2{tb.z, tb.w})));
+                    const icnn_f2 g0 = icnn_f2{acc[jt][1][q], acc[jt][1][q + 1]} + S2x;
+                    const icnn_f2 g1 = icnn_f2{acc[jt][2][q], acc[jt][2][q + 1]} + S2y;
+                    const icnn_f2 g2 = icnn_f2{acc[jt][3][q], acc[jt][3][q + 1]} + S2z;
+                    icnn_f2 sp, s1, s2;
+                    softplus3_pk(a2, sp, s1, s2);
+                    const icnn_f2 dl = w6 * sp * s1;
+                    const icnn_f2 curv = w6 * icnn_fma2(sp, s2, s1 * s1);
+                    icnn_split_pair(dl, Bdw.h[k], Bdw.m[k], Bdw.l[k]);
+                    const icnn_f2 cg0 = curv * g0, cg1 = curv * g1, cg2 = curv * g2;
+                    res[0] = icnn_fma2(dl, g0, res[0]); res[1] = icnn_fma2(dl, g1, res[1]); res[2] = icnn_fma2(dl, g2, res[2]);
+                    res[3] = icnn_fma2(cg0, g0, res[3]); res[4] = icnn_fma2(cg0, g1, res[4]); res[5] = icnn_fma2(cg0, g2, res[5]);
+                    res[6] = icnn_fma2(cg1, g1, res[6]); res[7] = icnn_fma2(cg1, g2, res[7]); res[8] = icnn_fma2(cg2, g2, res[8]);
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) DXO_ICNN_PIN2(res[r])
+                }
+                IcnnSplit A[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    A[it].h = AT_l[((it * 4 + g) * 3 + 0) * 64];
+                    A[it].m = AT_l[((it * 4 + g) * 3 + 1) * 64];
+                    A[it].l = AT_l[((it * 4 + g) * 3 + 2) * 64];
+                }
+                icnn_mma6(A, icnn_pack(Bdw), bacc[0], bacc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase 3: second Hessian term, beta_i (accumulator registers) x phi''(a1_i) (cph) x A1_i A1_i^T / 6 (table)
+#pragma unroll
+            for (int ip = 0; ip < 16; ++ip) {
+                const int it = ip >> 3, q = 2 * (ip & 7);
+                const int pr = icnn_row(it, q) >> 1;
+                const float4 pa = *reinterpret_cast<const float4*>(P3_h + pr * 12);
+                const float4 pb = *reinterpret_cast<const float4*>(P3_h + pr * 12 + 4);
+                const float4 pc = *reinterpret_cast<const float4*>(P3_h + pr * 12 + 8);
+                const icnn_f2 c = icnn_f2{bacc[it][q], bacc[it][q + 1]} * cph[ip];
+                res[3] = icnn_fma2(c, icnn_f2{pa.x, pa.y}, res[3]); res[4] = icnn_fma2(c, icnn_f2{pa.z, pa.w}, res[4]);
+                res[5] = icnn_fma2(c, icnn_f2{pb.x, pb.y}, res[5]); res[6] = icnn_fma2(c, icnn_f2{pb.z, pb.w}, res[6]);
+                res[7] = icnn_fma2(c, icnn_f2{pc.x, pc.y}, res[7]); res[8] = icnn_fma2(c, icnn_f2{pc.z, pc.w}, res[8]);
+#pragma unroll
+                for (int r = 3; r < 9; ++r) DXO_ICNN_PIN2(res[r])
+            }
+            // both half-waves hold partial sums of the SAME 32 points: add them, keep the tile this lane owns
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float part = res[q].x + res[q].y;
+                const float tot = part + xor32(part);
+                if (own) minep[q * 64] = tot;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (pidx < n) {
+            // the fp64 feature derivatives are formed here, after the GEMM phases (they would occupy 18 registers through them)
+            const double Fk[4] = {f01.x, f01.y, f23.x, f23.y};
+            const double t = Fk[0] * Fk[0] + Fk[1] * Fk[1] + Fk[2] * Fk[2] + Fk[3] * Fk[3];
+            const double D = Fk[0] * Fk[3] - Fk[1] * Fk[2];
+            const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
+            const double m = icnn_pow_m23(aD), nn = m * m;
+            float mine[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mine[q] = minep[q * 64];
+            const double kt[3] = {m, nn, 0.0};
+            const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
+                                  2.0 * (aD - 1.0) * sg};
+            const double ktD[3] = {(-2.0 / 3.0) * m * iD, (-4.0 / 3.0) * nn * iD, 0.0};
+            const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
+                                   -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
+            const float y1f[3] = {mine[0] + small.s3[0], mine[1] + small.s3[1], mine[2] + small.s3[2]};
+            icnn_chain(Fk, kt, kD, ktD, kDD, y1f, mine + 3, small.H, dP + pidx * 16, P + pidx * 4);
+        }
+    }
+}
+
 template <typename T>
 void launch_icnn(const IcnnDev<T>& m, int blocks, hipStream_t s, int64_t n, const double* F, double* dP, double* P) {
     IcnnSmall<T> small;
@@ -451,7 +764,10 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
         for (int k = 0; k < 4; ++k) small.H[k] = L.m->f32.H[k];
         int64_t mb = (n + 8 * 64 - 1) / (8 * 64);
         if (mb > ctx->compute_units) mb = ctx->compute_units;
-        hipLaunchKernelGGL((icnn_mfma2<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
+        if (ctx->icnn_variant != 1)   // 2 (default): the GEMMs as split-bf16 products on the bf16 matrix pipe; 1: fp32-input MFMA
+            hipLaunchKernelGGL((icnn_mfma_bf16x3<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
+        else
+            hipLaunchKernelGGL((icnn_mfma_f32<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
         return DXO_OK;
     }
     if (L.precision == 0) launch_icnn<float>(L.m->f32, (int)blocks, s, n, F, dP, P);

@@ -106,7 +106,9 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
  * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
- * (0 lane-per-point VALU kernel, 1 MFMA kernel — the default), "host_small_bytes" (host batches whose inputs + outputs
+ * (fp32 network: 0 lane-per-point VALU kernel; 1 MFMA kernel on fp32-input MFMA; 2 — the default — the same GEMMs with
+ * every fp32 operand split exactly into three bf16 numbers and six partial products on the bf16 MFMA pipe: fp32-level
+ * results (it agrees with the oracle as closely as variant 1) in about 0.68 of the time), "host_small_bytes" (host batches whose inputs + outputs
  * fit this many bytes, default 2 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
  * the chunked pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase
  * dxo_timing is recorded on it only with "timing" = 1), "host_zero_copy_bytes" (default 2 MiB: on that path, batches up

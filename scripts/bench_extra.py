@@ -125,7 +125,8 @@ del q, dT, ds
 # ICNN (BASELINE config 5): F = I + 0.1 N(0,1), det F > 0.2
 w = {k.replace("__", "."): v for k, v in np.load(ROOT / "tests" / "golden" / "icnn_isihara_weights.npz").items()}
 model = ctx.icnn_create(w)
-for n, prec, variant, label in ((10_000_000, 0, 1, "fp32 network, MFMA kernel"),
+for n, prec, variant, label in ((10_000_000, 0, 2, "fp32 network, split-bf16 MFMA kernel (default)"),
+                                (10_000_000, 0, 1, "fp32 network, fp32-input MFMA kernel"),
                                 (4_000_000, 0, 0, "fp32 network, VALU kernel"),
                                 (1_000_000, 1, 0, "fp64 network (tolerance study)")):
     ctx.set_option("icnn_variant", variant)

@@ -42,7 +42,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-res = {"fp32_mfma": run(0, 1), "fp32_valu": run(0, 0), "fp64": run(1, 0)}
+res = {"fp32_mfma_bf16x3": run(0, 2), "fp32_mfma_f32": run(0, 1), "fp32_valu": run(0, 0), "fp64": run(1, 0)}
 m = 20_000                                   # the NumPy oracle is slow: a sample of the batch
 o64 = icnn_stress_tangent(F[:m], w, net_dtype=np.float64)
 o32 = icnn_stress_tangent(F[:m], w, net_dtype=np.float32)

@@ -96,7 +96,8 @@ def test_hip_against_oracle_sizes(ctx, weights, n):
 
 @pytest.mark.gpu
 def test_mfma_and_valu_kernels_agree(ctx, weights):
-    """fp32 network: the MFMA kernel (variant 1, default) against the lane-per-point VALU kernel (variant 0) and the oracle.
+    """fp32 network: the two MFMA kernels (variant 1 fp32-input MFMA; variant 2, the default, split-bf16 MFMA) against the
+    lane-per-point VALU kernel (variant 0) and the oracle.
     Summation orders differ between the kernels, so they agree to fp32 rounding, not bit for bit."""
     from dolfinx_external_operator_amd import MEM_HOST
 
@@ -106,18 +107,19 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
     model = ctx.icnn_create(state_dict(weights))
     out = {}
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             ctx.set_option("icnn_variant", variant)
             dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
             ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
             assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
             out[variant] = (dP[: n * 16], P[: n * 4])
     finally:
-        ctx.set_option("icnn_variant", 1)
+        ctx.set_option("icnn_variant", 2)
         ctx.icnn_destroy(model)
     dPo, Po = icnn_stress_tangent(F, weights)
-    assert relerr(out[1][0], out[0][0]) <= RTOL_FP32 and relerr(out[1][1], out[0][1]) <= RTOL_FP32
-    for variant in (0, 1):
+    for variant in (1, 2):
+        assert relerr(out[variant][0], out[0][0]) <= RTOL_FP32 and relerr(out[variant][1], out[0][1]) <= RTOL_FP32
+    for variant in (0, 1, 2):
         assert relerr(out[variant][0], dPo) <= RTOL_FP32 and relerr(out[variant][1], Po) <= RTOL_FP32
 
 

@@ -28,6 +28,7 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md
 FP64_VALU_PEAK_TF = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TF = 2516.6  # v_mfma_f32_32x32x16_bf16 dense peak (16 x the fp32-input rate), MI355X_MICROARCH.md "~2.5 PF dense"
 
 
 def _time(torch, stream, fn, launches, warm=2, warm_s=0.15):
@@ -140,12 +141,29 @@ def icnn_cfg5(torch, ctx, stream, n, cpu):
         dP = torch.empty(n * 16, device=dev, dtype=torch.float64)
         P = torch.empty(n * 4, device=dev, dtype=torch.float64)
         ms, _ = _time(torch, stream, lambda: ctx.icnn_eval(model, 0, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr()), 5)
-        flop = 5 * 2 * 64 ** 3 / 64 * n   # the five 64x64x64 fp32 GEMMs per 64-point tile that the kernel issues on the matrix pipe
+        # the five 64x64x64 GEMMs per 64-point tile; the default kernel (icnn_variant 2) forms every fp32 product from six bf16
+        # MFMA products (operands split exactly into three bf16 parts), so it ISSUES six times that flop on the bf16 pipe
+        flop32 = 5 * 2 * 64 ** 3 / 64 * n
+        flop = 6 * flop32
         a = flop / ms / 1e9
+        ctx.set_option("icnn_variant", 1)
+        try:
+            ms_f32, _ = _time(torch, stream, lambda: ctx.icnn_eval(model, 0, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr()), 5)
+        finally:
+            ctx.set_option("icnn_variant", 2)
         out = {"workload": f"ICNN hyperelastic surrogate (fp32 network, fp64 in/out), stress + tangent, {n} points (BASELINE config 5)",
                "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms, "dtype": "f32 network / f64 I/O",
-               "roofline": {"bound": "mfma", "achieved": a, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": a / FP32_MFMA_PEAK_TF,
-                            "flop_per_launch": flop, "note": "fp32-input MFMA dense peak; flop = the five 64^3 GEMMs per 64-point tile only",
+               "roofline": {"bound": "mfma", "achieved": a, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": a / BF16_MFMA_PEAK_TF,
+                            "flop_per_launch": flop,
+                            "note": "bf16 MFMA dense peak; flop = six bf16 products per fp32 product of the five 64^3 GEMMs per 64-point tile "
+                                    "(fp32-level results). The matrix pipe is 0.43 of the kernel's issue cycles: MFMA and vector instructions "
+                                    "of the waves on one SIMD do not overlap on gfx950 (profiles/r03_mfma32_valu_probe.txt), and the "
+                                    "softplus / operand-split vector work is the rest",
+                            "fp32_equivalent": {"achieved": flop32 / ms / 1e9, "unit": "TFLOP/s",
+                                                "frac_of_fp32_mfma_peak": flop32 / ms / 1e9 / FP32_MFMA_PEAK_TF},
+                            "fp32_mfma_kernel": {"ms_per_launch": ms_f32, "achieved": flop32 / ms_f32 / 1e9, "peak": FP32_MFMA_PEAK_TF,
+                                                 "frac": flop32 / ms_f32 / 1e9 / FP32_MFMA_PEAK_TF,
+                                                 "note": "icnn_variant 1: the same GEMMs on v_mfma_f32_32x32x2_f32"},
                             "hbm": _hbm(192 * n, ms)}}
         if cpu:
             from oracle.icnn_oracle import icnn_stress_tangent
