@@ -124,6 +124,70 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant):
+    """The MFMA kernels evaluate 64 points per wave through shared matrix products: a point is one COLUMN of every product, so
+    a NaN / inf / singular deformation gradient must poison its own 20 outputs and nothing else — the other points come out
+    bit for bit as in a batch where the bad points are replaced by the identity."""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(5)
+    n = 1000
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    bad = {3: [np.nan, 0.0, 0.0, 1.0], 64: [np.inf, 0.0, 0.0, 1.0], 130: [1.0, 1.0, 1.0, 1.0],      # det F = 0
+           511: [0.0, 0.0, 0.0, 0.0], 999: [1e200, 0.0, 0.0, 1e200]}
+    Fb, Fc = F.copy(), F.copy()
+    for i, v in bad.items():
+        Fb[i], Fc[i] = v, [1.0, 0.0, 0.0, 1.0]
+    model = ctx.icnn_create(state_dict(weights))
+    try:
+        ctx.set_option("icnn_variant", variant)
+        out = []
+        for Fx in (Fb, Fc):
+            dP, P = np.zeros(n * 16), np.zeros(n * 4)
+            ctx.icnn_eval(model, 0, n, MEM_HOST, Fx, dP, P)
+            out.append((dP.reshape(n, 16), P.reshape(n, 4)))
+    finally:
+        ctx.set_option("icnn_variant", 2)
+        ctx.icnn_destroy(model)
+    good = np.ones(n, dtype=bool)
+    good[list(bad)] = False
+    assert np.array_equal(out[0][0][good], out[1][0][good]) and np.array_equal(out[0][1][good], out[1][1][good])
+    assert np.all(np.isfinite(out[1][0])) and np.all(np.isfinite(out[1][1]))
+    for i in bad:
+        assert not np.all(np.isfinite(out[0][0][i])) or not np.all(np.isfinite(out[0][1][i])), i
+
+
+@pytest.mark.gpu
+def test_large_and_inverted_deformations(ctx, weights):
+    """Stretches of 0.3 ... 3, shear, and det F < 0 (the features use |det F| and its sign, demo_hyperelasticity.py:263-283): the
+    default kernel's |det F|^(-2/3) comes from a seed and two Newton steps, the other kernels' from pow."""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(8)
+    n = 4096
+    F = rng.uniform(-1.5, 1.5, size=(n, 4))
+    F[:, 0] += np.where(rng.random(n) < 0.5, 1.5, -1.5)
+    F[:, 3] += 1.5
+    det = F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2]
+    F = F[np.abs(det) > 0.05]
+    n = F.shape[0]
+    assert (F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2] < 0).sum() > n // 5
+    model = ctx.icnn_create(state_dict(weights))
+    try:
+        dP, P = np.zeros(n * 16), np.zeros(n * 4)
+        ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
+    finally:
+        ctx.icnn_destroy(model)
+    dPo, Po = icnn_stress_tangent(F, weights)
+    # per point: the outputs span many decades over this batch, a batch-wide scale would hide the small ones
+    sd = np.abs(dPo).reshape(n, -1).max(axis=1)[:, None] + 1e-30
+    sp = np.abs(Po).reshape(n, -1).max(axis=1)[:, None] + 1e-30
+    assert np.max(np.abs(dP.reshape(n, -1) - dPo.reshape(n, -1)) / sd) <= 2e-5
+    assert np.max(np.abs(P.reshape(n, -1) - Po.reshape(n, -1)) / sp) <= 2e-5
+
+
+@pytest.mark.gpu
 def test_fp64_network_variant_tolerance_study(ctx, weights):
     """BASELINE config 5: the fp64 network differs from the fp32 one only by fp32 rounding (~1e-7), and
     matches the fp64-network oracle to fp64 accuracy."""
