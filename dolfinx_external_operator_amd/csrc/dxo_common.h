@@ -72,7 +72,7 @@ struct dxo_ctx {
     int64_t nontemporal = 1;
     int64_t timing = 0;
     int64_t blocks_per_cu = 0;          // 0: one wave-tile per wave (no grid stride)
-    int64_t mc_variant = 1;             // 0: lane = point; 1: classify + compacted Newton with lane refill
+    int64_t mc_variant = 2;             // 0: lane = point; 1: classify + compacted Newton with lane refill (two kernels); 2: both in one persistent kernel
     int64_t mc_blocks_per_cu = 3;       // persistent Newton workgroups per CU (2: 1.39 ms, 3: 1.36, 4: 1.36 at 10^7 points)
     int64_t icnn_variant = 2;           // fp32 network: 0 VALU lane-per-point kernel; wave-per-64-points MFMA kernels: 1 fp32-input MFMA, 2 split-bf16 MFMA
     int64_t adjoint_cell = 1;           // virtual work of eps on the standard elements: lane = cell kernel (0: wave-group kernel)

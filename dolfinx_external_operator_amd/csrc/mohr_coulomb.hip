@@ -317,6 +317,146 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
     }
 }
 
+// ------------------------------------------------------------------ variant 2: classification and Newton in ONE persistent kernel
+// mc_classify is HBM-bound with an idle vector pipe, mc_newton fp64-bound with an idle memory system, and they run one
+// after the other. Here every persistent wave does both: it classifies tiles of 64 points (elastic points are finished and
+// stored at once, plastic indices go to the wave's own LDS queue) whenever its queue cannot fill its idle Newton lanes,
+// refills idle lanes from that queue, and runs one Newton pass on the lanes that hold a point. A tile's 16 KB of loads and
+// stores are in flight while the SIMD's other wave iterates; there is no index list, no cursor atomic, no scratch.
+// Tiles are dealt round-robin over all waves (wave w gets tiles w, w + W, w + 2W, ...): whatever the spatial pattern of the
+// plastic zone, every wave samples the whole batch evenly.
+// Elastic outputs use masked stores (a plastic point's rows are written once, by its Newton lane: two stores of one wave
+// to one address from different lanes have no guaranteed order). The per-point arithmetic and its order are those of the
+// other variants: outputs are bit-identical.
+// Tried on this kernel and dropped (10^7 points, 31 % plastic; this form 1.006 ms, variant 1 1.09 ms on the same board):
+//   * the next tile's inputs fetched global -> LDS (global_load_lds) during the Newton pass, counted vmcnt waits: 1.014 ms
+//     (the register file is full: the spilled registers' scratch traffic waits on the same counter);
+//   * two or four tiles classified per visit with their loads issued first: 1.15 / 1.34 ms (spills);
+//   * the pass split into evaluation and step, finished lanes refilled between the two so that the step always runs on a
+//     full wave of unfinished points (a point with k steps holds its lane for k instead of k + 1 iterations): 1.045 ms at
+//     31 % plastic, 2.33 against 2.31 ms with every point plastic — the pass is bound by the latency of its dependent fp64
+//     chains at two waves per SIMD, not by the number of lanes at work.
+constexpr int MC_QCAP = 128;   // ring of plastic point indices per wave: at most 63 waiting + 64 from one more tile
+
+template <int MINW, bool SAME>
+__global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t n, const double* __restrict__ deps,
+                                                      const double* __restrict__ sigma_n, double* __restrict__ C_tang,
+                                                      double* __restrict__ sigma, int32_t* __restrict__ niter,
+                                                      double* __restrict__ yielding, double* __restrict__ norm_res,
+                                                      double* __restrict__ dlambda) {
+    constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
+    __shared__ double lane_state[WAVES * MC_LANE_SLOTS * DXO_WAVE];
+    __shared__ int32_t queue[WAVES * MC_QCAP];
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    int32_t* q = queue + wave * MC_QCAP;
+    mc::LaneT<LaneLds> L;
+    L.st.slots = lane_state + wave * (MC_LANE_SLOTS * DXO_WAVE) + lane;
+    bool active = false;
+    int32_t idx = 0;               // n <= 2^30 per launch (mc_launch splits larger batches)
+    int q_head = 0, q_count = 0;   // wave-uniform
+    const int n_tiles = (int)((n + DXO_WAVE - 1) / DXO_WAVE);
+    const int stride = (int)gridDim.x * WAVES;
+    int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
+    auto store_point = [&]() {
+        dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + (int64_t)idx * 16);
+        double Yc[4][5];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) L.st.get_col(m, Yc[m]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gc[2 * r] = dxo_f64x2{Yc[0][r], Yc[1][r]};
+            gc[2 * r + 1] = dxo_f64x2{Yc[2][r], Yc[3][r]};
+        }
+        dxo_f64x2* gg = reinterpret_cast<dxo_f64x2*>(sigma + (int64_t)idx * 4);
+        gg[0] = dxo_f64x2{L.sig[0], L.sig[1]};
+        gg[1] = dxo_f64x2{L.sig[2], L.sig[3]};
+        if (niter) niter[idx] = L.niter;
+        if (norm_res) norm_res[idx] = L.norm;
+        if (dlambda) dlambda[idx] = L.dl;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        // ---- classify tiles until the queue can fill the idle lanes (or the tiles run out)
+        while (q_count < n_idle && tile < n_tiles) {
+            const int64_t p0 = (int64_t)tile * DXO_WAVE;
+            tile += stride;
+            const int npts = (n - p0 < DXO_WAVE) ? (int)(n - p0) : DXO_WAVE;
+            const bool live = lane < npts;
+            const int64_t i = p0 + (live ? lane : 0);
+            const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + i * 4);
+            const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + i * 4);
+            const dxo_f64x2 e01 = ge[0], e23 = ge[1], s01 = gs[0], s23 = gs[1];
+            const double e[4] = {e01.x, e01.y, e23.x, e23.y};
+            const double sn[4] = {s01.x, s01.y, s23.x, s23.y};
+            double Ce[4], trial[4];
+            mc::C_times(k, e, Ce);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) trial[c] = sn[c] + Ce[c];
+            const double yld = mc::f_value(k, trial);                      // :422
+            const bool elastic = yld <= 0.0;                               // NaN -> plastic branch, as lax.cond does
+            mc::Result R;
+            mc::elastic_point(k, sn, Ce, trial, R);
+            const unsigned long long el_mask = __ballot(live && elastic);
+            const unsigned long long zero_mask = __ballot(live && elastic && R.niter == 0);
+            const unsigned long long pl_mask = __ballot(live && !elastic);
+            if (live && !elastic) q[(q_head + q_count + __popcll(pl_mask & ((1ull << lane) - 1ull))) & (MC_QCAP - 1)] = (int32_t)i;
+            q_count += __popcll(pl_mask);
+            if (live) {
+                if (yielding) yielding[i] = yld;
+                if (elastic) {
+                    if (niter) niter[i] = R.niter;
+                    if (norm_res) norm_res[i] = R.norm_res;
+                    if (dlambda) dlambda[i] = 0.0;
+                    // the lane's own 32-byte row (the neighbours' rows complete the lines in L2)
+                    dxo_f64x2* gg = reinterpret_cast<dxo_f64x2*>(sigma + i * 4);
+                    st16<true>(gg, dxo_f64x2{R.sigma[0], R.sigma[1]});
+                    st16<true>(gg + 1, dxo_f64x2{R.sigma[2], R.sigma[3]});
+                }
+            }
+            // C_tang of elastic points: constants in output order (chunk c = point c/8, entries 2(c%8), 2(c%8)+1)
+            dxo_f64x2* gc = reinterpret_cast<dxo_f64x2*>(C_tang + p0 * 16);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = it * DXO_WAVE + lane;
+                const int pt = c >> 3, cc = c & 7;
+                const int row = cc >> 1, col = (cc & 1) * 2;
+                dxo_f64x2 v;
+                v.x = ((row < 3 && col < 3) ? k.lmbda : 0.0) + (row == col ? k.mu2 : 0.0);
+                v.y = ((row < 3 && col + 1 < 3) ? k.lmbda : 0.0) + (row == col + 1 ? k.mu2 : 0.0);
+                if ((zero_mask >> pt) & 1ull) v = dxo_f64x2{0.0, 0.0};
+                if ((el_mask >> pt) & 1ull) st16<true>(gc + c, v);
+            }
+        }
+        // ---- refill idle lanes from the queue
+        if (n_idle && q_count) {
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+            const int take = n_idle < q_count ? n_idle : q_count;
+            if (!active && rank < take) {
+                idx = q[(q_head + rank) & (MC_QCAP - 1)];
+                const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + (int64_t)idx * 4);
+                const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + (int64_t)idx * 4);
+                const dxo_f64x2 e01 = ge[0], e23 = ge[1], s01 = gs[0], s23 = gs[1];
+                const double e[4] = {e01.x, e01.y, e23.x, e23.y};
+                const double sn[4] = {s01.x, s01.y, s23.x, s23.y};
+                mc::lane_init(L, e, sn);
+                active = true;
+            }
+            q_head = (q_head + take) & (MC_QCAP - 1);
+            q_count -= take;
+        }
+        if (!__ballot(active)) break;   // nothing waiting either: the queue would have refilled, the tiles would have been classified
+        // ---- one Newton pass on every lane that holds a point
+        if (active) {
+            if (mc::lane_pass<SAME>(k, L)) {
+                store_point();
+                active = false;
+            }
+        }
+    }
+}
+
 struct McLaunch {
     mc::Const k;
     bool d_niter, d_yield, d_res, d_dl;
@@ -332,6 +472,23 @@ int mc_launch(dxo_ctx* ctx, const McLaunch& L, int64_t n, const double* deps, co
         const int grid = dxo_grid_for_tiles(ctx, n_tiles, DXO_BLOCK / DXO_WAVE);
         hipLaunchKernelGGL(mc_point, dim3(grid), dim3(DXO_BLOCK), 0, s, L.k, n, deps, sigma_n, C_tang, sigma, niter,
                            yielding, norm_res, dlambda);
+        return DXO_OK;
+    }
+    if (ctx->mc_variant == 2) {
+        // one persistent kernel, two workgroups per CU (all resident: 248 registers and 66 KB of LDS each)
+        const int64_t max_idx = (int64_t)1 << 30;   // queue entries are int32
+        for (int64_t off = 0; off < n; off += max_idx) {
+            const int64_t m = (n - off < max_idx) ? (n - off) : max_idx;
+            int64_t blocks = (int64_t)ctx->compute_units * 2;
+            const int64_t enough = (m + DXO_BLOCK - 1) / DXO_BLOCK;
+            if (blocks > enough) blocks = enough;
+#define DXO_MC_FUSED(S_)                                                                                                       \
+    hipLaunchKernelGGL((mc_fused<2, S_>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, L.k, m, deps + off * 4, sigma_n + off * 4,   \
+                       C_tang + off * 16, sigma + off * 4, niter ? niter + off : nullptr, yielding ? yielding + off : nullptr,  \
+                       norm_res ? norm_res + off : nullptr, dlambda ? dlambda + off : nullptr)
+            if (L.k.same_angle != 0) DXO_MC_FUSED(true); else DXO_MC_FUSED(false);
+#undef DXO_MC_FUSED
+        }
         return DXO_OK;
     }
     // int32 list entries: split gigantic batches

@@ -103,7 +103,8 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * "nontemporal" (0/1 streaming stores), "timing" (0/1 record dxo_timing on device calls),
  * "blocks_per_cu" (0 = one tile per wave — except that dxo_von_mises / dxo_vm_expand_tangent writing into a block from
  * dxo_vm_output_alloc use the launch shape its calibration found best; k = grid-stride over k workgroups per CU),
- * "mc_variant" (0 lane-per-point Newton, 1 classify + compacted Newton with lane refill, default 1),
+ * "mc_variant" (0 lane-per-point Newton; 1 classify kernel + compacted Newton kernel with lane refill; 2 — the default —
+ * classification and Newton in one persistent kernel, plastic points queued per wave in LDS; outputs bit-identical),
  * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
  * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
  * (fp32 network: 0 lane-per-point VALU kernel; 1 MFMA kernel on fp32-input MFMA; 2 — the default — the same GEMMs with

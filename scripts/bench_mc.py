@@ -23,7 +23,7 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--diag", type=int, default=1)
 ap.add_argument("--launches", type=int, default=5)
 ap.add_argument("--pool", type=int, default=50_000)
-ap.add_argument("--variant", type=int, default=1)
+ap.add_argument("--variant", type=int, default=2, help="0 lane = point, 1 classify + Newton kernels, 2 single persistent kernel (default)")
 ap.add_argument("--bpc", type=int, default=3)
 ap.add_argument("--wps", type=int, default=1)
 ap.add_argument("--cpu", type=int, default=0, help="also time the CPU oracle (nested dual numbers, OpenMP) on this many points")

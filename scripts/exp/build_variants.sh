@@ -27,3 +27,5 @@ build base                               # same flags as the product (sanity: mu
 #   -DDXO_VMF_WAVES=2 / 4                                                         0.847 / 1.30 ms (3: 0.844)
 #   -DDXO_VMF_BLOCKS_PER_CU=8 / 32 / 64                                           0.819 / 0.827 / 0.867 ms (16: 0.816)
 #   -DDXO_MC_CLASSIFY_MINW=4 / 5 (mc_classify at <= 128 / <= 96 registers)        1.28-1.31 / 1.46 ms (1: 1.18-1.26)
+# round 3, single persistent Mohr-Coulomb kernel (mc_variant 2): tiles classified per visit
+for k in 0 1; do build mcpf$k -DDXO_MC_PREFETCH=$k; done

@@ -24,11 +24,16 @@ if [ -z "$QUICK" ]; then
     local cmd=(); while [ "$1" != "--" ]; do cmd+=("$1"); shift; done; shift
     timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o k -- python3 "${cmd[@]}" > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
   }
-  MC="scripts/bench_mc.py --launches 2"
+  MC="scripts/bench_mc.py --launches 2 --variant 1"     # two-kernel form: the flop count per plastic point / per classified point
   pass mc_valu $MC -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES
   pass mc_wave $MC -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
   pass mc_fetch $MC -- FETCH_SIZE
   pass mc_write $MC -- WRITE_SIZE
+  MCF="scripts/bench_mc.py --launches 2 --variant 2"    # the default single persistent kernel
+  pass mcf_valu $MCF -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES
+  pass mcf_wave $MCF -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+  pass mcf_fetch $MCF -- FETCH_SIZE
+  pass mcf_write $MCF -- WRITE_SIZE
   IC="scripts/bench_icnn.py --launches 2"
   pass icnn_p1 $IC -- SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_VALU
   pass icnn_p2 $IC -- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES

@@ -110,8 +110,8 @@ def counters(dirs, match):
 
 
 # ---- Mohr-Coulomb
-mc = counters(["mc_valu", "mc_wave", "mc_fetch", "mc_write"],
-              lambda n: "mc_newton" if "mc_newton" in n else "mc_classify" if "mc_classify" in n else None)
+mc = counters(["mc_valu", "mc_wave", "mc_fetch", "mc_write", "mcf_valu", "mcf_wave", "mcf_fetch", "mcf_write"],
+              lambda n: "mc_newton" if "mc_newton" in n else "mc_classify" if "mc_classify" in n else "mc_fused" if "mc_fused" in n else None)
 if mc:
     bench = None
     log = out / "mc_valu.log"
@@ -124,14 +124,20 @@ if mc:
             derived[k + "_fp64_flop_per_launch"] = 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"])
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             derived[k + "_hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
-    rec = {"counters": mc, "derived": derived, "bench_under_profiler": bench,
+    bench_fused = None
+    logf = out / "mcf_valu.log"
+    for line in (logf.read_text().splitlines() if logf.exists() else []):
+        if line.startswith("{"):
+            bench_fused = json.loads(line)
+    rec = {"counters": mc, "derived": derived, "bench_under_profiler": bench, "bench_under_profiler_single_kernel": bench_fused,
            "note": "flop = (ADD + MUL + 2 FMA wave-instructions) x 64 lanes, masked lanes counted; FETCH_SIZE doubled per MI355X_MICROARCH.md"}
     (out / f"{tag}_mc_pmc.json").write_text(json.dumps(rec, indent=1))
     if bench and "mc_newton_fp64_flop_per_launch" in derived:
         n, pl = bench["n"], bench["plastic_fraction"]
         flop = {"flop_per_plastic_point": derived["mc_newton_fp64_flop_per_launch"] / (n * pl),
                 "flop_per_point_classify": derived.get("mc_classify_fp64_flop_per_launch", 0.0) / n,
-                "measured": f"{tag}: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 around scripts/bench_mc.py, {n} points, plastic fraction {pl:.4f}; "
+                "measured": f"{tag}: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 around scripts/bench_mc.py --variant 1 (classification and "
+                            f"Newton as two kernels: the same per-point arithmetic as the default single kernel), {n} points, plastic fraction {pl:.4f}; "
                             "masked lanes counted (upper bound on useful flop)"}
         (out / "mc_flop.json").write_text(json.dumps(flop, indent=1))
         print("== Mohr-Coulomb:", json.dumps(derived), json.dumps(flop))

@@ -68,7 +68,7 @@ def test_reference_source_golden(ctx):
     assert got[2][zero] == 0 and np.all(got[0][zero] == 0.0)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 20000])
 def test_tracing_distribution_against_oracle(ctx, oracle, n, variant):
     deps, sn = mc_tracing_inputs(oracle, n, seed=50 + n)
@@ -76,7 +76,7 @@ def test_tracing_distribution_against_oracle(ctx, oracle, n, variant):
     try:
         got = run_device(ctx, deps, sn)
     finally:
-        ctx.set_option("mc_variant", 1)
+        ctx.set_option("mc_variant", 2)
     if n == 0:
         assert got[0].size == 0
         return
@@ -151,15 +151,40 @@ def test_drop_in_external_function(ctx, oracle):
         evaluate_external_operators([sigma], evaluated_operands)
 
 
-def test_both_kernel_variants_agree_bitwise_on_sigma(ctx, oracle):
-    deps, sn = mc_tracing_inputs(oracle, 50_000, seed=8, shear=0.2)
-    ctx.set_option("mc_variant", 0)
-    a = run_device(ctx, deps, sn)
-    ctx.set_option("mc_variant", 1)
-    b = run_device(ctx, deps, sn)
-    assert np.array_equal(a[2], b[2])                       # iteration counts
-    for x, y in zip(a, b):                                  # same per-lane arithmetic in both schedules
-        assert np.array_equal(x, y, equal_nan=True)
+def test_kernel_variants_agree_bitwise(ctx, oracle):
+    """Lane = point (0), classify + compacted Newton (1) and the single persistent kernel (2) schedule the SAME per-point
+    arithmetic (mc_core.h lane_pass): every output is bit-identical, whatever the order the points were taken in."""
+    deps, sn = mc_tracing_inputs(oracle, 150_001, seed=8, shear=0.2)
+    out = []
+    try:
+        for variant in (0, 1, 2):
+            ctx.set_option("mc_variant", variant)
+            out.append(run_device(ctx, deps, sn))
+    finally:
+        ctx.set_option("mc_variant", 2)
+    for b in out[1:]:
+        assert np.array_equal(out[0][2], b[2])                  # iteration counts
+        for x, y in zip(out[0], b):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.003, 1.0])
+def test_single_kernel_variant_at_extreme_plastic_fractions(ctx, oracle, frac):
+    """Variant 2 feeds its Newton lanes from a per-wave queue filled by its own classification: no plastic point at all, a
+    few per thousand (most tiles add nothing to the queue) and every point plastic (the queue is always full)."""
+    pool_d, pool_s = mc_tracing_inputs(oracle, 20000, seed=12)
+    ref = oracle.mohr_coulomb(pool_d, pool_s, nthreads=8)
+    pl, el = np.flatnonzero(ref[3] > 0), np.flatnonzero(ref[3] <= 0)
+    rng = np.random.default_rng(3)
+    n = 40_000
+    take = np.where(rng.random(n) < frac, rng.choice(pl, n), rng.choice(el, n))
+    deps, sn = pool_d[take], pool_s[take]
+    try:
+        ctx.set_option("mc_variant", 2)
+        got = run_device(ctx, deps, sn)
+    finally:
+        ctx.set_option("mc_variant", 2)
+    mc_compare(got, tuple(r[take] for r in ref), f"single kernel, plastic fraction {frac}", sn)
 
 
 def test_full_size_properties(ctx, oracle):
