@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh <tag> [quick]
 #     bench.json                 the default `python3 bench.py` line (headline + end_to_end + cpu_baseline + secondary)
 #     stats/                     rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-probe --no-e2e` (headline AND
-#                                secondary kernels: vm_tile, mc_classify / mc_newton, icnn_mfma, vm_field, ...)
+#                                secondary kernels: vm_tile, mc_fused, icnn_mfma_bf16x3 / icnn_mfma_f32, vm_field, ...)
 #     prof_fetch/, prof_write/   HBM counters of the headline kernel, separate --pmc passes (--no-secondary)
 #     mc_*/ icnn_*/ field_*/     counter passes of the secondary kernels (skipped with `quick`)
 # then scripts/summarize_round.py writes the text / JSON summaries next to them; copy those into profiles/.
