@@ -154,6 +154,80 @@ def test_icnn_at_one_million_points(ctx, golden):
     assert float((T - T.transpose(1, 2)).abs().max()) <= 2e-5 * float(T.abs().max())   # hyperelastic tangent: major symmetry, fp32 noise
 
 
+def test_icnn_kernels_agree_at_ten_million_points(ctx, golden):
+    """Config 5's upper size: the default kernel (GEMMs as split-bf16 products) against the fp32-input MFMA kernel over ALL 10^7
+    points on the device, and a strided sample of both against the oracle."""
+    import torch
+
+    from oracle.icnn_oracle import icnn_stress_tangent
+
+    w = dict(golden("icnn_isihara_weights.npz"))
+    n = 10_000_000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(4)
+    eye = torch.tensor([1.0, 0.0, 0.0, 1.0], device=dev, dtype=torch.float64)
+    F = torch.randn(n, 4, device=dev, dtype=torch.float64, generator=g) * 0.1 + eye
+    F[(F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2]) <= 0.2] = eye
+    model = ctx.icnn_create({k.replace("__", "."): v for k, v in w.items()})
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    try:
+        for variant in (2, 1):
+            ctx.set_option("icnn_variant", variant)
+            dP = torch.empty(n * 16, device=dev, dtype=torch.float64)
+            P = torch.empty(n * 4, device=dev, dtype=torch.float64)
+            ctx.icnn_eval(model, 0, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr())
+            out[variant] = (dP, P)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("icnn_variant", 2)
+        ctx.icnn_destroy(model)
+    sd, sp = float(out[1][0].abs().max()), float(out[1][1].abs().max())
+    assert float((out[2][0] - out[1][0]).abs().max()) <= 2e-6 * sd and float((out[2][1] - out[1][1]).abs().max()) <= 2e-6 * sp
+    assert bool(torch.isfinite(out[2][0]).all()) and bool(torch.isfinite(out[2][1]).all())
+    sel = _strided(n, 50_000, dev)
+    dPo, Po = icnn_stress_tangent(F[sel].cpu().numpy(), w)
+    for variant in (2, 1):
+        got_dP = out[variant][0].view(n, 16)[sel].cpu().numpy()
+        got_P = out[variant][1].view(n, 4)[sel].cpu().numpy()
+        assert np.max(np.abs(got_dP - dPo.reshape(-1, 16))) <= 2e-6 * np.max(np.abs(dPo))
+        assert np.max(np.abs(got_P - Po)) <= 2e-6 * np.max(np.abs(Po))
+
+
+def test_mohr_coulomb_schedules_agree_bitwise_at_ten_million_points(ctx, oracle):
+    """Config 4's size: the single persistent kernel (default) and the classify + Newton pair run the same per-point arithmetic
+    in different orders on different lanes — every one of the 10^7 x 24 outputs is the same bit pattern."""
+    import torch
+
+    from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device
+
+    n = 10_000_000
+    dev = torch.device("cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    prm = mc_default_params()
+    deps, sn = mc_tracing_inputs_device(ctx, n, seed=5)
+    out = {}
+    try:
+        for variant in (2, 1):
+            ctx.set_option("mc_variant", variant)
+            Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
+            s = torch.empty(n * 4, dtype=torch.float64, device=dev)
+            it = torch.empty(n, dtype=torch.int32, device=dev)
+            y, nr, dl = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+            ctx.mohr_coulomb(prm, n, MEM_DEVICE, deps.data_ptr(), sn.data_ptr(), Ct.data_ptr(), s.data_ptr(), it.data_ptr(),
+                             y.data_ptr(), nr.data_ptr(), dl.data_ptr())
+            out[variant] = (Ct, s, it, y, nr, dl)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("mc_variant", 2)
+    assert 0.1 < float((out[2][3] > 0).double().mean()) < 0.9           # a real mix of elastic and plastic points
+    for a, b in zip(out[2], out[1]):
+        if a.dtype == torch.int32:
+            assert bool(torch.equal(a, b))
+        else:                                                           # bit patterns, so that equal NaNs count as equal
+            assert bool(torch.equal(a.view(torch.int64), b.view(torch.int64)))
+
+
 def test_config_3_cell_blocks_at_a_hundred_million_points_on_one_gpu(ctx, oracle):
     """BASELINE config 3 (von Mises, 12.5 * 10^6 hexahedra x 8 points = 10^8 points, cell-block sharded over 8 GPUs) with
     the eight blocks run ONE AFTER ANOTHER on the single GPU of this box, each writing its slice of the full-length
