@@ -5,29 +5,33 @@ import argparse, json, pathlib, statistics, sys, time
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch  # noqa: E402
-from tools.mc_inputs import mc_tracing_inputs  # noqa: E402
-from dolfinx_external_operator_amd import MEM_DEVICE, Context, McParams  # noqa: E402
-from oracle import load_oracle  # noqa: E402  (input generation only)
+from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device  # noqa: E402
+from dolfinx_external_operator_amd import MEM_DEVICE, Context  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--variants", default="1,2")
 ap.add_argument("--fractions", default="0,0.05,0.31,1")
 a = ap.parse_args()
 n = a.n
-o = load_oracle()
-pool_d, pool_s = mc_tracing_inputs(o, 50_000, seed=2)
-ref = o.mohr_coulomb(pool_d, pool_s, nthreads=8)
-pl, el = np.flatnonzero(ref[3] > 0), np.flatnonzero(ref[3] <= 0)
 dev = torch.device("cuda:0")
-prm = McParams(6778.0, 0.25, 3.45, np.pi / 6, np.pi / 6, 26 * np.pi / 180, 0.26 * 3.45 / np.tan(np.pi / 6), 1e-8, 200, 0)
+prm = mc_default_params()
 ctx = Context(0)
 stream = torch.cuda.current_stream()
 ctx.set_stream(stream.cuda_stream)
+# a pool of tracing states (advanced by the library's own kernel), split into elastic and plastic by the library's yield value
+m = 50_000
+pd, ps = mc_tracing_inputs_device(ctx, m, seed=2)
+pC, psig = torch.empty(m * 16, dtype=torch.float64, device=dev), torch.empty(m * 4, dtype=torch.float64, device=dev)
+pit = torch.empty(m, dtype=torch.int32, device=dev)
+py, pnr, pdl = (torch.empty(m, dtype=torch.float64, device=dev) for _ in range(3))
+ctx.mohr_coulomb(prm, m, MEM_DEVICE, pd.data_ptr(), ps.data_ptr(), pC.data_ptr(), psig.data_ptr(), pit.data_ptr(), py.data_ptr(), pnr.data_ptr(), pdl.data_ptr())
+torch.cuda.synchronize()
+yh = py.cpu().numpy()
+pl, el = np.flatnonzero(yh > 0), np.flatnonzero(yh <= 0)
 rng = np.random.default_rng(1)
 Ct = torch.empty(n * 16, dtype=torch.float64, device=dev); s = torch.empty(n * 4, dtype=torch.float64, device=dev)
 it = torch.empty(n, dtype=torch.int32, device=dev)
 y, nr, dl = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
-pd, ps = torch.from_numpy(pool_d).to(dev), torch.from_numpy(pool_s).to(dev)
 for frac in [float(x) for x in a.fractions.split(",")]:
     take = np.where(rng.random(n) < frac, rng.choice(pl, n), rng.choice(el, n))
     idx = torch.from_numpy(take).to(dev)
