@@ -105,8 +105,9 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * dxo_vm_output_alloc use the launch shape its calibration found best; k = grid-stride over k workgroups per CU),
  * "mc_variant" (0 lane-per-point Newton; 1 classify kernel + compacted Newton kernel with lane refill; 2 — the default —
  * classification and Newton in one persistent kernel, plastic points queued per wave in LDS; outputs bit-identical),
- * "mc_blocks_per_cu" (persistent Newton workgroups per CU, default 3), "mc_waves_per_simd", "mc_part_points"
- * (points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32 entries), "icnn_variant"
+ * "mc_blocks_per_cu" (variant 1: persistent Newton workgroups per CU, default 3), "mc_waves_per_simd" (variant 1),
+ * "mc_part_points" (variant 1: points per classify/Newton pass, default and maximum 2^30: the compacted list holds int32
+ * entries; variant 2 splits batches beyond 2^30 points by itself), "icnn_variant"
  * (fp32 network: 0 lane-per-point VALU kernel; 1 MFMA kernel on fp32-input MFMA; 2 — the default — the same GEMMs with
  * every fp32 operand split exactly into three bf16 numbers and six partial products on the bf16 MFMA pipe: fp32-level
  * results (it agrees with the oracle as closely as variant 1) in about 0.68 of the time), "host_small_bytes" (host batches whose inputs + outputs
