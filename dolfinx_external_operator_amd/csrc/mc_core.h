@@ -38,6 +38,7 @@ struct Const {  // derived once on the host from dxo_mc_params
     double lmbda, mu2;              // C_elas = lmbda 1(x)1 + 2 mu I (Mandel), :405-415
     double inv_E, nu;               // S = C^-1: (1/E) [[1,-nu,-nu,0],...,[0,0,0,1+nu]]
     double c, theta_T, tol;
+    double sin3T;                   // sin(3 theta_T): |theta| > theta_T  <=>  |arg| > sin3T (asin is monotone)
     int32_t nitermax, same_angle;   // same_angle: phi == psi -> f and g share every derivative
     // per angle (index 0: phi -> f, 1: psi -> g)
     double sin_a[2], cos_a[2], k_lin[2];       // k_lin = sin(a)/sqrt(3)
@@ -150,11 +151,51 @@ struct Surf {
 // up to 1e-2 of the tangent at 1 - |arg| ~ 1e-5); in the plain branch |arg| <= sin(3 theta_T) < 1 keeps them tame.
 struct LodeArg {
     T23 a;                  // arg and its partials in (J2, J3)
-    double theta;           // asin(arg) / 3
-    double sn, cs;          // sin theta, cos theta (plain branch only)
+    double sn, cs;          // sin theta, cos theta, theta = asin(arg) / 3 (plain branch only)
     double t1, t2, t3;      // d theta / d arg, second, third derivative (plain branch only)
     bool rounded;
 };
+
+// sin(theta) and cos(theta) for theta = asin(u) / 3, |u| <= 1, given v = sqrt((1 - u)(1 + u)) = cos(3 theta) — WITHOUT asin, sin
+// and cos (about 280 fp64 instructions on the GPU, a 55-deep dependent chain in a pass that is bound by exactly that):
+// sin(theta) is the root of 3x - 4x^3 = u in [-1/2, 1/2] and cos(theta) the root of 4c^3 - 3c = v in [sqrt(3)/2, 1]. Newton on
+// whichever cubic is well conditioned (|u| <= 1/2: the sine's, derivative >= 2.6; else the cosine's, derivative >= 6): a cubic
+// fp32 seed (2e-5), one fp32 step (5e-8), two fp64 steps with the derivative's reciprocal taken in fp32 (its 1e-7 error only
+// slows the convergence: 5e-8 -> 6e-15 -> fp64 rounding). The other function follows from the triple-angle identities without
+// cancellation: cos = v / (1 - 4 sin^2), sin = u / (4 cos^2 - 1). Against a 40-digit evaluation both are within 3e-16 relative
+// over the whole range (the library chain: 3e-16), including u -> 1 where asin itself is ill-conditioned.
+DXO_HD float mc_rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+DXO_HD void lode_sin_cos(double u, double v, double& sn, double& cs) {
+    const double au = fabs(u);
+    const bool cb = au > 0.5;
+    const double rhs = cb ? v : au;
+    const double a1 = cb ? -3.0 : 3.0, a3 = cb ? 4.0 : -4.0;
+    const float rf = (float)rhs, a1f = cb ? -3.0f : 3.0f, a3f = cb ? 4.0f : -4.0f;
+    const float r2 = rf * rf;
+    float z = cb ? (0.8660486f + rf * (0.16574173f + rf * (-0.0420846f + rf * 0.01047643f)))
+                 : rf * (0.33336093f + r2 * (0.04846038f + r2 * 0.02903655f));
+    {
+        const float t = z * z;
+        z -= (z * (a1f + a3f * t) - rf) * mc_rcp_f32(a1f + 3.0f * a3f * t);
+    }
+    double zd = (double)z;
+    for (int it = 0; it < 2; ++it) {
+        const double t = zd * zd;
+        const double f = fma(zd, fma(a3, t, a1), -rhs);
+        const double rd = (double)mc_rcp_f32((float)fma(3.0 * a3, t, a1));
+        zd = fma(-f, rd, zd);
+    }
+    const double t = zd * zd;
+    const double other = (cb ? au : v) / (cb ? fma(4.0, t, -1.0) : fma(-4.0, t, 1.0));
+    sn = copysign(cb ? other : zd, u);
+    cs = cb ? zd : other;
+}
 
 DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
     const double r = sqrt(J2);
@@ -181,12 +222,11 @@ DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
         a.c[0] = v;
     }
     const double u = a.c[0];
-    o.theta = asin(u) * (1.0 / 3.0);
-    o.rounded = fabs(o.theta) > k.theta_T;
+    o.rounded = fabs(u) > k.sin3T;
     if (!o.rounded) {
-        o.sn = sin(o.theta);
-        o.cs = cos(o.theta);
-        const double w = 1.0 / sqrt(1.0 - u * u);
+        const double v = sqrt((1.0 - u) * (1.0 + u));
+        lode_sin_cos(u, v, o.sn, o.cs);
+        const double w = 1.0 / v;
         const double w3 = w * w * w;
         o.t1 = w * (1.0 / 3.0);
         o.t2 = u * w3 * (1.0 / 3.0);
@@ -201,7 +241,7 @@ DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const LodeArg& L) {
     double k0, k1, k2, k3;   // K and dK/darg, d2K/darg2, d3K/darg3
     const double u = L.a.c[0];
     if (L.rounded) {
-        const int sg = L.theta < 0.0 ? 0 : 1;  // sign(theta), :298-299
+        const int sg = u < 0.0 ? 0 : 1;  // sign(theta) = sign(arg), :298-299
         k0 = k.A[ia][sg] + (k.B[ia][sg] + k.Cc[ia][sg] * u) * u;
         k1 = k.B[ia][sg] + 2.0 * k.Cc[ia][sg] * u;
         k2 = 2.0 * k.Cc[ia][sg];
@@ -378,13 +418,14 @@ DXO_HD double f_value(const Const& k, const double* sig) {
     const double r = sqrt(J2);
     double arg = (-(3.0 * sqrt(3.0)) / 2.0) * J3 * (1.0 / (J2 * r));
     if (arg < -1.0 || arg > 1.0) arg = arg < 0.0 ? -1.0 : 1.0;
-    const double th = asin(arg) * (1.0 / 3.0);
     double K;
-    if (fabs(th) > k.theta_T) {
-        const int sg = th < 0.0 ? 0 : 1;
+    if (fabs(arg) > k.sin3T) {
+        const int sg = arg < 0.0 ? 0 : 1;
         K = k.A[0][sg] + k.B[0][sg] * arg + k.Cc[0][sg] * (arg * arg);
     } else {
-        K = cos(th) - k.k_lin[0] * sin(th);
+        double sn, cs;
+        lode_sin_cos(arg, sqrt((1.0 - arg) * (1.0 + arg)), sn, cs);
+        K = cs - k.k_lin[0] * sn;
     }
     return I1 / 3.0 * k.sin_a[0] + sqrt(J2 * (K * K) + k.ag2s2[0]) - k.c * k.cos_a[0];
 }
@@ -561,6 +602,7 @@ inline Const make_const(double E, double nu, double c, double phi, double psi, d
     k.nu = nu;
     k.c = c;
     k.theta_T = theta_T;
+    k.sin3T = sin(3.0 * theta_T);
     k.tol = tol;
     k.nitermax = nitermax;
     k.same_angle = (phi == psi) ? 1 : 0;
