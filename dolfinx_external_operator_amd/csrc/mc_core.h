@@ -534,8 +534,8 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     S_times(k, r_sig, rho);
     ldl_solve(F, rho, xh);
     ldl_solve(F, gradg, bh);
-    const double cb = dot4(gradf, bh);
-    const double t_l = (dot4(gradf, xh) - r_f) / cb;
+    const double icb = 1.0 / dot4(gradf, bh);   // the Schur complement's pivot: one division for the step and the four tangent columns
+    const double t_l = (dot4(gradf, xh) - r_f) * icb;
     double t_s[4];
     for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
     // tangent recursion Y <- J^-1 ([C; 0] + (D J[Y]) t), column by column (column m of the new Y depends on column m
@@ -557,7 +557,7 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
         for (int i = 0; i < 4; ++i) rhs[i] = (i == m ? 1.0 : 0.0) + dlm * Ht[i] + L.dl * Tv[i] + t_l * Hv[i];
         const double nu_m = dot4(Hft, v);
         ldl_solve(F, rhs, zh);
-        const double mu_m = (dot4(gradf, zh) - nu_m) / cb;
+        const double mu_m = (dot4(gradf, zh) - nu_m) * icb;
         for (int i = 0; i < 4; ++i) col[i] = zh[i] - bh[i] * mu_m;
         col[4] = mu_m;
         L.st.set_col(m, col);

@@ -334,8 +334,10 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 //   * two or four tiles classified per visit with their loads issued first: 1.15 / 1.34 ms (spills);
 //   * the pass split into evaluation and step, finished lanes refilled between the two so that the step always runs on a
 //     full wave of unfinished points (a point with k steps holds its lane for k instead of k + 1 iterations): 1.045 ms at
-//     31 % plastic, 2.33 against 2.31 ms with every point plastic — the pass is bound by the latency of its dependent fp64
-//     chains at two waves per SIMD, not by the number of lanes at work.
+//     31 % plastic, 2.33 against 2.31 ms with every point plastic (22 spilled registers). Again after the Lode angle's
+//     library calls were gone (no spills): 0.915 against 0.943 ms at 31 %, 1.85 against 1.96 ms all plastic, 0.665 against
+//     0.633 ms at 5 % — and the two inlined copies of the pass contract their FMAs differently, so the outputs were no
+//     longer bit-identical to the other variants. Not taken.
 constexpr int MC_QCAP = 128;   // ring of plastic point indices per wave: at most 63 waiting + 64 from one more tile
 
 template <int MINW, bool SAME>
