@@ -353,23 +353,95 @@ DXO_HD void third_apply(const Surf& e, int ia, const Third& T, const double* v, 
         out[i] = T.dFx * Pv[i] + T.dFy * Qv[i] + F[2] * Rv[i] + cp * e.s[i] + ep * T.Pt[i] + cq * e.q[i] + eq * T.Qt[i];
 }
 
+// ---- the same two operators as dense symmetric matrices (10 numbers: 00 01 02 03 11 12 13 22 23 33)
+// A pass applies hess(g) to six vectors (four unit vectors for M, the step, four tangent columns... ) and T(t) to four: formed
+// ONCE as matrices — hess = Fx P + Fy B(s) + [s q] [[Fxx Fxy][Fxy Fyy]] [s q]^T with P = dev and B(s) = dev Q(s) dev — they cost
+// 60 + 100 flops and every application 16 FMAs, instead of 60 / 110 flops per application of the structured forms above.
+// For deviatoric s (s0 + s1 + s2 = 0):  3 B(s) = [[2 s0, 2 s2, 2 s1, s3], [., 2 s1, 2 s0, s3], [., ., 2 s2, -2 s3], [., ., ., -3 s2]].
+struct Sym4 { double m[10]; };
+DXO_HD void sym_apply(const Sym4& A, const double* v, double* out) {
+    out[0] = A.m[0] * v[0] + A.m[1] * v[1] + A.m[2] * v[2] + A.m[3] * v[3];
+    out[1] = A.m[1] * v[0] + A.m[4] * v[1] + A.m[5] * v[2] + A.m[6] * v[3];
+    out[2] = A.m[2] * v[0] + A.m[5] * v[1] + A.m[7] * v[2] + A.m[8] * v[3];
+    out[3] = A.m[3] * v[0] + A.m[6] * v[1] + A.m[8] * v[2] + A.m[9] * v[3];
+}
+DXO_HD void dev_q_dev3(const double* s, double* B) {   // 3 B(s)
+    B[0] = 2.0 * s[0]; B[1] = 2.0 * s[2]; B[2] = 2.0 * s[1]; B[3] = s[3];
+    B[4] = 2.0 * s[1]; B[5] = 2.0 * s[0]; B[6] = s[3];
+    B[7] = 2.0 * s[2]; B[8] = -2.0 * s[3];
+    B[9] = -3.0 * s[2];
+}
+// x_i y_j + z_i w_j for i <= j, added to A (the caller's sum is symmetric as a whole)
+DXO_HD void sym_add_outer2(Sym4& A, const double* x, const double* y, const double* z, const double* w) {
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j, ++n) A.m[n] += x[i] * y[j] + z[i] * w[j];
+}
+DXO_HD void sym_add_dev(Sym4& A, double c) {   // A += c P,  P = dev
+    const double d = c * (2.0 / 3.0), o = c * (-1.0 / 3.0);
+    A.m[0] += d; A.m[1] += o; A.m[2] += o;
+    A.m[4] += d; A.m[5] += o;
+    A.m[7] += d;
+    A.m[9] += c;
+}
+// hess(surface) dense; also returns a = Fxx s + Fxy q, b = Fxy s + Fyy q (third_dense needs them again)
+DXO_HD void hess_dense(const Surf& e, int ia, Sym4& H, double* a, double* b) {
+    const double* F = e.F[ia].c;
+    for (int i = 0; i < 4; ++i) {
+        a[i] = F[3] * e.s[i] + F[4] * e.q[i];
+        b[i] = F[4] * e.s[i] + F[5] * e.q[i];
+    }
+    double B[10];
+    dev_q_dev3(e.s, B);
+    const double fy3 = F[2] * (1.0 / 3.0);
+    for (int n = 0; n < 10; ++n) H.m[n] = fy3 * B[n];
+    sym_add_dev(H, F[1]);
+    sym_add_outer2(H, a, e.s, b, e.q);
+}
+// T(t) = D_t hess(surface) dense, for the direction t
+DXO_HD void third_dense(const Surf& e, int ia, const double* t, const double* a, const double* b, Sym4& T) {
+    const double* F = e.F[ia].c;
+    double Pt[4], Qt[4], B[10], Bt[10];
+    devv(t, Pt);
+    dev_q_dev3(e.s, B);
+    {
+        Sym4 Bs;
+        for (int n = 0; n < 10; ++n) Bs.m[n] = B[n] * (1.0 / 3.0);
+        sym_apply(Bs, t, Qt);   // dev Q(s) dev t
+    }
+    dev_q_dev3(Pt, Bt);
+    const double al = dot4(e.s, t), be = dot4(e.q, t);
+    const double dFx = F[3] * al + F[4] * be, dFy = F[4] * al + F[5] * be;
+    const double dFxx = F[6] * al + F[7] * be, dFxy = F[7] * al + F[8] * be, dFyy = F[8] * al + F[9] * be;
+    double c1[4], c2[4];
+    for (int i = 0; i < 4; ++i) {
+        c1[i] = dFxx * e.s[i] + dFxy * e.q[i] + F[3] * Pt[i] + F[4] * Qt[i];
+        c2[i] = dFxy * e.s[i] + dFyy * e.q[i] + F[4] * Pt[i] + F[5] * Qt[i];
+    }
+    const double dfy3 = dFy * (1.0 / 3.0), fy3 = F[2] * (1.0 / 3.0);
+    for (int n = 0; n < 10; ++n) T.m[n] = dfy3 * B[n] + fy3 * Bt[n];
+    sym_add_dev(T, dFx);
+    sym_add_outer2(T, e.s, c1, e.q, c2);
+    sym_add_outer2(T, Pt, a, Qt, b);
+}
+
 // LDL^T of a symmetric 4x4 (lower triangle in m[10]: 00,10,11,20,21,22,30,31,32,33), no pivoting
 // (the four pivots are inverted once: a pass does 6 solves, and an fp64 division is ~12 instructions)
 struct Ldl { double l10, l20, l21, l30, l31, l32, i0, i1, i2, i3; };
-DXO_HD void ldl_factor(const double (*M)[4], Ldl& f) {
-    const double d0 = M[0][0];
+DXO_HD void ldl_factor(const Sym4& M, Ldl& f) {   // M.m: 00 01 02 03 11 12 13 22 23 33
+    const double d0 = M.m[0];
     f.i0 = 1.0 / d0;
-    f.l10 = M[1][0] * f.i0;
-    f.l20 = M[2][0] * f.i0;
-    f.l30 = M[3][0] * f.i0;
-    const double d1 = M[1][1] - f.l10 * f.l10 * d0;
+    f.l10 = M.m[1] * f.i0;
+    f.l20 = M.m[2] * f.i0;
+    f.l30 = M.m[3] * f.i0;
+    const double d1 = M.m[4] - f.l10 * f.l10 * d0;
     f.i1 = 1.0 / d1;
-    f.l21 = (M[2][1] - f.l20 * f.l10 * d0) * f.i1;
-    f.l31 = (M[3][1] - f.l30 * f.l10 * d0) * f.i1;
-    const double d2 = M[2][2] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
+    f.l21 = (M.m[5] - f.l20 * f.l10 * d0) * f.i1;
+    f.l31 = (M.m[6] - f.l30 * f.l10 * d0) * f.i1;
+    const double d2 = M.m[7] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
     f.i2 = 1.0 / d2;
-    f.l32 = (M[3][2] - f.l30 * f.l20 * d0 - f.l31 * f.l21 * d1) * f.i2;
-    const double d3 = M[3][3] - f.l30 * f.l30 * d0 - f.l31 * f.l31 * d1 - f.l32 * f.l32 * d2;
+    f.l32 = (M.m[8] - f.l30 * f.l20 * d0 - f.l31 * f.l21 * d1) * f.i2;
+    const double d3 = M.m[9] - f.l30 * f.l30 * d0 - f.l31 * f.l31 * d1 - f.l32 * f.l32 * d2;
     f.i3 = 1.0 / d3;
 }
 DXO_HD void ldl_solve(const Ldl& f, const double* b, double* x) {
@@ -515,14 +587,17 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     }
     if (L.norm0 < 0.0 || L.norm0 != L.norm0) L.norm0 = (L.niter == 0) ? L.norm : L.norm0;  // :501
     if (!((L.norm / L.norm0 > k.tol) && (L.niter < k.nitermax))) return true;
-    // M = S + dlambda H_g (symmetric)
-    double M[4][4];
-    for (int j = 0; j < 4; ++j) {
-        double ej[4] = {0.0, 0.0, 0.0, 0.0}, Hj[4], Sj[4];
-        ej[j] = 1.0;
-        hess_apply(e, 1, ej, Hj);
-        S_times(k, ej, Sj);
-        for (int i = 0; i < 4; ++i) M[i][j] = Sj[i] + L.dl * Hj[i];
+    // hess(g) as a dense symmetric matrix, once per pass; M = S + dlambda H_g (S = C^-1: (1/E) [[1, -nu, -nu, 0], ..., 1 + nu])
+    Sym4 H;
+    double av[4], bv[4];
+    hess_dense(e, 1, H, av, bv);
+    Sym4 M;
+    {
+        const double sd = k.inv_E * ((1.0 + k.nu) - k.nu), so = -(k.inv_E * k.nu);
+        M.m[0] = sd + L.dl * H.m[0]; M.m[1] = so + L.dl * H.m[1]; M.m[2] = so + L.dl * H.m[2]; M.m[3] = L.dl * H.m[3];
+        M.m[4] = sd + L.dl * H.m[4]; M.m[5] = so + L.dl * H.m[5]; M.m[6] = L.dl * H.m[6];
+        M.m[7] = sd + L.dl * H.m[7]; M.m[8] = L.dl * H.m[8];
+        M.m[9] = k.inv_E * (1.0 + k.nu) + L.dl * H.m[9];
     }
     Ldl F;
     ldl_factor(M, F);
@@ -541,19 +616,19 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     // tangent recursion Y <- J^-1 ([C; 0] + (D J[Y]) t), column by column (column m of the new Y depends on column m
     // of the old one only, so the update is done in place)
     double Ht[4], Hft[4];
-    hess_apply(e, 1, t_s, Ht);
+    sym_apply(H, t_s, Ht);
     if constexpr (SAME) { for (int i = 0; i < 4; ++i) Hft[i] = Ht[i]; }
     else hess_apply(e, 0, t_s, Hft);
-    Third T;
-    third_setup(e, 1, t_s, T);
+    Sym4 T;   // T(t_s) = D_t hess(g), dense, once per pass
+    third_dense(e, 1, t_s, av, bv, T);
     for (int m = 0; m < 4; ++m) {
         double col[5];
         L.st.get_col(m, col);
         const double v[4] = {col[0], col[1], col[2], col[3]};
         const double dlm = col[4];
         double Tv[4], Hv[4], rhs[4], zh[4];
-        third_apply(e, 1, T, v, Tv);
-        hess_apply(e, 1, v, Hv);
+        sym_apply(T, v, Tv);
+        sym_apply(H, v, Hv);
         for (int i = 0; i < 4; ++i) rhs[i] = (i == m ? 1.0 : 0.0) + dlm * Ht[i] + L.dl * Tv[i] + t_l * Hv[i];
         const double nu_m = dot4(Hft, v);
         ldl_solve(F, rhs, zh);
