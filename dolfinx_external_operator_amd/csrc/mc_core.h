@@ -481,7 +481,9 @@ DXO_HD double residual(const Const& k, const Surf& e, const double* sig, double 
 
 // f(sigma) only — the trial-stress test (:422, :440, :531). Same expressions as the value path of
 // surf_eval / F_taylor, without carrying derivatives.
-DXO_HD double f_value(const Const& k, const double* sig) {
+// `ia`: which angle's constants to read. f belongs to phi (index 0); a kernel compiled for phi == psi passes 1 — the same
+// numbers — so that only ONE set of per-angle constants is live in its scalar registers.
+DXO_HD double f_value(const Const& k, const double* sig, int ia = 0) {
     double s[4];
     devv(sig, s);
     const double I1 = sig[0] + sig[1] + sig[2];
@@ -493,13 +495,13 @@ DXO_HD double f_value(const Const& k, const double* sig) {
     double K;
     if (fabs(arg) > k.sin3T) {
         const int sg = arg < 0.0 ? 0 : 1;
-        K = k.A[0][sg] + k.B[0][sg] * arg + k.Cc[0][sg] * (arg * arg);
+        K = k.A[ia][sg] + k.B[ia][sg] * arg + k.Cc[ia][sg] * (arg * arg);
     } else {
         double sn, cs;
         lode_sin_cos(arg, sqrt((1.0 - arg) * (1.0 + arg)), sn, cs);
-        K = cs - k.k_lin[0] * sn;
+        K = cs - k.k_lin[ia] * sn;
     }
-    return I1 / 3.0 * k.sin_a[0] + sqrt(J2 * (K * K) + k.ag2s2[0]) - k.c * k.cos_a[0];
+    return I1 / 3.0 * k.sin_a[ia] + sqrt(J2 * (K * K) + k.ag2s2[ia]) - k.c * k.cos_a[ia];
 }
 
 // Elastic branch (:424-425, :442-443): r = [sigma - sigma_n - C deps, dlambda], J = I, one iteration.

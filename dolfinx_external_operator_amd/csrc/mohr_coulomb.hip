@@ -396,14 +396,16 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
             mc::C_times(k, e, Ce);
 #pragma unroll
             for (int c = 0; c < 4; ++c) trial[c] = sn[c] + Ce[c];
-            const double yld = mc::f_value(k, trial);                      // :422
+            const double yld = mc::f_value(k, trial, SAME ? 1 : 0);         // :422
             const bool elastic = yld <= 0.0;                               // NaN -> plastic branch, as lax.cond does
             mc::Result R;
             mc::elastic_point(k, sn, Ce, trial, R);
             const unsigned long long el_mask = __ballot(live && elastic);
             const unsigned long long zero_mask = __ballot(live && elastic && R.niter == 0);
             const unsigned long long pl_mask = __ballot(live && !elastic);
-            if (live && !elastic) q[(q_head + q_count + __popcll(pl_mask & ((1ull << lane) - 1ull))) & (MC_QCAP - 1)] = (int32_t)i;
+            if (live && !elastic)
+                q[(q_head + q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pl_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pl_mask, 0u))) &
+                  (MC_QCAP - 1)] = (int32_t)i;
             q_count += __popcll(pl_mask);
             if (live) {
                 if (yielding) yielding[i] = yld;
@@ -422,13 +424,15 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int c = it * DXO_WAVE + lane;
-                const int pt = c >> 3, cc = c & 7;
+                const int cc = lane & 7, sub = lane >> 3;            // chunk c belongs to point 8 it + sub
                 const int row = cc >> 1, col = (cc & 1) * 2;
                 dxo_f64x2 v;
                 v.x = ((row < 3 && col < 3) ? k.lmbda : 0.0) + (row == col ? k.mu2 : 0.0);
                 v.y = ((row < 3 && col + 1 < 3) ? k.lmbda : 0.0) + (row == col + 1 ? k.mu2 : 0.0);
-                if ((zero_mask >> pt) & 1ull) v = dxo_f64x2{0.0, 0.0};
-                if ((el_mask >> pt) & 1ull) st16<true>(gc + c, v);
+                // the eight points of this iteration: one byte of each mask (a scalar shift), tested with a 32-bit vector shift
+                const unsigned zero8 = (unsigned)(zero_mask >> (8 * it)) & 0xffu, el8 = (unsigned)(el_mask >> (8 * it)) & 0xffu;
+                if ((zero8 >> sub) & 1u) v = dxo_f64x2{0.0, 0.0};
+                if ((el8 >> sub) & 1u) st16<true>(gc + c, v);
             }
         }
         // ---- refill idle lanes from the queue
