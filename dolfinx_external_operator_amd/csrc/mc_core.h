@@ -87,10 +87,40 @@ DXO_HD T23 t_scale(const T23& u, double k) {
     return w;
 }
 
+// 1 / sqrt(x) to fp64 rounding: the hardware's v_rsq_f64 and two Newton steps (9 instructions); sqrt(x) = x y, 1 / x = y y and
+// x^-1.5 = y y y then cost one multiplication each — the library's sqrt and division are 14 and 12 instructions with long
+// dependent chains, and the pass needs them in threes. (x = 0, inf, nan, < 0 give the nan / inf combinations the callers treat
+// as "not a number" anyway: a hydrostatic stress has f = nan in the reference too.)
+DXO_HD double mc_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-(x * y), y, 1.0);
+        y = fma(y * 0.5, e, y);
+    }
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
+// 1 / x to fp64 rounding (v_rcp_f64 and two Newton steps, 5 instructions; the library division is 12 with the scaling it needs
+// for operands near the ends of the exponent range, which pivots of an SPD matrix of moduli are not)
+DXO_HD double mc_recip(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    for (int it = 0; it < 2; ++it) y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
+
 DXO_HD T23 t_sqrt(const T23& u) {
-    const double h0 = sqrt(u.c[0]);
-    const double iu = 1.0 / u.c[0];
-    const double h1 = 0.5 * h0 * iu;      // 1 / (2 sqrt u)
+    const double y = mc_rsqrt(u.c[0]);
+    const double h0 = u.c[0] * y;         // sqrt u
+    const double iu = y * y;              // 1 / u
+    const double h1 = 0.5 * y;            // 1 / (2 sqrt u)
     const double h2 = -0.5 * h1 * iu;
     const double h3 = -1.5 * h2 * iu;
     return t_compose(u, h0, h1, h2, h3);
@@ -192,15 +222,15 @@ DXO_HD void lode_sin_cos(double u, double v, double& sn, double& cs) {
         zd = fma(-f, rd, zd);
     }
     const double t = zd * zd;
-    const double other = (cb ? au : v) / (cb ? fma(4.0, t, -1.0) : fma(-4.0, t, 1.0));
+    const double other = (cb ? au : v) * mc_recip(cb ? fma(4.0, t, -1.0) : fma(-4.0, t, 1.0));
     sn = copysign(cb ? other : zd, u);
     cs = cb ? zd : other;
 }
 
 DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
-    const double r = sqrt(J2);
-    const double iJ2 = 1.0 / J2;
-    const double h0 = 1.0 / (J2 * r);   // J2^-1.5 (kept as one division: the value path must match f_value)
+    const double y2 = mc_rsqrt(J2);
+    const double iJ2 = y2 * y2;
+    const double h0 = iJ2 * y2;         // J2^-1.5 (the same expression as in f_value)
     const double h1 = -1.5 * h0 * iJ2;
     const double h2 = -2.5 * h1 * iJ2;
     const double h3 = -3.5 * h2 * iJ2;
@@ -224,9 +254,9 @@ DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
     const double u = a.c[0];
     o.rounded = fabs(u) > k.sin3T;
     if (!o.rounded) {
-        const double v = sqrt((1.0 - u) * (1.0 + u));
-        lode_sin_cos(u, v, o.sn, o.cs);
-        const double w = 1.0 / v;
+        const double x1 = (1.0 - u) * (1.0 + u);
+        const double w = mc_rsqrt(x1);      // 1 / cos(3 theta)
+        lode_sin_cos(u, x1 * w, o.sn, o.cs);
         const double w3 = w * w * w;
         o.t1 = w * (1.0 / 3.0);
         o.t2 = u * w3 * (1.0 / 3.0);
@@ -430,19 +460,19 @@ DXO_HD void third_dense(const Surf& e, int ia, const double* t, const double* a,
 struct Ldl { double l10, l20, l21, l30, l31, l32, i0, i1, i2, i3; };
 DXO_HD void ldl_factor(const Sym4& M, Ldl& f) {   // M.m: 00 01 02 03 11 12 13 22 23 33
     const double d0 = M.m[0];
-    f.i0 = 1.0 / d0;
+    f.i0 = mc_recip(d0);
     f.l10 = M.m[1] * f.i0;
     f.l20 = M.m[2] * f.i0;
     f.l30 = M.m[3] * f.i0;
     const double d1 = M.m[4] - f.l10 * f.l10 * d0;
-    f.i1 = 1.0 / d1;
+    f.i1 = mc_recip(d1);
     f.l21 = (M.m[5] - f.l20 * f.l10 * d0) * f.i1;
     f.l31 = (M.m[6] - f.l30 * f.l10 * d0) * f.i1;
     const double d2 = M.m[7] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
-    f.i2 = 1.0 / d2;
+    f.i2 = mc_recip(d2);
     f.l32 = (M.m[8] - f.l30 * f.l20 * d0 - f.l31 * f.l21 * d1) * f.i2;
     const double d3 = M.m[9] - f.l30 * f.l30 * d0 - f.l31 * f.l31 * d1 - f.l32 * f.l32 * d2;
-    f.i3 = 1.0 / d3;
+    f.i3 = mc_recip(d3);
 }
 DXO_HD void ldl_solve(const Ldl& f, const double* b, double* x) {
     const double z0 = b[0];
@@ -489,8 +519,8 @@ DXO_HD double f_value(const Const& k, const double* sig, int ia = 0) {
     const double I1 = sig[0] + sig[1] + sig[2];
     const double J2 = 0.5 * dot4(s, s);
     const double J3 = s[2] * (s[0] * s[1] - s[3] * s[3] / 2.0);
-    const double r = sqrt(J2);
-    double arg = (-(3.0 * sqrt(3.0)) / 2.0) * J3 * (1.0 / (J2 * r));
+    const double y2 = mc_rsqrt(J2);
+    double arg = (-(3.0 * sqrt(3.0)) / 2.0) * J3 * ((y2 * y2) * y2);
     if (arg < -1.0 || arg > 1.0) arg = arg < 0.0 ? -1.0 : 1.0;
     double K;
     if (fabs(arg) > k.sin3T) {
@@ -498,7 +528,8 @@ DXO_HD double f_value(const Const& k, const double* sig, int ia = 0) {
         K = k.A[ia][sg] + k.B[ia][sg] * arg + k.Cc[ia][sg] * (arg * arg);
     } else {
         double sn, cs;
-        lode_sin_cos(arg, sqrt((1.0 - arg) * (1.0 + arg)), sn, cs);
+        const double x1 = (1.0 - arg) * (1.0 + arg);
+        lode_sin_cos(arg, x1 * mc_rsqrt(x1), sn, cs);
         K = cs - k.k_lin[ia] * sn;
     }
     return I1 / 3.0 * k.sin_a[ia] + sqrt(J2 * (K * K) + k.ag2s2[ia]) - k.c * k.cos_a[ia];
@@ -611,7 +642,7 @@ DXO_HD bool lane_pass(const Const& k, LaneT<Store>& L) {
     S_times(k, r_sig, rho);
     ldl_solve(F, rho, xh);
     ldl_solve(F, gradg, bh);
-    const double icb = 1.0 / dot4(gradf, bh);   // the Schur complement's pivot: one division for the step and the four tangent columns
+    const double icb = mc_recip(dot4(gradf, bh));   // the Schur complement's pivot: one division for the step and the four tangent columns
     const double t_l = (dot4(gradf, xh) - r_f) * icb;
     double t_s[4];
     for (int i = 0; i < 4; ++i) t_s[i] = xh[i] - bh[i] * t_l;
