@@ -253,17 +253,18 @@ DXO_HD void lode_arg(const Const& k, double J2, double J3, LodeArg& o) {
     }
     const double u = a.c[0];
     o.rounded = fabs(u) > k.sin3T;
+    // (locals, not references into `o`: with the struct's fields written under the branch the compiler kept part of it in scratch)
+    double sn = 0.0, cs = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     if (!o.rounded) {
         const double x1 = (1.0 - u) * (1.0 + u);
         const double w = mc_rsqrt(x1);      // 1 / cos(3 theta)
-        lode_sin_cos(u, x1 * w, o.sn, o.cs);
+        lode_sin_cos(u, x1 * w, sn, cs);
         const double w3 = w * w * w;
-        o.t1 = w * (1.0 / 3.0);
-        o.t2 = u * w3 * (1.0 / 3.0);
-        o.t3 = (w3 + 3.0 * u * u * w3 * w * w) * (1.0 / 3.0);
-    } else {
-        o.sn = o.cs = o.t1 = o.t2 = o.t3 = 0.0;
+        t1 = w * (1.0 / 3.0);
+        t2 = u * w3 * (1.0 / 3.0);
+        t3 = (w3 + 3.0 * u * u * w3 * w * w) * (1.0 / 3.0);
     }
+    o.sn = sn; o.cs = cs; o.t1 = t1; o.t2 = t2; o.t3 = t3;
 }
 
 // F(J2, J3) = sqrt(J2 K(theta)^2 + a_g^2 sin^2 a) for angle index ia, :334-345, :364-374
@@ -271,10 +272,11 @@ DXO_HD T23 F_taylor(const Const& k, int ia, double J2, const LodeArg& L) {
     double k0, k1, k2, k3;   // K and dK/darg, d2K/darg2, d3K/darg3
     const double u = L.a.c[0];
     if (L.rounded) {
-        const int sg = u < 0.0 ? 0 : 1;  // sign(theta) = sign(arg), :298-299
-        k0 = k.A[ia][sg] + (k.B[ia][sg] + k.Cc[ia][sg] * u) * u;
-        k1 = k.B[ia][sg] + 2.0 * k.Cc[ia][sg] * u;
-        k2 = 2.0 * k.Cc[ia][sg];
+        const bool neg = u < 0.0;        // sign(theta) = sign(arg), :298-299; selects, not indexing: the constants live in scalar
+        const double Ak = neg ? k.A[ia][0] : k.A[ia][1], Bk = neg ? k.B[ia][0] : k.B[ia][1], Ck = neg ? k.Cc[ia][0] : k.Cc[ia][1];   // registers
+        k0 = Ak + (Bk + Ck * u) * u;
+        k1 = Bk + 2.0 * Ck * u;
+        k2 = 2.0 * Ck;
         k3 = 0.0;
     } else {
         const double kl = k.k_lin[ia];
@@ -524,8 +526,9 @@ DXO_HD double f_value(const Const& k, const double* sig, int ia = 0) {
     if (arg < -1.0 || arg > 1.0) arg = arg < 0.0 ? -1.0 : 1.0;
     double K;
     if (fabs(arg) > k.sin3T) {
-        const int sg = arg < 0.0 ? 0 : 1;
-        K = k.A[ia][sg] + k.B[ia][sg] * arg + k.Cc[ia][sg] * (arg * arg);
+        const bool neg = arg < 0.0;
+        const double Ak = neg ? k.A[ia][0] : k.A[ia][1], Bk = neg ? k.B[ia][0] : k.B[ia][1], Ck = neg ? k.Cc[ia][0] : k.Cc[ia][1];
+        K = Ak + Bk * arg + Ck * (arg * arg);
     } else {
         double sn, cs;
         const double x1 = (1.0 - arg) * (1.0 + arg);
