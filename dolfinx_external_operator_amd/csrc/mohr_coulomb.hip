@@ -338,6 +338,11 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 //     library calls were gone (no spills): 0.915 against 0.943 ms at 31 %, 1.85 against 1.96 ms all plastic, 0.665 against
 //     0.633 ms at 5 % — and the two inlined copies of the pass contract their FMAs differently, so the outputs were no
 //     longer bit-identical to the other variants. Not taken.
+//   * (after the pass had lost its scratch traffic) the global_load_lds prefetch again: 0.806 against 0.806 ms; and an
+//     iteration ordered so that every vmcnt wait sits directly after a pass and all stores are issued in one burst before
+//     the next (loads and stores retire through one in-order counter on gfx950, so a wait for a load also waits for
+//     the stores before it): 0.825 against 0.806 ms. Neither the load latency nor the store acknowledgements are what the
+//     mix waits for.
 constexpr int MC_QCAP = 128;   // ring of plastic point indices per wave: at most 63 waiting + 64 from one more tile
 
 template <int MINW, bool SAME>
