@@ -8,6 +8,21 @@
 
 namespace {
 
+// x^(-2/3), x > 0, for the features: an fp32 seed (v_log_f32 / v_exp_f32) and two Newton steps on y^-3 = x^2 in fp64 (the error
+// squares twice: 1e-6 -> 1e-12 -> fp64 rounding, within 2 ulp) instead of the library pow (about 120 fp64 instructions, a table of
+// constants and a long dependent chain). x = 0, inf, nan return the seed's inf / 0 / nan as pow does.
+__device__ __forceinline__ double hyper_pow_m23(double x) {
+    const double c = x * x;
+    const float y0 = __builtin_amdgcn_exp2f(-0.6666666666666666f * __builtin_amdgcn_logf((float)x));
+    double y = (double)y0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double r = fma(-(c * (y * y)), y, 1.0);   // 1 - x^2 y^3
+        y = fma(y * (1.0 / 3.0), r, y);
+    }
+    return y == y ? y : (double)y0;
+}
+
 // Chain rule from the network input x = (K1, K2, K3) to F in fp64 (shared by both kernels).
 // dK_k = kt_k gt + kD_k gD with gt = grad |F|^2 = 2F, gD = grad det F = cof F; W = grad_x y, hx = hess_x y packed
 // (00, 01, 02, 11, 12, 22). Writes P = grad_F W_NN + F @ H (:433-439) and dP[i][j] = dP_i/dF_j.
@@ -66,7 +81,7 @@ __device__ __forceinline__ void isihara_point(const IsiPrm& prm, const double (&
     const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
     const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
     const double iD = 1.0 / D;
-    const double m = D > 0.0 ? pow(D, -2.0 / 3.0) : __builtin_nan(""), nn = m * m;
+    const double m = D > 0.0 ? hyper_pow_m23(D) : __builtin_nan(""), nn = m * m;
     const double K1 = (t + 1.0) * m - 3.0;
     const double kt[3] = {m, nn, 0.0};
     const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,

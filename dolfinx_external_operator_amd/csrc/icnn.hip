@@ -499,20 +499,6 @@ __device__ __forceinline__ void icnn_mma6(const IcnnSplit (&A)[2], const IcnnSpl
 
 #define DXO_ICNN_PIN2(x) asm volatile("" : "+v"(x));
 
-// |D|^(-2/3) for icnn_mfma_bf16x3: an fp32 seed (v_log_f32 / v_exp_f32) and two Newton steps on y^-3 = D^2 in fp64 (the error squares
-// twice: 1e-6 -> 1e-12 -> fp64 rounding) instead of the library pow (about 120 fp64 instructions and a table of constants)
-__device__ __forceinline__ double icnn_pow_m23(double aD) {
-    const double c = aD * aD;
-    const float y0 = __builtin_amdgcn_exp2f(-0.6666666666666666f * __builtin_amdgcn_logf((float)aD));
-    double y = (double)y0;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double r = fma(-(c * (y * y)), y, 1.0);   // 1 - D^2 y^3
-        y = fma(y * (1.0 / 3.0), r, y);
-    }
-    return y == y ? y : (double)y0;   // D = 0 or not finite: the seed's inf / nan, as pow returns
-}
-
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const float* __restrict__ wT1, const float* __restrict__ wW2,
                                                         const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
@@ -584,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const 
             const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
             const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
             const double aD = fabs(D);
-            const double m = icnn_pow_m23(aD), nn = m * m;
+            const double m = hyper_pow_m23(aD), nn = m * m;
             x0 = (float)((t + 1.0) * m - 3.0); x1 = (float)((t + D * D) * nn - 3.0); x2 = (float)((aD - 1.0) * (aD - 1.0));
         }
         if (tile + tile_step < n_tiles) {
@@ -720,7 +706,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const 
             const double t = Fk[0] * Fk[0] + Fk[1] * Fk[1] + Fk[2] * Fk[2] + Fk[3] * Fk[3];
             const double D = Fk[0] * Fk[3] - Fk[1] * Fk[2];
             const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
-            const double m = icnn_pow_m23(aD), nn = m * m;
+            const double m = hyper_pow_m23(aD), nn = m * m;
             float mine[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) mine[q] = minep[q * 64];
