@@ -38,6 +38,7 @@ def mc_core(tmp_path_factory):
         lib.mc_core_cpu(C.byref(prm), n, *(a.ctypes.data for a in (deps, sn, Ct, s, it, y, nr, dl)))
         return Ct, s, it, y, nr, dl
 
+    run.lib = lib
     return run
 
 
@@ -218,3 +219,44 @@ def test_near_the_meridians_the_lane_math_is_the_more_accurate_side(oracle, mc_c
     assert err_k[near].max() < 1e-12                               # the lane math stays there at the meridians ...
     assert err_o[near].max() > 10 * err_k[near].max()              # ... the reference's fp64 chain does not
     assert np.max(np.abs(sk - sl)[sel]) < 1e-12 * max(np.max(np.abs(sl)), 1.0)
+
+
+def test_dense_hessian_and_third_derivative_matrices_against_the_structured_operators(oracle, mc_core):
+    """The pass forms hess(g) and T(t) = D_t hess(g) once as dense symmetric matrices (closed form of dev Q(s) dev for a
+    deviatoric s) and applies them with 16 FMAs; the literal chain-rule operators they replaced stay in mc_core.h as the
+    cross-check: same H v and T(t) v to rounding on stresses of the tracing distribution, both Abbo-Sloan branches."""
+    lib = mc_core.lib
+    lib.mc_dense_vs_structured.argtypes = [C.c_void_p] * 5
+    deps, sn = mc_tracing_inputs(oracle, 400, seed=21, shear=0.3)
+    from oracle.loader import mc_params
+
+    prm = mc_params(psi=20 * np.pi / 180)     # non-associated: surf_eval<false> evaluates both surfaces
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for i in range(deps.shape[0]):
+        sig = np.ascontiguousarray(sn[i] + rng.normal(size=4) * 0.3)
+        t, v = rng.normal(size=4), rng.normal(size=4)
+        out = np.zeros(16)
+        lib.mc_dense_vs_structured(C.byref(prm), sig.ctypes.data, t.ctypes.data, v.ctypes.data, out.ctypes.data)
+        if not np.all(np.isfinite(out)):
+            continue
+        for a, b in ((out[0:4], out[4:8]), (out[8:12], out[12:16])):
+            worst = max(worst, np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+    assert worst < 1e-11, worst      # the third-derivative terms cancel by several orders near the meridians
+
+
+def test_lode_angle_sine_and_cosine_without_library_calls(mc_core):
+    """sin(asin(u)/3) and cos(asin(u)/3) from Newton on the triple-angle cubics (mc_core.h lode_sin_cos) against libm over
+    the whole range, including u -> 1 where asin is ill-conditioned and the branch switch at |u| = 1/2."""
+    lib = mc_core.lib
+    lib.mc_lode_sin_cos.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0)
+    u = np.concatenate([rng.uniform(-1, 1, 20000), 1 - np.logspace(-16, -2, 200), -(1 - np.logspace(-16, -2, 200)),
+                        np.logspace(-300, -1, 200), [0.0, 0.5, -0.5, 0.5000000001, 1.0, -1.0]])
+    sn, cs = np.zeros_like(u), np.zeros_like(u)
+    lib.mc_lode_sin_cos(u.size, u.ctypes.data, sn.ctypes.data, cs.ctypes.data)
+    th = np.arcsin(u) / 3
+    # against a 40-digit evaluation: 3e-16 relative over (1e-38, 1], 1e-15 below the fp32 range of the seed (libm's chain: 3e-16)
+    assert np.all(np.abs(sn - np.sin(th)) <= 2e-15 * np.abs(np.sin(th)))
+    assert np.all(np.abs(cs - np.cos(th)) <= 1e-15)
+    assert np.array_equal(np.signbit(sn), np.signbit(u))
