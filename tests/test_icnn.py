@@ -188,6 +188,38 @@ def test_large_and_inverted_deformations(ctx, weights):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed, scale, rtol", [(1, 1.0, RTOL_FP32), (2, 0.2, RTOL_FP32), (3, 3.0, 1e-5)])
+def test_kernels_with_random_weights(ctx, weights, seed, scale, rtol):
+    """Other networks than the trained one: weights of the same architecture drawn at random (a fifth, once and three times the
+    trained magnitudes; the softplus re-parametrisation turns them into very differently scaled positive matrices). The split
+    of the GEMM operands into three bf16 parts is exact whatever the magnitudes are, so the default kernel must follow the
+    oracle as closely as the fp32-input kernel does. (With three times the magnitudes the outputs reach 1e6 and two correct fp32
+    evaluations differ by up to 3e-6 of that — the lane-per-point kernel and the oracle do — hence the wider bound there.)"""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(seed)
+    w = {k: (scale * np.abs(v).max() * rng.uniform(-1.0, 1.0, size=v.shape)).astype(np.float32) for k, v in weights.items()}
+    n = 3000
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.08 * rng.normal(size=(n, 4))
+    model = ctx.icnn_create(state_dict(w))
+    out = {}
+    try:
+        for variant in (0, 1, 2):
+            ctx.set_option("icnn_variant", variant)
+            dP, P = np.zeros(n * 16), np.zeros(n * 4)
+            ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
+            out[variant] = (dP, P)
+    finally:
+        ctx.set_option("icnn_variant", 2)
+        ctx.icnn_destroy(model)
+    dPo, Po = icnn_stress_tangent(F, w)
+    assert np.all(np.isfinite(dPo)) and np.max(np.abs(dPo)) > 0
+    for variant in (0, 1, 2):
+        assert relerr(out[variant][0], dPo) <= rtol and relerr(out[variant][1], Po) <= rtol, variant
+    assert relerr(out[2][0], out[1][0]) <= rtol and relerr(out[2][1], out[1][1]) <= rtol      # the two MFMA kernels against each other
+
+
+@pytest.mark.gpu
 def test_fp64_network_variant_tolerance_study(ctx, weights):
     """BASELINE config 5: the fp64 network differs from the fp32 one only by fp32 rounding (~1e-7), and
     matches the fp64-network oracle to fp64 accuracy."""
