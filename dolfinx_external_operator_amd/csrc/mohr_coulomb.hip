@@ -343,6 +343,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 //     the next (loads and stores retire through one in-order counter on gfx950, so a wait for a load also waits for
 //     the stores before it): 0.825 against 0.806 ms. Neither the load latency nor the store acknowledgements are what the
 //     mix waits for.
+#ifndef DXO_MC_PROF
+#define DXO_MC_PROF 0   // 1: instrumented build for scripts/exp/mc_phase_profile.py only (it corrupts dlambda)
+#endif
 constexpr int MC_QCAP = 128;   // ring of plastic point indices per wave: at most 63 waiting + 64 from one more tile
 
 template <int MINW, bool SAME>
@@ -382,6 +385,15 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
         if (norm_res) norm_res[idx] = L.norm;
         if (dlambda) dlambda[idx] = L.dl;
     };
+#if DXO_MC_PROF
+    // EXPERIMENT ONLY (scripts/exp/mc_phase_profile.py): cycles per wave in classification / refill / Newton pass, number of passes
+    long long prof[4] = {0, 0, 0, 0};
+    const long long prof_t0 = __builtin_readcyclecounter();
+    long long prof_t = prof_t0;
+#define DXO_PROF_MARK(slot) { const long long t_ = __builtin_readcyclecounter(); prof[slot] += t_ - prof_t; prof_t = t_; }
+#else
+#define DXO_PROF_MARK(slot)
+#endif
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
                 if ((el8 >> sub) & 1u) st16<true>(gc + c, v);
             }
         }
+        DXO_PROF_MARK(0)
         // ---- refill idle lanes from the queue
         if (n_idle && q_count) {
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
@@ -457,6 +470,7 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
             q_head = (q_head + take) & (MC_QCAP - 1);
             q_count -= take;
         }
+        DXO_PROF_MARK(1)
         if (!__ballot(active)) break;   // nothing waiting either: the queue would have refilled, the tiles would have been classified
         // ---- one Newton pass on every lane that holds a point
         if (active) {
@@ -465,7 +479,19 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
                 active = false;
             }
         }
+        DXO_PROF_MARK(2)
+#if DXO_MC_PROF
+        prof[3] += 1;
+#endif
     }
+#if DXO_MC_PROF
+    if (lane == 0 && dlambda) {   // overwrites the head of dlambda with the wave's counters: the results of such a build are NOT the operator's
+        const int64_t w = (int64_t)blockIdx.x * WAVES + wave;
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int c = 0; c < 4; ++c) dlambda[w * 5 + c] = (double)prof[c];
+        dlambda[w * 5 + 4] = (double)(__builtin_readcyclecounter() - prof_t0);
+    }
+#endif
 }
 
 struct McLaunch {
