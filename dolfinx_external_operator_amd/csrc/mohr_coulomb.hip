@@ -346,7 +346,8 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 #ifndef DXO_MC_PROF
 #define DXO_MC_PROF 0   // 1: instrumented build for scripts/exp/mc_phase_profile.py only (it corrupts dlambda)
 #endif
-constexpr int MC_QCAP = 128;   // ring of plastic point indices per wave: at most 63 waiting + 64 from one more tile
+constexpr int MC_QCAP = 128;   // plastic point indices waiting per wave: at most 63 + 64 from one more tile
+constexpr int MC_STASH = 64;   // of which the newest keep their inputs in LDS
 
 template <int MINW, bool SAME>
 __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t n, const double* __restrict__ deps,
@@ -357,14 +358,21 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
     constexpr int WAVES = DXO_BLOCK / DXO_WAVE;
     __shared__ double lane_state[WAVES * MC_LANE_SLOTS * DXO_WAVE];
     __shared__ int32_t queue[WAVES * MC_QCAP];
+    // the inputs (deps, sigma_n: 64 bytes) of the waiting points, written by the classifying lane that has them in registers, so
+    // that a refill is four LDS reads instead of a gather from L2 / HBM: slot = stack position mod 64, chunk-major (conflict-free)
+    __shared__ __attribute__((aligned(16))) dxo_f64x2 stash[WAVES * 4 * MC_STASH];
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     int32_t* q = queue + wave * MC_QCAP;
+    dxo_f64x2* sth = stash + wave * (4 * MC_STASH);
     mc::LaneT<LaneLds> L;
     L.st.slots = lane_state + wave * (MC_LANE_SLOTS * DXO_WAVE) + lane;
     bool active = false;
     int32_t idx = 0;               // n <= 2^30 per launch (mc_launch splits larger batches)
-    int q_head = 0, q_count = 0;   // wave-uniform
+    // The waiting points are a STACK (positions 0 .. q_count - 1; the newest leave first — which lane iterates a point, and when,
+    // does not change its result). Stack position p keeps its inputs in stash slot p mod 64, so the newest 64 entries always
+    // have theirs; an entry below `stash_lo` has had its slot overwritten by position p + 64 and is re-read from global memory.
+    int q_count = 0, stash_lo = 0;   // wave-uniform
     const int n_tiles = (int)((n + DXO_WAVE - 1) / DXO_WAVE);
     const int stride = (int)gridDim.x * WAVES;
     int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WAVES + wave);
@@ -420,10 +428,14 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
             const unsigned long long el_mask = __ballot(live && elastic);
             const unsigned long long zero_mask = __ballot(live && elastic && R.niter == 0);
             const unsigned long long pl_mask = __ballot(live && !elastic);
-            if (live && !elastic)
-                q[(q_head + q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pl_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pl_mask, 0u))) &
-                  (MC_QCAP - 1)] = (int32_t)i;
+            if (live && !elastic) {
+                const int pos = q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pl_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pl_mask, 0u));
+                q[pos] = (int32_t)i;
+                dxo_f64x2* st = sth + (pos & (MC_STASH - 1));
+                st[0] = e01; st[MC_STASH] = e23; st[2 * MC_STASH] = s01; st[3 * MC_STASH] = s23;
+            }
             q_count += __popcll(pl_mask);
+            if (q_count - MC_STASH > stash_lo) stash_lo = q_count - MC_STASH;
             if (live) {
                 if (yielding) yielding[i] = yld;
                 if (elastic) {
@@ -458,17 +470,24 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
             const int rank = __popcll(idle & ((1ull << lane) - 1ull));
             const int take = n_idle < q_count ? n_idle : q_count;
             if (!active && rank < take) {
-                idx = q[(q_head + rank) & (MC_QCAP - 1)];
-                const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + (int64_t)idx * 4);
-                const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + (int64_t)idx * 4);
-                const dxo_f64x2 e01 = ge[0], e23 = ge[1], s01 = gs[0], s23 = gs[1];
+                const int pos = q_count - 1 - rank;   // from the top of the stack
+                idx = q[pos];
+                dxo_f64x2 e01, e23, s01, s23;
+                if (pos >= stash_lo) {
+                    const dxo_f64x2* st = sth + (pos & (MC_STASH - 1));
+                    e01 = st[0]; e23 = st[MC_STASH]; s01 = st[2 * MC_STASH]; s23 = st[3 * MC_STASH];
+                } else {
+                    const dxo_f64x2* ge = reinterpret_cast<const dxo_f64x2*>(deps + (int64_t)idx * 4);
+                    const dxo_f64x2* gs = reinterpret_cast<const dxo_f64x2*>(sigma_n + (int64_t)idx * 4);
+                    e01 = ge[0]; e23 = ge[1]; s01 = gs[0]; s23 = gs[1];
+                }
                 const double e[4] = {e01.x, e01.y, e23.x, e23.y};
                 const double sn[4] = {s01.x, s01.y, s23.x, s23.y};
                 mc::lane_init(L, e, sn);
                 active = true;
             }
-            q_head = (q_head + take) & (MC_QCAP - 1);
             q_count -= take;
+            if (q_count < stash_lo) stash_lo = q_count;   // everything below the old mark is still stale, everything pushed from here on is fresh
         }
         DXO_PROF_MARK(1)
         if (!__ballot(active)) break;   // nothing waiting either: the queue would have refilled, the tiles would have been classified
