@@ -320,8 +320,8 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 // ------------------------------------------------------------------ variant 2: classification and Newton in ONE persistent kernel
 // mc_classify is HBM-bound with an idle vector pipe, mc_newton fp64-bound with an idle memory system, and they run one
 // after the other. Here every persistent wave does both: it classifies tiles of 64 points (elastic points are finished and
-// stored at once, plastic indices go to the wave's own LDS queue) whenever its queue cannot fill its idle Newton lanes,
-// refills idle lanes from that queue, and runs one Newton pass on the lanes that hold a point. A tile's 16 KB of loads and
+// stored at once, plastic points go on the wave's own LDS stack, index and inputs) whenever the stack cannot fill its idle
+// Newton lanes, refills idle lanes from it (LDS reads only), and runs one Newton pass on the lanes that hold a point. A tile's 16 KB of loads and
 // stores are in flight while the SIMD's other wave iterates; there is no index list, no cursor atomic, no scratch.
 // Tiles are dealt round-robin over all waves (wave w gets tiles w, w + W, w + 2W, ...): whatever the spatial pattern of the
 // plastic zone, every wave samples the whole batch evenly.
