@@ -59,20 +59,6 @@ template <> __device__ __forceinline__ float t_log1p<float>(float x) { return lo
 template <> __device__ __forceinline__ double t_log1p<double>(double x) { return log1p(x); }
 
 // softplus (beta = 1, threshold = 20 as torch.nn.functional.softplus) with first and second derivative
-// fp32 softplus on the hardware transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp): ~10 instructions instead of
-// ~120 for expf + log1pf. log(1 + e) loses RELATIVE accuracy for e < 1e-4, but there softplus < 1e-4 and only
-// enters through softplus^2/12 — absolute error < 1e-12 of the network output.
-__device__ __forceinline__ void softplus3_fast(float a, float& sp, float& s1, float& s2) {
-    // raw v_exp_f32 / v_log_f32 / v_rcp_f32: the arguments are bounded (e <= e^20, 1 + e >= 1), so the
-    // denormal-range fix-ups that __expf / __logf add are dead weight here
-    const float e = __builtin_amdgcn_exp2f(fminf(a, 20.0f) * 1.4426950408889634f);
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    const bool big = a > 20.0f;
-    sp = big ? a : __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
-    s1 = big ? 1.0f : e * r;
-    s2 = big ? 0.0f : e * r * r;
-}
-
 template <typename T>
 __device__ __forceinline__ void softplus3(T a, T& sp, T& s1, T& s2) {
     if (a > T(20)) {
