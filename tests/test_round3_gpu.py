@@ -264,6 +264,37 @@ def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle
         ctx.set_option("placement_candidates", saved[1])
 
 
+def test_isihara_device_calls_use_a_persistent_arena_block(ctx):
+    """The HBM-bound analytic operator, CUDA-tensor operand, default factory: above the arena threshold (dP, P) live in one
+    block chosen by timing the kernel itself, overwritten by the next call; results equal the fresh-tensor form bit for bit."""
+    import torch
+
+    from dolfinx_external_operator_amd import make_isihara
+
+    saved = ctx.get_option("placement_min_bytes"), ctx.get_option("placement_candidates")
+    ctx.set_option("placement_min_bytes", 1 << 22)
+    ctx.set_option("placement_candidates", 3)
+    try:
+        n = 60_000
+        g = torch.Generator(device="cuda:0").manual_seed(9)
+        F = torch.randn(n, 1, 2, 2, device="cuda:0", dtype=torch.float64, generator=g) * 0.05 + torch.eye(2, device="cuda:0", dtype=torch.float64)
+        ext, fresh = make_isihara(ctx=ctx), make_isihara(ctx=ctx, device_outputs="fresh")
+        dP1, P1 = ext((1,))(F)
+        assert dP1.dxo_block.info["mode"] == "candidates" and dP1.numel() == n * 16 and P1.numel() == n * 4
+        dPf, Pf = fresh((1,))(F)
+        assert torch.equal(dP1, dPf) and torch.equal(P1, Pf) and not hasattr(dPf, "dxo_block")
+        ptr = dP1.data_ptr()
+        dP2, _ = ext((1,))(F * 1.01)
+        assert dP2.data_ptr() == ptr and torch.equal(dP1, fresh((1,))(F * 1.01)[0])      # aliased: the first view sees the new call
+        small = ext((1,))(F[:100])[0], ext((1,))(F[:100])[0]
+        assert small[0].data_ptr() != small[1].data_ptr()                                 # below the threshold: fresh tensors
+        with pytest.raises(ValueError):
+            make_isihara(ctx=ctx, device_outputs="pinned")
+    finally:
+        ctx.set_option("placement_min_bytes", saved[0])
+        ctx.set_option("placement_candidates", saved[1])
+
+
 @pytest.mark.parametrize("form", ["single_process", "rank"])
 def test_mgpu_sharded_entry_points_of_the_other_operators(ctx, oracle, golden, form):
     """dxo_mgpu_mohr_coulomb / _icnn / _isihara / _heat with a world of one: the communicator comes up, every operator
