@@ -283,6 +283,19 @@ def heat_cfg1(torch, ctx, stream, cpu):
     out = {"workload": "nonlinear heat flux q, dq/dT, dq/dsigma on the 32 x 32 unit square of BASELINE config 1: 6 144 points, three "
                        "evaluate_external_operators-style calls (NumPy in, NumPy out) per step", "points": int(T.size),
            "us_per_step_three_calls": us, "value": T.size / (us * 1e-6), "unit": "qp/s", "dtype": "f64"}
+    # the opt-in that turns the step's three launches into one (make_heat(fuse_by_identity=True): the first call for a pair of
+    # operand OBJECTS computes q, dq/dT, dq/dsigma in one launch, the other two are served from it — what the demo's
+    # evaluate_external_operators does with ONE evaluated_operands dict, part2.py:307-309). A step = fresh operand arrays.
+    ext1 = make_heat(ctx=ctx, fuse_by_identity=True)
+    fns1 = [ext1(d) for d in ((0, 0), (1, 0), (0, 1))]
+    pairs = [(T.copy(), sigma.copy()) for _ in range(reps)]
+    for f in fns1:
+        f(T, sigma)
+    t0 = time.perf_counter()
+    for Tq, sq in pairs:
+        for f in fns1:
+            f(Tq, sq)
+    out["us_per_step_fused_by_identity"] = (time.perf_counter() - t0) / reps * 1e6
     n = 50_000_000
     dev = torch.device("cuda", ctx.device)
     Td = torch.rand(n, dtype=torch.float64, device=dev)
