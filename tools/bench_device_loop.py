@@ -1,0 +1,220 @@
+"""bench.py's `secondary.device_loop_*` legs: one Newton iteration of the reference's hot loop with quadrature data resident
+in HBM, and the dofmap assigner.
+
+The reference's loop is  evaluate_operands -> evaluate_external_operators -> assemble residual / Jacobian
+(doc/demo/demo_plasticity_von_mises.py:445-456, src/dolfinx_external_operator/petsc/petsc.py:55-68). On the device it is
+four library calls on device pointers (no PCIe traffic, only dof vectors leave the kernels):
+
+    dxo_von_mises_field_state   eps(Du) + radial return + consistent tangent, history variables in a dxo_vm_state
+    dxo_operand_adjoint         internal force  R = sum_q w|detJ| B^T sigma         (the residual form, :378-385)
+    dxo_tangent_apply           K v = sum_q w|detJ| B^T C_tang B v, K never formed  (one Krylov matvec; the Jacobian form :386-391)
+    dxo_vm_state_commit         p += dp, sigma_n <- sigma                           (:564-565; once per load step)
+
+Every call is timed with HIP events on the launch stream and carries its own `roofline` (HBM; algorithmic bytes in
+DESIGN.md 9.1, restated in `bytes` below). `iteration_ms` = field + internal force + one matvec. The cpu_baseline of the
+iteration is the same three steps with the checkers (NumPy operand / adjoint oracles + the C return map) on a bounded
+sample of the same mesh. Only that part touches oracle/.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from tools.bench_secondary import ROOT, _avail, _hbm, _time  # noqa: F401
+
+
+def _geo_bytes(m):
+    return m.x.nbytes + m.geom_dofmap.nbytes
+
+
+def loop_bytes(m, bs, d):
+    """Algorithmic HBM bytes per call (every array once; `out` of an accumulating call is read and written)."""
+    npts = m.num_cells * m.nq
+    vec = m.node_x.shape[0] * bs * 8
+    geo = _geo_bytes(m)
+    return {
+        "von_mises_field_state": vec + geo + m.dofmap.nbytes + npts * (d + 1) * 8 + npts * (d * d + d + 1) * 8,
+        "internal_force": npts * d * 8 + geo + m.dofmap.nbytes + 2 * vec,
+        "tangent_apply": npts * d * d * 8 + geo + m.dofmap.nbytes + vec + 2 * vec,
+        "tangent_diagonal": npts * d * d * 8 + geo + m.dofmap.nbytes + 2 * vec,
+        "state_commit": npts * (2 * d + 3) * 8,     # read sigma, dp, p; write sigma_n, p  (sigma_n is overwritten, not read)
+    }
+
+
+def field_dofs(m, rng):
+    """Nodal values of a displacement increment whose strains are of the size SURVEY.md 8(d) prescribes (N(0, 3e-3) per component):
+    independent N(0, s) values per dof with s = 1.2e-3 x the cell size (the gradient of nodal noise on a degree-2 element is about
+    2.5 / h times its standard deviation), so that — with sigma_n ~ N(0, 100) — the batch is a mix of elastic and plastic points."""
+    h = 1.0 / round(m.num_cells / (2 if m.cell == "triangle" else 1)) ** (1.0 / m.gdim)
+    return rng.normal(0.0, 1.2e-3 * h, size=m.node_x.shape[0] * m.gdim)
+
+
+def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
+    from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh
+    from tools.synthetic import structured_mesh
+
+    dev = torch.device("cuda", ctx.device)
+    t0 = time.perf_counter()
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=0)
+    mesh_s = time.perf_counter() - t0
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    st = None
+    try:
+        bs = m.gdim
+        d = 4 if bs == 2 else 6
+        npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
+        rng = np.random.Generator(np.random.PCG64(0))
+        u_h = field_dofs(m, rng)
+        u = torch.from_numpy(u_h).to(dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        sig0 = torch.randn(npts * d, generator=g, device=dev, dtype=torch.float64) * 100
+        p0 = (torch.randn(npts, generator=g, device=dev, dtype=torch.float64) * 1e-3).abs()
+        v = torch.randn(nn * bs, generator=g, device=dev, dtype=torch.float64)
+        R = torch.zeros(nn * bs, dtype=torch.float64, device=dev)
+        Kv = torch.zeros(nn * bs, dtype=torch.float64, device=dev)
+        st = ctx.vm_state(d, npts)
+        st.upload(sig0.data_ptr(), p0.data_ptr(), mem=MEM_DEVICE)
+        ptr = st.pointers()
+        by = loop_bytes(m, bs, d)
+        # C_tang in an arena block chosen by timing the producing kernel on the candidates (as the headline's outputs are)
+        (Ct,) = ctx.output_tensors_probed((npts * d * d,), lambda ptrs, shape: st.call_field(prm, dm._h, MEM_DEVICE, u.data_ptr(), ptrs[0]),
+                                          bytes_per_launch=float(by["von_mises_field_state"]))
+
+        def field():
+            st.call_field(prm, dm._h, MEM_DEVICE, u.data_ptr(), Ct.data_ptr())
+
+        def force():
+            R.zero_()
+            dm.adjoint("eps", bs, ptr["sigma"], R.data_ptr())
+
+        def matvec():
+            Kv.zero_()
+            dm.tangent_apply(Ct.data_ptr(), v.data_ptr(), Kv.data_ptr())
+
+        def diag():
+            Kv.zero_()
+            dm.tangent_diagonal(Ct.data_ptr(), Kv.data_ptr())
+
+        def iteration():
+            field()
+            force()
+            matvec()
+
+        field()
+        torch.cuda.synchronize()
+        plastic = float((torch.as_tensor(_view(torch, ptr["dp"], npts, dev)) > 0).double().mean())
+        calls = {}
+        for name, fn, kernels in (("von_mises_field_state", field, [f"vm_field<{bs}>"]),
+                                  ("internal_force", force, ["adjoint_cell_eps | operand_adjoint", "node_sum"]),
+                                  ("tangent_apply", matvec, ["tangent_apply", "node_sum"]),
+                                  ("tangent_diagonal", diag, ["tangent_diag", "node_sum"])):
+            ms, _ = _time(torch, stream, fn, launches, warm=3)
+            calls[name] = {"ms_per_call": ms, "qp_per_s": npts / ms * 1e3, "kernels": kernels,
+                           "roofline": {**_hbm(by[name], ms), "algorithmic_bytes_per_call": by[name], "bytes_per_qp": by[name] / npts}}
+        # the load-step update: commit needs a fresh result each time, so the pair (field, commit) is timed and the field's time subtracted
+        ms_pair, _ = _time(torch, stream, lambda: (field(), st.commit()), launches, warm=2)
+        ms_c = max(ms_pair - calls["von_mises_field_state"]["ms_per_call"], 1e-6)
+        calls["state_commit"] = {"ms_per_call": ms_c, "kernels": ["vm_commit"], "timed_as": "(field + commit) - field",
+                                 "roofline": {**_hbm(by["state_commit"], ms_c), "algorithmic_bytes_per_call": by["state_commit"],
+                                              "bytes_per_qp": by["state_commit"] / npts}}
+        st.upload(sig0.data_ptr(), p0.data_ptr(), mem=MEM_DEVICE)
+        ms_it, _ = _time(torch, stream, iteration, launches, warm=2)
+        it_bytes = by["von_mises_field_state"] + by["internal_force"] + by["tangent_apply"]
+        out = {"workload": f"one device-resident Newton iteration of the von Mises problem (petsc.py:55-68 / demo_plasticity_von_mises.py:445-456): "
+                           f"fused operand + return map with resident state, internal force, one matrix-free tangent matvec; "
+                           f"{cell} degree 2, {m.num_cells} cells x {m.nq} points = {npts} points, {nn * bs} dofs, Mandel d={d}, fp64",
+               "points": npts, "dofs": nn * bs, "cells": m.num_cells, "value": npts / ms_it * 1e3, "unit": "qp/s per Newton iteration (1 matvec)",
+               "iteration_ms": ms_it, "dtype": "f64", "plastic_fraction": plastic, "mesh_build_s": mesh_s, "calls": calls,
+               "roofline": {**_hbm(it_bytes, ms_it), "algorithmic_bytes_per_iteration": it_bytes, "bytes_per_qp": it_bytes / npts,
+                            "note": "sum of the three calls' algorithmic bytes over the iteration's time; each call has its own roofline under `calls`"},
+               "pcie_bytes_per_iteration": 0}
+        if cpu:
+            out["cpu_baseline"] = _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm)
+        return out
+    finally:
+        if st is not None:
+            st.close()
+        dm.close()
+
+
+def _view(torch, ptr, n, dev):
+    """float64 tensor over n doubles of library-owned device memory (no copy)."""
+    from dolfinx_external_operator_amd._lib import _CudaArrayView
+
+    return torch.as_tensor(_CudaArrayView(None, int(ptr), int(n), "<f8"), device=dev)
+
+
+def _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm, cells=40_000):
+    """The same three steps with the checkers on the first `cells` cells: NumPy operand oracle -> C return map (OpenMP) ->
+    NumPy adjoint oracle (internal force) and tangent action. ~10-30 s of CPU work."""
+    from oracle import load_oracle
+    from oracle.operand_oracle import EPS_MANDEL, eval_operand, operand_adjoint, tangent_apply
+
+    o = load_oracle()
+    nc = min(cells, m.num_cells)
+    sel = np.arange(nc)
+    nq = m.nq
+    dofmap, geom = m.dofmap[:nc], m.geom_dofmap[:nc]
+    s_h = sig0[: nc * nq * d].cpu().numpy().reshape(nc * nq, d)
+    p_h = p0[: nc * nq].cpu().numpy()
+    v_h = v.cpu().numpy()
+    nn = m.node_x.shape[0]
+    nt = min(32, _avail())
+    t0 = time.perf_counter()
+    deps = eval_operand(EPS_MANDEL, bs, u_h, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, sel)
+    t1 = time.perf_counter()
+    C, s, dp = o.von_mises(deps.reshape(-1, d), s_h, p_h, E=prm.E, nu=prm.nu, sigma_0=prm.sigma_0, H=prm.H, nthreads=nt)
+    t2 = time.perf_counter()
+    operand_adjoint(EPS_MANDEL, bs, s.reshape(nc, nq, d), m.weights, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, nn, sel)
+    t3 = time.perf_counter()
+    tangent_apply(C, v_h, m.weights, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, nn)
+    t4 = time.perf_counter()
+    n = nc * nq
+    return {"value": n / (t4 - t0), "unit": "qp/s per Newton iteration (1 matvec)", "cores": nt, "kind": "port",
+            "seconds": {"operand": t1 - t0, "return_map": t2 - t1, "internal_force": t3 - t2, "tangent_apply": t4 - t3},
+            "sample": f"first {nc} cells ({n} points) of the same mesh: oracle/operand_oracle.py (NumPy einsum, BLAS threads as configured) for "
+                      f"the operand, internal force and tangent action, oracle/dxo_oracle.c with {nt} OpenMP threads for the return map"}
+
+
+def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
+    """dxo_assign on a continuous (CG) dofmap: the Q2 hexahedral dofmap of the device_loop mesh, one scalar value per (cell, local
+    node) scattered with NumPy's last-writer-wins rule (external_operator.py:286-287 with get_unrolled_dofmap :18-26).
+    Algorithmic bytes: flat_dofs (int32) + values read once, coefficient written once."""
+    from dolfinx_external_operator_amd import AssignDesc
+    from tools.synthetic import structured_mesh
+
+    dev = torch.device("cuda", ctx.device)
+    m = structured_mesh("hexahedron", (cells_per_side,) * 3, 2)
+    nc, npt = m.dofmap.shape
+    size = m.node_x.shape[0]
+    dofs = torch.from_numpy(np.ascontiguousarray(m.dofmap.reshape(-1))).to(dev)
+    vals = torch.randn(nc * npt, dtype=torch.float64, device=dev)
+    coeff = torch.zeros(size, dtype=torch.float64, device=dev)
+    desc = AssignDesc(nc, npt, 1, 0, npt, 1, 0)
+    saved = ctx.get_option("assign_validate")
+    res = {}
+    try:
+        for validate in (1, 0):
+            ctx.set_option("assign_validate", validate)
+            ms, _ = _time(torch, stream, lambda: ctx.assign(desc, dofs.data_ptr(), vals.data_ptr(), coeff.data_ptr(), size), launches, warm=2)
+            res[validate] = ms
+    finally:
+        ctx.set_option("assign_validate", saved)
+    # NumPy's answer on a sample of dofs: the last (cell, node) entry that targets the dof
+    h_d = m.dofmap.reshape(-1)
+    probe = np.random.Generator(np.random.PCG64(5)).integers(0, size, 64)
+    last = {int(k): int(np.flatnonzero(h_d == k)[-1]) for k in probe[:8]}
+    got = coeff.cpu().numpy()
+    vh = vals.cpu().numpy()
+    ok = all(got[k] == vh[e] for k, e in last.items())
+    by = dofs.numel() * 4 + vals.numel() * 8 + size * 8
+    ms = res[0]
+    return {"workload": f"dxo_assign: CG (Q2 hexahedra, {cells_per_side}^3 cells) dofmap scatter of {nc * npt} values into {size} dofs, "
+                        "NumPy last-writer-wins order, fp64", "entries": nc * npt, "dofs": size, "value": nc * npt / ms * 1e3, "unit": "entries/s",
+            "ms_per_call": ms, "ms_per_call_with_range_check_sync": res[1], "last_writer_spot_check": "ok" if ok else "MISMATCH",
+            "kernels": ["hipMemsetAsync(owner)", "assign_owner", "assign_store"], "dtype": "f64 values / int32 dofs",
+            "roofline": {**_hbm(by, ms), "algorithmic_bytes_per_call": by,
+                         "note": "implementation traffic is higher by construction: an 8-byte owner word per dof is cleared, updated with atomicMax "
+                                 "(one per entry) and read back per entry so that the result is the reference's sequential one, not a race"}}

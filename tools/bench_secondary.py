@@ -14,6 +14,14 @@ own `roofline` (and, where a CPU restatement exists, its own bounded `cpu_baseli
                       (demo_plasticity_von_mises.py:230,295)
   vm_field_q2         operand eps(Du) formed in registers in front of the von Mises return map (dxo_von_mises_field),
                       Q2 hexahedra, 8 points per cell, 10^7 points
+  von_mises_cfg2_1e6  BASELINE config 2 at its stated size: 50^3 hexahedra x 8 points = 10^6 points, d = 6 (448 MB per launch, of
+                      which the inputs stay in the 256 MB Infinity Cache between launches: not an HBM measurement, see `note`)
+  device_loop_q2hex / device_loop_p2tri / assign_cg
+                      one device-resident Newton iteration (fused operand + return map with resident state -> internal force ->
+                      matrix-free tangent matvec -> state commit) and the dofmap assigner: tools/bench_device_loop.py
+
+`roofline.traffic` of every leg is measured by this run: two child runs of this file under `rocprofv3 --pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` (`measure_secondary_traffic`, same protocol as bench.py's headline) that launch every leg's kernels twice.
 """
 from __future__ import annotations
 
@@ -31,11 +39,16 @@ FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, MI355X_MICROARCH
 BF16_MFMA_PEAK_TF = 2516.6  # v_mfma_f32_32x32x16_bf16 dense peak (16 x the fp32-input rate), MI355X_MICROARCH.md "~2.5 PF dense"
 
 
+QUICK = False   # counter child runs (rocprofv3 --pmc): one warm-up and two launches per kernel, no probing, no CPU legs
+
+
 def _time(torch, stream, fn, launches, warm=2, warm_s=0.15):
     """Median and mean of per-launch HIP-event times (ms) over `launches` back-to-back launches. The warm-up lasts at least
     `warm_s` seconds of back-to-back launches: every leg starts after seconds of host-side set-up (mesh construction, input
     generation, a CPU baseline) during which the GPU idles and clocks down — the first ~20 launches after such a pause run
     10-15 % slow (measured on vm_field: 0.97 ms in the first ten launches, 0.85 ms from then on)."""
+    if QUICK:
+        launches, warm, warm_s = 2, 1, 0.0
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -56,7 +69,8 @@ def _time(torch, stream, fn, launches, warm=2, warm_s=0.15):
 
 def _hbm(bytes_per_launch, ms):
     a = bytes_per_launch / ms / 1e6
-    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None}
+    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
 
 
 def _avail():
@@ -199,7 +213,7 @@ def von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu):
     out = {"workload": f"von Mises radial return + consistent tangent in the reference demo's layout: Mandel d=4, 3 points per P2 triangle, "
                        f"{n // 3} cells = {n} points, fp64", "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms,
            "dtype": "f64", "plastic_fraction": float((dp > 0).double().mean()),
-           "roofline": {**_hbm(240 * n, ms), "bytes_per_qp": 240, "kernel": "vm_tile<4>",
+           "roofline": {**_hbm(240 * n, ms), "bytes_per_qp": 240, "kernel": "vm_tile<4>", "algorithmic_bytes_per_launch": 240 * n,
                         "output_memory": C.dxo_block.info["mode"] + " / " + C.dxo_block.info["chosen_kind"]}}
     if cpu:
         from oracle import load_oracle
@@ -221,7 +235,7 @@ def von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu):
     return out
 
 
-def vm_field_q2(torch, ctx, stream, cells_per_side, prm):
+def vm_field_q2(torch, ctx, stream, cells_per_side, prm, cpu=False):
     from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh
     from tools.synthetic import structured_mesh
 
@@ -234,7 +248,9 @@ def vm_field_q2(torch, ctx, stream, cells_per_side, prm):
         bs, d = 3, 6
         npts = m.num_cells * m.nq
         rng = np.random.Generator(np.random.PCG64(0))
-        u_h = rng.normal(0.0, 3e-3, size=m.node_x.shape[0] * bs)
+        from tools.bench_device_loop import field_dofs
+
+        u_h = field_dofs(m, rng)      # strains of the size SURVEY.md 8(d) prescribes: a mix of elastic and plastic points
         u = torch.from_numpy(u_h).to(dev)
         g = torch.Generator(device=dev)
         g.manual_seed(1)
@@ -250,13 +266,33 @@ def vm_field_q2(torch, ctx, stream, cells_per_side, prm):
             bytes_per_launch=float(in_bytes + out_bytes))
         ms, _ = _time(torch, stream, lambda: dm.von_mises(prm, u.data_ptr(), sig.data_ptr(), pp.data_ptr(), C.data_ptr(), s.data_ptr(),
                                                           dp.data_ptr(), mem=MEM_DEVICE), 10, warm=3)
-        return {"workload": f"operand eps(Du) fused in front of the von Mises return map (dxo_von_mises_field): Q2 hexahedra, "
-                            f"{m.num_cells} cells x 8 points = {npts} points, Mandel d=6, fp64", "points": npts, "value": npts / ms * 1e3,
-                "unit": "qp/s", "ms_per_launch": ms, "dtype": "f64", "plastic_fraction": float((dp > 0).double().mean()),
-                "mesh_build_s": mesh_s,
-                "roofline": {**_hbm(in_bytes + out_bytes, ms), "bytes_per_qp": (in_bytes + out_bytes) / npts, "kernel": "vm_field<3>",
-                             "output_memory": {k: C.dxo_block.info[k] for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")},
-                             "note": "algorithmic bytes = dof vector, coordinates and both dofmaps read once + (sigma_n, p) + the three outputs"}}
+        out = {"workload": f"operand eps(Du) fused in front of the von Mises return map (dxo_von_mises_field): Q2 hexahedra, "
+                           f"{m.num_cells} cells x 8 points = {npts} points, Mandel d=6, fp64", "points": npts, "value": npts / ms * 1e3,
+               "unit": "qp/s", "ms_per_launch": ms, "dtype": "f64", "plastic_fraction": float((dp > 0).double().mean()),
+               "mesh_build_s": mesh_s,
+               "roofline": {**_hbm(in_bytes + out_bytes, ms), "bytes_per_qp": (in_bytes + out_bytes) / npts, "kernel": "vm_field<3>",
+                            "algorithmic_bytes_per_launch": in_bytes + out_bytes,
+                            "output_memory": {k: C.dxo_block.info[k] for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")},
+                            "note": "algorithmic bytes = dof vector, coordinates and both dofmaps read once + (sigma_n, p) + the three outputs"}}
+        if cpu:     # the demo's pair on the host: operand oracle (NumPy) then the C return map (OpenMP), first 40 000 cells
+            from oracle import load_oracle
+            from oracle.operand_oracle import EPS_MANDEL, eval_operand
+
+            o = load_oracle()
+            nc = min(40_000, m.num_cells)
+            sh = sig[: nc * 8 * d].cpu().numpy().reshape(-1, d)
+            ph = pp[: nc * 8].cpu().numpy()
+            nt = min(32, _avail())
+            t0 = time.perf_counter()
+            e = eval_operand(EPS_MANDEL, bs, u_h, m.dofmap[:nc], m.geom_dofmap[:nc], m.x, m.phi, m.dphi, m.dpsi, np.arange(nc))
+            t1 = time.perf_counter()
+            o.von_mises(e.reshape(-1, d), sh, ph, nthreads=nt)
+            t2 = time.perf_counter()
+            out["cpu_baseline"] = {"value": nc * 8 / (t2 - t0), "unit": "qp/s", "cores": nt, "kind": "port",
+                                   "seconds": {"operand": t1 - t0, "return_map": t2 - t1},
+                                   "sample": f"first {nc} cells ({nc * 8} points) of the same mesh: oracle/operand_oracle.py (NumPy einsum, BLAS threads "
+                                             f"as configured) + oracle/dxo_oracle.c with {nt} OpenMP threads"}
+        return out
     finally:
         dm.close()
 
@@ -274,7 +310,7 @@ def heat_cfg1(torch, ctx, stream, cpu):
     fns = [ext(d) for d in ((0, 0), (1, 0), (0, 1))]
     for f in fns:
         f(T, sigma)
-    reps = 200
+    reps = 2 if QUICK else 200
     t0 = time.perf_counter()
     for _ in range(reps):
         for f in fns:
@@ -304,7 +340,7 @@ def heat_cfg1(torch, ctx, stream, cpu):
     q, dT, ds = ctx.output_tensors_probed((n * 2, n * 2, n * 4), lambda ptrs, shape: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, Td.data_ptr(), sg.data_ptr(),
                                                                                                   ptrs[0], ptrs[1], ptrs[2]), bytes_per_launch=88.0 * n)
     ms, _ = _time(torch, stream, lambda: ctx.heat(1.0, 1.0, 2, n, MEM_DEVICE, Td.data_ptr(), sg.data_ptr(), q.data_ptr(), dT.data_ptr(), ds.data_ptr()), 10)
-    out["roofline"] = {**_hbm(88 * n, ms), "bytes_per_qp": 88, "kernel": "heat_g2", "points": n, "ms_per_launch": ms,
+    out["roofline"] = {**_hbm(88 * n, ms), "bytes_per_qp": 88, "kernel": "heat_g2", "points": n, "ms_per_launch": ms, "algorithmic_bytes_per_launch": 88 * n,
                        "output_memory": {k: q.dxo_block.info.get(k) for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")},
                        "note": "fused q, dq/dT, dq/dsigma at 5*10^7 points (config 1 itself is 540 KB: cache-resident, latency-bound)"}
     if cpu:   # the reference's statements (part2.py:215-261) in NumPy on this host, same arrays
@@ -330,7 +366,7 @@ def heat_cfg1(torch, ctx, stream, cpu):
     return out
 
 
-def isihara_leg(torch, ctx, stream, n):
+def isihara_leg(torch, ctx, stream, n, cpu=False):
     from dolfinx_external_operator_amd import MEM_DEVICE, IsiharaParams
 
     dev = torch.device("cuda", ctx.device)
@@ -346,20 +382,88 @@ def isihara_leg(torch, ctx, stream, n):
                                       bytes_per_launch=192.0 * n)
     ms, _ = _time(torch, stream, lambda: ctx.isihara(prm, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr()), 10, warm=3)
     info = dP.dxo_block.info
-    return {"workload": f"analytic Isihara stress + tangent (the model the network of config 5 was trained on), {n} points, fp64",
-            "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms, "dtype": "f64",
-            "roofline": {**_hbm(192 * n, ms), "bytes_per_qp": 192, "kernel": "isihara_tile",
-                         "output_memory": {k: info.get(k) for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")}}}
+    out = {"workload": f"analytic Isihara stress + tangent (the model the network of config 5 was trained on), {n} points, fp64",
+           "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms, "dtype": "f64",
+           "roofline": {**_hbm(192 * n, ms), "bytes_per_qp": 192, "kernel": "isihara_tile", "algorithmic_bytes_per_launch": 192 * n,
+                        "output_memory": {k: info.get(k) for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")}}}
+    if cpu:
+        from oracle.icnn_oracle import isihara_stress_tangent
+
+        m = 1_000_000
+        Fh = F[:m].cpu().numpy()
+        isihara_stress_tangent(Fh[:10_000])
+        t0 = time.perf_counter()
+        isihara_stress_tangent(Fh)
+        out["cpu_baseline"] = {"value": m / (time.perf_counter() - t0), "unit": "qp/s", "cores": 1, "kind": "port",
+                               "sample": f"{m} points of the same batch, oracle/icnn_oracle.py::isihara_stress_tangent (vectorised NumPy "
+                                         "statements of the analytic model, no OpenMP: elementwise NumPy runs on one core)"}
+    return out
 
 
-def secondary_block(torch, ctx, stream, prm, n=10_000_000, cpu=True, field_cells=108, legs=None):
-    legs = legs or ("heat_cfg1", "mohr_coulomb_cfg4", "icnn_cfg5", "isihara", "von_mises_d4_nq3", "vm_field_q2")
+def von_mises_cfg2_1e6(torch, ctx, stream, prm, cpu):
+    """BASELINE config 2 at the size BASELINE.json states: 50^3 hexahedra x 8 points = 10^6 points, d = 6."""
+    from dolfinx_external_operator_amd import MEM_DEVICE
+
+    dev = torch.device("cuda", ctx.device)
+    d, n = 6, 1_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    deps = torch.empty(n, d, dtype=torch.float64, device=dev).normal_(0.0, 3e-3, generator=g)
+    deps[:, 3:] *= 2.0 ** 0.5
+    sigma_n = torch.empty(n, d, dtype=torch.float64, device=dev).normal_(0.0, 100.0, generator=g)
+    p = torch.empty(n, dtype=torch.float64, device=dev).normal_(0.0, 1e-3, generator=g).abs_()
+    C, s, dp = ctx.vm_output_tensors(n, d)
+    ms, _ = _time(torch, stream, lambda: ctx.von_mises(prm, d, n, MEM_DEVICE, deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(),
+                                                       C.data_ptr(), s.data_ptr(), dp.data_ptr()), 20, warm=3)
+    out = {"workload": "von Mises radial return + consistent tangent, 3-D hex mesh 50^3 cells x 8 points = 10^6 points, Mandel d=6, fp64 "
+                       "(BASELINE config 2 at its stated size)", "points": n, "value": n / ms * 1e3, "unit": "qp/s", "ms_per_launch": ms,
+           "dtype": "f64", "plastic_fraction": float((dp > 0).double().mean()),
+           "note": "448 MB per launch: the 104 MB of inputs (and part of the outputs) stay in the 256 MB Infinity Cache between back-to-back "
+                   "launches, so `achieved` is algorithmic bytes over time, NOT an HBM rate (the counter traffic below is what reaches the "
+                   "memory side); the HBM-roofline figure of this kernel is the headline's, at 10^7 points",
+           "roofline": {**_hbm(448 * n, ms), "bytes_per_qp": 448, "kernel": "vm_tile<6>", "algorithmic_bytes_per_launch": 448 * n,
+                        "output_memory": C.dxo_block.info["mode"] + " / " + C.dxo_block.info["chosen_kind"]}}
+    if cpu:
+        from oracle import load_oracle
+
+        o = load_oracle()
+        h = [t.cpu().numpy() for t in (deps, sigma_n, p)]
+        outb = (np.zeros((n, d, d)), np.zeros((n, d)), np.zeros(n))
+        nt = min(32, _avail())
+        o.von_mises(*h, nthreads=nt, out=outb)
+        rates = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            o.von_mises(*h, nthreads=nt, out=outb)
+            rates.append(n / (time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        o.von_mises(*h, nthreads=1, out=outb)
+        one = n / (time.perf_counter() - t0)
+        out["cpu_baseline"] = {"value": statistics.median(rates), "unit": "qp/s", "cores": nt, "kind": "port", "value_1core": one,
+                               "sample": "the whole 10^6-point batch x 5 passes (1 pass for the 1-thread figure), oracle/dxo_oracle.c, OpenMP"}
+    del C, s, dp
+    return out
+
+
+ALL_LEGS = ("heat_cfg1", "mohr_coulomb_cfg4", "icnn_cfg5", "isihara", "von_mises_d4_nq3", "von_mises_cfg2_1e6", "vm_field_q2",
+            "device_loop_q2hex", "device_loop_p2tri", "assign_cg")
+P2TRI_SIDE = 1291     # 1291^2 boxes x 2 triangles x 3 points = 10^7 points (the reference demos' element, demo_plasticity_von_mises.py:230,245,295)
+
+
+def secondary_block(torch, ctx, stream, prm, n=10_000_000, cpu=True, field_cells=108, legs=None, traffic=True):
+    from tools import bench_device_loop as dl
+
+    legs = legs or ALL_LEGS
     fns = {"heat_cfg1": lambda: heat_cfg1(torch, ctx, stream, cpu),
-           "isihara": lambda: isihara_leg(torch, ctx, stream, 2 * n),
+           "isihara": lambda: isihara_leg(torch, ctx, stream, 2 * n, cpu),
            "mohr_coulomb_cfg4": lambda: mohr_coulomb_cfg4(torch, ctx, stream, n, cpu),
            "icnn_cfg5": lambda: icnn_cfg5(torch, ctx, stream, n, cpu),
            "von_mises_d4_nq3": lambda: von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu),
-           "vm_field_q2": lambda: vm_field_q2(torch, ctx, stream, field_cells, prm)}
+           "von_mises_cfg2_1e6": lambda: von_mises_cfg2_1e6(torch, ctx, stream, prm, cpu),
+           "vm_field_q2": lambda: vm_field_q2(torch, ctx, stream, field_cells, prm, cpu),
+           "device_loop_q2hex": lambda: dl.device_loop(torch, ctx, stream, prm, "hexahedron", (field_cells,) * 3, cpu),
+           "device_loop_p2tri": lambda: dl.device_loop(torch, ctx, stream, prm, "triangle", (P2TRI_SIDE if field_cells >= 100 else 8 * field_cells,) * 2, cpu),
+           "assign_cg": lambda: dl.assign_leg(torch, ctx, stream, field_cells)}
     out = {}
     for name in legs:
         t0 = time.perf_counter()
@@ -369,4 +473,174 @@ def secondary_block(torch, ctx, stream, prm, n=10_000_000, cpu=True, field_cells
             out[name] = {"error": repr(exc)}
         out[name]["leg_wall_s"] = time.perf_counter() - t0
         torch.cuda.empty_cache()
+    if traffic and not QUICK:
+        t0 = time.perf_counter()
+        try:
+            detail = measure_secondary_traffic(legs, n, field_cells)
+            apply_traffic(out, detail)
+            out["traffic_method"] = detail.get("method")
+            if detail.get("error"):
+                out["traffic_error"] = detail["error"]
+        except Exception as exc:   # noqa: BLE001
+            out["traffic_error"] = repr(exc)
+        out["traffic_wall_s"] = time.perf_counter() - t0
     return out
+
+
+# ------------------------------------------------------------------------------------------------ live HBM counters of the legs
+# Which dispatches belong to which roofline: (leg, path to the roofline dict inside the leg's record) -> (substring of the OWNER
+# kernel's name, which of the owner's dispatch runs). `node_sum` / `assign_store` dispatches are added to the owner dispatched just
+# before them (the call that launched them). vm_commit has the same name and grid in both device-loop legs: the legs run one after
+# the other, so the first half of its dispatches is the hexahedral leg's and the second half the triangle leg's.
+TRAFFIC_KEYS = {
+    ("heat_cfg1", ("roofline",)): ("heat_g2(", "all"),
+    ("isihara", ("roofline",)): ("isihara_tile<", "all"),
+    ("mohr_coulomb_cfg4", ("roofline", "hbm")): ("mc_fused<", "all"),
+    ("icnn_cfg5", ("roofline", "hbm")): ("icnn_mfma_bf16x3<", "all"),
+    ("von_mises_d4_nq3", ("roofline",)): ("vm_tile<4,", "all"),
+    ("von_mises_cfg2_1e6", ("roofline",)): ("vm_tile<6,", "all"),
+    ("vm_field_q2", ("roofline",)): ("vm_field<3,", "all"),
+    ("device_loop_q2hex", ("calls", "von_mises_field_state", "roofline")): ("vm_field<3,", "all"),
+    ("device_loop_q2hex", ("calls", "internal_force", "roofline")): ("adjoint_cell_eps<3,", "all"),
+    ("device_loop_q2hex", ("calls", "tangent_apply", "roofline")): ("tangent_apply<3>", "all"),
+    ("device_loop_q2hex", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<3>", "all"),
+    ("device_loop_q2hex", ("calls", "state_commit", "roofline")): ("vm_commit(", "first_half"),
+    ("device_loop_p2tri", ("calls", "von_mises_field_state", "roofline")): ("vm_field<2,", "all"),
+    ("device_loop_p2tri", ("calls", "internal_force", "roofline")): ("adjoint_cell_eps<2,", "all"),
+    ("device_loop_p2tri", ("calls", "tangent_apply", "roofline")): ("tangent_apply<2>", "all"),
+    ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2>", "all"),
+    ("device_loop_p2tri", ("calls", "state_commit", "roofline")): ("vm_commit(", "second_half"),
+    ("assign_cg", ("roofline",)): ("assign_owner(", "all"),
+}
+FOLLOWERS = ("node_sum<", "assign_store(")
+
+
+def parse_counter_csv(files, counter):
+    """-> {owner substring: [[grid, bytes] per call, in dispatch order]}, bytes = (the owner's counter + its followers') x 1024."""
+    import csv
+
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") == counter:
+                    rows.append((int(r.get("Dispatch_Id", 0)), r.get("Kernel_Name", ""), int(r.get("Grid_Size", 0)), float(r["Counter_Value"])))
+    rows.sort()
+    owners = sorted({k for k, _ in TRAFFIC_KEYS.values()})
+    res, cur = {}, None
+    for _did, name, grid, val in rows:
+        key = next((k for k in owners if k in name), None)
+        if key is not None:
+            cur = [grid, val * 1024.0]
+            res.setdefault(key, []).append(cur)
+        elif cur is not None and any(f in name for f in FOLLOWERS):
+            cur[1] += val * 1024.0
+    return res
+
+
+def _pick(calls, which="all"):
+    """Mean bytes of the last two calls at the largest grid within the selected run of dispatches."""
+    if not calls:
+        return None
+    if which == "first_half":
+        calls = calls[: max(1, len(calls) // 2)]
+    elif which == "second_half":
+        calls = calls[len(calls) // 2:]
+    big = max(g for g, _ in calls)
+    sel = [b for g, b in calls if g == big][-2:]
+    return sum(sel) / len(sel)
+
+
+def measure_secondary_traffic(legs, n, field_cells, timeout_s=420):
+    """Two child runs of this file (`--child`) under rocprofv3, counters only (separate FETCH_SIZE / WRITE_SIZE passes as
+    MI355X_MICROARCH.md prescribes), each launching every leg's kernels at the leg's size with plain allocations.
+    bytes = counter x 1024; FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B) —
+    for the gather-heavy kernels (dofmap-indexed 8-byte loads) that factor is an upper bound, see `fetch_note`."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not pathlib.Path(prof).exists():
+        return {"error": "rocprofv3 not found"}
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(prefix="dxo_sec_pmc_", dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "s", "--", sys.executable, str(pathlib.Path(__file__).resolve()),
+                   "--child", "--legs", ",".join(legs), "--n", str(n), "--field-cells", str(field_cells)]
+            try:
+                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, cwd=tmp)
+            except (subprocess.TimeoutExpired, OSError) as exc:
+                return {"error": f"{counter} pass: {exc!r}"}
+            files = list(pathlib.Path(tmp).rglob("*counter_collection.csv"))
+            if not files:
+                return {"error": f"{counter} pass: no counter file (rc {res.returncode}): {res.stderr.decode(errors='replace')[-300:]}"}
+            got[counter] = parse_counter_csv(files, counter)
+    return {"fetch": got["FETCH_SIZE"], "write": got["WRITE_SIZE"],
+            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of tools/bench_secondary.py --child made by this run (two "
+                      "launches of every leg's kernels, plain allocations); bytes = counter*1024, FETCH_SIZE x2 (gfx950 under-count of wide "
+                      "coalesced reads, MI355X_MICROARCH.md); node_sum / assign_store dispatches are added to the call that launched them",
+            "fetch_note": "the x2 is calibrated for 16-byte-per-lane streaming reads; for kernels whose reads are dofmap-indexed 8-byte gathers "
+                          "(adjoint_cell_eps, tangent_apply, node_sum, assign_*) it is an upper bound"}
+
+
+def apply_traffic(out, detail):
+    if "fetch" not in detail:
+        return
+    for (leg, path), (key, which) in TRAFFIC_KEYS.items():
+        rec = out.get(leg)
+        if not isinstance(rec, dict) or "error" in rec:
+            continue
+        try:
+            for k in path:
+                rec = rec[k]
+        except (KeyError, TypeError):
+            continue
+        fb, wb = _pick(detail["fetch"].get(key), which), _pick(detail["write"].get(key), which)
+        if fb is None or wb is None:
+            continue
+        total = 2.0 * fb + wb
+        rec["traffic"] = total
+        rec["traffic_detail"] = {"fetch_bytes_x2": 2.0 * fb, "write_bytes": wb}
+        alg = rec.get("algorithmic_bytes_per_launch") or rec.get("algorithmic_bytes_per_call")
+        if alg:
+            rec["traffic_over_algorithmic"] = total / alg
+        if path[-1] == "hbm":      # compute-bound legs: the HBM figures live in roofline.hbm; `traffic` is mirrored one level up
+            out[leg]["roofline"]["traffic"] = total
+
+
+def _child_main():
+    """`python tools/bench_secondary.py --child --legs a,b,c --n N --field-cells C`: the legs' kernels, two launches each, for a
+    counter pass. Prints one JSON line with the legs that ran."""
+    import argparse
+    import json
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--child", action="store_true")
+    ap.add_argument("--legs", default=",".join(ALL_LEGS))
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--field-cells", type=int, default=108)
+    a = ap.parse_args()
+    import torch
+
+    from dolfinx_external_operator_amd import Context, VmParams
+
+    global QUICK
+    QUICK = True
+    ctx = Context(0)
+    ctx.set_option("placement_mode", 0)        # plain allocations: the counters do not depend on where the outputs land
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    E = 70e3
+    prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+    out = secondary_block(torch, ctx, stream, prm, n=a.n, cpu=False, field_cells=a.field_cells, legs=tuple(a.legs.split(",")), traffic=False)
+    torch.cuda.synchronize()
+    print(json.dumps({k: ("error" in v and v["error"]) or "ok" for k, v in out.items() if isinstance(v, dict)}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    _child_main()
