@@ -20,7 +20,8 @@ the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, of whic
 in the 256 MB Infinity Cache between steps; scripts/bench_extra.py reports it). Scaling is weak: with N > 1 every
 rank owns its own cell block of 1.25*10^7 points (BASELINE config 3: 10^8 points over 8 GPUs).
 
-Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (contract: task statement).
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (contract: task statement). Under torch.distributed (N > 1)
+a second, final line repeats it with `gather_check` (the verdict of libdxo's own RCCL path, run after the result) filled in.
 """
 from __future__ import annotations
 
@@ -309,11 +310,12 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     mg.close()
     done.set()
     ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13 and identical
-    log(json.dumps({"library_gather_check": "ok" if ok else "MISMATCH", "rank": rank, "rccl_ranks_in_libdxo": world, "points_per_rank": n,
-                    "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
-                    "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C,
-                    "compact_replicas_bit_identical": identical}))
-    return ok
+    rec = {"library_gather_check": "ok" if ok else "MISMATCH", "rank": rank, "rccl_ranks_in_libdxo": world, "points_per_rank": n,
+           "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
+           "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C,
+           "compact_replicas_bit_identical": identical}
+    log(json.dumps(rec))
+    return rec
 
 
 def launch_ranks(n_gpus: int, argv: list[str]) -> int:
@@ -430,7 +432,8 @@ def main():
     from dolfinx_external_operator_amd import MEM_DEVICE, Context, VmParams
     from dolfinx_external_operator_amd._build import build_library
     from dolfinx_external_operator_amd.sharding import (WAVE_TILE, all_gather_in_place, gather_von_mises_compact,
-                                                        gather_von_mises_compact_direct, gather_von_mises_compact_pipelined)
+                                                        gather_von_mises_compact_direct, gather_von_mises_compact_pipelined,
+                                                        in_place_status)
 
     if rank == 0:
         build_library()
@@ -511,26 +514,29 @@ def main():
 
     ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
 
-    # the same kernel through the drop-in factory with its DEFAULTS and CUDA-tensor operands: make_von_mises(...)((1,))(deps)
-    # keeps its outputs in a persistent arena block of its own (device_outputs="arena"), so this is what a device-resident
-    # caller gets without opting into anything
-    factory_GBps = None
+    # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
+    # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
+    # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
+    factory_GBps, factory_fresh_GBps = None, None
     if rank == 0 and not gather_on and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
         from dolfinx_external_operator_amd import make_von_mises
 
-        ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx)
-        f = ext((1,))
         deps3 = deps.view(n // args.nq, args.nq, d)
-        f(deps3)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(12):
+        rates = []
+        for kw in ({"device_outputs": "arena"}, {}):
+            ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
+            f = ext((1,))
             f(deps3)
-        e1.record(stream)
-        torch.cuda.synchronize(device)
-        factory_GBps = BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9
-        del ext, f
-        torch.cuda.empty_cache()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(12):
+                f(deps3)
+            e1.record(stream)
+            torch.cuda.synchronize(device)
+            rates.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
+            del ext, f
+            torch.cuda.empty_cache()
+        factory_GBps, factory_fresh_GBps = rates
 
     def expand(s_view, dp_view, C_view, npts):
         ctx.vm_expand_tangent(prm, d, npts, MEM_DEVICE, s_view.data_ptr(), dp_view.data_ptr(), C_view.data_ptr())
@@ -603,6 +609,7 @@ def main():
     bytes_per_launch = BYTES_PER_QP[d] * n
     MODES = ("compact", "compact_pipelined", "compact_direct", "full")
     emitted = threading.Lock()
+    last_result = {}
 
     def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True, degraded=False, mode=None):
         """Rank 0: build the result line and write it to the real stdout, once."""
@@ -662,6 +669,13 @@ def main():
                                                             "(every block on its own xGMI link at once) instead of the library's all-gather"}
                                          if gather_on else None),
                 "rccl_ranks": world if dist_on else 0,
+                "collective_backend": (dist.get_backend() if dist_on else None),
+                # what sharding.all_gather_in_place decided at its first call, on all ranks together (RCCL in-place form on the
+                # aliasing view, or the cloned send buffer every rank falls back to when any rank's in-place call raised)
+                "gather_in_place": (in_place_status() if gather_on else None),
+                "mode_status": ({m: ("timed" if (m == mode or m in other_) else "failed or skipped: see stderr") for m in MODES} if gather_on else None),
+                "placement_candidates_requested": args.placement, "placement_candidates_probed": placement.get("candidates"),
+                "placement_block_bytes": N_full * per_pt * 8,
                 "kernel": "vm_tile" if args.variant else "vm_point",
                 "arch": info["arch"], "compute_units": info["compute_units"],
             },
@@ -676,7 +690,8 @@ def main():
                 "output_memory": "dxo_output_alloc (library output arena, " + placement["mode"] + ")",
                 "placement": placement,
                 "achieved_plain_hipMalloc": plain_GBps,
-                "achieved_factory_default_device_call": factory_GBps,
+                "achieved_factory_device_call_arena_outputs": factory_GBps,
+                "achieved_factory_default_device_call": factory_fresh_GBps,
                 "stream_probe_GBps": probe_GBps,
             },
             "kernel_only_value": total_points / (kernel_ms_ * 1e-3),
@@ -690,7 +705,19 @@ def main():
             from tools.bench_secondary import secondary_block
 
             result["secondary"] = secondary_block(torch, ctx, stream, prm, n=args.secondary_points, cpu=not args.no_cpu)
+        if dist_on:
+            result["gather_check"] = ({"status": "skipped", "why": "dry_collective: libdxo's own RCCL path needs one GPU per rank"} if args.dry_collective
+                                      else {"status": "skipped", "why": "--no-library-gather"} if args.no_library_gather
+                                      else {"status": "pending", "why": "runs after this line; a second, final line repeats this one with the verdict"})
+        last_result.update(result)
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+    def emit_gather_check(rec):
+        """Rank 0: the second, final line = the first with the verdict of the library's own RCCL path."""
+        if rank != 0 or not last_result:
+            return
+        last_result["gather_check"] = rec
+        os.write(real_stdout, (json.dumps(last_result) + "\n").encode())
 
     # the other gather modes, same protocol, reported beside the headline (never as `value`). They are comparison figures:
     # if one of them — or the reduction of the times behind them — does not come back (a collective that hangs), rank 0
@@ -803,9 +830,11 @@ def main():
         try:    # evidence for dxo_mgpu_* with more than one rank; stderr only, after the result line
             C_tang = sigma = dp = C_full = sigma_full = dp_full = None
             torch.cuda.empty_cache()
-            library_gather_check(torch, dist, ctx, prm, d, rank, world, device)
+            rec = library_gather_check(torch, dist, ctx, prm, d, rank, world, device)
+            emit_gather_check({"status": rec["library_gather_check"], **{k: v for k, v in rec.items() if k not in ("library_gather_check", "rank")}})
         except Exception as exc:   # noqa: BLE001
             log(f"bench rank {rank}: library_gather_check failed: {exc!r}")
+            emit_gather_check({"status": "error", "why": repr(exc)})
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -306,8 +306,13 @@ class _PinnedPool:
         # lock-free on purpose (see the class docstring). After close() nobody drains any more: free right here.
         if self.closed:
             self.lib.dxo_host_free(None, _P(addr))
-        else:
-            self.returned.append((addr, cap))
+            return
+        self.returned.append((addr, cap))
+        if self.closed:      # close() finished both of its drains between the test above and the append: nobody drains again
+            doomed: list = []
+            self._drain(doomed)          # popleft is atomic: a block is freed by exactly one of the racing drains
+            for a in doomed:
+                self.lib.dxo_host_free(None, _P(a))
 
     def close(self) -> None:
         doomed: list = []
@@ -833,6 +838,7 @@ class MultiGpu:
     def __init__(self, devices=None, n_dev: int | None = None, _handle=None, _ctx=None):
         self.lib = load_library()
         self._keep_ctx = _ctx
+        self._borrowed: dict[int, Context] = {}
         if _handle is not None:
             self._h = _handle
             return
@@ -908,8 +914,15 @@ class MultiGpu:
 
     def context(self, i: int = 0) -> Context:
         """The context of local device i as a (borrowed) Context: options, output arena, single-GPU entry points. Arena
-        blocks of a group's contexts are hipMalloc memory ("placement_vmm" = 0): they may become RCCL buffers."""
-        return Context.borrow(self.ctx_handle(i))
+        blocks of a group's contexts are hipMalloc memory ("placement_vmm" = 0): they may become RCCL buffers. The wrapper
+        knows the device its dxo_ctx lives on (option "device") and dies with the group: close() releases what it allocated
+        and clears its handle, so arena blocks / states made through it must be dropped before the group is closed."""
+        i = int(i)
+        c = self._borrowed.get(i)
+        if c is None or c._h is None:
+            c = Context.borrow(self.ctx_handle(i), device=self.ctx_option(i, "device"))
+            self._borrowed[i] = c
+        return c
 
     def ctx_option(self, i: int, key: str) -> int:
         v = C.c_int64()
@@ -971,6 +984,9 @@ class MultiGpu:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for c in getattr(self, "_borrowed", {}).values():     # before the dxo_ctx objects go: no wrapper keeps a dangling handle
+                c.close()
+            self._borrowed = {}
             self.lib.dxo_mgpu_destroy(self._h)
             self._h = None
 

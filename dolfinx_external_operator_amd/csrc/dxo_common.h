@@ -180,9 +180,12 @@ void dxo_host_parallel_for(dxo_ctx* ctx, int64_t n, int64_t grain, const std::fu
 // of one chunk overlap the kernel of another. Blocks until every output byte is on the host.
 // `n` counts units of `points_per_unit` quadrature points (1: points; nq: cells — bytes_pp is then per cell); the
 // chunk size option host_chunk_points stays in points.
+// `stream_once`: the kernel reads every input byte once and writes every output byte once with full-width stores — only then
+// may tiny batches run it directly on the device-mapped pinned staging block (option host_zero_copy_bytes); kernels that re-read
+// inputs or store partial lines (Mohr-Coulomb's list gather / stash, the network kernels) keep the DMA copies.
 int dxo_run_host_pipeline(dxo_ctx* ctx, int64_t n, const std::vector<dxo_span>& inputs,
                           const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
-                          int64_t points_per_unit = 1, dxo_chunk_post post = nullptr);
+                          int64_t points_per_unit = 1, dxo_chunk_post post = nullptr, bool stream_once = false);
 
 // Device-path bracket: optional event timing around a launch sequence.
 int dxo_device_begin(dxo_ctx* ctx, hipStream_t s);

@@ -179,6 +179,10 @@ int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
 int dxo_ctx_get_option(dxo_ctx* c, const char* key, int64_t* value) {
     if (!c || !key || !value) return DXO_E_NULL;
     DXO_LOCK(c);
+    if (!std::strcmp(key, "device")) {     // read-only: the HIP device ordinal this context was created on
+        *value = c->device;
+        return DXO_OK;
+    }
     int64_t* slot = option_slot(c, key);
     if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
     *value = *slot;
@@ -348,7 +352,7 @@ int dxo_grid_for_tiles(const dxo_ctx* c, int64_t n_tiles, int tiles_per_block) {
 
 int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& inputs,
                           const std::vector<dxo_span>& outputs, dxo_chunk_launch launch, void* user,
-                          int64_t points_per_unit, dxo_chunk_post post) {
+                          int64_t points_per_unit, dxo_chunk_post post, bool stream_once) {
     DXO_HIP(c, hipSetDevice(c->device));
     c->last = {0, 0, 0, 0};
     c->ev_pending = false;
@@ -395,7 +399,7 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
             // reads its inputs from it and writes its outputs into it over PCIe directly; what is left of a call is two host
             // memcpys, one launch and one stream wait (option "host_zero_copy_bytes", 0 = off; spans that live on the
             // device take the copy path). At a few hundred points the two hipMemcpyAsync were half of the call.
-            bool zero_copy = !timed && (int64_t)need <= c->host_zero_copy_bytes;
+            bool zero_copy = stream_once && !timed && (int64_t)need <= c->host_zero_copy_bytes;
             for (const auto& sp : inputs) zero_copy = zero_copy && !sp.dev;
             for (const auto& sp : outputs) zero_copy = zero_copy && !sp.dev;
             if (zero_copy) {

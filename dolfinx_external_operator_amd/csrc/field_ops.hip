@@ -263,5 +263,5 @@ extern "C" int dxo_isihara_field(dxo_ctx* ctx, const dxo_isihara_params* prm, dx
     const size_t sd = sizeof(double) * (size_t)mesh->dev.nq;
     std::vector<dxo_span> in;
     std::vector<dxo_span> out = {{nullptr, dP, 16 * sd}, {nullptr, P, 4 * sd}};
-    return dxo_run_host_pipeline(ctx, mesh->num_cells, in, out, isi_field_chunk, &L, mesh->dev.nq);
+    return dxo_run_host_pipeline(ctx, mesh->num_cells, in, out, isi_field_chunk, &L, mesh->dev.nq, nullptr, true);
 }

@@ -125,7 +125,7 @@ extern "C" int dxo_heat(dxo_ctx* ctx, double A, double B, int gdim, int64_t n, i
     if (q) out.push_back({nullptr, q, gdim * sd});
     if (dqdT) out.push_back({nullptr, dqdT, gdim * sd});
     if (dqdsigma) out.push_back({nullptr, dqdsigma, (size_t)gdim * gdim * sd});
-    return dxo_run_host_pipeline(ctx, n, in, out, heat_chunk, &L);
+    return dxo_run_host_pipeline(ctx, n, in, out, heat_chunk, &L, 1, nullptr, true);
 }
 
 // ------------------------------------------------------------------ scalar conductivity of the part-1 demo
@@ -194,5 +194,5 @@ extern "C" int dxo_conductivity(dxo_ctx* ctx, double A, double B, int64_t n, int
     std::vector<dxo_span> out;
     if (k) out.push_back({nullptr, k, sd});
     if (dkdT) out.push_back({nullptr, dkdT, sd});
-    return dxo_run_host_pipeline(ctx, n, in, out, cond_chunk, &L);
+    return dxo_run_host_pipeline(ctx, n, in, out, cond_chunk, &L, 1, nullptr, true);
 }

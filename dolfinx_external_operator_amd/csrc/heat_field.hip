@@ -139,5 +139,5 @@ extern "C" int dxo_heat_field(dxo_ctx* ctx, double A, double B, dxo_mesh* mesh, 
     if (q) out.push_back({nullptr, q, G * sd});
     if (dqdT) out.push_back({nullptr, dqdT, G * sd});
     if (dqdsigma) out.push_back({nullptr, dqdsigma, G * G * sd});
-    return dxo_run_host_pipeline(ctx, nc, in, out, heat_field_chunk, &L, nq);
+    return dxo_run_host_pipeline(ctx, nc, in, out, heat_field_chunk, &L, nq, nullptr, true);
 }

@@ -847,7 +847,7 @@ extern "C" int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t 
     const size_t sd = sizeof(double);
     std::vector<dxo_span> in = {{F, nullptr, 4 * sd}};
     std::vector<dxo_span> out = {{nullptr, dP, 16 * sd}, {nullptr, P, 4 * sd}};
-    return dxo_run_host_pipeline(ctx, n, in, out, isihara_chunk, &k);
+    return dxo_run_host_pipeline(ctx, n, in, out, isihara_chunk, &k, 1, nullptr, true);
 }
 
 struct dxo_icnn : dxo_icnn_impl {};

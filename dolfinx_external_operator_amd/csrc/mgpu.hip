@@ -481,12 +481,17 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
     for (size_t i = 0; i < L; ++i) {
         const size_t off = gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n;
         if (compact && (!C_tang[i] || !sigma[i] || !dp[i])) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL output array");
-        const int64_t saved_mark = g->ctx[i]->vm_mark_indeterminate;
-        if (compact) g->ctx[i]->vm_mark_indeterminate = 1;
-        const int rc = dxo_von_mises(g->ctx[i], prm, d, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], p[i],
-                                     compact ? nullptr : (C_tang[i] ? C_tang[i] + off * d * d : nullptr),
-                                     sigma[i] ? sigma[i] + off * d : nullptr, dp[i] ? dp[i] + off : nullptr);
-        g->ctx[i]->vm_mark_indeterminate = saved_mark;
+        int rc;
+        {   // option switch, call and restore as ONE unit under the context's (recursive) lock: another thread calling
+            // dxo_von_mises on the same borrowed context never sees marks it did not ask for
+            DXO_LOCK(g->ctx[i]);
+            const int64_t saved_mark = g->ctx[i]->vm_mark_indeterminate;
+            if (compact) g->ctx[i]->vm_mark_indeterminate = 1;
+            rc = dxo_von_mises(g->ctx[i], prm, d, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], p[i],
+                               compact ? nullptr : (C_tang[i] ? C_tang[i] + off * d * d : nullptr),
+                               sigma[i] ? sigma[i] + off * d : nullptr, dp[i] ? dp[i] + off : nullptr);
+            g->ctx[i]->vm_mark_indeterminate = saved_mark;
+        }
         if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
     }
     // 2. the exchange step (a world of one has none; COMPACT still owes the tangent of its only block)

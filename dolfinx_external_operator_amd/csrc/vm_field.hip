@@ -288,11 +288,11 @@ extern "C" int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm,
         std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
-        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild);
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild, true);
         ctx->host_chunk_points = saved_chunk;
     } else {
         std::vector<dxo_span> out = {{nullptr, C_tang, D * D * sd}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
-        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq);
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, nullptr, true);
     }
     if (rc == DXO_OK) st->has_result = true;
     return rc;
@@ -337,10 +337,10 @@ extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_m
         std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
-        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild);
+        rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild, true);
         ctx->host_chunk_points = saved_chunk;
         return rc;
     }
     std::vector<dxo_span> out = {{nullptr, C_tang, D * D * sd}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
-    return dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq);
+    return dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, nullptr, true);
 }

@@ -244,8 +244,13 @@ int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, co
         }
         const bool nt = ctx->nontemporal != 0;
         if (!C_tang) {   // (sigma, dp) only
-            if (L.d == 4) hipLaunchKernelGGL((vm_tile<4, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
-            else          hipLaunchKernelGGL((vm_tile<6, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            if (L.d == 4) {
+                if (nt) hipLaunchKernelGGL((vm_tile<4, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+                else    hipLaunchKernelGGL((vm_tile<4, false, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            } else {
+                if (nt) hipLaunchKernelGGL((vm_tile<6, true, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+                else    hipLaunchKernelGGL((vm_tile<6, false, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
+            }
         } else if (L.d == 4) {
             if (nt) hipLaunchKernelGGL((vm_tile<4, true>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
             else    hipLaunchKernelGGL((vm_tile<4, false>), dim3(grid), dim3(DXO_BLOCK), 0, s, L.c, n, deps, sigma_n, p, C_tang, sigma, dp);
@@ -440,7 +445,7 @@ extern "C" int dxo_vm_expand_tangent(dxo_ctx* ctx, const dxo_vm_params* prm, int
     const size_t sd = sizeof(double);
     std::vector<dxo_span> in = {{sigma, nullptr, d * sd}, {dp, nullptr, sd}};
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}};
-    return dxo_run_host_pipeline(ctx, n, in, out, vm_expand_chunk, &L);
+    return dxo_run_host_pipeline(ctx, n, in, out, vm_expand_chunk, &L, 1, nullptr, true);
 }
 
 extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int64_t n, int mem,
@@ -481,12 +486,12 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
         // so the un-overlapped tail of the call is the rebuild of the last DXO_HOST_SLOTS chunks
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
-        const int rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+        const int rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild, true);
         ctx->host_chunk_points = saved_chunk;
         return rc;
     }
     std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
-    return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
+    return dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, nullptr, true);
 }
 
 // ------------------------------------------------------------------ output block calibrated with the kernel itself
@@ -698,11 +703,11 @@ extern "C" int dxo_von_mises_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_v
         std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
-        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild);
+        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild, true);
         ctx->host_chunk_points = saved_chunk;
     } else {
         std::vector<dxo_span> out = {{nullptr, C_tang, d * d * sd}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
-        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L);
+        rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, nullptr, true);
     }
     if (rc == DXO_OK) st->has_result = true;
     return rc;

@@ -147,7 +147,7 @@ def _dev_f64(t, what: str, numel: int | None = None):
 def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: float = 250.0,
                    H: float | None = None, ctx: Context | None = None, device: int = 0,
                    reuse_outputs: bool = False, host_tangent: str = "rebuild", state: str = "host",
-                   devices=None, outputs=None, device_outputs: str = "arena") -> Callable:
+                   devices=None, outputs=None, device_outputs: str = "fresh") -> Callable:
     """`sigma_external` of the von Mises demo (demo_plasticity_von_mises.py:364-368) on the GPU.
 
     Returns `external_function` with `external_function((1,))(deps) -> (C_tang, sigma, dp)`, flat arrays
@@ -182,12 +182,15 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
     Functions of the extras, installs `(operator.ref_coefficient, sigma_holder, dp_holder)` as the output targets and
     returns the external_function, so a script needs one extra statement after its operators exist:
         sigma.external_function.bind(J_external_operators[0], sigma_new, dp)
-    device_outputs (CUDA-tensor operands only): "arena" (default) — batches whose outputs exceed the arena's threshold
-    (option placement_min_bytes, 1 GiB: about 3*10^6 points at d = 6) are written into ONE persistent block of the
-    context's output arena, placed and launch-shaped by timing this kernel on candidate blocks (dxo_vm_output_alloc; 2-4 s
-    once per batch size): 0.77-0.81 of the HBM peak on a normal board instead of 0.66 into a fresh allocation. The tensors
-    returned are views of that block and are OVERWRITTEN by the operator's next device call (copy what must survive, or
-    pass `out=`); smaller batches and "fresh" return new tensors at every call.
+    device_outputs (CUDA-tensor operands only): "fresh" (default) returns new tensors at every call, as the reference's
+    callbacks return new arrays (:343-352) — results of call k stay valid after call k+1 (line searches, history copies).
+    "arena" is the opt-in for a solver that consumes the results before the next call: batches whose outputs exceed the
+    arena's threshold (option placement_min_bytes, 1 GiB: about 3*10^6 points at d = 6) are written into ONE persistent block
+    of the context's output arena, placed and launch-shaped by timing this kernel on candidate blocks (dxo_vm_output_alloc;
+    2-4 s once per batch size): 0.77-0.81 of the HBM peak on a normal board instead of 0.66-0.74 into a fresh allocation. The
+    tensors returned are then views of that block and are OVERWRITTEN by the operator's next device call; the block may be
+    chunk-backed virtual memory (ctx option placement_vmm), which must not be handed to RCCL / IPC — sharding.py refuses it;
+    set placement_vmm = 0 on the context if the results go into a collective.
     devices (NumPy operands only): a list of GPU indices, e.g. [0, 1, 2, 3] — the arrays are cut into one contiguous cell
     block per GPU and every GPU streams its block over its own PCIe link concurrently (dxo_mgpu_von_mises_host; no
     collective, RCCL is not loaded). The NumPy path is PCIe-bound, so this is how one process scales it. Not combined
@@ -225,6 +228,7 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         c = _ctx()
         if _is_device_tensor(deps):
             if out is None and device_outputs == "arena":
+                _check_device_operand(c, deps)        # device, dtype and shape before any allocation or calibration
                 out = _persistent_device_outputs(c, holder, deps)
             return _von_mises_device(c, prm, deps, _state_array(sigma_n), _state_array(p), out)
         if isinstance(deps, LazyOperand) and deps.kind == "eps" and deps.mesh.ctx is c:
@@ -367,6 +371,17 @@ class _StateMirror:
         return float(max(np.max(np.abs(sn - hs), initial=0.0), np.max(np.abs(pp - hp), initial=0.0)))
 
 
+def _check_device_operand(c: Context, deps) -> None:
+    import torch
+
+    if deps.device.index != c.device:
+        raise ValueError(f"tensor lives on cuda:{deps.device.index}, the context on device {c.device}")
+    if deps.dtype != torch.float64:
+        raise TypeError(f"deps: the HIP kernels are fp64, got {deps.dtype}")
+    if deps.dim() != 3 or deps.shape[2] not in (4, 6):
+        raise ValueError(f"deps must have shape (num_cells, nq, d) with d = 4 or 6, got {tuple(deps.shape)}")
+
+
 def _persistent_device_outputs(c: Context, holder: dict, deps):
     """The operator's persistent (C_tang, sigma, dp) block in the output arena for this batch size, or None for batches
     below the arena's threshold (they get fresh tensors). Made at the first large call, replaced when the batch size
@@ -439,13 +454,41 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     three outputs in one launch and the next two calls (part2.py:307-309 evaluates F- and J-operators
     from the same `evaluated_operands` dict) are served from that result. Only enable it if the operand
     arrays are not modified in place between those calls (evaluate_operands returns fresh arrays).
+    Why this is not the default: a NumPy array carries no modification stamp, so "the same operands came back" can
+    only be PROVEN by comparing contents, which at BASELINE config 1 (6 144 points) costs as much as the launch it
+    would save (two np.array_equal + two copies, ~30 us against ~29 us per call), and at large sizes far more. The
+    caller knows: `external_function.bind(q_operator, dqdT_operator, dqdsigma_operator)` is the one-line statement
+    "this function is driven by evaluate_external_operators with ONE evaluated_operands dict per pass" (part2.py:307-309).
+    It (i) turns identity fusion on and (ii) installs the three operators' coefficient arrays as output targets (entries
+    may be None), so one launch per pass fills all three coefficients and the reference's `x.array[:] = values`
+    (external_operator.py:441) finds source == destination: 36-45 us per step at config 1 against 63 us for the reference's
+    NumPy statements and 87 us for three separate launches.
     """
-    holder = {"ctx": ctx, "keep": None, "val": None}
+    holder = {"ctx": ctx, "keep": None, "val": None, "targets": None, "fuse": bool(fuse_by_identity)}
+    names = ("q", "dqdT", "dqdsigma")
+
+    def _host_outs(sizes, which, fuse):
+        tg = holder["targets"]
+        outs = []
+        for k, sz in enumerate(sizes):
+            if not (fuse or k == which):
+                outs.append(None)
+                continue
+            a = None if tg is None or tg[k] is None else _state_array(tg[k])
+            if a is not None:
+                if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]:
+                    raise TypeError(f"bind: the coefficient of {names[k]} must be a writable C-contiguous float64 ndarray")
+                if a.size != sz:
+                    raise ValueError(f"bind: the coefficient of {names[k]} has {a.size} entries, the call produces {sz}")
+                a = a.reshape(-1)
+            outs.append(np.empty(sz) if a is None else a)
+        return outs
 
     def _eval(T, sigma, which: int):
         if holder["ctx"] is None:
             holder["ctx"] = default_context(device)
         c = holder["ctx"]
+        fuse_by_identity = holder["fuse"]
         if fuse_by_identity and holder["keep"] is not None and holder["keep"][0] is T and holder["keep"][1] is sigma:
             return holder["val"][which]
         if (isinstance(T, LazyOperand) and isinstance(sigma, LazyOperand) and T.kind == "value" and sigma.kind == "grad"
@@ -490,7 +533,7 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
                 raise ValueError(f"sigma size {sig_.size} is not a multiple of the number of points {n}")
             gdim = sig_.size // n
         sizes = (n * gdim, n * gdim, n * gdim * gdim)
-        outs = [np.empty(sz) if (fuse_by_identity or k == which) else None for k, sz in enumerate(sizes)]
+        outs = _host_outs(sizes, which, fuse_by_identity)
         c.heat(A, B, gdim, n, MEM_HOST, T_, sig_, outs[0], outs[1], outs[2])
         if getattr(T, "dtype", None) == np.float32:
             outs = [o if o is None else o.astype(np.float32) for o in outs]
@@ -517,6 +560,13 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
             return dqdsigma_impl
         raise NotImplementedError(f"No external function is defined for the requested derivative {derivatives}.")
 
+    def bind(q_operator=None, dqdT_operator=None, dqdsigma_operator=None):
+        holder["targets"] = tuple(None if o is None else _coefficient_of(o) for o in (q_operator, dqdT_operator, dqdsigma_operator))
+        holder["fuse"] = True
+        holder["keep"] = holder["val"] = None
+        return q_external
+
+    q_external.bind = bind
     return q_external
 
 
@@ -813,7 +863,7 @@ def make_icnn(state_dict, *, precision: str = "fp32", ctx: Context | None = None
 
 
 def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float = 1.5, ctx: Context | None = None,
-                 device: int = 0, reuse_outputs: bool = False, outputs=None, device_outputs: str = "arena") -> Callable:
+                 device: int = 0, reuse_outputs: bool = False, outputs=None, device_outputs: str = "fresh") -> Callable:
     """The analytic Isihara model behind the same `P_external` contract as `make_icnn`.
 
     The reference states it in UFL only (demo_hyperelasticity.py:686-703, `P = ufl.diff(W_Isihara, F_)`) and
@@ -821,10 +871,11 @@ def make_isihara(*, c1: float = 0.5, c2: float = 1.0, c3: float = 1.0, c4: float
     operand `F = I + grad u` exactly like the network: `external_function((1,))(Fvals) -> (dP, P)`.
     W = c1 (I1bar-3) + c2 (I2bar-3) + c3 (I1bar-3)^2 + c4 (J-1)^2; defaults are the reference's (:700).
 
-    device_outputs (CUDA-tensor operands only), as for `make_von_mises`: "arena" (default) — batches whose outputs exceed the
-    arena's threshold are written into ONE persistent block of the library's output arena, chosen at the first such call by
-    timing this kernel on the candidate blocks (the operator is HBM-bound: where its 160 bytes per point land decides 10-15 %
-    of its rate); the returned tensors then alias across calls. "fresh" — new tensors per call."""
+    device_outputs (CUDA-tensor operands only), as for `make_von_mises`: "fresh" (default) — new tensors per call, as the
+    reference's callbacks return new arrays. "arena" (opt-in) — batches whose outputs exceed the arena's threshold are written
+    into ONE persistent block of the library's output arena, chosen at the first such call by timing this kernel on the
+    candidate blocks (the operator is HBM-bound: where its 160 bytes per point land decides 10-15 % of its rate); the returned
+    tensors then ALIAS across calls (the next call overwrites them) and may be chunk-backed memory that must not go to RCCL."""
     if device_outputs not in ("arena", "fresh"):
         raise ValueError('device_outputs must be "arena" or "fresh"')
     prm = IsiharaParams(float(c1), float(c2), float(c3), float(c4))

@@ -134,11 +134,26 @@ def all_gather_flat_into(out, local, group=None, async_op: bool = False):
     return dist.all_gather(chunks, local, group=group, async_op=async_op)
 
 
-def all_gather_in_place(full, rank: int, group=None):
+_IN_PLACE: dict = {}   # (backend, id(group)) -> {"ok": bool, "why": str}: decided ONCE, by all ranks together
+
+
+def in_place_status(group=None) -> dict | None:
+    """What `all_gather_in_place` decided for this group at its first call ({"ok": bool, "why": ...}), None before it."""
+    import torch.distributed as dist
+
+    return _IN_PLACE.get((dist.get_backend(group), id(group)))
+
+
+def all_gather_in_place(full, rank: int, group=None, *, try_in_place: bool | None = None):
     """All-gather where every rank has already written its block into `full` at [rank*m, (rank+1)*m).
 
     With RCCL the send buffer is that view itself (NCCL's in-place all-gather: sendbuff == recvbuff + rank*count),
-    so the kernel's output is never copied locally; other backends (gloo in the tests) get a clone of the block."""
+    so the kernel's output is never copied locally; other backends (gloo in the tests) get a clone of the block.
+    The in-place form has never met RCCL with more than one rank on this project's hardware, so the FIRST call on a group is a
+    trial: if the aliased call raises on any rank, an all-reduce of the failure flags makes EVERY rank fall back — once and for
+    good — to a cloned send buffer (`in_place_status` reports it; bench.py puts it into config.gather_in_place).
+    `try_in_place` overrides the backend rule (tests)."""
+    import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
@@ -146,7 +161,27 @@ def all_gather_in_place(full, rank: int, group=None):
         raise ValueError(f"gather buffer of {full.numel()} elements does not split into {world} equal blocks")
     m = full.numel() // world
     local = full[rank * m:(rank + 1) * m]
-    if dist.get_backend(group) != "nccl":
+    key = (dist.get_backend(group), id(group))
+    st = _IN_PLACE.get(key)
+    if st is None:
+        want = (key[0] == "nccl") if try_in_place is None else bool(try_in_place)
+        if not want:
+            st = _IN_PLACE[key] = {"ok": False, "why": f"backend {key[0]}: cloned send buffer"}
+        else:
+            failed, why, work = 0, "in-place all_gather_into_tensor on the aliasing view", None
+            try:
+                work = all_gather_flat_into(full, local, group)
+            except Exception as exc:   # noqa: BLE001 — any refusal of the aliased call is a reason to fall back, together
+                failed, why = 1, f"in-place form raised on rank {rank}: {exc!r}; every rank uses a cloned send buffer"
+            flag = torch.tensor([failed], dtype=torch.int32, device=full.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            ok = int(flag.item()) == 0
+            if not ok and not failed:
+                why = "in-place form raised on another rank; every rank uses a cloned send buffer"
+            st = _IN_PLACE[key] = {"ok": ok, "why": why}
+            if ok:
+                return work
+    if not st["ok"]:
         local = local.clone()
     return all_gather_flat_into(full, local, group)
 
@@ -170,7 +205,7 @@ def _rebuild_ranges(rank: int, world: int, m: int, identical: bool) -> list[tupl
     return [(0, world * m)] if identical and m > 0 else remote_point_ranges(rank, world, m)
 
 
-def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None, *, identical: bool = True,
+def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None, *, identical: bool = False,
                              clear_marks=None) -> None:
     """Reassemble (C_tang, sigma, dp) on every rank while moving only (sigma, dp) over the links.
 
@@ -180,11 +215,13 @@ def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int
     the tangents locally — read 56 B + write 288 B per point at HBM speed, ~5 ms for 8*10^7 points, against ~50 ms
     saved on the links at 8 GPUs.
 
-    `identical=True` (default): EVERY block's tangent is rebuilt, the rank's own included, in one launch over the whole
-    range — all ranks run the same arithmetic on the same gathered values, so the replicas of the coefficient vector are
-    bit-identical across ranks; the owner's kernel then need not write a tangent at all (dxo_von_mises with
-    C_tang = NULL). `identical=False`: only the remote blocks are rebuilt and the owner keeps the tangent its kernel
-    wrote (the replicas then agree to rounding, <= 1e-14 of the scale, not bit for bit).
+    `identical=False` (default): only the remote blocks are rebuilt and the owner keeps the tangent its kernel wrote,
+    including the reference's NaN tangent at f_el == 0 (the replicas then agree to rounding, <= 1e-14 of the scale, not bit
+    for bit). `identical=True` (what bench.py uses): EVERY block's tangent is rebuilt, the rank's own included, in one
+    launch over the whole range — all ranks run the same arithmetic on the same gathered values, so the replicas of the
+    coefficient vector are bit-identical across ranks; the owner's kernel then need not write a tangent at all (dxo_von_mises
+    with C_tang = NULL), but it MUST have run with option "vm_mark_indeterminate" and `clear_marks` must be given, or the
+    owner's NaN tangents are rebuilt as C_elas.
 
     The reference's 0/0 point (f_elastic == 0 exactly, demo_plasticity_von_mises.py:318: NaN tangent) leaves no trace in
     the VALUES of (sigma, dp); a producer run with option "vm_mark_indeterminate" returns dp = -0.0 there, the rebuild
@@ -205,7 +242,7 @@ def gather_von_mises_compact(C_tang_full, sigma_full, dp_full, rank: int, d: int
 
 
 def gather_von_mises_compact_pipelined(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, chunks: int = 4,
-                                       group=None, *, identical: bool = True, clear_marks=None) -> None:
+                                       group=None, *, identical: bool = False, clear_marks=None) -> None:
     """`gather_von_mises_compact` with the tangent rebuild overlapped with the link traffic (SURVEY.md 8e iii).
 
     Every rank's block of m points is cut into `chunks` pieces on 64-point borders. All pieces are put on the wire
@@ -268,7 +305,7 @@ def exchange_blocks_direct(full, rank: int, group=None) -> None:
 
 
 def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int, d: int, expand, group=None, *,
-                                    identical: bool = True, clear_marks=None) -> None:
+                                    identical: bool = False, clear_marks=None) -> None:
     """`gather_von_mises_compact` with the exchange of (sigma, dp) as direct peer-to-peer sends / receives
     (`exchange_blocks_direct`) instead of the backend's all-gather; the rebuild of the tangents is the same."""
     import torch.distributed as dist
@@ -283,5 +320,5 @@ def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int,
         clear_marks(dp_full, world * m)
 
 
-__all__ = ["CellBlockPartition", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
+__all__ = ["CellBlockPartition", "in_place_status", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
            "remote_point_ranges", "gather_von_mises_compact", "gather_von_mises_compact_pipelined", "WAVE_TILE"]

@@ -117,7 +117,9 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * to this size are not copied by DMA at all — the kernel reads its inputs from and writes its outputs to the page-locked,
  * device-mapped staging block over PCIe directly, which removes the two copy launches from the call: 49 -> 34 us at 600
  * points, 153 -> 86 us at 6 144 points (von Mises d = 4), 39 -> 24 us for the heat flux of config 1; results are
- * bit-identical; 0 = off; with "timing" = 1 the copy form is used so that the phases can be timed), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
+ * bit-identical; 0 = off; with "timing" = 1 the copy form is used so that the phases can be timed; only the operators whose
+ * kernels read every input once and store whole lines take this path — von Mises, heat, conductivity, Isihara and their
+ * fused-operand forms; the Mohr-Coulomb and network kernels re-read inputs / store partial lines and keep the DMA copies), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0

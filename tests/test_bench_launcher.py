@@ -72,17 +72,49 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_two_rank_path_logic_on_one_gpu():
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_path_logic_on_one_gpu(ranks):
     """The N > 1 control flow of bench.py (cell-block offsets into full-length arena buffers, the four gather modes,
-    the remote-tangent rebuild and its finiteness / symmetry check, max-over-ranks timing) with two ranks sharing the
-    one GPU of the test box and gloo collectives (`--dry-collective`): RCCL itself needs one device per rank and is
-    exercised with a world of one (tests/test_round2_gpu.py) and by the driver's 8-GPU run."""
+    the remote-tangent rebuild and its finiteness / symmetry check, max-over-ranks timing) with two and three ranks sharing
+    the one GPU of the test box and gloo collectives (`--dry-collective`): RCCL itself needs one device per rank and is
+    exercised with a world of one (tests/test_round2_gpu.py) and by the driver's 8-GPU run. The line must carry what the
+    first real 8-GPU run will be read by: the ranks, the backend, the per-mode status, the in-place decision, the gather
+    check and how many placement candidates were probed for the FULL-length block."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "2", "--dry-collective", "--steps", "2",
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29571 + ranks), str(ROOT / "bench.py"), "--gpus", str(ranks), "--dry-collective", "--steps", "2",
                           "--warmup", "1", "--nqp", "500000", "--no-probe"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
-    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and "dry_collective" in line and line["config"]["rccl_ranks"] == 2
-    assert set(line["config"]["gather_modes"]) == {"compact", "compact_pipelined", "compact_direct", "full"}
-    assert line["config"]["points_per_gpu"] % 128 == 0 and line["value"] > 0
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # dry mode: no second line (the library check needs one GPU per rank)
+    line = json.loads(lines[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == ranks and "dry_collective" in line and cfg["rccl_ranks"] == ranks
+    assert set(cfg["gather_modes"]) == {"compact", "compact_pipelined", "compact_direct", "full"}
+    assert cfg["points_per_gpu"] % 128 == 0 and line["value"] > 0
+    assert cfg["collective_backend"] == "gloo"
+    assert cfg["mode_status"] == {m: "timed" for m in ("compact", "compact_pipelined", "compact_direct", "full")}
+    assert cfg["gather_in_place"] == {"ok": False, "why": "backend gloo: cloned send buffer"}
+    assert line["gather_check"]["status"] == "skipped" and "dry_collective" in line["gather_check"]["why"]
+    assert cfg["placement_block_bytes"] == ranks * cfg["points_per_gpu"] * 43 * 8
+    assert 1 <= cfg["placement_candidates_probed"] <= cfg["placement_candidates_requested"]
+
+
+@pytest.mark.gpu
+def test_single_rank_under_torchrun_prints_the_gather_check_line():
+    """A world of one under torch.distributed.run with the gather on: RCCL comes up, the in-place form is tried (and works
+    or falls back — either way the decision is in the line), and the library's own RCCL path is cross-checked AFTER the result
+    line: the second, final line repeats the first with `gather_check` filled in."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29579", str(ROOT / "bench.py"), "--gpus", "1", "--gather", "1", "--steps", "2", "--warmup", "1",
+                          "--nqp", "500000", "--no-probe", "--no-cpu", "--no-e2e", "--no-secondary", "--no-traffic"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 2
+    first, last = lines
+    assert first["gather_check"]["status"] == "pending" and last["gather_check"]["status"] == "ok", last["gather_check"]
+    assert {k: v for k, v in first.items() if k != "gather_check"} == {k: v for k, v in last.items() if k != "gather_check"}
+    assert last["config"]["collective_backend"] == "nccl" and last["config"]["gather_in_place"]["ok"] in (True, False)
+    assert last["gather_check"]["compact_replicas_bit_identical"] is True

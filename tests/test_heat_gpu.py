@@ -55,6 +55,43 @@ def test_fused_by_identity_gives_same_values(ctx, golden):
         assert np.array_equal(fused(idx)(T, s), plain(idx)(T, s))
 
 
+def test_bind_fuses_one_pass_and_writes_the_three_coefficients_in_place(ctx, golden):
+    """q_external.bind(q, dqdT, dqdsigma): one launch per evaluate_external_operators pass fills all three coefficient arrays
+    (same bits as the unbound calls), the dispatcher's assignment is array-to-itself, and fresh operand arrays (the next
+    pass's evaluate_operands) trigger a new launch."""
+    g = golden("heat_c1.npz")
+    T_full, s_full = g["T"], g["sigma"]
+    nc, nq = T_full.shape
+    scale = {"v": 1.0}
+    T = Operand(lambda cells: T_full[cells] * scale["v"], "T")
+    sigma = Operand(lambda cells: s_full[cells].reshape(len(cells), -1), "grad(T)")
+    q_external = make_heat(A=float(g["A"]), B=float(g["B"]), ctx=ctx)
+    ops = [QuadratureExternalOperator(T, sigma, num_cells=nc, num_points=nq, value_shape=shape, external_function=q_external, derivatives=dv)
+           for shape, dv in (((2,), (0, 0)), ((2,), (1, 0)), ((2, 2), (0, 1)))]
+    assert q_external.bind(*ops) is q_external
+    launches = []
+    real = ctx.heat
+    ctx.heat = lambda *a, **k: (launches.append(1), real(*a, **k))[1]
+    try:
+        ev = evaluate_operands(ops)
+        res = evaluate_external_operators(ops, ev)
+        assert len(launches) == 1
+        for op, r, key in zip(ops, res, ("q", "dqdT", "dqdsigma")):
+            assert np.shares_memory(r, op.ref_coefficient.x.array)
+            assert rel(op.ref_coefficient.x.array, g[key]) <= RTOL
+        scale["v"] = 1.5                                    # a new Newton iterate: evaluate_operands returns new arrays
+        ev = evaluate_operands(ops)
+        evaluate_external_operators(ops, ev)
+        assert len(launches) == 2
+    finally:
+        ctx.heat = real
+    plain = make_heat(A=float(g["A"]), B=float(g["B"]), ctx=ctx)
+    for op, dv in zip(ops, ((0, 0), (1, 0), (0, 1))):
+        assert np.array_equal(op.ref_coefficient.x.array, plain(dv)(T_full * 1.5, s_full))
+    with pytest.raises(ValueError):
+        make_heat(ctx=ctx).bind(ops[2], None, None)((0, 0))(T_full, s_full)     # wrong coefficient size for q
+
+
 @pytest.mark.parametrize("gdim", [1, 2, 3])
 @pytest.mark.parametrize("n", [0, 1, 63, 65, 1000, 6144])
 def test_sizes_and_dims_against_oracle(ctx, oracle, gdim, n):

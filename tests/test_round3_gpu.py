@@ -227,8 +227,10 @@ def test_bind_puts_the_results_into_the_operators_coefficient(ctx, oracle):
 
 
 def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle):
-    """CUDA-tensor operands, default factory: above the arena threshold the outputs live in ONE calibrated block that the
-    next call overwrites (documented aliasing); below it, and with device_outputs="fresh", every call returns new tensors."""
+    """CUDA-tensor operands, device_outputs="arena" (opt-in): above the arena threshold the outputs live in ONE calibrated block
+    that the next call overwrites (documented aliasing); below it, and with the default device_outputs="fresh", every call
+    returns new tensors — the reference's callbacks return new arrays, so results of call k survive call k+1 by default.
+    Operand device / dtype are checked before anything is allocated or calibrated."""
     import torch
 
     from dolfinx_external_operator_amd import make_von_mises
@@ -241,7 +243,9 @@ def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle
         n = 64_000
         deps, sigma_n, p = vm_inputs(n, d, seed=42)
         t = [_dev(a) for a in (deps.reshape(n // nq, nq, d), sigma_n.reshape(-1), p)]
-        ext = make_von_mises(t[1], t[2], ctx=ctx)
+        ext = make_von_mises(t[1], t[2], ctx=ctx, device_outputs="arena")
+        with pytest.raises(TypeError):
+            ext((1,))(t[0].float())                                  # refused before the arena block is made
         C1, s1, dp1 = ext((1,))(t[0])
         ptr = C1.data_ptr()
         assert C1.dxo_block.info["mode"] == "candidates"
@@ -251,22 +255,24 @@ def test_device_calls_keep_their_outputs_in_a_persistent_arena_block(ctx, oracle
         assert C2.data_ptr() == ptr                                  # the same block: the first result has been overwritten
         assert_close_scaled(C1.cpu().numpy(), oracle.von_mises(deps * 0.5, sigma_n, p)[0], 1e-13, "aliased view sees the new call")
         small = [_dev(a) for a in (deps[:800].reshape(100, nq, d), sigma_n[:800].reshape(-1), p[:800])]
-        ext_s = make_von_mises(small[1], small[2], ctx=ctx)
+        ext_s = make_von_mises(small[1], small[2], ctx=ctx, device_outputs="arena")
         a = ext_s((1,))(small[0])[0]
         b = ext_s((1,))(small[0])[0]
         assert a.data_ptr() != b.data_ptr()                          # below the threshold: fresh tensors
-        fresh = make_von_mises(t[1], t[2], ctx=ctx, device_outputs="fresh")
+        fresh = make_von_mises(t[1], t[2], ctx=ctx)                  # the default
         x = fresh((1,))(t[0])[0]
-        y = fresh((1,))(t[0])[0]
-        assert x.data_ptr() != y.data_ptr() and torch.equal(x, y)
+        y = fresh((1,))(t[0] * 0.5)[0]
+        assert x.data_ptr() != y.data_ptr() and not hasattr(x, "dxo_block")
+        assert_close_scaled(x.cpu().numpy(), Co, 1e-13, "the first result survives the second call")
     finally:
         ctx.set_option("placement_min_bytes", saved[0])
         ctx.set_option("placement_candidates", saved[1])
 
 
 def test_isihara_device_calls_use_a_persistent_arena_block(ctx):
-    """The HBM-bound analytic operator, CUDA-tensor operand, default factory: above the arena threshold (dP, P) live in one
-    block chosen by timing the kernel itself, overwritten by the next call; results equal the fresh-tensor form bit for bit."""
+    """The HBM-bound analytic operator, CUDA-tensor operand, device_outputs="arena" (opt-in): above the arena threshold (dP, P)
+    live in one block chosen by timing the kernel itself, overwritten by the next call; results equal the default
+    fresh-tensor form bit for bit."""
     import torch
 
     from dolfinx_external_operator_amd import make_isihara
@@ -278,7 +284,7 @@ def test_isihara_device_calls_use_a_persistent_arena_block(ctx):
         n = 60_000
         g = torch.Generator(device="cuda:0").manual_seed(9)
         F = torch.randn(n, 1, 2, 2, device="cuda:0", dtype=torch.float64, generator=g) * 0.05 + torch.eye(2, device="cuda:0", dtype=torch.float64)
-        ext, fresh = make_isihara(ctx=ctx), make_isihara(ctx=ctx, device_outputs="fresh")
+        ext, fresh = make_isihara(ctx=ctx, device_outputs="arena"), make_isihara(ctx=ctx)
         dP1, P1 = ext((1,))(F)
         assert dP1.dxo_block.info["mode"] == "candidates" and dP1.numel() == n * 16 and P1.numel() == n * 4
         dPf, Pf = fresh((1,))(F)

@@ -245,3 +245,68 @@ def test_gloo_compact_gather_rebuilds_tangents_nan_exact_and_replica_identical(o
     assert {r: v[0] for r, v in got.items()} == {r: True for r in range(world)}
     if identical:
         assert len({v[1] for v in got.values()}) == 1, "replicas differ between ranks"
+
+
+def _worker_in_place_fallback(rank, world, port, ret, fail_rank):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dolfinx_external_operator_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        real = sharding.all_gather_flat_into
+        calls = {"aliased": 0, "cloned": 0}
+
+        def picky(out, local, group=None, async_op=False):
+            aliased = out.data_ptr() <= local.data_ptr() < out.data_ptr() + out.numel() * out.element_size()
+            calls["aliased" if aliased else "cloned"] += 1
+            if aliased and rank == fail_rank:
+                raise RuntimeError("backend refuses an input that aliases the output")
+            if aliased:   # a rank on which the trial "works" has completed a collective the failing rank never entered: with a
+                return None   # real backend that call would be pending; here it is simply not issued (gloo would deadlock)
+            return real(out, local, group, async_op)
+
+        sharding.all_gather_flat_into = picky
+        m = 96
+        full = torch.zeros(world * m, dtype=torch.float64)
+        for it in range(3):
+            full.zero_()
+            full[rank * m:(rank + 1) * m] = torch.arange(m, dtype=torch.float64) + 1000 * rank + it
+            sharding.all_gather_in_place(full, rank, try_in_place=True)
+            if it == 0 and fail_rank is not None:
+                # the trial round: ranks that did not raise skipped the (mock) aliased collective; everyone redoes it cloned
+                pass
+            want = torch.cat([torch.arange(m, dtype=torch.float64) + 1000 * r + it for r in range(world)])
+            if fail_rank is None and it == 0:
+                continue        # mock "success" issues nothing: only the decision is checked in that configuration
+            assert torch.equal(full, want), (rank, it)
+        st = sharding.in_place_status()
+        ret[rank] = (st["ok"], calls["aliased"], calls["cloned"], "cloned send buffer" in st["why"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_in_place_gather_falls_back_on_every_rank_when_one_rank_refuses(world):
+    """First call = trial of the aliased (RCCL in-place) form; rank 1 refuses it -> the all-reduced flag makes ALL ranks use a
+    cloned send buffer from then on (one trial only), and the gathered vectors are right."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_in_place_fallback, args=(r, world, port, ret, 1)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=180)
+        assert pr.exitcode == 0
+    for r in range(world):
+        ok, aliased, cloned, says = ret[r]
+        assert ok is False and aliased == 1 and cloned == 3 and says
