@@ -97,7 +97,9 @@ def test_multi_rank_path_logic_on_one_gpu(ranks):
     assert cfg["gather_in_place"] == {"ok": False, "why": "backend gloo: cloned send buffer"}
     assert line["gather_check"]["status"] == "skipped" and "dry_collective" in line["gather_check"]["why"]
     assert cfg["placement_block_bytes"] == ranks * cfg["points_per_gpu"] * 43 * 8
-    assert 1 <= cfg["placement_candidates_probed"] <= cfg["placement_candidates_requested"]
+    # the test-sized block is below placement_min_bytes: a plain hipMalloc, nothing probed; a full-size run reports how many
+    # candidates of the FULL-length block fitted 60 % of the free memory and were timed
+    assert 0 <= cfg["placement_candidates_probed"] <= cfg["placement_candidates_requested"]
 
 
 @pytest.mark.gpu
