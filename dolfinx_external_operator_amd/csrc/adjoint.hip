@@ -22,7 +22,101 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+// experiment switches (scripts/exp/ab_adjoint.py builds variants with -D...)
+#ifndef DXO_TA_NT
+#define DXO_TA_NT 0          // non-temporal loads of the tangent rows
+#endif
+#ifndef DXO_TA_PIPE
+#define DXO_TA_PIPE 1        // register-pipelined dof gather
+#endif
+#ifndef DXO_TA_EARLY_C
+#define DXO_TA_EARLY_C 1     // request the tangent row before the contraction
+#endif
+#ifndef DXO_ADJ_PAD
+#define DXO_ADJ_PAD 1        // odd per-point stride of the parked tensors
+#endif
+#ifndef DXO_TA_WAVES
+#define DXO_TA_WAVES 2
+#endif
+#ifndef DXO_TA_KO
+#define DXO_TA_KO 0          // knock-out experiments (wrong results!): 1 no element-vector stores, 2 no tangent loads, 4 no dof gather
+#endif
+#ifndef DXO_TA_STAGE
+#define DXO_TA_STAGE 1       // tangent rows requested lane-linear and passed through LDS (TangentRows) instead of row-per-lane loads
+#endif
+
 namespace {
+
+template <bool NT>
+__device__ __forceinline__ dxo_f64x2 ta_load(const dxo_f64x2* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// ---- the tangent rows of a wave group, coalesced. A lane needs the D*D entries of ITS point; asking for them row-per-lane makes
+// every load instruction touch 64 different cache lines, 16 bytes of each, and with ~150 KB of such rows in flight per CU the
+// lines are evicted from the 32 KB L1 between the instructions that use their other pieces (tangent_apply ran at a third of the
+// rate its traffic allows). So the group's rows are requested LANE-LINEAR (16 bytes per lane, consecutive lanes consecutive
+// addresses: every line is fetched once) at the top of the iteration and kept in registers; once the wave's LDS region is free
+// they pass through it in two chunks of TR_PC points and every lane picks up its own row.
+constexpr int TR_PC = 32;                       // points per chunk
+template <int D>
+struct TangentRows {
+    static constexpr int CV = D * D / 2;        // 16-byte units per point
+    static constexpr int LPC = TR_PC * CV / DXO_WAVE;   // lane-linear loads per lane per chunk (9 at d = 6, 4 at d = 4)
+    static constexpr int LDS_DOUBLES = TR_PC * D * D;   // staging space one chunk needs
+    dxo_f64x2 r[2][LPC];
+    __device__ __forceinline__ void request(const double* __restrict__ C_tang, int64_t p0, int npts, int lane) {
+        const dxo_f64x2* base = reinterpret_cast<const dxo_f64x2*>(C_tang + p0 * (D * D));
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < LPC; ++k) {
+                const int u = c * TR_PC * CV + k * DXO_WAVE + lane;
+                r[c][k] = (u < npts * CV && !(DXO_TA_KO & 2)) ? ta_load<DXO_TA_NT != 0>(base + u) : dxo_f64x2{1.0, 0.5};
+            }
+    }
+    // t = C_row e for this lane's point straight from the staged rows (the row never sits in registers)
+    __device__ __forceinline__ void times(double* S, int lane, const double (&e)[D], double (&t)[D]) const {
+        dxo_f64x2* S2 = reinterpret_cast<dxo_f64x2*>(S);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int k = 0; k < LPC; ++k) S2[k * DXO_WAVE + lane] = r[c][k];
+            op_fence();
+            if (lane / TR_PC == c) {
+                const dxo_f64x2* R = S2 + (lane - c * TR_PC) * CV;
+#pragma unroll
+                for (int rr = 0; rr < D; ++rr) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < D; cc += 2) {
+                        const dxo_f64x2 c2 = R[(rr * D + cc) / 2];
+                        acc += c2.x * e[cc];
+                        acc += c2.y * e[cc + 1];
+                    }
+                    t[rr] = acc;
+                }
+            }
+            op_fence();
+        }
+    }
+    // -> row[CV] of this lane's point (lane = point index inside the group); S = the wave's LDS region (16-byte aligned)
+    __device__ __forceinline__ void deliver(double* S, int lane, dxo_f64x2 (&row)[CV]) const {
+        dxo_f64x2* S2 = reinterpret_cast<dxo_f64x2*>(S);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int k = 0; k < LPC; ++k) S2[k * DXO_WAVE + lane] = r[c][k];
+            op_fence();
+            if (lane / TR_PC == c) {
+#pragma unroll
+                for (int j = 0; j < CV; ++j) row[j] = S2[(lane - c * TR_PC) * CV + j];
+            }
+            op_fence();
+        }
+    }
+};
 
 // Mandel / row-major operand value -> dual tensor Ghat[i][j] = d(pairing)/d(grad u)_ij, and the value part
 template <int G, int BS, int KIND>
@@ -68,7 +162,10 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
                                                 double scale, int64_t c0, int ncell, const int32_t* __restrict__ cells,
                                                 double* __restrict__ out, double* __restrict__ fe) {
     const OperandLayout<G> L(m);
-    constexpr int PT = BS * (G + 1);
+    // per-point stride: an ODD number of doubles. Phase 2's lanes read the same slot of up to three different cells at once
+    // (cell stride = nq points); with the natural stride 12 (hexahedra: 8 x 12 doubles = 192 dwords = 0 mod 64 banks) those
+    // reads collided on one bank — a quarter of the kernel's LDS cycles were conflict cycles (profiles/r04_device_loop_sq.json)
+    constexpr int PT = DXO_ADJ_PAD ? ((BS * (G + 1)) | 1) : BS * (G + 1);
     if (active) {
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
@@ -102,6 +199,7 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
             }
         }
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
+        if ((DXO_TA_KO & 1) && acc[0] != 1.2345e300) continue;
         if (fe) {        // two-pass form: the element vector entry, summed per node afterwards (node_sum).
             // Layout fe[a][cell][i]: the cells of a wave group are consecutive, so each local node's entries leave as one
             // contiguous run per group, and in node_sum neighbouring nodes (same local role in neighbouring cells) read
@@ -210,13 +308,20 @@ __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int
     }
 }
 
-// K v without K: gather v, eps(v) per point, t = C_tang e, scatter B^T t (bs = gdim, Mandel pairing)
-template <int G>
-__global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
+// K v without K: gather v, eps(v) per point, t = C_tang e, scatter B^T t (bs = gdim, Mandel pairing).
+// Round 4: the kernel spent two thirds of its wave cycles parked in s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.65) — the
+// dofmap -> v gather was a dependent pair of scattered loads issued and awaited inside every group, and the point's 36
+// tangent entries were requested only after the strain was known. Now (i) the gather runs as the register pipeline vm_field
+// uses (values of group g+1 and indices of group g+2 in flight while group g is computed), (ii) the lane's tangent row is
+// requested at the top of the iteration, 16 bytes per load, and is consumed after the contraction has hidden its latency,
+// (iii) the parked tensors have an odd stride (adjoint_scatter). ND_CT / NG_CT as in operand_compute_geo.
+template <int G, int ND_CT = 0, int NG_CT = 0>
+__global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                               const double* __restrict__ C_tang, const double* __restrict__ v,
                                                               int64_t n_cells, double* __restrict__ out,
                                                               double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
+    constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
@@ -228,16 +333,58 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, cons
     double* Tm = W + cpw * (op_odd(m.ndofs * G) + op_odd(m.ngeom * G));
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
     const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
-    for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    const bool piped = DXO_TA_PIPE && operand_can_pipe(m);
+    OperandPipe<G, G> pf;
+    int64_t grp = walk.first;
+    if (piped) {
+        pipe_load_indices<G, G>(m, pf, grp * cpw, cells_in(grp), lane);
+        pipe_load_values<G, G>(m, pf, v);
+        pipe_load_indices<G, G>(m, pf, (grp + stride) * cpw, cells_in(grp + stride), lane);
+    }
+#if DXO_TA_KO & 4
+#define DXO_TA_SKIP_GATHER 1
+#else
+#define DXO_TA_SKIP_GATHER 0
+#endif
+    const int q_l = lane - (lane / m.nq) * m.nq;
+    const double w_l = lane < cpw * m.nq ? wq[q_l] : 0.0;
+    for (; grp < walk.end; grp += stride) {
         const int64_t c0 = grp * cpw;
-        const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
-        operand_gather<G, G>(m, W, v, nullptr, c0, ncell, lane);
+        const int ncell = cells_in(grp);
+        const bool has_point = lane < ncell * m.nq;
+        // the tangent of this lane's point: requested now, used after the contraction
+#if DXO_TA_STAGE
+        TangentRows<D> rows;
+        rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
+#else
+        dxo_f64x2 Cq[CV];
+        const dxo_f64x2* Cp = reinterpret_cast<const dxo_f64x2*>(C_tang + (c0 * m.nq + lane) * (D * D));
+#if DXO_TA_EARLY_C
+#pragma unroll
+        for (int k = 0; k < CV; ++k) Cq[k] = has_point ? ta_load<DXO_TA_NT != 0>(Cp + k) : dxo_f64x2{0.0, 0.0};
+#endif
+#endif
+        if (piped) {
+            pipe_commit<G, G>(m, pf, W, ncell, lane);
+            if (!DXO_TA_SKIP_GATHER) {
+                pipe_load_values<G, G>(m, pf, v);
+                pipe_load_indices<G, G>(m, pf, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+            }
+        } else {
+            operand_gather<G, G>(m, W, v, nullptr, c0, ncell, lane);
+        }
         double e[D], K[G][G], det = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int j = 0; j < G; ++j) K[i][j] = 0.0;
-        const bool active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, ncell, lane, e, K, det);
+        const bool active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e, K, det);
         double vh[G], gh[G][G], scale = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -245,33 +392,59 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply(OperandDev m, cons
 #pragma unroll
             for (int j = 0; j < G; ++j) gh[i][j] = 0.0;
         }
+        double t[D];
+#if DXO_TA_STAGE
+        if (!active) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[k] = 0.0;
+        }
+        rows.times(W, lane, e, t);     // compute_geo has fenced: the gather buffer is free, the parked tensors are not written yet
         if (active) {
-            const int q = lane - (lane / m.nq) * m.nq;
-            scale = wq[q] * fabs(det);
-            const double* Cp = C_tang + (c0 * m.nq + lane) * (D * D);     // lane = local point index
-            double t[D];
+            scale = w_l * fabs(det);
+            dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
+        }
+#else
+        if (active) {
+            scale = w_l * fabs(det);
+#if !DXO_TA_EARLY_C
+#pragma unroll
+            for (int k = 0; k < CV; ++k) Cq[k] = ta_load<DXO_TA_NT != 0>(Cp + k);
+#endif
 #pragma unroll
             for (int r = 0; r < D; ++r) {
                 double acc = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < D; ++cc) acc += Cp[r * D + cc] * e[cc];
+                for (int cc = 0; cc < D; cc += 2) {
+                    const dxo_f64x2 c2 = Cq[(r * D + cc) / 2];
+                    acc += c2.x * e[cc];
+                    acc += c2.y * e[cc + 1];
+                }
                 t[r] = acc;
             }
             dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
         }
+#endif
         adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
     }
 }
 
 // diag(K) without K, for a Jacobi preconditioner: K_(a,i),(a,i) = sum_q w|detJ| e_(a,i)^T C_q e_(a,i) with e_(a,i) the Mandel
-// strain of the unit dof (local node a, component i). Phase 1 parks (J^-1, w|detJ|) per point; phase 2, lane = (cell, node).
-// Runs once per Newton iteration, not per Krylov iteration: C_tang is read through the caches, not staged.
+// strain of the unit dof (local node a, component i). With g = K^T dphi_a (physical gradient of the node's basis function) that
+// strain is linear in g, e = E_i g, so the quadratic form is g^T M_i g with the 3x3 (2x2) matrix M_i = E_i^T C E_i picked out of C
+// (rows / columns m(i,j) of the Mandel vector, weight 1 on the diagonal pair and 1/sqrt2 otherwise), and in reference gradients
+// dphi^T (w|detJ| K M_i K^T) dphi. Round 4: phase 1, lane = (cell, point), builds the SYMMETRISED reference-space matrices
+// NS_i (G(G+1)/2 numbers per component: 18 per point on hexahedra instead of the 36 of C) from its own tangent row, requested
+// at the top of the iteration, and parks them in the wave's LDS slice; phase 2, lane = (cell, node), sums
+// dphi_k dphi_k' NS_i[kk'] over the cell's points. Before, phase 2 read the 36 entries of C_q from global memory for every
+// (node, point) pair — 27 times each on Q2 hexahedra: 4.5 ms per 10^7 points, 2.3 matvecs' worth; now see profiles/README.md.
 template <int G>
-__global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
-                                                         const double* __restrict__ C_tang, int64_t n_cells,
-                                                         double* __restrict__ out, double* __restrict__ fe) {
+__global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
+                                                            const double* __restrict__ C_tang, int64_t n_cells,
+                                                            double* __restrict__ out, double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
-    constexpr int PT = G * G + 1;
+    constexpr int CV = D * D / 2;
+    constexpr int NS1 = G * (G + 1) / 2;            // unique entries of one symmetrised matrix
+    constexpr int PT = (G * NS1) | 1;               // odd per-point stride (bank spread across cells)
     constexpr double r2 = 0.70710678118654752440;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
@@ -282,14 +455,29 @@ __global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const do
     const int wave = threadIdx.x >> 6;
     double* W = lds + m.table_doubles + wave * lds_wave;
     const int cpw = m.cells_per_wave, nd = m.ndofs, nq = m.nq, ng = m.ngeom;
-    double* X = W + cpw * op_odd(nd * G);
-    double* Pm = X + cpw * op_odd(ng * G);           // [point][K (G*G), scale]
+    const int sx = op_odd(ng * G);
+    double* X = W;
+    double* Pm = X + ((cpw * sx + 1) & ~1);          // [point][PT]; even offset: the slice also stages the tangent rows (16-byte units)
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
     const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    const int c_l = lane / nq, q_l = lane - c_l * nq;
+    const double w_l = lane < cpw * nq ? wq[q_l] : 0.0;
     for (int64_t grp = walk.first; grp < walk.end; grp += walk.stride) {
         const int64_t c0 = grp * cpw;
         const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
-        const int sx = op_odd(ng * G);
+        const bool has_point = c_l < ncell;
+        dxo_f64x2 Cq[CV];
+#if DXO_TA_STAGE
+        TangentRows<D> rows;
+        rows.request(C_tang, c0 * nq, ncell * nq, lane);
+        rows.deliver(Pm, lane, Cq);          // the parked matrices of the last group have been consumed (fence at the loop's end)
+#else
+        {
+            const dxo_f64x2* Cp = reinterpret_cast<const dxo_f64x2*>(C_tang + (c0 * nq + lane) * (D * D));
+#pragma unroll
+            for (int k = 0; k < CV; ++k) Cq[k] = has_point ? ta_load<DXO_TA_NT != 0>(Cp + k) : dxo_f64x2{0.0, 0.0};
+        }
+#endif
         for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
             const int c = idx / ng, v = idx - c * ng;
             const int64_t node = m.geom_dofmap[(c0 + c) * ng + v];
@@ -297,27 +485,64 @@ __global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const do
             for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = m.x[node * G + j];
         }
         op_fence();
-        {
-            const int c = lane / nq, q = lane - c * nq;
-            if (c < ncell) {
-                const double* dpsi = tab + L.o_dpsi + q * L.sdpsi;
-                const double* Xc = X + c * sx;
-                double J[G][G], K[G][G];
+        if (has_point) {
+            const double* dpsi = tab + L.o_dpsi + q_l * L.sdpsi;
+            const double* Xc = X + c_l * sx;
+            double J[G][G], K[G][G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int k = 0; k < G; ++k) J[j][k] = 0.0;
+            for (int v = 0; v < ng; ++v)
 #pragma unroll
                 for (int j = 0; j < G; ++j)
 #pragma unroll
-                    for (int k = 0; k < G; ++k) J[j][k] = 0.0;
-                for (int v = 0; v < ng; ++v)
+                    for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
+            const double det = invert<G>(J, K);
+            const double scale = w_l * fabs(det);
+            auto Cat = [&](int r, int cc) -> double {
+                const dxo_f64x2 c2 = Cq[(r * D + cc) / 2];
+                return ((r * D + cc) & 1) ? c2.y : c2.x;
+            };
 #pragma unroll
-                    for (int j = 0; j < G; ++j)
+            for (int i = 0; i < G; ++i) {
+                // Mandel slot of the pair (i, j) and its weight: the diagonal pair sits at i with weight 1, an off-diagonal pair at
+                // 3 (01), 4 (02), 5 (12) with weight 1/sqrt2 (two dimensions: only (01) -> 3)
+                int mi[G];
+                double wi[G];
 #pragma unroll
-                        for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
-                const double det = invert<G>(J, K);
+                for (int j = 0; j < G; ++j) {
+                    mi[j] = i == j ? i : (G == 2 ? 3 : (i + j + 2));
+                    wi[j] = i == j ? 1.0 : r2;
+                }
+                double M[G][G], KM[G][G];
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int jj = 0; jj < G; ++jj) M[j][jj] = wi[j] * wi[jj] * Cat(mi[j], mi[jj]);
 #pragma unroll
                 for (int k = 0; k < G; ++k)
 #pragma unroll
-                    for (int j = 0; j < G; ++j) Pm[lane * PT + k * G + j] = K[k][j];
-                Pm[lane * PT + G * G] = wq[q] * fabs(det);
+                    for (int jj = 0; jj < G; ++jj) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int j = 0; j < G; ++j) t += K[k][j] * M[j][jj];
+                        KM[k][jj] = t;
+                    }
+                int slot = 0;
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+#pragma unroll
+                    for (int kk = k; kk < G; ++kk) {
+                        double a = 0.0, b = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < G; ++jj) {
+                            a += KM[k][jj] * K[kk][jj];
+                            b += KM[kk][jj] * K[k][jj];
+                        }
+                        Pm[lane * PT + i * NS1 + slot] = scale * (k == kk ? a : a + b);
+                        ++slot;
+                    }
             }
         }
         op_fence();
@@ -329,38 +554,20 @@ __global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const do
             for (int q = 0; q < nq; ++q) {
                 const double* P = Pm + (c * nq + q) * PT;
                 const double* dp = tab + L.o_dphi + q * L.sdphi + a * G;
-                double g[G];
+                double d[G], pp[NS1];
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    double t = 0.0;
+                for (int k = 0; k < G; ++k) d[k] = dp[k];
+                int slot = 0;
 #pragma unroll
-                    for (int k = 0; k < G; ++k) t += dp[k] * P[k * G + j];
-                    g[j] = t;                                   // d phi_a / d x_j
-                }
-                const double* Cq = C_tang + ((c0 + c) * nq + q) * (D * D);
+                for (int k = 0; k < G; ++k)
+#pragma unroll
+                    for (int kk = k; kk < G; ++kk) pp[slot++] = d[k] * d[kk];
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    double e[D];
+                    double t = 0.0;
 #pragma unroll
-                    for (int r = 0; r < D; ++r) e[r] = 0.0;
-                    if constexpr (G == 2) {
-                        e[i] = g[i];
-                        e[3] = r2 * g[1 - i];
-                    } else {
-                        e[i] = g[i];
-                        if (i == 0) { e[3] = r2 * g[1]; e[4] = r2 * g[2]; }
-                        else if (i == 1) { e[3] = r2 * g[0]; e[5] = r2 * g[2]; }
-                        else { e[4] = r2 * g[0]; e[5] = r2 * g[1]; }
-                    }
-                    double s = 0.0;
-#pragma unroll
-                    for (int r = 0; r < D; ++r) {
-                        double row = 0.0;
-#pragma unroll
-                        for (int cc = 0; cc < D; ++cc) row += Cq[r * D + cc] * e[cc];
-                        s += e[r] * row;
-                    }
-                    acc[i] += P[G * G] * s;
+                    for (int s2 = 0; s2 < NS1; ++s2) t += pp[s2] * P[i * NS1 + s2];
+                    acc[i] += t;
                 }
             }
             const int64_t cell = c0 + c;
@@ -377,10 +584,22 @@ __global__ __launch_bounds__(DXO_BLOCK) void tangent_diag(OperandDev m, const do
     }
 }
 
+int diag_lds_wave(const dxo_mesh* m) {
+    const OperandDev& v = m->dev;
+    const int G = m->gdim;
+    const int D = G == 2 ? 4 : 6;
+    int park = DXO_WAVE * ((G * (G * (G + 1) / 2)) | 1);
+    if (park < TR_PC * D * D) park = TR_PC * D * D;      // the parked-matrix slice doubles as the staging space of the tangent rows
+    int wd = ((v.cells_per_wave * op_odd(v.ngeom * G) + 1) & ~1) + park;
+    return (wd + 1) & ~1;
+}
+
 int adjoint_lds_wave(const dxo_mesh* m) {
     const OperandDev& v = m->dev;
     const int G = m->gdim;
-    int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G)) + DXO_WAVE * G * (G + 1);
+    int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G)) + DXO_WAVE * (DXO_ADJ_PAD ? ((G * (G + 1)) | 1) : G * (G + 1));
+    const int D = G == 2 ? 4 : 6;
+    if (wd < TR_PC * D * D) wd = TR_PC * D * D;          // tangent_apply stages the tangent rows through the whole region (TangentRows)
     return (wd + 1) & ~1;
 }
 
@@ -509,7 +728,8 @@ extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_diagonal: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;
     if (!C_tang || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: NULL array");
-    const int wd = adjoint_lds_wave(mesh);
+    if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang must be 16-byte aligned");
+    const int wd = diag_lds_wave(mesh);
     const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
@@ -537,6 +757,7 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_apply: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;
     if (!C_tang || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
+    if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang must be 16-byte aligned");
     const int wd = adjoint_lds_wave(mesh);
     const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
@@ -551,9 +772,11 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     if (mesh->gdim == 2)
-        hipLaunchKernelGGL(tangent_apply<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
+        hipLaunchKernelGGL((tangent_apply<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
+    else if (mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8)    // Q2 hexahedra: trip counts known at compile time
+        hipLaunchKernelGGL((tangent_apply<3, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
     else
-        hipLaunchKernelGGL(tangent_apply<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
+        hipLaunchKernelGGL((tangent_apply<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
     if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
 }

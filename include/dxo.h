@@ -457,6 +457,7 @@ int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* 
  * bit-reproducible); entity subsets, or option "adjoint_atomics" = 1, add with fp64 hardware atomics instead
  * (reproducible to rounding only). Option "adjoint_cell" = 0 switches off the lane-per-cell kernel that the internal
  * force (kind EPS_MANDEL) uses on the standard elements.
+ * C_tang of dxo_tangent_apply / dxo_tangent_diagonal must be 16-byte aligned (the operator kernels' outputs are).
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
