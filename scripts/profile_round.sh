@@ -8,7 +8,7 @@
 #     mc_*/ icnn_*/ field_*/     counter passes of the secondary kernels (skipped with `quick`)
 # then scripts/summarize_round.py writes the text / JSON summaries next to them; copy those into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -32,6 +32,7 @@ if [ -z "$QUICK" ]; then
   MCF="scripts/bench_mc.py --launches 2 --variant 2"    # the default single persistent kernel
   pass mcf_valu $MCF -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES
   pass mcf_wave $MCF -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+  pass mcf_lane $MCF -- SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU     # lane utilisation of the default kernel: thread-cycles / (64 x wave-cycles)
   pass mcf_fetch $MCF -- FETCH_SIZE
   pass mcf_write $MCF -- WRITE_SIZE
   IC="scripts/bench_icnn.py --launches 2"

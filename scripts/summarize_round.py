@@ -110,7 +110,7 @@ def counters(dirs, match):
 
 
 # ---- Mohr-Coulomb
-mc = counters(["mc_valu", "mc_wave", "mc_fetch", "mc_write", "mcf_valu", "mcf_wave", "mcf_fetch", "mcf_write"],
+mc = counters(["mc_valu", "mc_wave", "mc_fetch", "mc_write", "mcf_valu", "mcf_wave", "mcf_fetch", "mcf_write", "mcf_lane"],
               lambda n: "mc_newton" if "mc_newton" in n else "mc_classify" if "mc_classify" in n else "mc_fused" if "mc_fused" in n else None)
 if mc:
     bench = None
@@ -139,6 +139,21 @@ if mc:
                 "measured": f"{tag}: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 around scripts/bench_mc.py --variant 1 (classification and "
                             f"Newton as two kernels: the same per-point arithmetic as the default single kernel), {n} points, plastic fraction {pl:.4f}; "
                             "masked lanes counted (upper bound on useful flop)"}
+        # the default single kernel priced with ITS OWN counters, and how many of the 64 lanes of its vector instructions did work
+        cf = mc.get("mc_fused", {})
+        if bench_fused and "mc_fused_fp64_flop_per_launch" in derived:
+            fused = {"flop_per_launch": derived["mc_fused_fp64_flop_per_launch"], "points": bench_fused["n"],
+                     "plastic_fraction": bench_fused["plastic_fraction"],
+                     "measured": f"{tag}: SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 of mc_fused itself (scripts/bench_mc.py --variant 2), masked lanes counted"}
+            if cf.get("SQ_THREAD_CYCLES_VALU") and cf.get("SQ_ACTIVE_INST_VALU"):
+                # SQ_ACTIVE_INST_VALU counts quad-cycles of a wave issuing vector instructions, SQ_THREAD_CYCLES_VALU the same cycles
+                # weighted by the active lanes: their ratio / 64 (x 4 if the units differ — both forms are stored) is the mean
+                # fraction of lanes that do work in the kernel's vector instructions
+                raw = cf["SQ_THREAD_CYCLES_VALU"] / (64.0 * cf["SQ_ACTIVE_INST_VALU"])
+                fused["lane_utilisation_raw_ratio"] = raw
+                fused["lane_utilisation"] = raw if raw <= 1.0 else raw / 4.0
+                fused["lane_utilisation_source"] = "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), pass mcf_lane (divided by 4 when the raw ratio exceeds 1: thread-cycles in cycles, wave-cycles in quad-cycles)"
+            flop["fused"] = fused
         (out / "mc_flop.json").write_text(json.dumps(flop, indent=1))
         print("== Mohr-Coulomb:", json.dumps(derived), json.dumps(flop))
 

@@ -98,9 +98,10 @@ def mohr_coulomb_cfg4(torch, ctx, stream, n, cpu):
            "ms_per_launch": ms, "dtype": "f64", "plastic_fraction": plastic,
            "iteration_histogram": {int(a): int(b) for a, b in zip(u.tolist(), c.tolist())},
            "max_norm_res_converged": float(nr[it < 200].max())}
-    # The binding roof is the fp64 vector pipe, not HBM: both are reported. The flop count of a launch is
-    # the PMC figure of the tracked profile (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64, masked lanes counted) scaled to this batch's
-    # plastic points; the HBM figure is live.
+    # The binding roof is the fp64 vector pipe, not HBM: both are reported. The flop count of a launch is the PMC
+    # figure of the tracked profile for THIS kernel (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of mc_fused, masked lanes counted), scaled
+    # by the point count (same input distribution); `useful` multiplies it by the measured lane utilisation of the kernel's
+    # vector instructions — the flop that belong to points that needed them. The HBM figure is live.
     flop_file = ROOT / "profiles" / "mc_flop.json"
     rl = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": None,
           "hbm": _hbm(bpp * n, ms), "bytes_per_qp": bpp}
@@ -108,9 +109,20 @@ def mohr_coulomb_cfg4(torch, ctx, stream, n, cpu):
         import json
 
         fj = json.loads(flop_file.read_text())
-        flop = fj["flop_per_plastic_point"] * plastic * n + fj.get("flop_per_point_classify", 0.0) * n
-        rl.update(achieved=flop / ms / 1e9, frac=flop / ms / 1e9 / FP64_VALU_PEAK_TF, flop_per_launch=flop,
-                  flop_source=f"profiles/mc_flop.json ({fj.get('measured', '')})")
+        fu = fj.get("fused")
+        if fu:
+            flop = fu["flop_per_launch"] * n / fu["points"]
+            rl.update(achieved=flop / ms / 1e9, frac=flop / ms / 1e9 / FP64_VALU_PEAK_TF, flop_per_launch=flop,
+                      flop_source=f"profiles/mc_flop.json fused ({fu.get('measured', '')}; profile batch {fu['points']} points, "
+                                  f"{fu['plastic_fraction']:.3f} plastic)", counts="masked lanes counted (issued flop)")
+            if fu.get("lane_utilisation"):
+                u = fu["lane_utilisation"]
+                rl["useful"] = {"lane_utilisation": u, "achieved": u * flop / ms / 1e9, "frac": u * flop / ms / 1e9 / FP64_VALU_PEAK_TF,
+                                "source": fu.get("lane_utilisation_source")}
+        else:
+            flop = fj["flop_per_plastic_point"] * plastic * n + fj.get("flop_per_point_classify", 0.0) * n
+            rl.update(achieved=flop / ms / 1e9, frac=flop / ms / 1e9 / FP64_VALU_PEAK_TF, flop_per_launch=flop,
+                      flop_source=f"profiles/mc_flop.json ({fj.get('measured', '')})", counts="masked lanes counted; two-kernel variant's counters")
     out["roofline"] = rl
     if cpu:
         from oracle import load_oracle
