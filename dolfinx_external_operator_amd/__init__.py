@@ -4,7 +4,7 @@
 Product path: `operators.make_*` -> ctypes (`_lib`) -> libdxo_hip.so (hand-written HIP, include/dxo.h).
 There is no CPU fallback; `oracle/` is test infrastructure and is never imported from here.
 """
-from ._lib import GATHER_COMPACT, GATHER_FULL, GATHER_NONE, MEM_DEVICE, MEM_HOST, AssignDesc, Context, MultiGpu, DxoError, IsiharaParams, McParams, VmParams, default_context, load_library
+from ._lib import GATHER_COMPACT, GATHER_FULL, GATHER_NONE, MEM_DEVICE, MEM_HOST, AssignDesc, AssignPlan, Context, MultiGpu, DxoError, IsiharaParams, McParams, VmParams, default_context, load_library
 from .evaluation import (
     Coefficient,
     MixedExternalOperator,
@@ -20,6 +20,7 @@ from .operators import make_conductivity, make_heat, make_icnn, make_isihara, ma
 __version__ = "0.1.0"
 
 __all__ = [
+    "AssignPlan",
     "Context", "DxoError", "VmParams", "MEM_HOST", "MEM_DEVICE", "default_context", "load_library",
     "make_von_mises", "make_heat", "make_conductivity", "make_mohr_coulomb", "make_icnn", "make_isihara", "McParams", "IsiharaParams", "von_mises_commit_state",
     "QuadratureExternalOperator", "MixedExternalOperator", "Operand", "Coefficient",

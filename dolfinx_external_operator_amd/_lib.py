@@ -138,6 +138,9 @@ _SIGNATURES = {
     "dxo_eval_operand_facets": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_von_mises_field": (C.c_int, [_P, C.POINTER(VmParams), _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "dxo_assign": (C.c_int, [_P, C.POINTER(AssignDesc), _P, _P, _P, C.c_int64]),
+    "dxo_assign_plan_create": (C.c_int, [_P, C.POINTER(AssignDesc), _P, C.c_int64, C.POINTER(_P)]),
+    "dxo_assign_plan_destroy": (None, [_P, _P]),
+    "dxo_assign_apply": (C.c_int, [_P, _P, _P, _P]),
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),
     "dxo_operand_adjoint": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
@@ -564,6 +567,11 @@ class Context:
         rc = self.lib.dxo_assign(self._h, C.byref(desc), _ptr(flat_dofs), _ptr(values), _ptr(coeff), int(coeff_size))
         self.check(rc, "dxo_assign")
 
+    def assign_plan(self, desc: "AssignDesc", flat_dofs, coeff_size: int) -> "AssignPlan":
+        """dxo_assign_plan_create: the ownership pass of dxo_assign done ONCE for a dofmap; `.apply(values, coeff)` is then a
+        single gather (DEVICE pointers). Use it when the same operator is assigned at every Newton iteration."""
+        return AssignPlan(self, desc, flat_dofs, coeff_size)
+
     def stream_probe(self, read_chunks: int, write_chunks: int, n_tiles: int, src, dst) -> None:
         rc = self.lib.dxo_stream_probe(self._h, int(read_chunks), int(write_chunks), int(n_tiles), _ptr(src), _ptr(dst))
         self.check(rc, "dxo_stream_probe")
@@ -717,6 +725,27 @@ class _ArenaBlock:
                 ctx.output_free(ptr)
             except Exception:
                 pass   # the context (and with it every arena block) is already gone
+
+
+class AssignPlan:
+    """dxo_assign_plan: per coefficient entry the position in `values` of the entry NumPy's sequential assignment leaves there."""
+
+    def __init__(self, ctx: "Context", desc: "AssignDesc", flat_dofs, coeff_size: int):
+        self.ctx, self.coeff_size = ctx, int(coeff_size)
+        h = _P()
+        ctx.check(ctx.lib.dxo_assign_plan_create(ctx._h, C.byref(desc), _ptr(flat_dofs), self.coeff_size, C.byref(h)), "dxo_assign_plan_create")
+        self._h = h
+        self._fin = weakref.finalize(self, AssignPlan._destroy, ctx, h)
+
+    @staticmethod
+    def _destroy(ctx, h):
+        ctx.lib.dxo_assign_plan_destroy(ctx._h, h)      # a closed context passes NULL: the plan's device block is still freed
+
+    def apply(self, values, coeff) -> None:
+        self.ctx.check(self.ctx.lib.dxo_assign_apply(self.ctx._h, self._h, _ptr(values), _ptr(coeff)), "dxo_assign_apply")
+
+    def close(self) -> None:
+        self._fin()
 
 
 class _CudaArrayView:

@@ -58,7 +58,114 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int
     }
 }
 
+// ---- assignment plans. Which entry wins a shared dof depends on the dofmap alone, and a function space's dofmap never changes
+// between the calls of a solve: the plan keeps, for every coefficient entry, the position in `values` of the LAST entry that
+// targets it (-1: none), so applying it is one gather with coalesced stores, no atomics and no owner table.
+template <typename I>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_plan_finish(AssignDev a, const unsigned long long* __restrict__ owner,
+                                                                I* __restrict__ src, int64_t coeff_size) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < coeff_size; d += stride) {
+        const unsigned long long o = owner[d];
+        src[d] = o ? (I)assign_src(a, (int64_t)o - 1) : (I)-1;
+    }
+}
+
+template <typename I>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_apply(const I* __restrict__ src, const double* __restrict__ values,
+                                                          double* __restrict__ coeff, int64_t coeff_size) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < coeff_size; d += stride) {
+        const I s = src[d];
+        if (s >= 0) coeff[d] = values[s];
+    }
+}
+
 }  // namespace
+
+struct dxo_assign_plan {
+    int64_t coeff_size = 0, n_values = 0;
+    bool wide = false;          // int64 source positions (values array beyond 2^31 entries)
+    void* src = nullptr;        // device: int32 or int64 per coefficient entry
+};
+
+extern "C" int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, int64_t coeff_size,
+                                      dxo_assign_plan** out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!d || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_plan_create: NULL argument");
+    *out = nullptr;
+    if (d->n_cells < 0 || d->n_pts < 1 || d->val_size < 1 || d->offset < 0 || d->comp_size < d->val_size ||
+        d->n_points_total < d->offset + d->n_pts || coeff_size < 0)
+        return dxo_fail(ctx, DXO_E_SIZE, "dxo_assign_plan_create: inconsistent sizes");
+    const int64_t n = d->n_cells * d->n_pts * d->val_size;
+    if (n > 0 && !flat_dofs) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_plan_create: flat_dofs is NULL");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    dxo_assign_plan* pl = new dxo_assign_plan;
+    pl->coeff_size = coeff_size;
+    pl->n_values = d->n_cells * (int64_t)d->n_points_total * d->comp_size;
+    pl->wide = pl->n_values > 0x7fffffffLL;
+    const size_t sb = (size_t)(coeff_size ? coeff_size : 1) * (pl->wide ? 8 : 4);
+    if (hipMalloc(&pl->src, sb) != hipSuccess) {
+        (void)hipGetLastError();
+        delete pl;
+        return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign_plan_create: plan allocation");
+    }
+    const size_t need = ((size_t)coeff_size + 1) * sizeof(unsigned long long);
+    unsigned long long* owner = static_cast<unsigned long long*>(dxo_scratch(ctx, s, need));
+    auto bail = [&](int rc) { (void)hipFree(pl->src); delete pl; return rc; };
+    if (!owner) return bail(dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign_plan_create: scratch allocation"));
+    if (hipMemsetAsync(owner, 0, need, s) != hipSuccess) return bail(dxo_hip_fail(ctx, hipGetLastError(), "dxo_assign_plan_create: memset"));
+    AssignDev a{d->n_cells, d->n_pts, d->val_size, d->offset, d->n_points_total, d->comp_size};
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (n > 0) {
+        int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, coeff_size);
+    }
+    if (coeff_size > 0) {
+        int64_t blocks = (coeff_size + DXO_BLOCK - 1) / DXO_BLOCK;
+        if (blocks > cap) blocks = cap;
+        if (pl->wide) hipLaunchKernelGGL(assign_plan_finish<int64_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, owner, (int64_t*)pl->src, coeff_size);
+        else          hipLaunchKernelGGL(assign_plan_finish<int32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, owner, (int32_t*)pl->src, coeff_size);
+    }
+    unsigned long long bad = 0;
+    if (hipMemcpyAsync(&bad, owner + coeff_size, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return bail(dxo_hip_fail(ctx, hipGetLastError(), "dxo_assign_plan_create: synchronisation"));
+    if (bad) {   // the NumPy assigner raises IndexError (external_operator.py:287); no plan is made
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "dxo_assign_plan_create: %llu flat_dofs entries outside [0, coeff_size = %lld)", bad, (long long)coeff_size);
+        return bail(dxo_fail(ctx, DXO_E_SIZE, msg));
+    }
+    *out = pl;
+    return DXO_OK;
+}
+
+extern "C" void dxo_assign_plan_destroy(dxo_ctx* ctx, dxo_assign_plan* plan) {
+    if (!plan) return;
+    DXO_LOCK(ctx);
+    if (plan->src) (void)hipFree(plan->src);
+    delete plan;
+}
+
+extern "C" int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const double* values, double* coeff) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!plan) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_apply: plan is NULL");
+    if (plan->coeff_size == 0) return DXO_OK;
+    if (!values || !coeff) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_apply: NULL array");
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    int64_t blocks = (plan->coeff_size + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    if (plan->wide) hipLaunchKernelGGL(assign_apply<int64_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, (const int64_t*)plan->src, values, coeff, plan->coeff_size);
+    else            hipLaunchKernelGGL(assign_apply<int32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, (const int32_t*)plan->src, values, coeff, plan->coeff_size);
+    return dxo_device_end(ctx, s);
+}
 
 extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, const double* values,
                           double* coeff, int64_t coeff_size) {

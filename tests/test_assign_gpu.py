@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
+    """dxo_assign, and the same assignment through a plan (dxo_assign_plan_create + dxo_assign_apply, applied twice: a plan
+    is made once per dofmap and reused): both must leave the same bits."""
     import torch
 
     d = torch.from_numpy(np.ascontiguousarray(flat_dofs, dtype=np.int32)).cuda()
@@ -19,6 +21,14 @@ def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.assign(desc, d.data_ptr(), v.data_ptr(), c.data_ptr(), coeff_size)
     torch.cuda.synchronize()
+    plan = ctx.assign_plan(desc, d.data_ptr(), coeff_size)
+    del d                                                   # the plan does not keep the dofmap
+    for _ in range(2):
+        c2 = torch.from_numpy(initial.copy()).cuda()
+        plan.apply(v.data_ptr(), c2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(c2, c)
+    plan.close()
     return c.cpu().numpy()
 
 
@@ -81,3 +91,10 @@ def test_argument_checks_and_empty(ctx):
     with pytest.raises(ValueError):
         ctx.assign(AssignDesc(2, 2, 1, 3, 4, 1, 0), i.data_ptr(), t.data_ptr(), t.data_ptr(), 8)   # offset + n_pts > total
     ctx.assign(AssignDesc(0, 2, 1, 0, 2, 1, 0), None, None, None, 0)
+    with pytest.raises(ValueError):
+        ctx.assign_plan(AssignDesc(2, 2, 2, 0, 2, 1, 0), i.data_ptr(), 8)                          # comp_size < val_size
+    bad = torch.tensor([0, 1, 99, 2], dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError, match="outside"):
+        ctx.assign_plan(AssignDesc(2, 2, 1, 0, 2, 1, 0), bad.data_ptr(), 8)                        # NumPy raises IndexError here
+    empty = ctx.assign_plan(AssignDesc(0, 2, 1, 0, 2, 1, 0), None, 0)
+    empty.apply(None, None)

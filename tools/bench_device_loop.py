@@ -193,6 +193,7 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
     vals = torch.randn(nc * npt, dtype=torch.float64, device=dev)
     coeff = torch.zeros(size, dtype=torch.float64, device=dev)
     desc = AssignDesc(nc, npt, 1, 0, npt, 1, 0)
+    plan = ctx.assign_plan(desc, dofs.data_ptr(), size)     # first: the counter pass takes the LAST assign_owner dispatches as dxo_assign's
     saved = ctx.get_option("assign_validate")
     res = {}
     try:
@@ -202,6 +203,10 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
             res[validate] = ms
     finally:
         ctx.set_option("assign_validate", saved)
+    coeff_p = torch.zeros(size, dtype=torch.float64, device=dev)
+    ms_plan, _ = _time(torch, stream, lambda: plan.apply(vals.data_ptr(), coeff_p.data_ptr()), launches, warm=2)
+    plan_equal = bool(torch.equal(coeff_p, coeff))
+    plan.close()
     # NumPy's answer on a sample of dofs: the last (cell, node) entry that targets the dof
     h_d = m.dofmap.reshape(-1)
     probe = np.random.Generator(np.random.PCG64(5)).integers(0, size, 64)
@@ -215,6 +220,10 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
                         "NumPy last-writer-wins order, fp64", "entries": nc * npt, "dofs": size, "value": nc * npt / ms * 1e3, "unit": "entries/s",
             "ms_per_call": ms, "ms_per_call_with_range_check_sync": res[1], "last_writer_spot_check": "ok" if ok else "MISMATCH",
             "kernels": ["hipMemsetAsync(owner)", "assign_owner", "assign_store"], "dtype": "f64 values / int32 dofs",
+            "plan": {"ms_per_call": ms_plan, "equal_to_dxo_assign": plan_equal, "kernels": ["assign_apply"],
+                     "meaning": "dxo_assign_plan_create once per dofmap, then dxo_assign_apply per call: one gather coeff[d] = values[src[d]]",
+                     "roofline": {**_hbm(size * (4 + 8 + 8), ms_plan),
+                                  "note": "algorithmic bytes of the planned form: a 4-byte source position, the winning value and the coefficient entry per dof"}},
             "roofline": {**_hbm(by, ms), "algorithmic_bytes_per_call": by,
                          "note": "implementation traffic is higher by construction: an 8-byte owner word per dof is cleared, updated with atomicMax "
                                  "(one per entry) and read back per entry so that the result is the reference's sequential one, not a race"}}

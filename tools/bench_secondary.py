@@ -541,6 +541,7 @@ TRAFFIC_KEYS = {
     ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2>", "all"),
     ("device_loop_p2tri", ("calls", "state_commit", "roofline")): ("vm_commit(", "second_half"),
     ("assign_cg", ("roofline",)): ("assign_owner(", "all"),
+    ("assign_cg", ("plan", "roofline")): ("assign_apply<", "all"),
 }
 FOLLOWERS = ("node_sum<", "assign_store(")
 
