@@ -41,6 +41,9 @@
 #ifndef DXO_TA_KO
 #define DXO_TA_KO 0          // knock-out experiments (wrong results!): 1 no element-vector stores, 2 no tangent loads, 4 no dof gather
 #endif
+#ifndef DXO_TA_RS
+#define DXO_TA_RS 1          // Q2 hexahedra: scatter phase in registers with a DPP reduce-scatter (scatter_rs)
+#endif
 #ifndef DXO_TA_STAGE
 #define DXO_TA_STAGE 1       // tangent rows requested lane-linear and passed through LDS (TangentRows) instead of row-per-lane loads
 #endif
@@ -308,6 +311,87 @@ __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int
     }
 }
 
+// ---- scatter phase in registers for cells of EIGHT points and at most 32 nodes (Q2 / Q1 hexahedra): `scatter_rs`.
+// The element-vector entry f_(a,i) = sum_q sum_k T_q[i][k] dphi_a,k(q) is a sum over the cell's 8 points = the 8 lanes that hold
+// the T_q. The round-3 form parked every T_q in LDS and let lane = (cell, node) read 96 words per entry: the kernel was bound by
+// LDS wave-instructions (profiles/r04_adjoint_experiments.txt: 1.0 ms with ALL global traffic knocked out). Here every lane forms
+// its point's partial of every entry and the 8 lanes are summed by a REDUCE-SCATTER over DPP lane permutations: three rounds
+// (partner q^7 by row_half_mirror, q^2 and q^1 by quad_perm), each halving the number of live partials, 7 exchanges per 8
+// partials instead of the 24 of a butterfly. For the rounds to pair equal entries without selects, lane q evaluates register
+// j = (h, m, l) at node (16h + 8m + 4l + t) XOR M(q), M(q) = 28 b2 ^ 8 b1 ^ 4 b0 (M(q^7) ^ M(q) = 16, M(q^2) ^ M(q) = 8,
+// M(q^1) ^ M(q) = 4), so after the three rounds lane q owns nodes M(q) .. M(q)+3. The table is padded to 32 nodes x 4 doubles
+// with zeros (nodes >= ndofs contribute nothing and are not stored). LDS traffic of the phase: 64 reads per lane and group
+// instead of 393, no parking, no fences; the order of the additions is fixed (bit-reproducible).
+constexpr int RS_NODES = 32, RS_TAB = 8 * RS_NODES * 4;      // padded table [q][node][4]
+
+template <int CTRL>
+__device__ __forceinline__ double rs_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int RS_HALF_MIRROR = 0x141, RS_XOR2 = 0x4E, RS_XOR1 = 0xB1;   // row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]
+
+__device__ __forceinline__ void rs_fill_table(const OperandDev& m, double* tabP) {
+    for (int e = threadIdx.x; e < RS_TAB; e += blockDim.x) {
+        const int k = e & 3, a = (e >> 2) & (RS_NODES - 1), q = e >> 7;
+        tabP[e] = (k < 3 && a < m.ndofs) ? m.dphi[(q * m.ndofs + a) * 3 + k] : 0.0;
+    }
+}
+
+struct RsLane {
+    const double* row[8];     // table row of register j = (h, m, l) at t = 0
+    int node0;                // M(q): first of the four nodes this lane owns after the reduction
+    __device__ __forceinline__ RsLane(const double* tabP, int lane) {
+        const int q = lane & 7;
+        node0 = ((q & 4) ? 28 : 0) ^ ((q & 2) ? 8 : 0) ^ ((q & 1) ? 4 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = tabP + (q * RS_NODES + ((4 * j) ^ node0)) * 4;      // 4 j = 16 h + 8 m + 4 l
+    }
+};
+
+// T[i][k] = w|detJ| sum_j gh[i][j] K[k][j] of this lane's point (zero for lanes without a point) -> the cell's element vector
+template <int ND>
+__device__ __forceinline__ void scatter_rs(const OperandDev& m, const RsLane& rs, const double (&T)[3][3], int lane, int64_t c0, int ncell,
+                                           double* __restrict__ out, double* __restrict__ fe) {
+    const int c = lane >> 3;
+    const int64_t cell = c0 + c;
+    // one group of four table rows at a time (not unrolled: the compiler would hoist all 64 table reads of the phase into registers)
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        double d[8][3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const dxo_f64x2 a = *reinterpret_cast<const dxo_f64x2*>(rs.row[j] + 4 * t);
+            d[j][0] = a.x; d[j][1] = a.y; d[j][2] = rs.row[j][4 * t + 2];
+        }
+        double o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = T[i][0] * d[j][0] + T[i][1] * d[j][1] + T[i][2] * d[j][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] += rs_dpp<RS_HALF_MIRROR>(p[4 + j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) p[j] += rs_dpp<RS_XOR2>(p[2 + j]);
+            o[i] = p[0] + rs_dpp<RS_XOR1>(p[1]);
+        }
+        const int a = rs.node0 + t;
+        if (c >= ncell || a >= ND) continue;
+        if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) continue;
+        if (fe) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+        } else {
+            const int64_t node = m.dofmap[cell * ND + a];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
+        }
+    }
+}
+
 // K v without K: gather v, eps(v) per point, t = C_tang e, scatter B^T t (bs = gdim, Mandel pairing).
 // Round 4: the kernel spent two thirds of its wave cycles parked in s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.65) — the
 // dofmap -> v gather was a dependent pair of scattered loads issued and awaited inside every group, and the point's 36
@@ -322,15 +406,19 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
                                                               double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
+    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= RS_NODES;   // launched only for nq = 8 (see dxo_tangent_apply)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
+    double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;     // behind the waves' regions (RS only)
+    if constexpr (RS) rs_fill_table(m, tabP);
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     double* W = lds + m.table_doubles + wave * lds_wave;
     const int cpw = m.cells_per_wave;
     double* Tm = W + cpw * (op_odd(m.ndofs * G) + op_odd(m.ngeom * G));
+    const RsLane rs(tabP, lane);
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
     const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
     const int64_t stride = walk.stride;
@@ -361,7 +449,9 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
         // the tangent of this lane's point: requested now, used after the contraction
 #if DXO_TA_STAGE
         TangentRows<D> rows;
+#if DXO_TA_EARLY_C
         rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
+#endif
 #else
         dxo_f64x2 Cq[CV];
         const dxo_f64x2* Cp = reinterpret_cast<const dxo_f64x2*>(C_tang + (c0 * m.nq + lane) * (D * D));
@@ -398,6 +488,9 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
 #pragma unroll
             for (int k = 0; k < D; ++k) e[k] = 0.0;
         }
+#if !DXO_TA_EARLY_C
+        rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
+#endif
         rows.times(W, lane, e, t);     // compute_geo has fenced: the gather buffer is free, the parked tensors are not written yet
         if (active) {
             scale = w_l * fabs(det);
@@ -424,7 +517,21 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
             dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
         }
 #endif
-        adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
+        if constexpr (RS) {
+            double T[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
+                    T[i][k] = scale * tt;          // scale = 0 (and gh = 0) for lanes without a point
+                }
+            scatter_rs<ND_CT>(m, rs, T, lane, c0, ncell, out, fe);
+        } else {
+            adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
+        }
     }
 }
 
@@ -594,6 +701,15 @@ int diag_lds_wave(const dxo_mesh* m) {
     return (wd + 1) & ~1;
 }
 
+// tangent_apply with the register scatter (scatter_rs) parks nothing: gather buffer or the staging space of the tangent rows
+int apply_rs_lds_wave(const dxo_mesh* m) {
+    const OperandDev& v = m->dev;
+    const int G = m->gdim, D = G == 2 ? 4 : 6;
+    int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G));
+    if (wd < TR_PC * D * D) wd = TR_PC * D * D;
+    return (wd + 1) & ~1;
+}
+
 int adjoint_lds_wave(const dxo_mesh* m) {
     const OperandDev& v = m->dev;
     const int G = m->gdim;
@@ -758,8 +874,9 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (mesh->num_cells == 0) return DXO_OK;
     if (!C_tang || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
     if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang must be 16-byte aligned");
-    const int wd = adjoint_lds_wave(mesh);
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
+    const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;
+    const int wd = rs ? apply_rs_lds_wave(mesh) : adjoint_lds_wave(mesh);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? RS_TAB : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -773,7 +890,7 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     blocks = (blocks + 7) / 8 * 8;
     if (mesh->gdim == 2)
         hipLaunchKernelGGL((tangent_apply<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
-    else if (mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8)    // Q2 hexahedra: trip counts known at compile time
+    else if (mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8)    // Q2 hexahedra, 2x2x2 rule: trip counts known at compile time
         hipLaunchKernelGGL((tangent_apply<3, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
     else
         hipLaunchKernelGGL((tangent_apply<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
