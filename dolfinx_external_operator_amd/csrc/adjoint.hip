@@ -19,6 +19,7 @@
 #include "dxo_common.h"
 #include "operand_core.h"
 #include "adjoint_cell.h"
+#include "cell8_dpp.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -43,6 +44,12 @@
 #endif
 #ifndef DXO_TA_RS
 #define DXO_TA_RS 1          // Q2 hexahedra: scatter phase in registers with a DPP reduce-scatter (scatter_rs)
+#endif
+#ifndef DXO_TA_C8_FORWARD
+#define DXO_TA_C8_FORWARD 0  // experiment: tangent_apply_c8 (contraction across the lanes as well); slower, see the kernel's comment
+#endif
+#ifndef DXO_C8_EARLY_C
+#define DXO_C8_EARLY_C 0     // tangent_apply_c8: 0 = the tangent rows are requested after the contraction (72 registers the pass does not have)
 #endif
 #ifndef DXO_TA_STAGE
 #define DXO_TA_STAGE 1       // tangent rows requested lane-linear and passed through LDS (TangentRows) instead of row-per-lane loads
@@ -311,87 +318,6 @@ __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int
     }
 }
 
-// ---- scatter phase in registers for cells of EIGHT points and at most 32 nodes (Q2 / Q1 hexahedra): `scatter_rs`.
-// The element-vector entry f_(a,i) = sum_q sum_k T_q[i][k] dphi_a,k(q) is a sum over the cell's 8 points = the 8 lanes that hold
-// the T_q. The round-3 form parked every T_q in LDS and let lane = (cell, node) read 96 words per entry: the kernel was bound by
-// LDS wave-instructions (profiles/r04_adjoint_experiments.txt: 1.0 ms with ALL global traffic knocked out). Here every lane forms
-// its point's partial of every entry and the 8 lanes are summed by a REDUCE-SCATTER over DPP lane permutations: three rounds
-// (partner q^7 by row_half_mirror, q^2 and q^1 by quad_perm), each halving the number of live partials, 7 exchanges per 8
-// partials instead of the 24 of a butterfly. For the rounds to pair equal entries without selects, lane q evaluates register
-// j = (h, m, l) at node (16h + 8m + 4l + t) XOR M(q), M(q) = 28 b2 ^ 8 b1 ^ 4 b0 (M(q^7) ^ M(q) = 16, M(q^2) ^ M(q) = 8,
-// M(q^1) ^ M(q) = 4), so after the three rounds lane q owns nodes M(q) .. M(q)+3. The table is padded to 32 nodes x 4 doubles
-// with zeros (nodes >= ndofs contribute nothing and are not stored). LDS traffic of the phase: 64 reads per lane and group
-// instead of 393, no parking, no fences; the order of the additions is fixed (bit-reproducible).
-constexpr int RS_NODES = 32, RS_TAB = 8 * RS_NODES * 4;      // padded table [q][node][4]
-
-template <int CTRL>
-__device__ __forceinline__ double rs_dpp(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-constexpr int RS_HALF_MIRROR = 0x141, RS_XOR2 = 0x4E, RS_XOR1 = 0xB1;   // row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]
-
-__device__ __forceinline__ void rs_fill_table(const OperandDev& m, double* tabP) {
-    for (int e = threadIdx.x; e < RS_TAB; e += blockDim.x) {
-        const int k = e & 3, a = (e >> 2) & (RS_NODES - 1), q = e >> 7;
-        tabP[e] = (k < 3 && a < m.ndofs) ? m.dphi[(q * m.ndofs + a) * 3 + k] : 0.0;
-    }
-}
-
-struct RsLane {
-    const double* row[8];     // table row of register j = (h, m, l) at t = 0
-    int node0;                // M(q): first of the four nodes this lane owns after the reduction
-    __device__ __forceinline__ RsLane(const double* tabP, int lane) {
-        const int q = lane & 7;
-        node0 = ((q & 4) ? 28 : 0) ^ ((q & 2) ? 8 : 0) ^ ((q & 1) ? 4 : 0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) row[j] = tabP + (q * RS_NODES + ((4 * j) ^ node0)) * 4;      // 4 j = 16 h + 8 m + 4 l
-    }
-};
-
-// T[i][k] = w|detJ| sum_j gh[i][j] K[k][j] of this lane's point (zero for lanes without a point) -> the cell's element vector
-template <int ND>
-__device__ __forceinline__ void scatter_rs(const OperandDev& m, const RsLane& rs, const double (&T)[3][3], int lane, int64_t c0, int ncell,
-                                           double* __restrict__ out, double* __restrict__ fe) {
-    const int c = lane >> 3;
-    const int64_t cell = c0 + c;
-    // one group of four table rows at a time (not unrolled: the compiler would hoist all 64 table reads of the phase into registers)
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-        double d[8][3];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const dxo_f64x2 a = *reinterpret_cast<const dxo_f64x2*>(rs.row[j] + 4 * t);
-            d[j][0] = a.x; d[j][1] = a.y; d[j][2] = rs.row[j][4 * t + 2];
-        }
-        double o[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double p[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = T[i][0] * d[j][0] + T[i][1] * d[j][1] + T[i][2] * d[j][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[j] += rs_dpp<RS_HALF_MIRROR>(p[4 + j]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) p[j] += rs_dpp<RS_XOR2>(p[2 + j]);
-            o[i] = p[0] + rs_dpp<RS_XOR1>(p[1]);
-        }
-        const int a = rs.node0 + t;
-        if (c >= ncell || a >= ND) continue;
-        if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) continue;
-        if (fe) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
-        } else {
-            const int64_t node = m.dofmap[cell * ND + a];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
-        }
-    }
-}
-
 // K v without K: gather v, eps(v) per point, t = C_tang e, scatter B^T t (bs = gdim, Mandel pairing).
 // Round 4: the kernel spent two thirds of its wave cycles parked in s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.65) — the
 // dofmap -> v gather was a dependent pair of scattered loads issued and awaited inside every group, and the point's 36
@@ -406,19 +332,21 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
                                                               double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
-    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= RS_NODES;   // launched only for nq = 8 (see dxo_tangent_apply)
+    // cells of 8 points and at most 32 nodes (launched so only for nq = 8): the scatter phase runs in registers, a DPP
+    // reduce-scatter over the cell's 8 lanes (cell8_dpp.h) instead of parked tensors and 96 LDS reads per (cell, node) pair
+    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
     double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;     // behind the waves' regions (RS only)
-    if constexpr (RS) rs_fill_table(m, tabP);
+    if constexpr (RS) c8_fill_tables(m, tabP);
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     double* W = lds + m.table_doubles + wave * lds_wave;
     const int cpw = m.cells_per_wave;
     double* Tm = W + cpw * (op_odd(m.ndofs * G) + op_odd(m.ngeom * G));
-    const RsLane rs(tabP, lane);
+    const C8Lane L8(tabP, lane);
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
     const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
     const int64_t stride = walk.stride;
@@ -526,12 +454,128 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
                     double tt = 0.0;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
-                    T[i][k] = scale * tt;          // scale = 0 (and gh = 0) for lanes without a point
+                    T[i][k] = scale * tt;          // scale = 0 and gh = 0 for lanes without a point
                 }
-            scatter_rs<ND_CT>(m, rs, T, lane, c0, ncell, out, fe);
+            const int64_t cell = c0 + (lane >> 3);
+            c8_scatter<ND_CT>(L8, T, [&](int a, const double (&o)[3]) {
+                if (!active) return;
+                if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) return;
+                if (fe) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+                } else {
+                    const int64_t node = m.dofmap[cell * ND_CT + a];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
+                }
+            });
         } else {
             adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
         }
+    }
+}
+
+// EXPERIMENT, not launched by default (-DDXO_TA_C8_FORWARD=1): the same operator with the strain contraction ALSO across the lanes
+// — NO gather buffer in LDS, dof values and vertex coordinates go from global memory into the registers of the lane that owns
+// them and are all-gathered over the cell's 8 lanes (cell8_dpp.h). Correct (tests/test_adjoint_gpu.py passes on it) but slower
+// than the shipped hybrid (LDS gather + contraction, DPP scatter): 1.65 against 1.31 ms per 10^7 points — the all-gather is 210
+// dependent DPP moves per lane and group that the two resident waves per SIMD do not cover, while LDS reads are asynchronous;
+// it also needs the tangent rows requested late (they do not fit beside the contraction's registers: 23 spilled otherwise).
+template <int ND>
+__global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply_c8(OperandDev m, const double* __restrict__ wq,
+                                                                 const double* __restrict__ C_tang, const double* __restrict__ v,
+                                                                 int64_t n_cells, double* __restrict__ out, double* __restrict__ fe) {
+    constexpr int D = 6;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    c8_fill_tables(m, lds);
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* W = lds + C8_LDS + wave * TangentRows<D>::LDS_DOUBLES;
+    const C8Lane L(lds, lane);
+    constexpr int cpw = 8;
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    C8Pipe pf;
+    int64_t grp = walk.first;
+    c8_load_indices<ND>(m, pf, L, grp * cpw, cells_in(grp), lane);
+    c8_load_values(m, pf, v);
+    c8_load_indices<ND>(m, pf, L, (grp + stride) * cpw, cells_in(grp + stride), lane);
+    const double w_l = wq[lane & 7];
+    for (; grp < walk.end; grp += stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = cells_in(grp);
+        const bool has_point = (lane >> 3) < ncell;
+        TangentRows<D> rows;
+#if DXO_C8_EARLY_C
+        rows.request(C_tang, c0 * 8, ncell * 8, lane);
+#endif
+        // pf.ud / pf.xd hold THIS group's values (requested during the last iteration), pf.un / pf.xn the next group's indices
+        double K[3][3], gref[3][3];
+        const double det = c8_geometry(L, pf.xd, K);
+        c8_forward(L, pf.ud, gref);
+        // consumed in place: now the next group's values (indices have been here for an iteration) and the indices of the one after;
+        // their latency runs under the tangent product and the scatter phase of this group and the geometry of the next
+        c8_load_values(m, pf, v);
+        c8_load_indices<ND>(m, pf, L, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+        double e[D];
+        {
+            double val[3] = {0.0, 0.0, 0.0}, g[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sacc += gref[i][k] * K[k][j];
+                    g[i][j] = sacc;
+                }
+            shape_operand<3, 3, DXO_OPERAND_EPS_MANDEL>(val, g, e);
+        }
+        if (!has_point) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[k] = 0.0;
+        }
+#if !DXO_C8_EARLY_C
+        __builtin_amdgcn_sched_barrier(0);     // keep the 18 row loads (72 registers) below the contraction
+        rows.request(C_tang, c0 * 8, ncell * 8, lane);
+#endif
+        double t6[D];
+        rows.times(W, lane, e, t6);
+        double T[3][3];
+        {
+            double vh[3], gh[3][3];
+            dual_tensor<3, 3, DXO_OPERAND_EPS_MANDEL>(t6, vh, gh);
+            const double scale = w_l * fabs(det);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
+                    T[i][k] = has_point ? scale * tt : 0.0;      // lanes without a point: zero vertices, singular J
+                }
+        }
+        const int64_t cell = c0 + (lane >> 3);
+        c8_scatter<ND>(L, T, [&](int a, const double (&o)[3]) {
+            if (!has_point) return;
+            if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) return;
+            if (fe) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+            } else {
+                const int64_t node = m.dofmap[cell * ND + a];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
+            }
+        });
     }
 }
 
@@ -701,7 +745,7 @@ int diag_lds_wave(const dxo_mesh* m) {
     return (wd + 1) & ~1;
 }
 
-// tangent_apply with the register scatter (scatter_rs) parks nothing: gather buffer or the staging space of the tangent rows
+// tangent_apply with the register scatter parks nothing: the gather buffer, or the staging space of the tangent rows
 int apply_rs_lds_wave(const dxo_mesh* m) {
     const OperandDev& v = m->dev;
     const int G = m->gdim, D = G == 2 ? 4 : 6;
@@ -874,9 +918,11 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (mesh->num_cells == 0) return DXO_OK;
     if (!C_tang || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
     if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang must be 16-byte aligned");
-    const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;
+    const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
+    const bool c8 = rs && DXO_TA_C8_FORWARD;
     const int wd = rs ? apply_rs_lds_wave(mesh) : adjoint_lds_wave(mesh);
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? RS_TAB : 0)) * sizeof(double);
+    const size_t shm = c8 ? (size_t)(C8_LDS + 4 * TangentRows<6>::LDS_DOUBLES) * sizeof(double)
+                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -888,9 +934,11 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
-    if (mesh->gdim == 2)
+    if (c8)
+        hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
+    else if (mesh->gdim == 2)
         hipLaunchKernelGGL((tangent_apply<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
-    else if (mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8)    // Q2 hexahedra, 2x2x2 rule: trip counts known at compile time
+    else if (rs)    // Q2 hexahedra, 2x2x2 rule: trip counts known at compile time, scatter phase in registers (instantiated for nq = 8 only)
         hipLaunchKernelGGL((tangent_apply<3, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
     else
         hipLaunchKernelGGL((tangent_apply<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
