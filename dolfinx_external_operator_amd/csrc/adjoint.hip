@@ -588,7 +588,8 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply_c8(OperandDev m, c
 // at the top of the iteration, and parks them in the wave's LDS slice; phase 2, lane = (cell, node), sums
 // dphi_k dphi_k' NS_i[kk'] over the cell's points. Before, phase 2 read the 36 entries of C_q from global memory for every
 // (node, point) pair — 27 times each on Q2 hexahedra: 4.5 ms per 10^7 points, 2.3 matvecs' worth; now see profiles/README.md.
-template <int G>
+// ND_CT > 0 (launched for cells of 8 points, at most 32 nodes): phase 2 in registers with the DPP reduce-scatter of cell8_dpp.h.
+template <int G, int ND_CT = 0>
 __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                             const double* __restrict__ C_tang, int64_t n_cells,
                                                             double* __restrict__ out, double* __restrict__ fe) {
@@ -597,14 +598,18 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
     constexpr int NS1 = G * (G + 1) / 2;            // unique entries of one symmetrised matrix
     constexpr int PT = (G * NS1) | 1;               // odd per-point stride (bank spread across cells)
     constexpr double r2 = 0.70710678118654752440;
+    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
+    double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;
+    if constexpr (RS) c8_fill_tables(m, tabP);
     __syncthreads();
     const OperandLayout<G> L(m);
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     double* W = lds + m.table_doubles + wave * lds_wave;
+    const C8Lane L8(tabP, lane);
     const int cpw = m.cells_per_wave, nd = m.ndofs, nq = m.nq, ng = m.ngeom;
     const int sx = op_odd(ng * G);
     double* X = W;
@@ -636,6 +641,9 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
             for (int j = 0; j < G; ++j) X[c * sx + v * G + j] = m.x[node * G + j];
         }
         op_fence();
+        double NSr[G * NS1];             // RS: this point's matrices stay in registers
+#pragma unroll
+        for (int k = 0; k < G * NS1; ++k) NSr[k] = 0.0;
         if (has_point) {
             const double* dpsi = tab + L.o_dpsi + q_l * L.sdpsi;
             const double* Xc = X + c_l * sx;
@@ -691,10 +699,56 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
                             a += KM[k][jj] * K[kk][jj];
                             b += KM[kk][jj] * K[k][jj];
                         }
-                        Pm[lane * PT + i * NS1 + slot] = scale * (k == kk ? a : a + b);
+                        if constexpr (RS) NSr[i * NS1 + slot] = scale * (k == kk ? a : a + b);
+                        else Pm[lane * PT + i * NS1 + slot] = scale * (k == kk ? a : a + b);
                         ++slot;
                     }
             }
+        }
+        if constexpr (RS) {
+            // phase 2 in registers: every lane forms its point's partial of K_(a,i),(a,i) for 8 nodes at a time and the cell's 8
+            // lanes reduce-scatter them (cell8_dpp.h); the lane ends up with the entries of its own four nodes
+            const int64_t cell = c0 + (lane >> 3);
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {
+                double pp[8][NS1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double* r = L8.row(j, t);
+                    const dxo_f64x2 a = *reinterpret_cast<const dxo_f64x2*>(r);
+                    const double d[3] = {a.x, a.y, r[2]};
+                    int slot = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int kk = k; kk < 3; ++kk) pp[j][slot++] = d[k] * d[kk];
+                }
+                double o[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    double pj[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        double tt = 0.0;
+#pragma unroll
+                        for (int s2 = 0; s2 < NS1; ++s2) tt += pp[j][s2] * NSr[i * NS1 + s2];
+                        pj[j] = tt;
+                    }
+                    o[i] = c8_reduce_scatter(pj);
+                }
+                const int a = L8.node0 + t;
+                if (!has_point || a >= ND_CT) continue;
+                if (fe) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+                } else {
+                    const int64_t node = m.dofmap[cell * ND_CT + a];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
+                }
+            }
+            op_fence();      // the staging slice (Pm) is rewritten by the next group's tangent rows
+            continue;
         }
         op_fence();
         for (int idx = lane; idx < ncell * nd; idx += DXO_WAVE) {
@@ -889,8 +943,9 @@ extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
     if (mesh->num_cells == 0) return DXO_OK;
     if (!C_tang || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: NULL array");
     if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang must be 16-byte aligned");
+    const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
     const int wd = diag_lds_wave(mesh);
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd) * sizeof(double);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -903,9 +958,10 @@ extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     if (mesh->gdim == 2)
-        hipLaunchKernelGGL(tangent_diag<2>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+        hipLaunchKernelGGL((tangent_diag<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
     else
-        hipLaunchKernelGGL(tangent_diag<3>, dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+        if (rs) hipLaunchKernelGGL((tangent_diag<3, 27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+        else    hipLaunchKernelGGL((tangent_diag<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
     if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
 }
