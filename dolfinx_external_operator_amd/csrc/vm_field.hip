@@ -31,6 +31,9 @@ namespace {
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
+#ifndef DXO_VMF_KO
+#define DXO_VMF_KO 0    // knock-out experiments (wrong results): 1 no stores, 2 no state loads, 4 no dof gather
+#endif
 #ifndef DXO_VMF_BLOCKS_PER_CU
 #define DXO_VMF_BLOCKS_PER_CU 16
 #endif
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         bool active;
         if (piped) {
             pipe_commit<G, G>(m, pf, W, ncell, lane);
-            pipe_load_values<G, G>(m, pf, u);
-            pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+            if (!(DXO_VMF_KO & 4)) {
+                pipe_load_values<G, G>(m, pf, u);
+                pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
+            }
             active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e);
         } else {
             active = operand_point<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, e);
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
             const int idx = k * DXO_WAVE + lane;
-            Y2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{0.0, 0.0};
+            Y2[idx] = (idx < nvec && !(DXO_VMF_KO & 2)) ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
         }
-        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
+        const double p_l = (lane < npts && !(DXO_VMF_KO & 2)) ? p[p0 + lane] : 0.0;
 #endif
         wave_lds_fence();
         double sn[D];
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         }
         Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
         wave_lds_fence();
+        if ((DXO_VMF_KO & 1) && dp != 1.2345e300) { wave_lds_fence(); continue; }
         if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);
         dxo_f64x2* g_o = reinterpret_cast<dxo_f64x2*>(sigma + p0 * D);
 #pragma unroll
