@@ -39,6 +39,11 @@ if [ -z "$QUICK" ]; then
   pass icnn_p1 $IC -- SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_VALU
   pass icnn_p2 $IC -- SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
   pass icnn_p3 $IC -- SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
+  DL="tools/bench_secondary.py --child --legs device_loop_q2hex,device_loop_p2tri,assign_cg"   # the device-resident Newton iteration + assigner
+  pass dl_fetch $DL -- FETCH_SIZE
+  pass dl_write $DL -- WRITE_SIZE
+  pass dl_sq1 $DL -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+  pass dl_sq2 $DL -- SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
   OP="scripts/bench_operand.py --launches 2 --case 0 --operand-cell 0"
   pass field_fetch $OP -- FETCH_SIZE
   pass field_write $OP -- WRITE_SIZE

@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 out, tag = pathlib.Path(sys.argv[1]), sys.argv[2]
-ours = ("vm_", "mc_", "icnn_", "isihara", "heat_", "operand_", "adjoint", "node_sum", "assign", "stream_probe", "cond_", "arena_sweep")
+ours = ("vm_", "mc_", "icnn_", "isihara", "heat_", "operand_", "adjoint", "tangent_", "node_sum", "assign", "stream_probe", "cond_", "arena_sweep")
 
 
 def short(name):
@@ -183,3 +183,32 @@ if fd:
             d[k + "_tcc_miss_MB"] = c["TCC_MISS_sum"] * 128 / 1e6
     (out / f"{tag}_field_pmc.json").write_text(json.dumps({"counters": fd, "derived": d}, indent=1))
     print("== operand / vm_field:", json.dumps(d))
+
+# ---- device-resident Newton iteration (tools/bench_device_loop.py): HBM bytes per call and SQ ratios per kernel
+dl_files = {c: list((out / d).rglob("*counter_collection.csv")) for c, d in (("FETCH_SIZE", "dl_fetch"), ("WRITE_SIZE", "dl_write"))}
+if all(dl_files.values()):
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+    from tools import bench_secondary as bs
+
+    f, w = bs.parse_counter_csv(dl_files["FETCH_SIZE"], "FETCH_SIZE"), bs.parse_counter_csv(dl_files["WRITE_SIZE"], "WRITE_SIZE")
+    rec = {"hbm_bytes_per_call": {}, "note": "bytes = counter x 1024, FETCH_SIZE x 2 (upper bound for the gather-heavy kernels); node_sum / "
+                                             "assign_store dispatches added to the call that launched them (tools/bench_secondary.py)"}
+    for (leg, path), (key, which) in bs.TRAFFIC_KEYS.items():
+        if not leg.startswith(("device_loop", "assign")):
+            continue
+        fb, wb = bs._pick(f.get(key), which), bs._pick(w.get(key), which)
+        if fb is not None and wb is not None:
+            rec["hbm_bytes_per_call"][leg + ":" + "/".join(path[:-1] or ("call",))] = {"kernel": key, "fetch_x2": 2 * fb, "write": wb, "total": 2 * fb + wb}
+    names = ("tangent_apply<", "tangent_diag<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
+    sq = counters(["dl_sq1", "dl_sq2"], lambda n: next((k + n.split(k, 1)[1].split("(")[0] for k in names if k in n), None))
+    ratios = {}
+    for k, c in sq.items():
+        wc = c.get("SQ_WAVE_CYCLES")
+        if wc:
+            ratios[k] = {r: round(c[r] / wc, 3) for r in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS") if r in c}
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                ratios[k]["lds_bank_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
+    rec["sq_counters_sampled"] = sq
+    rec["sq_ratios_of_wave_cycles"] = ratios
+    (out / f"{tag}_device_loop_pmc.json").write_text(json.dumps(rec, indent=1))
+    print("== device loop:", json.dumps(rec["hbm_bytes_per_call"]), json.dumps(ratios))
