@@ -27,7 +27,12 @@
 namespace {
 
 constexpr int C8_NODES = 32;
-constexpr int C8_TAB = 8 * C8_NODES * 4;        // doubles: [q][node][dphi_x, dphi_y, dphi_z, 0]
+// per-point stride of the dphi table: 32 rows of 4 doubles + 2. The 8 lanes of a cell read 8 different rows in one instruction —
+// row (4j + t) ^ M(q) of point q — and with the natural stride (256 dwords = 0 mod 64 banks) those rows fall on two bank
+// positions only (M(q) mod 8 is 0 or 4): a 4-way conflict, a third to a half of the kernels' LDS cycles
+// (profiles/r04_device_loop_pmc.json). With 4 dwords more per point the 8 reads land on 8 different 4-bank slots.
+constexpr int C8_QSTRIDE = C8_NODES * 4 + 2;
+constexpr int C8_TAB = 8 * C8_QSTRIDE;          // doubles: [q][node][dphi_x, dphi_y, dphi_z, 0] (+ 2 per q)
 constexpr int C8_GEO = 8 * 8 * 4;               // doubles: [q][vertex][dpsi_x, dpsi_y, dpsi_z, 0]
 constexpr int C8_LDS = C8_TAB + C8_GEO;
 constexpr int C8_HALF_MIRROR = 0x141, C8_XOR2 = 0x4E, C8_XOR1 = 0xB1;   // row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]
@@ -62,9 +67,9 @@ __device__ __forceinline__ double c8_reduce_scatter(double (&p)[8]) {
 
 // whole workgroup, followed by __syncthreads() in the caller
 __device__ __forceinline__ void c8_fill_tables(const OperandDev& m, double* tabP) {
-    for (int e = threadIdx.x; e < C8_TAB; e += blockDim.x) {
+    for (int e = threadIdx.x; e < 8 * C8_NODES * 4; e += blockDim.x) {
         const int k = e & 3, a = (e >> 2) & (C8_NODES - 1), q = e >> 7;
-        tabP[e] = (k < 3 && a < m.ndofs) ? m.dphi[(q * m.ndofs + a) * 3 + k] : 0.0;
+        tabP[q * C8_QSTRIDE + a * 4 + k] = (k < 3 && a < m.ndofs) ? m.dphi[(q * m.ndofs + a) * 3 + k] : 0.0;
     }
     for (int e = threadIdx.x; e < C8_GEO; e += blockDim.x) {
         const int k = e & 3, v = (e >> 2) & 7, q = e >> 5;
@@ -79,7 +84,7 @@ struct C8Lane {
     __device__ __forceinline__ C8Lane(const double* tabP, int lane) {
         q = lane & 7;
         node0 = ((q & 4) ? 28 : 0) ^ ((q & 2) ? 8 : 0) ^ ((q & 1) ? 4 : 0);
-        tabq = tabP + q * C8_NODES * 4;
+        tabq = tabP + q * C8_QSTRIDE;
         geoq = tabP + C8_TAB + q * 8 * 4;
     }
     // dphi row of register j in group t: node (4 j + t) ^ M(q)  (addresses are formed where they are used: two integers per lane

@@ -84,7 +84,7 @@ if args.diag:
 # Not HBM-bound: the binding roof is the fp64 vector pipe; both are reported.
 out["roofline"] = {"bound": "hbm", "achieved": bpp * n / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                    "frac": bpp * n / ms / 1e6 / 8000.0,
-                   "note": "fp64-VALU/divergence-bound, see profiles/r01_mc_pmc_summary.json for the VALU-pipe fraction"}
+                   "note": "fp64-VALU/divergence-bound, see profiles/mc_flop.json and the round's *_mc_pmc.json for the VALU-pipe fraction"}
 if args.cpu:
     import os
     import time

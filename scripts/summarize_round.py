@@ -65,7 +65,7 @@ if trace:
             # in start order: calibration (dxo_vm_output_alloc), the plain-allocation leg, warm-up, the K timed steps; the headline
             # block's launches are the last W + K of that grid group before the secondary legs start -> take the K before the
             # first dispatch of any secondary kernel
-            first_secondary = min((dd[0][0] for nn, dd in disp.items() if nn.startswith(("mc_", "icnn_", "vm_field", "vm_tile<4"))), default=1 << 62)
+            first_secondary = min((dd[0][0] for nn, dd in disp.items() if nn.startswith(("mc_", "icnn_", "vm_field", "vm_tile<4", "heat_", "isihara", "tangent_", "adjoint", "assign"))), default=1 << 62)
             head = [d for d in ds if d[0] < first_secondary]
             timed = head[-K:]
             lines.append(f"{name}: {len(ds)} dispatches; the K = {K} timed steps (last {K} before the secondary legs): mean {sum(d[1] for d in timed) / len(timed) / 1e3:.1f} us "
@@ -80,8 +80,12 @@ if trace:
                      f"frac {prof['roofline']['frac']:.4f}, ms_per_step {prof['ms_per_step'] * 1e3:.1f} us")
         sec = prof.get("secondary", {})
         for k, v in sec.items():
+            if not isinstance(v, dict):
+                continue
             if "ms_per_launch" in v:
                 lines.append(f"#   secondary.{k}.ms_per_launch (HIP events, median) = {v['ms_per_launch'] * 1e3:.1f} us")
+            for c, cv in (v.get("calls") or {}).items():
+                lines.append(f"#   secondary.{k}.calls.{c}.ms_per_call (HIP events, median; fill + element kernel + node_sum) = {cv['ms_per_call'] * 1e3:.1f} us")
     (out / f"{tag}_kernel_trace_summary.txt").write_text("\n".join(lines) + "\n")
     print("== kernel trace summary\n" + "\n".join(lines))
 bj = out / "bench.json"
