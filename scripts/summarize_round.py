@@ -195,14 +195,14 @@ if all(dl_files.values()):
     from tools import bench_secondary as bs
 
     f, w = bs.parse_counter_csv(dl_files["FETCH_SIZE"], "FETCH_SIZE"), bs.parse_counter_csv(dl_files["WRITE_SIZE"], "WRITE_SIZE")
-    rec = {"hbm_bytes_per_call": {}, "note": "bytes = counter x 1024, FETCH_SIZE x 2 (upper bound for the gather-heavy kernels); node_sum / "
-                                             "assign_store dispatches added to the call that launched them (tools/bench_secondary.py)"}
+    rec = {"hbm_bytes_per_call": {}, "note": "bytes = counter x 1024; FETCH_SIZE x2 for streaming kernels, x1 for the gather kernels (FETCH_X1 in "
+                                             "tools/bench_secondary.py); node_sum / assign_store dispatches added to the call that launched them"}
     for (leg, path), (key, which) in bs.TRAFFIC_KEYS.items():
         if not leg.startswith(("device_loop", "assign")):
             continue
         fb, wb = bs._pick(f.get(key), which), bs._pick(w.get(key), which)
         if fb is not None and wb is not None:
-            rec["hbm_bytes_per_call"][leg + ":" + "/".join(path[:-1] or ("call",))] = {"kernel": key, "fetch_x2": 2 * fb, "write": wb, "total": 2 * fb + wb}
+            rec["hbm_bytes_per_call"][leg + ":" + "/".join(path[:-1] or ("call",))] = {"kernel": key, "fetch_corrected": fb, "write": wb, "total": fb + wb}
     names = ("tangent_apply<", "tangent_diag<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
     sq = counters(["dl_sq1", "dl_sq2"], lambda n: next((k + n.split(k, 1)[1].split("(")[0] for k in names if k in n), None))
     ratios = {}

@@ -24,15 +24,15 @@ def test_counter_parser_attributes_followers_and_halves(tmp_path):
             ("vm_field<2, true, 6, 3>(VmConst, ...)", 64, 5), ("vm_field<2, true, 6, 3>(VmConst, ...)", 640, 50),
             ("vm_commit(long, long, double*, ...)", 40, 30), ("vm_commit(long, long, double*, ...)", 40, 30)]
     got = bs.parse_counter_csv([_csv(tmp_path, "FETCH_SIZE", rows)], "FETCH_SIZE")
-    assert got["adjoint_cell_eps<3,"] == [[100, 1500 * 1024.0]]          # node_sum added to the call that launched it
-    assert got["tangent_apply<3,"] == [[100, 3500 * 1024.0]]
-    assert bs._pick(got["vm_commit("], "first_half") == 10 * 1024.0 and bs._pick(got["vm_commit("], "second_half") == 30 * 1024.0
-    assert bs._pick(got["vm_field<2,"]) == 50 * 1024.0                    # largest grid only (small set-up dispatches ignored)
+    assert got["adjoint_cell_eps<3,"] == [[100, 1500 * 1024.0]]          # node_sum added to the call that launched it; gather kernels: x1
+    assert got["tangent_apply<3,"] == [[100, (2 * 3000 + 500) * 1024.0]]  # streaming kernel x2, its node_sum x1
+    assert bs._pick(got["vm_commit("], "first_half") == 20 * 1024.0 and bs._pick(got["vm_commit("], "second_half") == 60 * 1024.0
+    assert bs._pick(got["vm_field<2,"]) == 100 * 1024.0                   # largest grid only (small set-up dispatches ignored)
     out = {"device_loop_q2hex": {"calls": {"internal_force": {"roofline": {"algorithmic_bytes_per_launch": 1024.0 * 1000}}}}}
     w = bs.parse_counter_csv([_csv(tmp_path, "WRITE_SIZE", rows)], "WRITE_SIZE")
     bs.apply_traffic(out, {"fetch": got, "write": w})
     r = out["device_loop_q2hex"]["calls"]["internal_force"]["roofline"]
-    assert r["traffic"] == (2 * 1500 + 1500) * 1024.0 and r["traffic_over_algorithmic"] == pytest.approx(4.5)
+    assert r["traffic"] == (1500 + 1500) * 1024.0 and r["traffic_over_algorithmic"] == pytest.approx(3.0)
 
 
 def test_every_traffic_key_names_a_registered_leg():

@@ -544,10 +544,17 @@ TRAFFIC_KEYS = {
     ("assign_cg", ("plan", "roofline")): ("assign_apply<", "all"),
 }
 FOLLOWERS = ("node_sum<", "assign_store(")
+# FETCH_SIZE on gfx950 tallies the 128-byte requests of wide coalesced reads (16 bytes per lane) at 64 bytes: x2 for the streaming
+# kernels (MI355X_MICROARCH.md). Kernels whose reads are 8-byte dofmap-indexed gathers or row-per-lane pieces issue 64-byte
+# requests, which the counter tallies in full: x1 (checked on dxo_operand_adjoint: counter 1.74 GB against 1.87 GB of reads by
+# count — the stress field, the element vectors read back by node_sum, its index arrays, geometry; x2 would claim 3.5 GB).
+# tangent_apply / tangent_diag read their 2.9 GB of tangent rows lane-linear (x2) and gather the rest: x2 is an upper bound there.
+FETCH_X1 = ("node_sum<", "assign_owner(", "assign_store(", "assign_apply<", "adjoint_cell_eps<", "operand_adjoint<")
 
 
 def parse_counter_csv(files, counter):
-    """-> {owner substring: [[grid, bytes] per call, in dispatch order]}, bytes = (the owner's counter + its followers') x 1024."""
+    """-> {owner substring: [[grid, bytes] per call, in dispatch order]}, bytes = (the owner's counter + its followers') x 1024,
+    FETCH_SIZE already corrected (x2 for streaming kernels, x1 for the gather kernels of FETCH_X1)."""
     import csv
 
     rows = []
@@ -560,12 +567,13 @@ def parse_counter_csv(files, counter):
     owners = sorted({k for k, _ in TRAFFIC_KEYS.values()})
     res, cur = {}, None
     for _did, name, grid, val in rows:
+        b = val * 1024.0 * (2.0 if counter == "FETCH_SIZE" and not any(k in name for k in FETCH_X1) else 1.0)
         key = next((k for k in owners if k in name), None)
         if key is not None:
-            cur = [grid, val * 1024.0]
+            cur = [grid, b]
             res.setdefault(key, []).append(cur)
         elif cur is not None and any(f in name for f in FOLLOWERS):
-            cur[1] += val * 1024.0
+            cur[1] += b
     return res
 
 
@@ -610,10 +618,11 @@ def measure_secondary_traffic(legs, n, field_cells, timeout_s=420):
             got[counter] = parse_counter_csv(files, counter)
     return {"fetch": got["FETCH_SIZE"], "write": got["WRITE_SIZE"],
             "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of tools/bench_secondary.py --child made by this run (two "
-                      "launches of every leg's kernels, plain allocations); bytes = counter*1024, FETCH_SIZE x2 (gfx950 under-count of wide "
-                      "coalesced reads, MI355X_MICROARCH.md); node_sum / assign_store dispatches are added to the call that launched them",
-            "fetch_note": "the x2 is calibrated for 16-byte-per-lane streaming reads; for kernels whose reads are dofmap-indexed 8-byte gathers "
-                          "(adjoint_cell_eps, tangent_apply, node_sum, assign_*) it is an upper bound"}
+                      "launches of every leg's kernels, plain allocations); bytes = counter*1024; FETCH_SIZE x2 for the streaming kernels (gfx950 "
+                      "under-count of wide coalesced reads, MI355X_MICROARCH.md), x1 for the gather kernels " + ", ".join(FETCH_X1) + "; node_sum / "
+                      "assign_store dispatches are added to the call that launched them",
+            "fetch_note": "tangent_apply / tangent_diag read their tangent rows lane-linear (x2 applies) and gather dofs and vertices (x1 would): "
+                          "x2 on the whole kernel is an upper bound there"}
 
 
 def apply_traffic(out, detail):
@@ -631,9 +640,9 @@ def apply_traffic(out, detail):
         fb, wb = _pick(detail["fetch"].get(key), which), _pick(detail["write"].get(key), which)
         if fb is None or wb is None:
             continue
-        total = 2.0 * fb + wb
+        total = fb + wb
         rec["traffic"] = total
-        rec["traffic_detail"] = {"fetch_bytes_x2": 2.0 * fb, "write_bytes": wb}
+        rec["traffic_detail"] = {"fetch_bytes_corrected": fb, "write_bytes": wb}
         alg = rec.get("algorithmic_bytes_per_launch") or rec.get("algorithmic_bytes_per_call")
         if alg:
             rec["traffic_over_algorithmic"] = total / alg
