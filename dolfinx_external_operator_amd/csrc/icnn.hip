@@ -16,12 +16,15 @@
 //                       hess_x y = sum_j w3p_j phi''(a2_j) g_j g_j^T + sum_i beta_i phi''(a1_i) A1_i A1_i^T,  beta = W2p^T delta
 //                     i.e. three mat-vec shaped products with the 64x64 matrix W2p per point: ~20.5 k FMA.
 //
-// Roofline: compute (fp32 VALU). 192 B/point of HBM traffic against ~45 kflop/point: > 200 flop/B.
-// Weights are wave-uniform: they are read through the scalar path (s_load into SGPRs) and enter the FMAs
-// as scalar operands; the per-point vectors h1, phi'(a1), beta live in VGPRs (3 x 64 floats per lane).
-// The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here): the default fp32
-// kernel is icnn_mfma_f32 below (five 64x64x64 GEMMs per 64-point wave tile on v_mfma_f32_32x32x2_f32); icnn_point is the
-// fp64-network path of the tolerance study and the cross-check of the MFMA kernel (option icnn_variant = 0).
+// Roofline: compute — the matrix pipe. 192 B/point of HBM traffic against ~45 kflop/point: > 200 flop/B.
+// The 64x64 products are a genuine dense contraction (SURVEY.md 8d notes MFMA is legitimate here): five 64x64x64 GEMMs per
+// 64-point wave tile. Kernels, by option icnn_variant:
+//   2 (DEFAULT)  icnn_mfma_bf16x3: every fp32 operand split exactly into three bf16 numbers, six products per term on
+//                v_mfma_f32_32x32x16_bf16 with fp32 accumulate — fp32-level results at 3/8 of the fp32-input pipe time
+//                (2.7-2.8 ms per 10^7 points, 0.36 of the bf16 MFMA peak issued)
+//   1            icnn_mfma_f32: the same GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32; 4.1 ms, 0.62 of that pipe's peak); cross-check
+//   0            icnn_point: lane per point on the vector pipe, weights through the scalar path (s_load into SGPRs); the
+//                fp64-network path of BASELINE config 5's tolerance study and the cross-check of both MFMA kernels
 #include <cmath>
 
 #include "dxo_common.h"
