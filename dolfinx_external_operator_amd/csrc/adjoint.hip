@@ -303,18 +303,116 @@ template <int BS>
 __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int64_t* __restrict__ ptr,
                                                       const uint32_t* __restrict__ ent, const double* __restrict__ fe,
                                                       double* __restrict__ out) {
+    // A node's sum is a chain of dependent loads (ptr -> ent -> fe) per entry: with one entry at a time the wave sat in s_waitcnt
+    // 92 % of its cycles (profiles/r04_device_loop_pmc.json). The entries are taken four at a time — the four indices, then the
+    // four element-vector pieces, are in flight together — and `out` is requested before the loop. The additions keep the order
+    // of the transposed dofmap (bit-reproducible, same result as the one-at-a-time form).
+    constexpr int U = 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += stride) {
-        double acc[BS];
+        const int64_t e0 = ptr[n], e1 = ptr[n + 1];
+        double acc[BS], cur[BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) acc[i] = 0.0;
-        for (int64_t e = ptr[n]; e < ptr[n + 1]; ++e) {
-            const double* f = fe + (int64_t)ent[e] * BS;
+        for (int i = 0; i < BS; ++i) {
+            acc[i] = 0.0;
+            cur[i] = out[n * BS + i];
+        }
+        for (int64_t e = e0; e < e1; e += U) {
+            uint32_t idx[U];
+            double f[U][BS];
 #pragma unroll
-            for (int i = 0; i < BS; ++i) acc[i] += f[i];
+            for (int k = 0; k < U; ++k) idx[k] = e + k < e1 ? ent[e + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+#pragma unroll
+                for (int i = 0; i < BS; ++i) f[k][i] = e + k < e1 ? fe[(int64_t)idx[k] * BS + i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (e + k < e1) {
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) acc[i] += f[k][i];
+                }
         }
 #pragma unroll
-        for (int i = 0; i < BS; ++i) out[n * BS + i] += acc[i];
+        for (int i = 0; i < BS; ++i) out[n * BS + i] = cur[i] + acc[i];
+    }
+}
+
+// Internal force on cells of eight points and at most 32 nodes (Q2 / Q1 hexahedra, 2x2x2 rule), kind EPS_MANDEL: no LDS staging at
+// all. Lane = (cell, point): vertex q of the cell goes from global memory into lane q's registers (requested one group ahead) and
+// the 8 lanes all-gather the coordinates for J (cell8_dpp.h); the point's stress row is three 16-byte loads at a 48-byte lane
+// stride (every line is used in full by consecutive lanes); the pulled-back tensor stays in registers and the element-vector
+// entries are reduce-scattered over the cell's lanes. ~100 registers. Replaces the lane = cell kernel (adjoint_cell_eps: the
+// whole cell in one lane's registers, one wave per SIMD, 0.56 ms per 10^7 points) on these elements.
+template <int ND>
+__global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8(OperandDev m, const double* __restrict__ wq, const double* __restrict__ S,
+                                                                int64_t n_cells, double* __restrict__ out, double* __restrict__ fe) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    c8_fill_tables(m, lds);
+    __syncthreads();
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const C8Lane L(lds, lane);
+    constexpr int cpw = 8;
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    const double w_l = wq[lane & 7];
+    const int c_l = lane >> 3, q_l = lane & 7;
+    auto vertex_index = [&](int64_t g) -> int32_t { return c_l < cells_in(g) ? m.geom_dofmap[(g * cpw + c_l) * 8 + q_l] : -1; };
+    auto vertex = [&](int32_t xn, double (&xv)[3]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[j] = xn >= 0 ? m.x[(int64_t)xn * 3 + j] : 0.0;
+    };
+    int64_t grp = walk.first;
+    int32_t xn = vertex_index(grp);
+    double xv[3];
+    vertex(xn, xv);
+    xn = vertex_index(grp + stride);
+    for (; grp < walk.end; grp += stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = cells_in(grp);
+        const bool has_point = c_l < ncell;
+        dxo_f64x2 s2[3];
+        {
+            const dxo_f64x2* Sp = reinterpret_cast<const dxo_f64x2*>(S + (c0 * 8 + lane) * 6);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s2[k] = has_point ? Sp[k] : dxo_f64x2{0.0, 0.0};
+        }
+        double K[3][3];
+        const double det = c8_geometry(L, xv, K);
+        vertex(xn, xv);                              // the next group's vertex (its index has been here for an iteration)
+        xn = vertex_index(grp + 2 * stride);
+        const double s[6] = {s2[0].x, s2[0].y, s2[1].x, s2[1].y, s2[2].x, s2[2].y};
+        double vh[3], gh[3][3], T[3][3];
+        dual_tensor<3, 3, DXO_OPERAND_EPS_MANDEL>(s, vh, gh);
+        const double scale = w_l * fabs(det);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double tt = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
+                T[i][k] = has_point ? scale * tt : 0.0;       // lanes without a point: zero vertices, singular J
+            }
+        const int64_t cell = c0 + c_l;
+        c8_scatter<ND>(L, T, [&](int a, const double (&o)[3]) {
+            if (!has_point) return;
+            if (fe) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+            } else {
+                const int64_t node = m.dofmap[cell * ND + a];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
+            }
+        });
     }
 }
 
@@ -924,6 +1022,20 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     double* fe = two_pass_buffer(ctx, mesh, bs, cells, n_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
+    if (kind == DXO_OPERAND_EPS_MANDEL && ctx->adjoint_cell && !cells && n_cells == mesh->num_cells && mesh->gdim == 3 && bs == 3 &&
+        mesh->dev.nq == 8 && mesh->dev.ngeom == 8 && (mesh->dev.ndofs == 27 || mesh->dev.ndofs == 8) && (((uintptr_t)S & 15u) == 0)) {
+        // hexahedra with the 2x2x2 rule: contraction across the cell's lanes, nothing staged in LDS (operand_adjoint_c8)
+        const int64_t n_groups = (n_cells + 7) / 8;
+        int64_t blocks = (n_groups + 3) / 4;
+        const int64_t cap = (int64_t)ctx->compute_units * 16;
+        if (blocks > cap) blocks = cap;
+        blocks = (blocks + 7) / 8 * 8;
+        const size_t shm = (size_t)C8_LDS * sizeof(double);
+        if (mesh->dev.ndofs == 27) hipLaunchKernelGGL((operand_adjoint_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
+        else                       hipLaunchKernelGGL((operand_adjoint_c8<8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
+        if (fe) launch_node_sum(ctx, mesh, bs, out, s);
+        return dxo_device_end(ctx, s);
+    }
     if (fe && kind == DXO_OPERAND_EPS_MANDEL && ctx->adjoint_cell && launch_adjoint_cell_eps(ctx, mesh, S, fe, s)) {
         launch_node_sum(ctx, mesh, bs, out, s);      // lane = cell form (adjoint_cell.h) for the standard elements
         return dxo_device_end(ctx, s);
