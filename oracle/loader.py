@@ -43,6 +43,14 @@ def _dp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class _IcnnWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("W0", "b0", "W1", "S1", "c1", "W2", "S2", "c2", "W3", "S3")]
+
+
+_ICNN_KEYS = ("layers__0__weight", "layers__0__bias", "layers__1__weights", "skip_layers__1__weight", "skip_layers__1__bias",
+              "layers__2__weights", "skip_layers__2__weight", "skip_layers__2__bias", "layers__3__weights", "skip_layers__3__weights")
+
+
 class OracleLib:
     def __init__(self, path=LIB):
         self.lib = C.CDLL(str(path))
@@ -63,6 +71,21 @@ class OracleLib:
             self.lib.oracle_mohr_coulomb_ld.argtypes = [P, C.c_int64] + [P] * 5 + [C.c_int]
             self.lib.oracle_mc_surface.restype = C.c_int
             self.lib.oracle_mc_surface.argtypes = [P, C.c_int64, P, P, P, P]
+
+    def icnn(self, F, weights, *, nthreads=1):
+        """oracle/icnn_oracle_c.c: F (N,4) fp64 -> dP (N,4,4), P (N,4), H (4,4) fp32; `weights`: the raw state_dict arrays
+        (tests/golden/icnn_isihara_weights.npz, keys with `__` for `.`). The compiled, threaded form of icnn_oracle.py."""
+        self.lib.oracle_icnn.restype = C.c_int
+        self.lib.oracle_icnn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        keep = [np.ascontiguousarray(weights[k], dtype=np.float32) for k in _ICNN_KEYS]
+        w = _IcnnWeights(*[a.ctypes.data for a in keep])
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 4)
+        n = F.shape[0]
+        dP, P, H = np.empty((n, 4, 4)), np.empty((n, 4)), np.empty((4, 4), dtype=np.float32)
+        rc = self.lib.oracle_icnn(C.byref(w), n, _dp(F), _dp(dP), _dp(P), _dp(H), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_icnn rc={rc}")
+        return dP, P, H
 
     def max_threads(self) -> int:
         return int(self.lib.oracle_max_threads())

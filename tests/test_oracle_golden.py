@@ -100,3 +100,21 @@ def test_conductivity_oracle_matches_reference_golden(oracle, golden):
     with np.errstate(all="ignore"):
         k, dk = oracle.conductivity(g["T_rand"], A=float(g["A"]), B=float(g["B"]))
     assert np.array_equal(k, g["k_rand"], equal_nan=True) and np.array_equal(dk, g["dkdT_rand"], equal_nan=True)
+
+
+def test_icnn_c_port_matches_golden_and_numpy_oracle(oracle, golden):
+    """oracle/icnn_oracle_c.c (per-point jets, OpenMP) — the compiled form of icnn_oracle.py that bench.py times as the CPU baseline
+    of BASELINE config 5 — against the golden produced by the reference's own classes under torch and against the NumPy oracle."""
+    from oracle.icnn_oracle import h_correction, icnn_stress_tangent
+
+    g = golden("icnn_isihara.npz")
+    w = dict(golden("icnn_isihara_weights.npz"))
+    dP, P, H = oracle.icnn(g["F"], w, nthreads=4)
+    sP, sdP = np.abs(g["P"]).max(), np.abs(g["dP"]).max()
+    assert np.abs(P - g["P"]).max() <= 2e-6 * sP and np.abs(dP - g["dP"]).max() <= 2e-6 * sdP      # the GPU parity tolerance
+    dPn, Pn = icnn_stress_tangent(g["F"], w)
+    assert np.abs(P - Pn).max() <= 5e-7 * sP and np.abs(dP - dPn).max() <= 5e-7 * sdP              # same jets, other summation order
+    # H = -P_NN(I) is fp32 rounding noise of the reference's evaluation at the identity (2^-22 on its diagonal); both restatements get 0
+    assert np.allclose(H, h_correction(w), rtol=0, atol=1e-9) and np.allclose(H, g["H"], rtol=0, atol=1e-6)
+    one = oracle.icnn(g["F"], w, nthreads=1)
+    assert np.array_equal(one[0], dP) and np.array_equal(one[1], P)                                  # threads do not change the result
