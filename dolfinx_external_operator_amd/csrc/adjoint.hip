@@ -1102,7 +1102,9 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
-    if (c8)
+    if (fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
+        // lane = cell form (adjoint_cell.h) for P2 triangles
+    } else if (c8)
         hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
     else if (mesh->gdim == 2)
         hipLaunchKernelGGL((tangent_apply<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);

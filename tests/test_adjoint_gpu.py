@@ -119,6 +119,15 @@ def test_matrix_free_tangent(ctx, oracle, cell, n):
         Kv, Kw = K_times(v), K_times(w)
         ref = tangent_apply(Ch, v, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn)
         assert np.abs(Kv - ref).max() <= 1e-12 * np.abs(ref).max()
+        # the specialised forms (lane = cell on P2 triangles, register scatter on hexahedra keep running; the internal force's
+        # specialised kernels are switched off by the same option) against the generic wave-group kernels
+        ctx.set_option("adjoint_cell", 0)
+        try:
+            Kv_generic = K_times(v)
+        finally:
+            ctx.set_option("adjoint_cell", 1)
+        assert np.abs(Kv - Kv_generic).max() <= 1e-13 * np.abs(ref).max()
+        assert np.array_equal(K_times(v), Kv)                               # bit-reproducible
         assert abs(w @ Kv - v @ Kw) <= 1e-11 * abs(w @ Kv)                  # the consistent tangent is symmetric
         assert v @ Kv > 0                                                   # and positive here (hardening material)
         # internal force from the stresses of the same launch, against the oracle
