@@ -48,6 +48,9 @@
 #ifndef DXO_TA_C8_FORWARD
 #define DXO_TA_C8_FORWARD 0  // experiment: tangent_apply_c8 (contraction across the lanes as well); slower, see the kernel's comment
 #endif
+#ifndef DXO_TANGENT_CELL
+#define DXO_TANGENT_CELL 0   // experiment: lane = cell tangent action on P2 triangles (slower, see dxo_tangent_apply)
+#endif
 #ifndef DXO_C8_EARLY_C
 #define DXO_C8_EARLY_C 0     // tangent_apply_c8: 0 = the tangent rows are requested after the contraction (72 registers the pass does not have)
 #endif
@@ -1102,8 +1105,10 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
-    if (fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
-        // lane = cell form (adjoint_cell.h) for P2 triangles
+    if (DXO_TANGENT_CELL && fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
+        // EXPERIMENT (-DDXO_TANGENT_CELL=1): lane = cell form (adjoint_cell.h) for P2 triangles — correct, but 0.61 against 0.55-0.58 ms
+        // per 10^7 points for the wave-group kernel: a lane's three 128-byte tangent rows arrive as 24 sixteen-byte pieces of lines
+        // that 64 lanes touch at a 384-byte stride
     } else if (c8)
         hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
     else if (mesh->gdim == 2)

@@ -203,7 +203,7 @@ if all(dl_files.values()):
         fb, wb = bs._pick(f.get(key), which), bs._pick(w.get(key), which)
         if fb is not None and wb is not None:
             rec["hbm_bytes_per_call"][leg + ":" + "/".join(path[:-1] or ("call",))] = {"kernel": key, "fetch_corrected": fb, "write": wb, "total": fb + wb}
-    names = ("tangent_apply<", "tangent_diag<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
+    names = ("tangent_apply<", "tangent_diag<", "tangent_cell<", "operand_adjoint_c8<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
     sq = counters(["dl_sq1", "dl_sq2"], lambda n: next((k + n.split(k, 1)[1].split("(")[0] for k in names if k in n), None))
     ratios = {}
     for k, c in sq.items():

@@ -107,7 +107,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
         plastic = float((torch.as_tensor(_view(torch, ptr["dp"], npts, dev)) > 0).double().mean())
         calls = {}
         for name, fn, kernels in (("von_mises_field_state", field, [f"vm_field<{bs}>"]),
-                                  ("internal_force", force, ["adjoint_cell_eps | operand_adjoint", "node_sum"]),
+                                  ("internal_force", force, ["operand_adjoint_c8 (hexahedra) | adjoint_cell_eps", "node_sum"]),
                                   ("tangent_apply", matvec, ["tangent_apply", "node_sum"]),
                                   ("tangent_diagonal", diag, ["tangent_diag", "node_sum"])):
             ms, _ = _time(torch, stream, fn, launches, warm=3)

@@ -545,7 +545,7 @@ TRAFFIC_KEYS = {
     ("von_mises_cfg2_1e6", ("roofline",)): ("vm_tile<6,", "all"),
     ("vm_field_q2", ("roofline",)): ("vm_field<3,", "all"),
     ("device_loop_q2hex", ("calls", "von_mises_field_state", "roofline")): ("vm_field<3,", "all"),
-    ("device_loop_q2hex", ("calls", "internal_force", "roofline")): ("adjoint_cell_eps<3,", "all"),
+    ("device_loop_q2hex", ("calls", "internal_force", "roofline")): ("operand_adjoint_c8<", "all"),
     ("device_loop_q2hex", ("calls", "tangent_apply", "roofline")): ("tangent_apply<3,", "all"),
     ("device_loop_q2hex", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<3,", "all"),
     ("device_loop_q2hex", ("calls", "state_commit", "roofline")): ("vm_commit(", "first_half"),
@@ -563,7 +563,7 @@ FOLLOWERS = ("node_sum<", "assign_store(")
 # requests, which the counter tallies in full: x1 (checked on dxo_operand_adjoint: counter 1.74 GB against 1.87 GB of reads by
 # count — the stress field, the element vectors read back by node_sum, its index arrays, geometry; x2 would claim 3.5 GB).
 # tangent_apply / tangent_diag read their 2.9 GB of tangent rows lane-linear (x2) and gather the rest: x2 is an upper bound there.
-FETCH_X1 = ("node_sum<", "assign_owner(", "assign_store(", "assign_apply<", "adjoint_cell_eps<", "operand_adjoint<")
+FETCH_X1 = ("node_sum<", "assign_owner(", "assign_store(", "assign_apply<", "adjoint_cell_eps<", "operand_adjoint<", "operand_adjoint_c8<", "tangent_cell<")
 
 
 def parse_counter_csv(files, counter):
