@@ -77,7 +77,13 @@ template <int D>
 struct TangentRows {
     static constexpr int CV = D * D / 2;        // 16-byte units per point
     static constexpr int LPC = TR_PC * CV / DXO_WAVE;   // lane-linear loads per lane per chunk (9 at d = 6, 4 at d = 4)
-    static constexpr int LDS_DOUBLES = TR_PC * D * D;   // staging space one chunk needs
+    // a staged row occupies CV + 1 units: lanes read their rows 16 bytes at a time at a stride of one row, and with the natural
+    // strides (128 bytes at d = 4: 32 dwords; 288 at d = 6: 8 mod 64 dwords) the 16 lanes of a read group hit two / eight bank
+    // positions — an 8-way and a 2-way conflict (28-32 % of the triangle kernels' LDS cycles, profiles/r04_device_loop_pmc.json);
+    // 144 / 304 bytes put the 16 rows on 16 different 4-bank slots
+    static constexpr int RS = CV + 1;
+    static constexpr int LDS_DOUBLES = TR_PC * RS * 2;  // staging space one chunk needs
+    static __device__ __forceinline__ int slot(int u) { return (u / CV) * RS + (u % CV); }   // u-th 16-byte unit of the chunk
     dxo_f64x2 r[2][LPC];
     __device__ __forceinline__ void request(const double* __restrict__ C_tang, int64_t p0, int npts, int lane) {
         const dxo_f64x2* base = reinterpret_cast<const dxo_f64x2*>(C_tang + p0 * (D * D));
@@ -95,10 +101,10 @@ struct TangentRows {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int k = 0; k < LPC; ++k) S2[k * DXO_WAVE + lane] = r[c][k];
+            for (int k = 0; k < LPC; ++k) S2[slot(k * DXO_WAVE + lane)] = r[c][k];
             op_fence();
             if (lane / TR_PC == c) {
-                const dxo_f64x2* R = S2 + (lane - c * TR_PC) * CV;
+                const dxo_f64x2* R = S2 + (lane - c * TR_PC) * RS;
 #pragma unroll
                 for (int rr = 0; rr < D; ++rr) {
                     double acc = 0.0;
@@ -120,11 +126,11 @@ struct TangentRows {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int k = 0; k < LPC; ++k) S2[k * DXO_WAVE + lane] = r[c][k];
+            for (int k = 0; k < LPC; ++k) S2[slot(k * DXO_WAVE + lane)] = r[c][k];
             op_fence();
             if (lane / TR_PC == c) {
 #pragma unroll
-                for (int j = 0; j < CV; ++j) row[j] = S2[(lane - c * TR_PC) * CV + j];
+                for (int j = 0; j < CV; ++j) row[j] = S2[(lane - c * TR_PC) * RS + j];
             }
             op_fence();
         }
@@ -895,7 +901,7 @@ int diag_lds_wave(const dxo_mesh* m) {
     const int G = m->gdim;
     const int D = G == 2 ? 4 : 6;
     int park = DXO_WAVE * ((G * (G * (G + 1) / 2)) | 1);
-    if (park < TR_PC * D * D) park = TR_PC * D * D;      // the parked-matrix slice doubles as the staging space of the tangent rows
+    if (park < TR_PC * (D * D + 2)) park = TR_PC * (D * D + 2);      // the parked-matrix slice doubles as the staging space of the tangent rows
     int wd = ((v.cells_per_wave * op_odd(v.ngeom * G) + 1) & ~1) + park;
     return (wd + 1) & ~1;
 }
@@ -905,7 +911,7 @@ int apply_rs_lds_wave(const dxo_mesh* m) {
     const OperandDev& v = m->dev;
     const int G = m->gdim, D = G == 2 ? 4 : 6;
     int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G));
-    if (wd < TR_PC * D * D) wd = TR_PC * D * D;
+    if (wd < TR_PC * (D * D + 2)) wd = TR_PC * (D * D + 2);
     return (wd + 1) & ~1;
 }
 
@@ -914,7 +920,7 @@ int adjoint_lds_wave(const dxo_mesh* m) {
     const int G = m->gdim;
     int wd = v.cells_per_wave * (op_odd(v.ndofs * G) + op_odd(v.ngeom * G)) + DXO_WAVE * (DXO_ADJ_PAD ? ((G * (G + 1)) | 1) : G * (G + 1));
     const int D = G == 2 ? 4 : 6;
-    if (wd < TR_PC * D * D) wd = TR_PC * D * D;          // tangent_apply stages the tangent rows through the whole region (TangentRows)
+    if (wd < TR_PC * (D * D + 2)) wd = TR_PC * (D * D + 2);          // tangent_apply stages the tangent rows through the whole region (TangentRows)
     return (wd + 1) & ~1;
 }
 
