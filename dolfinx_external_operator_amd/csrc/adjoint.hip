@@ -20,6 +20,7 @@
 #include "operand_core.h"
 #include "adjoint_cell.h"
 #include "cell8_dpp.h"
+#include "vm_core.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -53,6 +54,9 @@
 #endif
 #ifndef DXO_C8_EARLY_C
 #define DXO_C8_EARLY_C 0     // tangent_apply_c8: 0 = the tangent rows are requested after the contraction (72 registers the pass does not have)
+#endif
+#ifndef DXO_TA_VM_WAVES
+#define DXO_TA_VM_WAVES 2    // waves per SIMD of the state-based tangent action (3: 45 registers spilled on hexahedra)
 #endif
 #ifndef DXO_TA_STAGE
 #define DXO_TA_STAGE 1       // tangent rows requested lane-linear and passed through LDS (TangentRows) instead of row-per-lane loads
@@ -134,6 +138,35 @@ struct TangentRows {
             }
             op_fence();
         }
+    }
+};
+
+// ---- the tangent's action from the RETURNED STATE of the von Mises operator instead of from its d x d block (dxo_tangent_apply_vm,
+// dxo_tangent_diagonal_vm): a point's (sigma, dp) are 56 bytes at d = 6 where its tangent is 288, the tangent is a function of
+// them (vm_tangent_state, vm_core.h — the formulas dxo_vm_expand_tangent rebuilds blocks with), and t = C e costs ~40 flops without
+// the matrix (vm_tangent_times). A matrix-free Newton-Krylov solve then never needs C_tang to exist: the fused operator runs with
+// C_tang = NULL (160 instead of 448 bytes per point) and every Krylov matvec reads a fifth of the bytes.
+struct VmStateSrc {
+    VmConst c;
+    const double* sigma;   // [n][d]
+    const double* dp;      // [n]
+};
+
+template <int D>
+struct VmPoint {
+    dxo_f64x2 s2[D / 2];
+    double dp;
+    __device__ __forceinline__ void request(const VmStateSrc& vs, int64_t point, bool has) {
+        const dxo_f64x2* Sp = reinterpret_cast<const dxo_f64x2*>(vs.sigma + point * D);
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) s2[k] = has ? Sp[k] : dxo_f64x2{1.0, 0.0};     // a harmless non-singular state for idle lanes
+        dp = has ? vs.dp[point] : 0.0;
+    }
+    __device__ __forceinline__ void state(const VmStateSrc& vs, double (&nrm)[D], double& a, double& b) const {
+        double sig[D];
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) { sig[2 * k] = s2[k].x; sig[2 * k + 1] = s2[k].y; }
+        vm_tangent_state<D>(vs.c, sig, dp, nrm, a, b);
     }
 };
 
@@ -432,11 +465,12 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8(OperandDev m, co
 // uses (values of group g+1 and indices of group g+2 in flight while group g is computed), (ii) the lane's tangent row is
 // requested at the top of the iteration, 16 bytes per load, and is consumed after the contraction has hidden its latency,
 // (iii) the parked tensors have an odd stride (adjoint_scatter). ND_CT / NG_CT as in operand_compute_geo.
-template <int G, int ND_CT = 0, int NG_CT = 0>
-__global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
-                                                              const double* __restrict__ C_tang, const double* __restrict__ v,
-                                                              int64_t n_cells, double* __restrict__ out,
-                                                              double* __restrict__ fe) {
+// VM: the tangent's action comes from the von Mises state (VmStateSrc) instead of from C_tang rows.
+template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false>
+__global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
+                                                              const double* __restrict__ C_tang, VmStateSrc vs,
+                                                              const double* __restrict__ v, int64_t n_cells,
+                                                              double* __restrict__ out, double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
     // cells of 8 points and at most 32 nodes (launched so only for nq = 8): the scatter phase runs in registers, a DPP
@@ -484,8 +518,10 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
         // the tangent of this lane's point: requested now, used after the contraction
 #if DXO_TA_STAGE
         TangentRows<D> rows;
+        VmPoint<D> vp;
+        if constexpr (VM) vp.request(vs, c0 * m.nq + lane, has_point);
 #if DXO_TA_EARLY_C
-        rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
+        if constexpr (!VM) rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
 #endif
 #else
         dxo_f64x2 Cq[CV];
@@ -523,10 +559,16 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_TA_WAVES) void tangent_apply(Operand
 #pragma unroll
             for (int k = 0; k < D; ++k) e[k] = 0.0;
         }
+        if constexpr (VM) {
+            double nrm[D], a, b;
+            vp.state(vs, nrm, a, b);
+            vm_tangent_times<D>(vs.c, nrm, a, b, e, t);
+        } else {
 #if !DXO_TA_EARLY_C
-        rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
+            rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
 #endif
-        rows.times(W, lane, e, t);     // compute_geo has fenced: the gather buffer is free, the parked tensors are not written yet
+            rows.times(W, lane, e, t);     // compute_geo has fenced: the gather buffer is free, the parked tensors are not written yet
+        }
         if (active) {
             scale = w_l * fabs(det);
             dual_tensor<G, G, DXO_OPERAND_EPS_MANDEL>(t, vh, gh);
@@ -696,9 +738,9 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply_c8(OperandDev m, c
 // dphi_k dphi_k' NS_i[kk'] over the cell's points. Before, phase 2 read the 36 entries of C_q from global memory for every
 // (node, point) pair — 27 times each on Q2 hexahedra: 4.5 ms per 10^7 points, 2.3 matvecs' worth; now see profiles/README.md.
 // ND_CT > 0 (launched for cells of 8 points, at most 32 nodes): phase 2 in registers with the DPP reduce-scatter of cell8_dpp.h.
-template <int G, int ND_CT = 0>
+template <int G, int ND_CT = 0, bool VM = false>
 __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
-                                                            const double* __restrict__ C_tang, int64_t n_cells,
+                                                            const double* __restrict__ C_tang, VmStateSrc vs, int64_t n_cells,
                                                             double* __restrict__ out, double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     constexpr int CV = D * D / 2;
@@ -730,10 +772,17 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
         const int ncell = (n_cells - c0 < cpw) ? (int)(n_cells - c0) : cpw;
         const bool has_point = c_l < ncell;
         dxo_f64x2 Cq[CV];
+        double vn[D], va = 0.0, vb = 0.0;       // VM: the point's tangent state
 #if DXO_TA_STAGE
         TangentRows<D> rows;
-        rows.request(C_tang, c0 * nq, ncell * nq, lane);
-        rows.deliver(Pm, lane, Cq);          // the parked matrices of the last group have been consumed (fence at the loop's end)
+        if constexpr (VM) {
+            VmPoint<D> vp;
+            vp.request(vs, c0 * nq + lane, has_point);
+            vp.state(vs, vn, va, vb);
+        } else {
+            rows.request(C_tang, c0 * nq, ncell * nq, lane);
+            rows.deliver(Pm, lane, Cq);          // the parked matrices of the last group have been consumed (fence at the loop's end)
+        }
 #else
         {
             const dxo_f64x2* Cp = reinterpret_cast<const dxo_f64x2*>(C_tang + (c0 * nq + lane) * (D * D));
@@ -767,6 +816,7 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
             const double det = invert<G>(J, K);
             const double scale = w_l * fabs(det);
             auto Cat = [&](int r, int cc) -> double {
+                if constexpr (VM) return c_elas_ij(vs.c, r, cc) - va * (vn[r] * vn[cc]) - vb * dev_ij(r, cc);
                 const dxo_f64x2 c2 = Cq[(r * D + cc) / 2];
                 return ((r * D + cc) & 1) ? c2.y : c2.x;
             };
@@ -1056,14 +1106,17 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     return dxo_device_end(ctx, s);
 }
 
-extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out) {
-    if (!ctx) return DXO_E_NULL;
-    DXO_LOCK(ctx);
+namespace {
+
+// shared body of dxo_tangent_diagonal / dxo_tangent_diagonal_vm (vs == nullptr: rows of C_tang)
+int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const VmStateSrc* vs, double* out, const char* who) {
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_diagonal: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;
-    if (!C_tang || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: NULL array");
-    if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang must be 16-byte aligned");
+    if ((!vs && !C_tang) || (vs && (!vs->sigma || !vs->dp)) || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_diagonal: NULL array");
+    if (((uintptr_t)(vs ? (const void*)vs->sigma : (const void*)C_tang) & 15u) != 0)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang / sigma must be 16-byte aligned");
+    (void)who;
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
     const int wd = diag_lds_wave(mesh);
     const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
@@ -1078,26 +1131,30 @@ extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* 
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
-    if (mesh->gdim == 2)
-        hipLaunchKernelGGL((tangent_diag<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
-    else
-        if (rs) hipLaunchKernelGGL((tangent_diag<3, 27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
-        else    hipLaunchKernelGGL((tangent_diag<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, mesh->num_cells, out, fe);
+    const VmStateSrc none{};
+    const VmStateSrc& src = vs ? *vs : none;
+#define DXO_DIAG_LAUNCH(...) hipLaunchKernelGGL((tangent_diag<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, mesh->num_cells, out, fe)
+    if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
+    else if (rs)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true); else DXO_DIAG_LAUNCH(3, 27, false); }
+    else                 { if (vs) DXO_DIAG_LAUNCH(3, 0, true); else DXO_DIAG_LAUNCH(3, 0, false); }
+#undef DXO_DIAG_LAUNCH
     if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
 }
 
-extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out) {
-    if (!ctx) return DXO_E_NULL;
-    DXO_LOCK(ctx);
+// shared body of dxo_tangent_apply / dxo_tangent_apply_vm
+int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const VmStateSrc* vs, const double* v, double* out) {
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_tangent_apply: quadrature weights not set (dxo_mesh_set_weights)");
     if (mesh->num_cells == 0) return DXO_OK;
-    if (!C_tang || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
-    if (((uintptr_t)C_tang & 15u) != 0) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang must be 16-byte aligned");
+    if ((!vs && !C_tang) || (vs && (!vs->sigma || !vs->dp)) || !v || !out) return dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_apply: NULL array");
+    if (((uintptr_t)(vs ? (const void*)vs->sigma : (const void*)C_tang) & 15u) != 0)
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang / sigma must be 16-byte aligned");
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
-    const bool c8 = rs && DXO_TA_C8_FORWARD;
-    const int wd = rs ? apply_rs_lds_wave(mesh) : adjoint_lds_wave(mesh);
+    const bool c8 = rs && DXO_TA_C8_FORWARD && !vs;
+    // the state form stages nothing: its wave region is the gather buffer (and the parked tensors where the scatter uses them)
+    const int wd = rs ? (vs ? ((mesh->dev.cells_per_wave * (op_odd(mesh->dev.ndofs * 3) + op_odd(mesh->dev.ngeom * 3)) + 1) & ~1) : apply_rs_lds_wave(mesh))
+                      : adjoint_lds_wave(mesh);
     const size_t shm = c8 ? (size_t)(C8_LDS + 4 * TangentRows<6>::LDS_DOUBLES) * sizeof(double)
                           : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
@@ -1108,21 +1165,62 @@ extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_t
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    const int64_t cap = (int64_t)ctx->compute_units * (vs ? 12 : 8);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
-    if (DXO_TANGENT_CELL && fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
+    const VmStateSrc none{};
+    const VmStateSrc& src = vs ? *vs : none;
+#define DXO_APPLY_LAUNCH(...) hipLaunchKernelGGL((tangent_apply<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, v, mesh->num_cells, out, fe)
+    if (!vs && DXO_TANGENT_CELL && fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
         // EXPERIMENT (-DDXO_TANGENT_CELL=1): lane = cell form (adjoint_cell.h) for P2 triangles — correct, but 0.61 against 0.55-0.58 ms
         // per 10^7 points for the wave-group kernel: a lane's three 128-byte tangent rows arrive as 24 sixteen-byte pieces of lines
         // that 64 lanes touch at a 384-byte stride
     } else if (c8)
         hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
-    else if (mesh->gdim == 2)
-        hipLaunchKernelGGL((tangent_apply<2>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
-    else if (rs)    // Q2 hexahedra, 2x2x2 rule: trip counts known at compile time, scatter phase in registers (instantiated for nq = 8 only)
-        hipLaunchKernelGGL((tangent_apply<3, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
-    else
-        hipLaunchKernelGGL((tangent_apply<3>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, v, mesh->num_cells, out, fe);
+    else if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
+    else if (rs)              { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true); else DXO_APPLY_LAUNCH(3, 27, 8, false); }   // Q2 hexahedra, 2x2x2 rule: compile-time trip counts, scatter in registers
+    else                      { if (vs) DXO_APPLY_LAUNCH(3, 0, 0, true); else DXO_APPLY_LAUNCH(3, 0, 0, false); }
+#undef DXO_APPLY_LAUNCH
     if (fe) launch_node_sum(ctx, mesh, mesh->gdim, out, s);
     return dxo_device_end(ctx, s);
+}
+
+bool vm_state_src(dxo_ctx* ctx, const dxo_mesh* mesh, const dxo_vm_params* prm, const double* sigma, const double* dp, VmStateSrc& out) {
+    if (!mesh || !prm) { dxo_fail(ctx, DXO_E_NULL, "dxo_tangent_*_vm: NULL mesh or params"); return false; }
+    out.c = make_const(*prm);
+    out.sigma = sigma;
+    out.dp = dp;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    return tangent_diagonal_impl(ctx, mesh, C_tang, nullptr, out, "dxo_tangent_diagonal");
+}
+
+extern "C" int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    return tangent_apply_impl(ctx, mesh, C_tang, nullptr, v, out);
+}
+
+extern "C" int dxo_tangent_apply_vm(dxo_ctx* ctx, dxo_mesh* mesh, const dxo_vm_params* prm, const double* sigma, const double* dp,
+                                    const double* v, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    VmStateSrc vs;
+    if (!vm_state_src(ctx, mesh, prm, sigma, dp, vs)) return DXO_E_NULL;
+    return tangent_apply_impl(ctx, mesh, nullptr, &vs, v, out);
+}
+
+extern "C" int dxo_tangent_diagonal_vm(dxo_ctx* ctx, dxo_mesh* mesh, const dxo_vm_params* prm, const double* sigma, const double* dp,
+                                       double* out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    VmStateSrc vs;
+    if (!vm_state_src(ctx, mesh, prm, sigma, dp, vs)) return DXO_E_NULL;
+    return tangent_diagonal_impl(ctx, mesh, nullptr, &vs, out, "dxo_tangent_diagonal_vm");
 }

@@ -75,6 +75,44 @@ __device__ __forceinline__ void vm_return_map(const VmConst& c, const double (&d
     if (c.mark_indeterminate && f_el == 0.0) dp = -0.0;          // value unchanged (0), sign bit = "n_elas was 0/0"
 }
 
+// The tangent's state (n, a, b) from the RETURNED (sigma, dp) alone (derivation: the comment above vm_expand_point in von_mises.hip).
+// Shared by the tangent rebuild (dxo_vm_expand_tangent) and by the state-based matrix-free tangent action (adjoint.hip).
+template <int D>
+__device__ __forceinline__ void vm_tangent_state(const VmConst& c, const double (&sig)[D], double dp,
+                                                 double (&nrm)[D], double& a, double& b) {
+    const double mean = (sig[0] + sig[1] + sig[2]) * (1.0 / 3.0);
+    double s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = i < 3 ? sig[i] - mean : sig[i];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ss += s[i] * s[i];
+    const double sigma_eq = sqrt(3.0 / 2.0 * ss);
+    const double beta = c.mu3 * dp / (sigma_eq + c.mu3 * dp);
+    const double ind = dp > 0.0 ? 1.0 : 0.0;
+    const bool marked = dp == 0.0 && __builtin_signbit(dp);   // the producer's mark for f_elastic == 0 (vm_core.h)
+#pragma unroll
+    for (int i = 0; i < D; ++i) nrm[i] = s[i] / sigma_eq * ind;
+    a = marked ? __builtin_nan("") : c.mu3 * (c.ratio - beta);   // NaN * (n_i n_j) = NaN in every entry, as in the reference
+    b = c.mu2 * beta;
+}
+
+// t = C_tang e for C_tang = C_elas - a n(x)n - b dev WITHOUT forming the matrix: 56 bytes of state per point instead of the 288 of
+// the d = 6 tangent block, ~40 flops instead of 36 loads + 36 FMAs.
+template <int D>
+__device__ __forceinline__ void vm_tangent_times(const VmConst& c, const double (&nrm)[D], double a, double b, const double (&e)[D],
+                                                 double (&t)[D]) {
+    const double tr = e[0] + e[1] + e[2];
+    double ne = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ne += nrm[i] * e[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double vol = i < 3 ? tr : 0.0;
+        t[i] = (c.lmbda * vol + c.mu2 * e[i]) - a * (nrm[i] * ne) - b * (e[i] - vol * (1.0 / 3.0));
+    }
+}
+
 // Entry (i, j) of C_elas and of `deviatoric` on the Mandel vector (:193-204).
 __device__ __forceinline__ double c_elas_ij(const VmConst& c, int i, int j) {
     return ((i < 3 && j < 3) ? c.lmbda : 0.0) + (i == j ? c.mu2 : 0.0);

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
             const int idx = k * DXO_WAVE + lane;
             if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
         }
+        if (!C_tang) {      // (sigma, dp) only: a matrix-free solver rebuilds the tangent's action from them (dxo_tangent_apply_vm)
+            wave_lds_fence();
+            continue;
+        }
 #if DXO_VMF_FULL
         // a full group of 64 points (8 cells x 8 points on hexahedra): guard-free tangent stores, as in vm_tile
         if (npts == DXO_WAVE) vm_store_tangent<D, NT, true>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
@@ -261,7 +265,7 @@ extern "C" int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm,
     if (st->d != D || st->n != nc * nq)
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field_state: the state does not cover num_cells*nq points of this mesh's d");
     if (nc == 0) return DXO_OK;
-    if (!u || !C_tang) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field_state: NULL array");
+    if (!u || (!C_tang && mem != DXO_MEM_DEVICE)) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field_state: NULL array (C_tang may be NULL on the device path only)");
     if (((uintptr_t)u | (uintptr_t)C_tang | (uintptr_t)sigma | (uintptr_t)dp) & 7u)
         return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_field_state: arrays must be 8-byte aligned");
     FieldLaunch L{make_const(*prm), mesh, u, 0};
@@ -312,7 +316,8 @@ extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_m
     if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_von_mises_field: bad mem");
     const int64_t nc = mesh->num_cells;
     if (nc == 0) return DXO_OK;
-    if (!u || !sigma_n || !p || !C_tang || !sigma || !dp) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field: NULL array");
+    if (!u || !sigma_n || !p || (!C_tang && mem != DXO_MEM_DEVICE) || !sigma || !dp)
+        return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_field: NULL array (C_tang may be NULL on the device path only)");
     const uintptr_t all = (uintptr_t)u | (uintptr_t)sigma_n | (uintptr_t)p | (uintptr_t)C_tang | (uintptr_t)sigma | (uintptr_t)dp;
     if (all & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_field: arrays must be 8-byte aligned");
     const int G = mesh->gdim, D = G == 2 ? 4 : 6, nq = mesh->dev.nq;

@@ -284,26 +284,6 @@ int vm_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const
 // dp = -0.0 there, and the mark comes out as the reference's all-NaN tangent here, exactly as in vm_host.h. Without the
 // mark such a point is rebuilt as C_elas.
 template <int D>
-__device__ __forceinline__ void vm_tangent_state(const VmConst& c, const double (&sig)[D], double dp,
-                                                 double (&nrm)[D], double& a, double& b) {
-    const double mean = (sig[0] + sig[1] + sig[2]) * (1.0 / 3.0);
-    double s[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = i < 3 ? sig[i] - mean : sig[i];
-    double ss = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) ss += s[i] * s[i];
-    const double sigma_eq = sqrt(3.0 / 2.0 * ss);
-    const double beta = c.mu3 * dp / (sigma_eq + c.mu3 * dp);
-    const double ind = dp > 0.0 ? 1.0 : 0.0;
-    const bool marked = dp == 0.0 && __builtin_signbit(dp);   // the producer's mark for f_elastic == 0 (vm_core.h)
-#pragma unroll
-    for (int i = 0; i < D; ++i) nrm[i] = s[i] / sigma_eq * ind;
-    a = marked ? __builtin_nan("") : c.mu3 * (c.ratio - beta);   // NaN * (n_i n_j) = NaN in every entry, as in the reference
-    b = c.mu2 * beta;
-}
-
-template <int D>
 __global__ __launch_bounds__(DXO_BLOCK) void vm_expand_point(VmConst c, int64_t n, const double* __restrict__ sigma,
                                                              const double* __restrict__ dp_in,
                                                              double* __restrict__ C_tang) {

@@ -214,6 +214,19 @@ class DeviceMesh:
         rc = self.ctx.lib.dxo_tangent_diagonal(self.ctx._h, self._h, C.c_void_p(C_tang_ptr), C.c_void_p(out_ptr))
         self.ctx.check(rc, "dxo_tangent_diagonal")
 
+    def tangent_apply_vm(self, prm, sigma_ptr: int, dp_ptr: int, v_ptr: int, out_ptr: int) -> None:
+        """out += K v with the von Mises consistent tangent formed per point from the operator's returned (sigma, dp) — no C_tang
+        array (dxo_tangent_apply_vm; DEVICE pointers, e.g. VmState.pointers()): 56 instead of 288 bytes per point."""
+        rc = self.ctx.lib.dxo_tangent_apply_vm(self.ctx._h, self._h, C.byref(prm), C.c_void_p(sigma_ptr), C.c_void_p(dp_ptr),
+                                               C.c_void_p(v_ptr), C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_tangent_apply_vm")
+
+    def tangent_diagonal_vm(self, prm, sigma_ptr: int, dp_ptr: int, out_ptr: int) -> None:
+        """out += diag(K) from the returned (sigma, dp) (dxo_tangent_diagonal_vm)."""
+        rc = self.ctx.lib.dxo_tangent_diagonal_vm(self.ctx._h, self._h, C.byref(prm), C.c_void_p(sigma_ptr), C.c_void_p(dp_ptr),
+                                                  C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_tangent_diagonal_vm")
+
     def heat(self, A: float, B: float, T_dofs, q=None, dqdT=None, dqdsigma=None, mem: int = MEM_HOST) -> None:
         """dxo_heat_field: T and grad T of a scalar field + the heat-flux kernels in one launch (all cells)."""
         def ptr(a):

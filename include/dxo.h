@@ -436,7 +436,8 @@ int dxo_eval_operand_facets(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int 
  * evaluate_operands + evaluate_external_operators pair (demo_plasticity_von_mises.py:445-456) when the operand is
  * eps(u) of a vector Lagrange field on `mesh` (gdim 2 -> d = 4, gdim 3 -> d = 6). u: num_field_nodes*gdim doubles;
  * state and outputs cover ALL cells of the mesh in cell order: n = num_cells*nq points, same layout and meaning as
- * dxo_von_mises. The strain increment is never written to memory. */
+ * dxo_von_mises. The strain increment is never written to memory. With DXO_MEM_DEVICE C_tang may be NULL: (sigma, dp) only, for a
+ * matrix-free solve that forms the tangent's action from them (dxo_tangent_apply_vm below). */
 int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, int mem, const double* u,
                         const double* sigma_n, const double* p, double* C_tang, double* sigma, double* dp);
 /* The same with the history variables in a dxo_vm_state (n = num_cells*nq, d as the mesh gives it): a host call sends the
@@ -463,6 +464,16 @@ int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
                         int64_t n_cells, double* out);
 int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out);
+/* The same two operators for the von Mises operator WITHOUT its tangent array (round 4): the consistent tangent is a function of the
+ * returned state (dxo_vm_expand_tangent), so K v and diag(K) are formed from (sigma, dp) — 56 instead of 288 bytes per point at
+ * d = 6, ~40 flops per point instead of 36 loads and FMAs. A matrix-free Newton-Krylov solve then never needs C_tang to exist:
+ * dxo_von_mises_field / _field_state accept C_tang = NULL on the device path (160 instead of 448 bytes per point) and every Krylov
+ * matvec reads a fifth of the bytes. sigma [n][d] (16-byte aligned), dp [n]: the operator's outputs for all cells of the mesh in cell
+ * order (e.g. the arrays of dxo_vm_state_pointers); prm: the parameters the operator ran with. Agrees with dxo_tangent_apply on the
+ * C_tang of the same call to rounding (1e-13 of the scale; a point the producer marked with dp = -0.0 gives the reference's NaN). */
+int dxo_tangent_apply_vm(dxo_ctx* ctx, dxo_mesh* mesh, const dxo_vm_params* prm, const double* sigma, const double* dp,
+                         const double* v, double* out);
+int dxo_tangent_diagonal_vm(dxo_ctx* ctx, dxo_mesh* mesh, const dxo_vm_params* prm, const double* sigma, const double* dp, double* out);
 /* out[dof] += K_(dof,dof): the diagonal of the same operator (Jacobi preconditioner of a matrix-free Krylov solve). */
 int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out);
 

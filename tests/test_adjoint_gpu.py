@@ -128,6 +128,22 @@ def test_matrix_free_tangent(ctx, oracle, cell, n):
             ctx.set_option("adjoint_cell", 1)
         assert np.abs(Kv - Kv_generic).max() <= 1e-13 * np.abs(ref).max()
         assert np.array_equal(K_times(v), Kv)                               # bit-reproducible
+        # the same operator WITHOUT the tangent array: K v and diag(K) from the returned (sigma, dp) (dxo_tangent_apply_vm /
+        # dxo_tangent_diagonal_vm), and the fused operator run with C_tang = NULL leaves the same (sigma, dp)
+        vt = torch.from_numpy(v).cuda()
+        out_vm = torch.zeros(nn * G, dtype=torch.float64, device="cuda")
+        dm.tangent_apply_vm(prm, s.data_ptr(), dp.data_ptr(), vt.data_ptr(), out_vm.data_ptr())
+        torch.cuda.synchronize()
+        assert np.abs(out_vm.cpu().numpy() - Kv).max() <= 1e-13 * np.abs(ref).max()
+        dg, dg_vm = (torch.zeros(nn * G, dtype=torch.float64, device="cuda") for _ in range(2))
+        dm.tangent_diagonal(C.data_ptr(), dg.data_ptr())
+        dm.tangent_diagonal_vm(prm, s.data_ptr(), dp.data_ptr(), dg_vm.data_ptr())
+        torch.cuda.synchronize()
+        assert float((dg - dg_vm).abs().max()) <= 1e-13 * float(dg.abs().max()) and float(dg.min()) > 0
+        s2, dp2 = torch.empty_like(s), torch.empty_like(dp)
+        dm.von_mises(prm, t["u"].data_ptr(), t["sn"].data_ptr(), t["p"].data_ptr(), None, s2.data_ptr(), dp2.data_ptr(), mem=MEM_DEVICE)
+        torch.cuda.synchronize()
+        assert torch.equal(s2, s) and torch.equal(dp2, dp)
         assert abs(w @ Kv - v @ Kw) <= 1e-11 * abs(w @ Kv)                  # the consistent tangent is symmetric
         assert v @ Kv > 0                                                   # and positive here (hardening material)
         # internal force from the stresses of the same launch, against the oracle

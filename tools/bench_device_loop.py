@@ -102,6 +102,23 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
             force()
             matvec()
 
+        # the same iteration WITHOUT a tangent array: the fused operator writes (sigma, dp) only, K v and diag(K) come from them
+        def field_state_only():
+            st.call_field(prm, dm._h, MEM_DEVICE, u.data_ptr(), None)
+
+        def matvec_vm():
+            Kv.zero_()
+            dm.tangent_apply_vm(prm, ptr["sigma"], ptr["dp"], v.data_ptr(), Kv.data_ptr())
+
+        def diag_vm():
+            Kv.zero_()
+            dm.tangent_diagonal_vm(prm, ptr["sigma"], ptr["dp"], Kv.data_ptr())
+
+        def iteration_vm():
+            field_state_only()
+            force()
+            matvec_vm()
+
         field()
         torch.cuda.synchronize()
         plastic = float((torch.as_tensor(_view(torch, ptr["dp"], npts, dev)) > 0).double().mean())
@@ -113,6 +130,23 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
             ms, _ = _time(torch, stream, fn, launches, warm=3)
             calls[name] = {"ms_per_call": ms, "qp_per_s": npts / ms * 1e3, "kernels": kernels,
                            "roofline": {**_hbm(by[name], ms), "algorithmic_bytes_per_call": by[name], "bytes_per_qp": by[name] / npts}}
+        vec_b = nn * bs * 8
+        by_vm = {"von_mises_field_state_no_tangent": by["von_mises_field_state"] - npts * d * d * 8,
+                 "tangent_apply_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + 3 * vec_b,
+                 "tangent_diagonal_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + 2 * vec_b}
+        matvec()
+        ref_Kv = Kv.clone()
+        matvec_vm()
+        vm_err = float((Kv - ref_Kv).abs().max() / ref_Kv.abs().max())
+        calls_vm = {}
+        for name, fn, kernels in (("von_mises_field_state_no_tangent", field_state_only, [f"vm_field<{bs}> with C_tang = NULL"]),
+                                  ("tangent_apply_vm", matvec_vm, ["tangent_apply<..., VM>", "node_sum"]),
+                                  ("tangent_diagonal_vm", diag_vm, ["tangent_diag<..., VM>", "node_sum"])):
+            ms, _ = _time(torch, stream, fn, launches, warm=3)
+            calls_vm[name] = {"ms_per_call": ms, "qp_per_s": npts / ms * 1e3, "kernels": kernels,
+                              "roofline": {**_hbm(by_vm[name], ms), "algorithmic_bytes_per_call": by_vm[name], "bytes_per_qp": by_vm[name] / npts}}
+        ms_it_vm, _ = _time(torch, stream, iteration_vm, launches, warm=2)
+        field()        # leave the full outputs (with tangent) in place for the legs below
         # the load-step update: commit needs a fresh result each time, so the pair (field, commit) is timed and the field's time subtracted
         ms_pair, _ = _time(torch, stream, lambda: (field(), st.commit()), launches, warm=2)
         ms_c = max(ms_pair - calls["von_mises_field_state"]["ms_per_call"], 1e-6)
@@ -129,7 +163,12 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
                "iteration_ms": ms_it, "dtype": "f64", "plastic_fraction": plastic, "mesh_build_s": mesh_s, "calls": calls,
                "roofline": {**_hbm(it_bytes, ms_it), "algorithmic_bytes_per_iteration": it_bytes, "bytes_per_qp": it_bytes / npts,
                             "note": "sum of the three calls' algorithmic bytes over the iteration's time; each call has its own roofline under `calls`"},
-               "pcie_bytes_per_iteration": 0}
+               "pcie_bytes_per_iteration": 0,
+               "without_tangent_array": {
+                   "meaning": "the same iteration with the von Mises tangent's action formed from the returned (sigma, dp) (dxo_tangent_apply_vm): "
+                              "the fused operator runs with C_tang = NULL, a Krylov matvec reads 56 instead of 288 bytes per point",
+                   "iteration_ms": ms_it_vm, "value": npts / ms_it_vm * 1e3, "calls": calls_vm,
+                   "matvec_max_rel_diff_vs_tangent_array": vm_err}}
         if cpu:
             out["cpu_baseline"] = _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm)
         return out
