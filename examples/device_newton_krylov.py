@@ -7,7 +7,8 @@ and assembles a sparse Jacobian from it. Here, per Newton iteration:
 
     sigma, C_tang, dp = von Mises(eps(Du), sigma_n, p)      dxo_von_mises_field   (strain + return map + tangent, one launch)
     R = sum w|J| B^T sigma  on the free dofs                dxo_operand_adjoint   (internal force; no external load here)
-    solve K d = -R with Jacobi-preconditioned CG, K v by    dxo_tangent_apply, diag(K) by dxo_tangent_diagonal   (K is never formed)
+    solve K d = -R with Jacobi-preconditioned CG, K v by    dxo_tangent_apply_vm, diag(K) by dxo_tangent_diagonal_vm   (K is never formed,
+                                                            and neither is C_tang: both act from the returned (sigma, dp))
     Du += d
 and at the end of a load step  p += dp, sigma_n <- sigma    dxo_vm_commit_state.
 Only dof vectors (and a few scalars of the CG) are touched outside the kernels; they are torch CUDA tensors.
@@ -29,7 +30,11 @@ from dolfinx_external_operator_amd import MEM_DEVICE, Context, DeviceMesh, VmPar
 from tools.synthetic import structured_mesh  # noqa: E402
 
 
-def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool = True) -> dict:
+def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool = True, tangent_array: bool = False) -> dict:
+    """tangent_array = False (default): the tangent block C_tang never exists — the fused operator writes (sigma, dp) only and the
+    Krylov matvec / the Jacobi diagonal form the consistent tangent's action from them (dxo_tangent_apply_vm, dxo_tangent_diagonal_vm:
+    56 instead of 288 bytes per point at d = 6). True: the operator writes C_tang as the reference's callback does and the matvec
+    reads it (dxo_tangent_apply)."""
     dev = torch.device("cuda:0")
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -50,12 +55,12 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
     u, u_n = torch.zeros(nn * G, **f64), torch.zeros(nn * G, **f64)         # total displacement, last converged one
     sigma_n, p = torch.zeros(npts * d, **f64), torch.zeros(npts, **f64)     # state at the last converged step
     sigma, dp = torch.zeros(npts * d, **f64), torch.zeros(npts, **f64)
-    C_tang = torch.zeros(npts * d * d, **f64)
+    C_tang = torch.zeros(npts * d * d, **f64) if tangent_array else None
     R, Kv = torch.zeros(nn * G, **f64), torch.zeros(nn * G, **f64)
 
     def constitutive(Du):
-        dm.von_mises(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr(),
-                     mem=MEM_DEVICE)
+        dm.von_mises(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr() if tangent_array else None, sigma.data_ptr(),
+                     dp.data_ptr(), mem=MEM_DEVICE)
 
     def residual():
         R.zero_()
@@ -64,7 +69,10 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
 
     def K_times(v):
         Kv.zero_()
-        dm.tangent_apply(C_tang.data_ptr(), v.data_ptr(), Kv.data_ptr())
+        if tangent_array:
+            dm.tangent_apply(C_tang.data_ptr(), v.data_ptr(), Kv.data_ptr())
+        else:
+            dm.tangent_apply_vm(prm, sigma.data_ptr(), dp.data_ptr(), v.data_ptr(), Kv.data_ptr())
         return torch.where(free, Kv, torch.zeros_like(Kv))
 
     diag = torch.zeros(nn * G, **f64)
@@ -72,7 +80,10 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
     def cg(b, tol=1e-10, maxit=4000):
         """Jacobi-preconditioned conjugate gradients; diag(K) comes from dxo_tangent_diagonal, also matrix-free."""
         diag.zero_()
-        dm.tangent_diagonal(C_tang.data_ptr(), diag.data_ptr())
+        if tangent_array:
+            dm.tangent_diagonal(C_tang.data_ptr(), diag.data_ptr())
+        else:
+            dm.tangent_diagonal_vm(prm, sigma.data_ptr(), dp.data_ptr(), diag.data_ptr())
         minv = torch.where(free, 1.0 / diag, torch.zeros_like(diag))
         xk = torch.zeros_like(b)
         r = b.clone()

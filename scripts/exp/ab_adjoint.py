@@ -33,6 +33,9 @@ Ct = (A @ A.transpose(1, 2) + torch.eye(d, device=dev, dtype=torch.float64)).res
 del A
 S = torch.randn(npts * d, generator=g, device=dev, dtype=torch.float64)
 v = torch.randn(nn * bs, generator=g, device=dev, dtype=torch.float64)
+dpv = (torch.randn(npts, generator=g, device=dev, dtype=torch.float64) * 1e-3).clamp_(min=0.0)     # half the points plastic
+from dolfinx_external_operator_amd import VmParams  # noqa: E402
+prm = VmParams(70e3, 0.3, 250.0, 70e3 * 700.0 / (70e3 - 700.0))
 stream = torch.cuda.current_stream()
 runs, ref = [], None
 for path in libs:
@@ -40,10 +43,12 @@ for path in libs:
     ctx = Context(0)
     ctx.set_stream(stream.cuda_stream)
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
-    outs = {k: torch.zeros(nn * bs, dtype=torch.float64, device=dev) for k in ("apply", "diag", "force")}
+    outs = {k: torch.zeros(nn * bs, dtype=torch.float64, device=dev) for k in ("apply", "diag", "force", "apply_vm", "diag_vm")}
     fns = {"apply": lambda dm=dm, o=outs["apply"]: (o.zero_(), dm.tangent_apply(Ct.data_ptr(), v.data_ptr(), o.data_ptr())),
            "diag": lambda dm=dm, o=outs["diag"]: (o.zero_(), dm.tangent_diagonal(Ct.data_ptr(), o.data_ptr())),
-           "force": lambda dm=dm, o=outs["force"]: (o.zero_(), dm.adjoint("eps", bs, S.data_ptr(), o.data_ptr()))}
+           "force": lambda dm=dm, o=outs["force"]: (o.zero_(), dm.adjoint("eps", bs, S.data_ptr(), o.data_ptr())),
+           "apply_vm": lambda dm=dm, o=outs["apply_vm"]: (o.zero_(), dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), o.data_ptr())),
+           "diag_vm": lambda dm=dm, o=outs["diag_vm"]: (o.zero_(), dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), o.data_ptr()))}
     for f in fns.values():
         f()
     torch.cuda.synchronize()

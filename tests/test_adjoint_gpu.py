@@ -188,11 +188,13 @@ def test_weights_are_required(ctx):
         dm.close()
 
 
-def test_device_newton_krylov_converges_quadratically():
+@pytest.mark.parametrize("tangent_array", [False, True])
+def test_device_newton_krylov_converges_quadratically(tangent_array):
     """examples/device_newton_krylov.py: load stepping with the fused constitutive kernel, the internal force and the
     matrix-free tangent, all on the device. Newton only converges quadratically if the tangent IS the derivative of the
     stress that the residual is built from — the kernel-level version of the reference's Taylor test
-    (demo_plasticity_mohr_coulomb.py:1149-1235)."""
+    (demo_plasticity_mohr_coulomb.py:1149-1235). Both forms of the tangent: acting from the returned (sigma, dp) with no
+    tangent array at all (the default), and read from the C_tang block the operator wrote."""
     import importlib.util
     import pathlib
 
@@ -200,7 +202,7 @@ def test_device_newton_krylov_converges_quadratically():
     spec = importlib.util.spec_from_file_location("nk_example", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    rep = mod.main(20, verbose=False)
+    rep = mod.main(20, verbose=False, tangent_array=tangent_array)
     assert rep["steps"][0]["newton_residuals"][-1] <= 1e-8 * rep["steps"][0]["newton_residuals"][0]
     assert len(rep["steps"][0]["newton_residuals"]) == 2                       # elastic step: one linear solve
     last = rep["steps"][-1]
