@@ -203,4 +203,59 @@ __device__ __forceinline__ void vm_store_tangent(const VmConst& c, const double*
 }
 
 
+// Phase C, row form: every lane builds the D x D tangent of ITS OWN point in registers (the 0/1 patterns of C_elas and of the
+// deviatoric projector are compile-time constants per entry: two FMAs and a shared product n_i n_j each) and the wave turns the
+// point-per-lane rows into output order through LDS, half a tile (32 points) at a time so the staging block stays at
+// 32 * D*D doubles. Same arithmetic per entry as vm_store_tangent, but ~90 instead of ~650 vector instructions per lane and
+// tile at d = 6 (that walk pays index carries, flag selects and three LDS reads for every 16-byte store); the price is
+// D*D/2 ds_write_b128 + D*D/2 ds_read_b128 per lane. W: the wave's LDS slice, at least VM_ROWS_DOUBLES<D> doubles, free on entry.
+template <int D>
+constexpr int VM_ROWS_STRIDE = (D * D / 2) % 4 == 0 ? D * D / 2 + 1 : D * D / 2;   // 16-byte chunks per staged point (odd multiple of 4 banks)
+template <int D>
+constexpr int VM_ROWS_DOUBLES = 32 * VM_ROWS_STRIDE<D> * 2;
+
+template <int D, bool NT>
+__device__ __forceinline__ void vm_store_tangent_rows(const VmConst& c, double* W, const double (&nrm)[D], double a, double b,
+                                                      dxo_f64x2* g_c, int nct, int lane) {
+    constexpr int CT = D * D / 2, HV = D / 2, RS = VM_ROWS_STRIDE<D>;
+    dxo_f64x2* S2 = reinterpret_cast<dxo_f64x2*>(W);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        // the half's 32 lanes build and stage their rows one at a time (D/2 chunks live, not D*D/2: the kernels that call this
+        // sit at their register budget); the other half idles through the branch
+        if ((lane >> 5) == h) {
+            double ah = a, bh = b;
+            double nh[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                nh[i] = nrm[i];
+                asm volatile("" : "+v"(nh[i]));
+            }
+            asm volatile("" : "+v"(ah), "+v"(bh));     // not loop-invariant: keeps the D*D entries from being hoisted (and held) across the halves
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int jj = 0; jj < HV; ++jj) {
+                    const int j0 = 2 * jj;
+                    const double e0 = (i < 3 && j0 < 3) ? 1.0 : 0.0, e1 = (i < 3 && j0 + 1 < 3) ? 1.0 : 0.0;
+                    const double d0 = i == j0 ? 1.0 : 0.0, d1 = i == j0 + 1 ? 1.0 : 0.0;
+                    dxo_f64x2 out;
+                    out.x = (e0 * c.lmbda + d0 * c.mu2) - ah * (nh[i] * nh[j0]) - bh * (d0 - e0 * (1.0 / 3.0));
+                    out.y = (e1 * c.lmbda + d1 * c.mu2) - ah * (nh[i] * nh[j0 + 1]) - bh * (d1 - e1 * (1.0 / 3.0));
+                    S2[(lane & 31) * RS + i * HV + jj] = out;
+                }
+        }
+        wave_lds_fence();
+#pragma unroll 3
+        for (int it = 0; it < CT / 2; ++it) {
+            const int q = it * DXO_WAVE + lane;                 // chunk inside the half tile, output order
+            const int src = RS == CT ? q : (q / CT) * RS + (q % CT);
+            const int gq = h * 32 * CT + q;
+            if (gq < nct) store16<NT>(g_c + gq, S2[src]);
+        }
+        wave_lds_fence();
+    }
+}
+
+
 }  // namespace

@@ -28,6 +28,10 @@ namespace {
 #ifndef DXO_VMF_PRELOAD
 #define DXO_VMF_PRELOAD 0   // request sigma_n / p before the strain is formed: no gain (0.844 vs 0.844 ms with two waves per SIMD, 1.00 with three: spills)
 #endif
+#ifndef DXO_VMF_ROWS
+#define DXO_VMF_ROWS 0   // 1: tangent rows built per lane and turned to output order through LDS (vm_store_tangent_rows: ~90 instead of ~650 vector
+                         // instructions per tile, bit-identical output) — 0.836 against 0.832 ms: the walk's arithmetic is not what the kernel waits for
+#endif
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
@@ -158,6 +162,11 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
             wave_lds_fence();
             continue;
         }
+#if DXO_VMF_ROWS
+        wave_lds_fence();       // sigma has left X: the whole slice stages tangent rows now
+        vm_store_tangent_rows<D, NT>(c, W, nrm, a, b, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
+        continue;
+#endif
 #if DXO_VMF_FULL
         // a full group of 64 points (8 cells x 8 points on hexahedra): guard-free tangent stores, as in vm_tile
         if (npts == DXO_WAVE) vm_store_tangent<D, NT, true>(c, Y, reinterpret_cast<dxo_f64x2*>(C_tang + p0 * (D * D)), npts * T::CH_CT, lane);
@@ -185,7 +194,10 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     const OperandDev& m = L.mesh->dev;
     const int D = L.mesh->gdim == 2 ? 4 : 6;
     int wd = m.cells_per_wave * (op_odd(m.ndofs * L.mesh->gdim) + op_odd(m.ngeom * L.mesh->gdim));
-    const int tile = DXO_WAVE * D + DXO_WAVE * (D + 2);
+    int tile = DXO_WAVE * D + DXO_WAVE * (D + 2);
+#if DXO_VMF_ROWS
+    if (C_tang && tile < (D == 4 ? VM_ROWS_DOUBLES<4> : VM_ROWS_DOUBLES<6>)) tile = D == 4 ? VM_ROWS_DOUBLES<4> : VM_ROWS_DOUBLES<6>;
+#endif
     if (wd < tile) wd = tile;
     wd = (wd + 1) & ~1;
     const size_t shm = (size_t)(m.table_doubles + 4 * wd) * sizeof(double);
