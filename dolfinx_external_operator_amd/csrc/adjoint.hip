@@ -339,6 +339,12 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
     }
 }
 
+#ifndef DXO_NS_WIDE
+#define DXO_NS_WIDE 1    // node_sum: 16-byte index and element-vector loads
+#endif
+typedef uint32_t NodeEnt4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef double NodeF64x2 __attribute__((ext_vector_type(2), aligned(8)));
+
 // second pass of the two-pass form: out[node] += sum of the node's element-vector entries, in the fixed order of the
 // transposed dofmap — no atomics, bit-reproducible
 template <int BS>
@@ -362,12 +368,33 @@ __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int
         for (int64_t e = e0; e < e1; e += U) {
             uint32_t idx[U];
             double f[U][BS];
+            // the kernel is bound by the ISSUE of its scattered loads (SQ_WAIT_INST_ANY 0.49 of the wave cycles): the four indices are
+            // one 16-byte load (4-byte aligned: the array is padded by U - 1 entries), an entry's BS doubles one or two loads
+#if DXO_NS_WIDE
+            const NodeEnt4 i4 = *reinterpret_cast<const NodeEnt4*>(ent + e);
+#pragma unroll
+            for (int k = 0; k < U; ++k) idx[k] = e + k < e1 ? i4[k] : 0u;
+#else
 #pragma unroll
             for (int k = 0; k < U; ++k) idx[k] = e + k < e1 ? ent[e + k] : 0u;
+#endif
 #pragma unroll
-            for (int k = 0; k < U; ++k)
+            for (int k = 0; k < U; ++k) {
+                const double* src = fe + (int64_t)idx[k] * BS;
+                if constexpr (BS >= 2 && DXO_NS_WIDE) {
+                    const NodeF64x2 v = *reinterpret_cast<const NodeF64x2*>(src);
+                    f[k][0] = v.x;
+                    f[k][1] = v.y;
+                    if constexpr (BS == 3) f[k][2] = src[2];
+                } else {
 #pragma unroll
-                for (int i = 0; i < BS; ++i) f[k][i] = e + k < e1 ? fe[(int64_t)idx[k] * BS + i] : 0.0;
+                    for (int i = 0; i < BS; ++i) f[k][i] = src[i];
+                }
+                if (!(e + k < e1)) {
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) f[k][i] = 0.0;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < U; ++k)
                 if (e + k < e1) {
@@ -987,7 +1014,7 @@ int ensure_transpose(dxo_ctx* ctx, dxo_mesh* m) {
     for (int64_t e = 0; e < nc * nd; ++e)      // visited in ascending (cell, a): a fixed order per node; stored as the fe index a*nc + cell
         ent[(size_t)fill[(size_t)m->h_dofmap[(size_t)e]]++] = (uint32_t)((e % nd) * nc + e / nd);
     DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ptr, ptr.size() * sizeof(int64_t)));
-    DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ent, (ent.size() ? ent.size() : 1) * sizeof(uint32_t)));
+    DXO_HIP(ctx, hipMalloc((void**)&m->d_node_ent, (ent.size() + 4) * sizeof(uint32_t)));   // + 4: node_sum reads four indices at a time
     DXO_HIP(ctx, hipMemcpy(m->d_node_ptr, ptr.data(), ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     if (!ent.empty()) DXO_HIP(ctx, hipMemcpy(m->d_node_ent, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return DXO_OK;
