@@ -146,6 +146,7 @@ _SIGNATURES = {
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
     "dxo_tangent_diagonal": (C.c_int, [_P, _P, _P, _P]),
     "dxo_tangent_apply_vm": (C.c_int, [_P, _P, C.POINTER(VmParams), _P, _P, _P, _P]),
+    "dxo_von_mises_residual": (C.c_int, [_P, C.POINTER(VmParams), _P, _P, _P, _P, _P, _P, _P]),
     "dxo_tangent_diagonal_vm": (C.c_int, [_P, _P, C.POINTER(VmParams), _P, _P, _P]),
     "dxo_heat_field": (C.c_int, [_P, C.c_double, C.c_double, _P, C.c_int, _P, _P, _P, _P]),
     "dxo_isihara": (C.c_int, [_P, C.POINTER(IsiharaParams), C.c_int64, C.c_int, _P, _P, _P]),

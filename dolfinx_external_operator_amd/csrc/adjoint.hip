@@ -1222,6 +1222,35 @@ bool vm_state_src(dxo_ctx* ctx, const dxo_mesh* mesh, const dxo_vm_params* prm, 
 
 }  // namespace
 
+// Residual of a von Mises Newton iteration in ONE call: (sigma, dp) = return map(eps(u), sigma_n, p) and R += sum_q w|J| B^T sigma.
+// dxo_von_mises_field (no tangent) and dxo_operand_adjoint back to back; with option vm_residual_fused = 1, on Q2 hexahedra with the
+// 2x2x2 rule, one kernel (vm_field RES) scatters the stress while it is in registers — an experiment that measured no faster.
+extern "C" int dxo_von_mises_residual(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, const double* u, const double* sigma_n,
+                                      const double* p, double* sigma, double* dp, double* R) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!prm || !mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_residual: NULL params or mesh");
+    if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_von_mises_residual: quadrature weights not set (dxo_mesh_set_weights)");
+    if (mesh->num_cells == 0) return DXO_OK;
+    if (!u || !sigma_n || !p || !sigma || !dp || !R) return dxo_fail(ctx, DXO_E_NULL, "dxo_von_mises_residual: NULL array");
+    if (((uintptr_t)u | (uintptr_t)p | (uintptr_t)dp | (uintptr_t)R) & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_residual: arrays must be 8-byte aligned");
+    if (((uintptr_t)sigma_n | (uintptr_t)sigma) & 15u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_von_mises_residual: sigma_n, sigma must be 16-byte aligned");
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    double* fe = (ctx->vm_residual_fused && dxo_vmf_residual_eligible(mesh)) ? two_pass_buffer(ctx, mesh, 3, nullptr, mesh->num_cells) : nullptr;
+    if (!fe) {
+        int rc = dxo_von_mises_field(ctx, prm, mesh, DXO_MEM_DEVICE, u, sigma_n, p, nullptr, sigma, dp);
+        if (rc != DXO_OK) return rc;
+        return dxo_operand_adjoint(ctx, mesh, DXO_OPERAND_EPS_MANDEL, mesh->gdim, sigma, nullptr, -1, R);
+    }
+    hipStream_t s = dxo_launch_stream(ctx);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    rc = dxo_vmf_residual_launch(ctx, prm, mesh, u, sigma_n, p, sigma, dp, fe, s);
+    if (rc != DXO_OK) return rc;
+    launch_node_sum(ctx, mesh, 3, R, s);
+    return dxo_device_end(ctx, s);
+}
+
 extern "C" int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, double* out) {
     if (!ctx) return DXO_E_NULL;
     DXO_LOCK(ctx);

@@ -77,6 +77,8 @@ struct dxo_ctx {
     int64_t icnn_variant = 2;           // fp32 network: 0 VALU lane-per-point kernel; wave-per-64-points MFMA kernels: 1 fp32-input MFMA, 2 split-bf16 MFMA
     int64_t adjoint_cell = 1;           // virtual work of eps on the standard elements: lane = cell kernel (0: wave-group kernel)
     int64_t operand_cell = 1;           // dxo_eval_operand, eps on the 2-D standard elements: lane = cell kernel (operand_cell.h); 0: wave-group kernel
+    int64_t vm_residual_fused = 0;      // dxo_von_mises_residual on Q2 hexahedra: 1 = one kernel (stress scattered from registers; measured no faster:
+                                        // 1.19 against 1.16-1.19 ms per 10^7 points, profiles/r04_adjoint_experiments.txt), 0 = field + adjoint calls
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and
@@ -213,6 +215,10 @@ int dxo_icnn_launch_device(dxo_ctx* ctx, const dxo_icnn* m, int precision, int64
                            hipStream_t s);
 int dxo_isihara_launch_device(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, const double* F, double* dP, double* P,
                               hipStream_t s);
+// vm_field.hip: fused strain + return map + element vectors of the returned stress (fe[node][cell][i]) — dxo_von_mises_residual
+bool dxo_vmf_residual_eligible(const dxo_mesh* mesh);
+int dxo_vmf_residual_launch(dxo_ctx* ctx, const dxo_vm_params* prm, const dxo_mesh* mesh, const double* u, const double* sigma_n,
+                            const double* p, double* sigma, double* dp, double* fe, hipStream_t s);
 
 // Device mirror of the Mohr-Coulomb history variable plus the stress of the last call (include/dxo.h, dxo_mc_state_*):
 // ONE allocation, [sigma_n n*4 | sigma n*4] doubles.

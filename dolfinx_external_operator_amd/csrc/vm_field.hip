@@ -16,6 +16,7 @@
 #include "operand_core.h"
 #include "vm_core.h"
 #include "vm_host.h"
+#include "cell8_dpp.h"
 
 namespace {
 
@@ -32,6 +33,10 @@ namespace {
 #define DXO_VMF_ROWS 0   // 1: tangent rows built per lane and turned to output order through LDS (vm_store_tangent_rows: ~90 instead of ~650 vector
                          // instructions per tile, bit-identical output) — 0.836 against 0.832 ms: the walk's arithmetic is not what the kernel waits for
 #endif
+#ifndef DXO_VMF_RES_WAVES
+#define DXO_VMF_RES_WAVES 2   // residual form: 224 registers. Three waves per SIMD spill 136 registers even with w|J|J^-1 parked in LDS (1.80 ms
+                              // against 1.19 for the whole call): the scatter's 8 table rows and partials sit on top of the gather pipeline
+#endif
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
@@ -41,17 +46,24 @@ namespace {
 #ifndef DXO_VMF_BLOCKS_PER_CU
 #define DXO_VMF_BLOCKS_PER_CU 16
 #endif
-template <int G, bool NT, int ND_CT = 0, int NG_CT = 0>
-__global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
+// RES (hexahedra with the 2x2x2 rule, cell8_dpp.h; EXPERIMENT, option vm_residual_fused, off by default): the kernel also forms the internal force of the stress it has just returned —
+// element vectors fe[node][cell][i] = sum_q w|J| B^T sigma, reduce-scattered over the cell's 8 lanes while sigma, J^-1 and |J| are
+// still in registers (dxo_von_mises_residual; node_sum follows). No tangent is written in this form.
+template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, bool RES = false>
+__global__ __launch_bounds__(DXO_BLOCK, RES ? DXO_VMF_RES_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
                                                          const double* __restrict__ p, double* __restrict__ C_tang,
-                                                         double* __restrict__ sigma, double* __restrict__ dp_out) {
+                                                         double* __restrict__ sigma, double* __restrict__ dp_out,
+                                                         const double* __restrict__ wq, double* __restrict__ fe) {
+    static_assert(!RES || (G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8), "the residual form is the eight-point hexahedron's");
     constexpr int D = G == 2 ? 4 : 6;
     using T = VmTile<D>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
+    double* tab8 = lds + m.table_doubles + T::WAVES * wave_doubles;     // RES: the padded dphi rows c8_scatter reads
+    if constexpr (RES) c8_fill_tables(m, tab8);
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -60,6 +72,8 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
     double* Y = X + T::X_DOUBLES;
     dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
     dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
+    dxo_f64x2* N2 = RES ? X2 : Y2;      // where sigma_n turns from lane-linear to point-per-lane (RES keeps w|J|J^-1 in Y)
+    const double w_l = RES ? wq[lane & 7] : 0.0;
     const int cpw = m.cells_per_wave;
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
     const GroupWalk walk = xcd_group_walk(n_groups, T::WAVES, wave);
@@ -101,13 +115,25 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         // ---- A1: strain increment of this lane's point from the displacement dofs
         double e[D];
         bool active;
+        double sK22 = 0.0;                  // RES only
         if (piped) {
             pipe_commit<G, G>(m, pf, W, ncell, lane);
             if (!(DXO_VMF_KO & 4)) {
                 pipe_load_values<G, G>(m, pf, u);
                 pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
             }
-            active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e);
+            if constexpr (RES) {
+                double Kinv[G][G], detJ;
+                active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e, Kinv, detJ);
+                // w |J| J^-1 waits for the returned stress in the wave's LDS slice (behind the 384 doubles the stress rows are staged in),
+                // not in registers: the return map and the scatter each need the file at three waves per SIMD
+                const double scale = w_l * fabs(detJ);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Y[k * DXO_WAVE + lane] = scale * Kinv[k / 3][k % 3];
+                sK22 = scale * Kinv[2][2];
+            } else {
+                active = operand_compute<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e);
+            }
         } else {
             active = operand_point<G, G, DXO_OPERAND_EPS_MANDEL>(m, tab, W, u, nullptr, cell0 + c0, ncell, lane, e);
         }
@@ -118,13 +144,13 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         // ---- A2: sigma_n lane-linear -> LDS -> point-per-lane
 #if DXO_VMF_PRELOAD
 #pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) Y2[k * DXO_WAVE + lane] = sreg[k];
+        for (int k = 0; k < T::CH_VEC; ++k) N2[k * DXO_WAVE + lane] = sreg[k];
 #else
         const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
             const int idx = k * DXO_WAVE + lane;
-            Y2[idx] = (idx < nvec && !(DXO_VMF_KO & 2)) ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
+            N2[idx] = (idx < nvec && !(DXO_VMF_KO & 2)) ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
         }
         const double p_l = (lane < npts && !(DXO_VMF_KO & 2)) ? p[p0 + lane] : 0.0;
 #endif
@@ -132,7 +158,7 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         double sn[D];
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
-            const dxo_f64x2 b2 = Y2[lane * T::CH_VEC + k];
+            const dxo_f64x2 b2 = N2[lane * T::CH_VEC + k];
             sn[2 * k] = b2.x;
             sn[2 * k + 1] = b2.y;
         }
@@ -146,9 +172,9 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
             X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
-            Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+            if constexpr (!RES) Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
         }
-        Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+        if constexpr (!RES) Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
         wave_lds_fence();
         if ((DXO_VMF_KO & 1) && dp != 1.2345e300) { wave_lds_fence(); continue; }
         if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);
@@ -157,6 +183,34 @@ __global__ __launch_bounds__(DXO_BLOCK, DXO_VMF_WAVES) void vm_field(VmConst c, 
         for (int k = 0; k < T::CH_VEC; ++k) {
             const int idx = k * DXO_WAVE + lane;
             if (idx < nvec) store16<NT>(g_o + idx, X2[idx]);
+        }
+        if constexpr (RES) {
+            // virtual work of the returned stress: T = w |J| sigma_hat J^-T per point, then f_a = sum_q T_q dphi_a(q) across the cell's lanes
+            constexpr double r2 = 0.70710678118654752440;
+            const double gh[3][3] = {{sig[0], r2 * sig[3], r2 * sig[4]}, {r2 * sig[3], sig[1], r2 * sig[5]}, {r2 * sig[4], r2 * sig[5], sig[2]}};
+            const bool has_point = lane < npts;
+            double sK[3][3], Tq[3][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sK[k / 3][k % 3] = Y[k * DXO_WAVE + lane];
+            sK[2][2] = sK22;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tt += gh[i][j] * sK[k][j];
+                    Tq[i][k] = has_point ? tt : 0.0;
+                }
+            const C8Lane L8(tab8, lane);
+            const int64_t cell = cell0 + c0 + (lane >> 3);
+            c8_scatter<ND_CT>(L8, Tq, [&](int a, const double (&o)[3]) {
+                if (!has_point) return;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
+            });
+            wave_lds_fence();
+            continue;
         }
         if (!C_tang) {      // (sigma, dp) only: a matrix-free solver rebuilds the tangent's action from them (dxo_tangent_apply_vm)
             wave_lds_fence();
@@ -189,7 +243,7 @@ struct FieldLaunch {
 };
 
 int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_cells, const double* sigma_n,
-                 const double* p, double* C_tang, double* sigma, double* dp, hipStream_t s) {
+                 const double* p, double* C_tang, double* sigma, double* dp, hipStream_t s, double* fe = nullptr) {
     if (n_cells == 0) return DXO_OK;
     const OperandDev& m = L.mesh->dev;
     const int D = L.mesh->gdim == 2 ? 4 : 6;
@@ -200,7 +254,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
 #endif
     if (wd < tile) wd = tile;
     wd = (wd + 1) & ~1;
-    const size_t shm = (size_t)(m.table_doubles + 4 * wd) * sizeof(double);
+    const size_t shm = (size_t)(m.table_doubles + 4 * wd + (fe ? C8_LDS : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");
     const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
@@ -208,17 +262,22 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;
+    if (fe) {       // residual form (dxo_vmf_residual_eligible has been checked by the caller)
+        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, nullptr, sigma, dp, L.mesh->d_wq, fe);
+        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, nullptr, sigma, dp, L.mesh->d_wq, fe);
+        return DXO_OK;
+    }
     if (DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8) {   // Q2 hexahedra: trip counts known at compile time
-        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
-        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
+        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
+        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
         return DXO_OK;
     }
     if (L.mesh->gdim == 2) {
-        if (nt) hipLaunchKernelGGL((vm_field<2, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
-        else    hipLaunchKernelGGL((vm_field<2, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
+        if (nt) hipLaunchKernelGGL((vm_field<2, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
+        else    hipLaunchKernelGGL((vm_field<2, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
     } else {
-        if (nt) hipLaunchKernelGGL((vm_field<3, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
-        else    hipLaunchKernelGGL((vm_field<3, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp);
+        if (nt) hipLaunchKernelGGL((vm_field<3, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
+        else    hipLaunchKernelGGL((vm_field<3, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
     }
     return DXO_OK;
 }
@@ -261,6 +320,20 @@ int field_upload_u(dxo_ctx* ctx, dxo_mesh* mesh, const double* u) {
 }
 
 }  // namespace
+
+// Residual form for dxo_von_mises_residual (adjoint.hip owns the element-vector buffer and the node sums): Q2 hexahedra with the
+// 2x2x2 rule whose gather fits the register pipeline.
+bool dxo_vmf_residual_eligible(const dxo_mesh* mesh) {
+    const OperandDev& m = mesh->dev;
+    return DXO_OP_CT && mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8 && m.nq == 8 && m.cells_per_wave == 8 &&
+           m.cells_per_wave * m.ndofs <= OP_GI * DXO_WAVE && m.cells_per_wave * m.ngeom <= OP_XI * DXO_WAVE;
+}
+
+int dxo_vmf_residual_launch(dxo_ctx* ctx, const dxo_vm_params* prm, const dxo_mesh* mesh, const double* u, const double* sigma_n,
+                            const double* p, double* sigma, double* dp, double* fe, hipStream_t s) {
+    FieldLaunch L{make_const(*prm), mesh, u, 0};
+    return field_launch(ctx, L, 0, mesh->num_cells, sigma_n, p, nullptr, sigma, dp, s, fe);
+}
 
 // Fused strain + return map with the history variables in a dxo_vm_state (von_mises.hip): of a host call only the dof
 // vector goes up (one value per dof, not per quadrature point) and, with option vm_host_tangent, only (sigma, dp) come

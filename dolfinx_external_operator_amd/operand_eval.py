@@ -227,6 +227,13 @@ class DeviceMesh:
                                                   C.c_void_p(out_ptr))
         self.ctx.check(rc, "dxo_tangent_diagonal_vm")
 
+    def von_mises_residual(self, prm, u_ptr: int, sigma_n_ptr: int, p_ptr: int, sigma_ptr: int, dp_ptr: int, R_ptr: int) -> None:
+        """(sigma, dp) = von Mises return map of (eps(u), sigma_n, p) and R += sum_q w|J| B^T sigma in one call
+        (dxo_von_mises_residual; DEVICE pointers): the residual evaluation of a Newton iteration of a matrix-free solve."""
+        rc = self.ctx.lib.dxo_von_mises_residual(self.ctx._h, C.byref(prm), self._h, *(C.c_void_p(a) for a in
+                                                 (u_ptr, sigma_n_ptr, p_ptr, sigma_ptr, dp_ptr, R_ptr)))
+        self.ctx.check(rc, "dxo_von_mises_residual")
+
     def heat(self, A: float, B: float, T_dofs, q=None, dqdT=None, dqdsigma=None, mem: int = MEM_HOST) -> None:
         """dxo_heat_field: T and grad T of a scalar field + the heat-flux kernels in one launch (all cells)."""
         def ptr(a):

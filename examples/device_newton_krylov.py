@@ -5,8 +5,8 @@ The reference solves the same kind of problem (doc/demo/demo_plasticity_von_mise
 SNES; per Newton iteration it evaluates the operands, calls the external operator, copies the tangent into a coefficient
 and assembles a sparse Jacobian from it. Here, per Newton iteration:
 
-    sigma, C_tang, dp = von Mises(eps(Du), sigma_n, p)      dxo_von_mises_field   (strain + return map + tangent, one launch)
-    R = sum w|J| B^T sigma  on the free dofs                dxo_operand_adjoint   (internal force; no external load here)
+    sigma, dp = von Mises(eps(Du), sigma_n, p)              dxo_von_mises_residual (strain + return map, then the internal force of
+    R = sum w|J| B^T sigma  on the free dofs                                        the returned stress; no external load here)
     solve K d = -R with Jacobi-preconditioned CG, K v by    dxo_tangent_apply_vm, diag(K) by dxo_tangent_diagonal_vm   (K is never formed,
                                                             and neither is C_tang: both act from the returned (sigma, dp))
     Du += d
@@ -58,13 +58,14 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
     C_tang = torch.zeros(npts * d * d, **f64) if tangent_array else None
     R, Kv = torch.zeros(nn * G, **f64), torch.zeros(nn * G, **f64)
 
-    def constitutive(Du):
-        dm.von_mises(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr() if tangent_array else None, sigma.data_ptr(),
-                     dp.data_ptr(), mem=MEM_DEVICE)
-
-    def residual():
+    def residual(Du):
+        """(sigma, dp[, C_tang]) of the increment and the internal force of the returned stress on the free dofs"""
         R.zero_()
-        dm.adjoint("eps", G, sigma.data_ptr(), R.data_ptr())
+        if tangent_array:
+            dm.von_mises(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr(), mem=MEM_DEVICE)
+            dm.adjoint("eps", G, sigma.data_ptr(), R.data_ptr())
+        else:
+            dm.von_mises_residual(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), sigma.data_ptr(), dp.data_ptr(), R.data_ptr())
         return torch.where(free, R, torch.zeros_like(R))
 
     def K_times(v):
@@ -116,8 +117,7 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
         prev = load
         history, t0, cg_its = [], time.perf_counter(), 0
         for it in range(25):
-            constitutive(u - u_n)
-            res = residual()
+            res = residual(u - u_n)
             rn = float(torch.linalg.norm(res))
             history.append(rn)
             if rn <= 1e-9 * max(history[0], 1e-30) or rn < 1e-9:

@@ -90,3 +90,54 @@ def test_state_only_launch_honours_nontemporal(ctx, d):
     finally:
         ctx.set_option("nontemporal", saved)
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
+@pytest.mark.parametrize("cell,n,degree", [("hexahedron", (5, 4, 3), 2), ("hexahedron", (2, 2, 2), 2), ("hexahedron", (3, 3, 2), 1),
+                                           ("triangle", (7, 6), 2), ("tetrahedron", (2, 3, 2), 2)])
+def test_residual_in_one_call_equals_field_then_adjoint(ctx, cell, n, degree):
+    """dxo_von_mises_residual = dxo_von_mises_field (no tangent) followed by dxo_operand_adjoint of the returned stress: bit-identical.
+    With option vm_residual_fused = 1 one kernel does both on Q2 hexahedra (the stress is scattered from registers): (sigma, dp)
+    bit-identical, R to rounding of the Jacobian's sum order; on every other element the option changes nothing."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh
+    from tools.synthetic import structured_mesh
+
+    m = structured_mesh(cell, n, degree, distort=0.2, seed=4)
+    G, d = m.gdim, 4 if m.gdim == 2 else 6
+    nn, npts = m.node_x.shape[0], m.num_cells * m.nq
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    prm = VmParams(E, NU, 250.0, H)
+    rng = np.random.Generator(np.random.PCG64(11))
+    f64 = dict(dtype=torch.float64, device="cuda")
+    u = torch.from_numpy(rng.normal(0.0, 4e-3, size=nn * G)).cuda()
+    sn = torch.from_numpy(rng.normal(0.0, 100.0, size=npts * d)).cuda()
+    p = torch.from_numpy(np.abs(rng.normal(0.0, 1e-3, size=npts))).cuda()
+    R0 = torch.from_numpy(rng.normal(size=nn * G)).cuda()            # the call ADDS to R
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        sig_a, dp_a, R_a = torch.zeros(npts * d, **f64), torch.zeros(npts, **f64), R0.clone()
+        dm.von_mises(prm, u.data_ptr(), sn.data_ptr(), p.data_ptr(), None, sig_a.data_ptr(), dp_a.data_ptr(), mem=MEM_DEVICE)
+        dm.adjoint("eps", G, sig_a.data_ptr(), R_a.data_ptr())
+        results = {}
+        for fused in (1, 0):
+            ctx.set_option("vm_residual_fused", fused)
+            sig, dpo, R = torch.full((npts * d,), np.nan, **f64), torch.full((npts,), np.nan, **f64), R0.clone()
+            dm.von_mises_residual(prm, u.data_ptr(), sn.data_ptr(), p.data_ptr(), sig.data_ptr(), dpo.data_ptr(), R.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(sig, sig_a) and torch.equal(dpo, dp_a), (cell, fused)
+            results[fused] = R
+        assert float((dp_a > 0).double().mean()) > 0.2                   # plastic and elastic points both present
+        assert torch.equal(results[0], R_a)
+        scale = float((R_a - R0).abs().max())
+        assert float((results[1] - R_a).abs().max()) <= 1e-12 * scale
+        if not (cell == "hexahedron" and degree == 2):
+            assert torch.equal(results[1], R_a)                             # no fused kernel for this element: the same two calls
+        again = R0.clone()
+        ctx.set_option("vm_residual_fused", 1)
+        dm.von_mises_residual(prm, u.data_ptr(), sn.data_ptr(), p.data_ptr(), sig.data_ptr(), dpo.data_ptr(), again.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(again, results[1])                               # no atomics: bit-reproducible
+    finally:
+        ctx.set_option("vm_residual_fused", 0)
+        dm.close()
