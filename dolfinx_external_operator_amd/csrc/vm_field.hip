@@ -37,6 +37,9 @@ namespace {
 #define DXO_VMF_RES_WAVES 2   // residual form: 224 registers. Three waves per SIMD spill 136 registers even with w|J|J^-1 parked in LDS (1.80 ms
                               // against 1.19 for the whole call): the scatter's 8 table rows and partials sit on top of the gather pipeline
 #endif
+#ifndef DXO_VMF_STATE2D_WAVES
+#define DXO_VMF_STATE2D_WAVES 4   // (sigma, dp)-only launch in 2-D: 132 registers at three waves per SIMD
+#endif
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
@@ -49,13 +52,16 @@ namespace {
 // RES (hexahedra with the 2x2x2 rule, cell8_dpp.h; EXPERIMENT, option vm_residual_fused, off by default): the kernel also forms the internal force of the stress it has just returned —
 // element vectors fe[node][cell][i] = sum_q w|J| B^T sigma, reduce-scattered over the cell's 8 lanes while sigma, J^-1 and |J| are
 // still in registers (dxo_von_mises_residual; node_sum follows). No tangent is written in this form.
-template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, bool RES = false>
-__global__ __launch_bounds__(DXO_BLOCK, RES ? DXO_VMF_RES_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
+// MODE 0: (C_tang, sigma, dp). MODE 1: (sigma, dp) only — its own instantiation, so that the profiler's kernel names tell the two
+// launches apart (the arithmetic of the stores that remain is the same). MODE 2: RES.
+template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, int MODE = 0>
+__global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE == 1 && G == 2) ? DXO_VMF_STATE2D_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
                                                          const double* __restrict__ p, double* __restrict__ C_tang,
                                                          double* __restrict__ sigma, double* __restrict__ dp_out,
                                                          const double* __restrict__ wq, double* __restrict__ fe) {
+    constexpr bool RES = MODE == 2;
     static_assert(!RES || (G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8), "the residual form is the eight-point hexahedron's");
     constexpr int D = G == 2 ? 4 : 6;
     using T = VmTile<D>;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(DXO_BLOCK, RES ? DXO_VMF_RES_WAVES : DXO_VMF_WAVES)
             wave_lds_fence();
             continue;
         }
-        if (!C_tang) {      // (sigma, dp) only: a matrix-free solver rebuilds the tangent's action from them (dxo_tangent_apply_vm)
+        if constexpr (MODE == 1) {      // (sigma, dp) only: a matrix-free solver rebuilds the tangent's action from them (dxo_tangent_apply_vm)
             wave_lds_fence();
             continue;
         }
@@ -262,23 +268,26 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;
-    if (fe) {       // residual form (dxo_vmf_residual_eligible has been checked by the caller)
-        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, nullptr, sigma, dp, L.mesh->d_wq, fe);
-        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, nullptr, sigma, dp, L.mesh->d_wq, fe);
-        return DXO_OK;
-    }
-    if (DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8) {   // Q2 hexahedra: trip counts known at compile time
-        if (nt) hipLaunchKernelGGL((vm_field<3, true, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
-        else    hipLaunchKernelGGL((vm_field<3, false, 27, 8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
-        return DXO_OK;
-    }
-    if (L.mesh->gdim == 2) {
-        if (nt) hipLaunchKernelGGL((vm_field<2, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
-        else    hipLaunchKernelGGL((vm_field<2, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
+#define DXO_VMF_LAUNCH(...)                                                                                                         \
+    do {                                                                                                                            \
+        hipLaunchKernelGGL((vm_field<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u,  \
+                           sigma_n, p, C_tang, sigma, dp, L.mesh->d_wq, fe);                                                       \
+    } while (0)
+    const int mode = fe ? 2 : (C_tang ? 0 : 1);
+    const bool q2hex = DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8;   // trip counts known at compile time
+    if (mode == 2) {            // residual form (dxo_vmf_residual_eligible has been checked by the caller)
+        if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 2); else DXO_VMF_LAUNCH(3, false, 27, 8, 2);
+    } else if (q2hex) {
+        if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 0); else DXO_VMF_LAUNCH(3, false, 27, 8, 0); }
+        else           { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 1); else DXO_VMF_LAUNCH(3, false, 27, 8, 1); }
+    } else if (L.mesh->gdim == 2) {
+        if (mode == 0) { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 0); else DXO_VMF_LAUNCH(2, false, 0, 0, 0); }
+        else           { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 1); else DXO_VMF_LAUNCH(2, false, 0, 0, 1); }
     } else {
-        if (nt) hipLaunchKernelGGL((vm_field<3, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
-        else    hipLaunchKernelGGL((vm_field<3, false>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u, sigma_n, p, C_tang, sigma, dp, nullptr, nullptr);
+        if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 0); else DXO_VMF_LAUNCH(3, false, 0, 0, 0); }
+        else           { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 1); else DXO_VMF_LAUNCH(3, false, 0, 0, 1); }
     }
+#undef DXO_VMF_LAUNCH
     return DXO_OK;
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of builds of the consumer-side kernels (dxo_tangent_apply, dxo_tangent_diagonal, dxo_operand_adjoint) on ONE mesh
-in ONE process (GPU box). usage: python scripts/exp/ab_adjoint.py [hex|tri] [lib.so ...]
+in ONE process (GPU box). usage: python scripts/exp/ab_adjoint.py [hex|tri|tet] [lib.so ...]
 (default libs: the in-tree library + every build_exp/libdxo_*.so). Rounds are interleaved; results are compared with the first
 library's (1e-12 of the scale)."""
 import glob
@@ -19,9 +19,11 @@ import dolfinx_external_operator_amd._lib as L  # noqa: E402
 from dolfinx_external_operator_amd import Context, DeviceMesh  # noqa: E402
 from tools.synthetic import structured_mesh  # noqa: E402
 
-cell = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("hex", "tri") else "hex"
+cell = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("hex", "tri", "tet") else "hex"
 libs = [a for a in sys.argv[1:] if a.endswith(".so")] or [str(L.LIB_PATH)] + sorted(glob.glob(str(ROOT / "dolfinx_external_operator_amd" / "build_exp" / "libdxo_*.so")))
-m = structured_mesh("hexahedron", (108,) * 3, 2, distort=0.2, seed=0) if cell == "hex" else structured_mesh("triangle", (1291, 1291), 2, distort=0.2, seed=0)
+m = (structured_mesh("hexahedron", (108,) * 3, 2, distort=0.2, seed=0) if cell == "hex" else
+     structured_mesh("triangle", (1291, 1291), 2, distort=0.2, seed=0) if cell == "tri" else
+     structured_mesh("tetrahedron", (75,) * 3, 2, distort=0.2, seed=0))
 dev = torch.device("cuda:0")
 bs = m.gdim
 d = 4 if bs == 2 else 6

@@ -19,14 +19,19 @@ from dolfinx_external_operator_amd import MEM_DEVICE, Context, DeviceMesh, VmPar
 from tools.synthetic import structured_mesh  # noqa: E402
 
 libs = sys.argv[1:] or [str(L.LIB_PATH)] + sorted(glob.glob(str(ROOT / "dolfinx_external_operator_amd" / "build_exp" / "libdxo_*.so")))
-n = int(__import__("os").environ.get("VMF_N", "108"))
-m = structured_mesh("hexahedron", (n, n, n), 2, distort=0.2, seed=0)
+import os  # noqa: E402
+n = int(os.environ.get("VMF_N", "108"))
+tri = os.environ.get("VMF_CELL", "hex") == "tri"               # VMF_CELL=tri: P2 triangles, 1291^2 x 2 cells
+tet = os.environ.get("VMF_CELL", "hex") == "tet"               # VMF_CELL=tet: P2 tetrahedra, 75^3 x 6 cells, 4 points each
+no_tangent = os.environ.get("VMF_NOTANGENT", "0") == "1"       # VMF_NOTANGENT=1: the (sigma, dp)-only launch (C_tang = NULL)
+m = (structured_mesh("triangle", (1291, 1291), 2, distort=0.2, seed=0) if tri else structured_mesh("tetrahedron", (75,) * 3, 2, distort=0.2, seed=0) if tet
+     else structured_mesh("hexahedron", (n, n, n), 2, distort=0.2, seed=0))
 dev = torch.device("cuda:0")
-npts, d = m.num_cells * m.nq, 6
+npts, d = m.num_cells * m.nq, 4 if tri else 6
 E = 70e3
 prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
 rng = np.random.Generator(np.random.PCG64(0))
-u = torch.from_numpy(rng.normal(0.0, 3e-3, size=m.node_x.shape[0] * 3)).to(dev)
+u = torch.from_numpy(rng.normal(0.0, 3e-3, size=m.node_x.shape[0] * m.gdim)).to(dev)
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 sig = torch.randn(npts * d, generator=g, device=dev, dtype=torch.float64) * 100
@@ -43,7 +48,7 @@ for path in libs:
     if not runs:
         shared_out = ctx.vm_output_tensors(npts, d)   # ONE block for every variant (calibrated with vm_tile: the fused kernel stores in the same pattern)
     Ct, st, dpt = shared_out
-    fn = lambda dm=dm, Ct=Ct, st=st, dpt=dpt: dm.von_mises(prm, u.data_ptr(), sig.data_ptr(), pp.data_ptr(), Ct.data_ptr(), st.data_ptr(), dpt.data_ptr(), mem=MEM_DEVICE)  # noqa: E731
+    fn = lambda dm=dm, Ct=Ct, st=st, dpt=dpt: dm.von_mises(prm, u.data_ptr(), sig.data_ptr(), pp.data_ptr(), None if no_tangent else Ct.data_ptr(), st.data_ptr(), dpt.data_ptr(), mem=MEM_DEVICE)  # noqa: E731
     fn()
     torch.cuda.synchronize()
     if first is None:

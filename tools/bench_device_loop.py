@@ -139,7 +139,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
         matvec_vm()
         vm_err = float((Kv - ref_Kv).abs().max() / ref_Kv.abs().max())
         calls_vm = {}
-        for name, fn, kernels in (("von_mises_field_state_no_tangent", field_state_only, [f"vm_field<{bs}> with C_tang = NULL"]),
+        for name, fn, kernels in (("von_mises_field_state_no_tangent", field_state_only, [f"vm_field<{bs}, ..., 1> (C_tang = NULL: its own instantiation)"]),
                                   ("tangent_apply_vm", matvec_vm, ["tangent_apply<..., VM>", "node_sum"]),
                                   ("tangent_diagonal_vm", diag_vm, ["tangent_diag<..., VM>", "node_sum"])):
             ms, _ = _time(torch, stream, fn, launches, warm=3)

@@ -543,8 +543,10 @@ TRAFFIC_KEYS = {
     ("icnn_cfg5", ("roofline", "hbm")): ("icnn_mfma_bf16x3<", "all"),
     ("von_mises_d4_nq3", ("roofline",)): ("vm_tile<4,", "all"),
     ("von_mises_cfg2_1e6", ("roofline",)): ("vm_tile<6,", "all"),
-    ("vm_field_q2", ("roofline",)): ("vm_field<3,", "all"),
-    ("device_loop_q2hex", ("calls", "von_mises_field_state", "roofline")): ("vm_field<3,", "all"),
+    ("vm_field_q2", ("roofline",)): ("vm_field<3,*, 0>(", "all"),
+    ("device_loop_q2hex", ("calls", "von_mises_field_state", "roofline")): ("vm_field<3,*, 0>(", "all"),
+    ("device_loop_q2hex", ("without_tangent_array", "calls", "von_mises_field_state_no_tangent", "roofline")): ("vm_field<3,*, 1>(", "all"),
+    ("device_loop_p2tri", ("without_tangent_array", "calls", "von_mises_field_state_no_tangent", "roofline")): ("vm_field<2,*, 1>(", "all"),
     ("device_loop_q2hex", ("calls", "internal_force", "roofline")): ("operand_adjoint_c8<", "all"),
     ("device_loop_q2hex", ("calls", "tangent_apply", "roofline")): ("tangent_apply<3, 27, 8, false>", "all"),
     ("device_loop_q2hex", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<3, 27, false>", "all"),
@@ -553,7 +555,7 @@ TRAFFIC_KEYS = {
     ("device_loop_q2hex", ("without_tangent_array", "calls", "tangent_diagonal_vm", "roofline")): ("tangent_diag<3, 27, true>", "all"),
     ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_apply_vm", "roofline")): ("tangent_apply<2, 0, 0, true>", "all"),
     ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_diagonal_vm", "roofline")): ("tangent_diag<2, 0, true>", "all"),
-    ("device_loop_p2tri", ("calls", "von_mises_field_state", "roofline")): ("vm_field<2,", "all"),
+    ("device_loop_p2tri", ("calls", "von_mises_field_state", "roofline")): ("vm_field<2,*, 0>(", "all"),
     ("device_loop_p2tri", ("calls", "internal_force", "roofline")): ("adjoint_cell_eps<2,", "all"),
     ("device_loop_p2tri", ("calls", "tangent_apply", "roofline")): ("tangent_apply<2, 0, 0, false>", "all"),
     ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2, 0, false>", "all"),
@@ -568,6 +570,17 @@ FOLLOWERS = ("node_sum<", "assign_store(")
 # count — the stress field, the element vectors read back by node_sum, its index arrays, geometry; x2 would claim 3.5 GB).
 # tangent_apply / tangent_diag read their 2.9 GB of tangent rows lane-linear (x2) and gather the rest: x2 is an upper bound there.
 FETCH_X1 = ("node_sum<", "assign_owner(", "assign_store(", "assign_apply<", "adjoint_cell_eps<", "operand_adjoint<", "operand_adjoint_c8<", "tangent_cell<")
+
+
+def _name_has(key, name):
+    """`key` occurs in `name`; a '*' in the key stands for any run of characters (template arguments in between)."""
+    pos = 0
+    for part in key.split("*"):
+        pos = name.find(part, pos)
+        if pos < 0:
+            return False
+        pos += len(part)
+    return True
 
 
 def parse_counter_csv(files, counter):
@@ -586,7 +599,7 @@ def parse_counter_csv(files, counter):
     res, cur = {}, None
     for _did, name, grid, val in rows:
         b = val * 1024.0 * (2.0 if counter == "FETCH_SIZE" and not any(k in name for k in FETCH_X1) else 1.0)
-        key = next((k for k in owners if k in name), None)
+        key = next((k for k in owners if _name_has(k, name)), None)
         if key is not None:
             cur = [grid, b]
             res.setdefault(key, []).append(cur)
