@@ -350,7 +350,7 @@ typedef double NodeF64x2 __attribute__((ext_vector_type(2), aligned(8)));
 template <int BS>
 __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int64_t* __restrict__ ptr,
                                                       const uint32_t* __restrict__ ent, const double* __restrict__ fe,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, int overwrite) {
     // A node's sum is a chain of dependent loads (ptr -> ent -> fe) per entry: with one entry at a time the wave sat in s_waitcnt
     // 92 % of its cycles (profiles/r04_device_loop_pmc.json). The entries are taken four at a time — the four indices, then the
     // four element-vector pieces, are in flight together — and `out` is requested before the loop. The additions keep the order
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void node_sum(int64_t n_nodes, const int
 #pragma unroll
         for (int i = 0; i < BS; ++i) {
             acc[i] = 0.0;
-            cur[i] = out[n * BS + i];
+            cur[i] = overwrite ? 0.0 : out[n * BS + i];     // option consumer_overwrite: out = sum (no memset before, no read here)
         }
         for (int64_t e = e0; e < e1; e += U) {
             uint32_t idx[U];
@@ -1035,14 +1035,21 @@ double* two_pass_buffer(dxo_ctx* ctx, dxo_mesh* m, int bs, const int32_t* cells,
     return m->d_fe;
 }
 
+// option consumer_overwrite with the atomics form of the scatter (entity subsets, adjoint_atomics): the vector is cleared first
+int clear_for_atomics(dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out, const double* fe, hipStream_t s) {
+    if (fe || !ctx->consumer_overwrite) return DXO_OK;
+    DXO_HIP(ctx, hipMemsetAsync(out, 0, (size_t)m->num_field_nodes * bs * sizeof(double), s));
+    return DXO_OK;
+}
+
 void launch_node_sum(const dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out, hipStream_t s) {
     int64_t blocks = (m->num_field_nodes + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (bs == 1) hipLaunchKernelGGL(node_sum<1>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
-    else if (bs == 2) hipLaunchKernelGGL(node_sum<2>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
-    else hipLaunchKernelGGL(node_sum<3>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out);
+    if (bs == 1) hipLaunchKernelGGL(node_sum<1>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
+    else if (bs == 2) hipLaunchKernelGGL(node_sum<2>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
+    else hipLaunchKernelGGL(node_sum<3>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
 }
 
 template <int G, int BS, int KIND>
@@ -1108,6 +1115,8 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     double* fe = two_pass_buffer(ctx, mesh, bs, cells, n_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
+    rc = clear_for_atomics(ctx, mesh, bs, out, fe, s);
+    if (rc != DXO_OK) return rc;
     if (kind == DXO_OPERAND_EPS_MANDEL && ctx->adjoint_cell && !cells && n_cells == mesh->num_cells && mesh->gdim == 3 && bs == 3 &&
         mesh->dev.nq == 8 && mesh->dev.ngeom == 8 && (mesh->dev.ndofs == 27 || mesh->dev.ndofs == 8) && (((uintptr_t)S & 15u) == 0)) {
         // hexahedra with the 2x2x2 rule: contraction across the cell's lanes, nothing staged in LDS (operand_adjoint_c8)
@@ -1153,6 +1162,8 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
+    rc = clear_for_atomics(ctx, mesh, mesh->gdim, out, fe, s);
+    if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
     const int64_t cap = (int64_t)ctx->compute_units * 8;
@@ -1189,6 +1200,8 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
     int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    rc = clear_for_atomics(ctx, mesh, mesh->gdim, out, fe, s);
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;

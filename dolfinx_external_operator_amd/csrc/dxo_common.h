@@ -79,6 +79,8 @@ struct dxo_ctx {
     int64_t operand_cell = 1;           // dxo_eval_operand, eps on the 2-D standard elements: lane = cell kernel (operand_cell.h); 0: wave-group kernel
     int64_t vm_residual_fused = 0;      // dxo_von_mises_residual on Q2 hexahedra: 1 = one kernel (stress scattered from registers; measured no faster:
                                         // 1.19 against 1.16-1.19 ms per 10^7 points, profiles/r04_adjoint_experiments.txt), 0 = field + adjoint calls
+    int64_t consumer_overwrite = 0;     // dxo_operand_adjoint / dxo_tangent_apply* / dxo_tangent_diagonal* / dxo_von_mises_residual: 1 = out is SET to the
+                                        // assembled vector instead of added to (a Krylov matvec needs no memset and node_sum no read of out)
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and

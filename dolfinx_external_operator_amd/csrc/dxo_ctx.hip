@@ -144,6 +144,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "adjoint_atomics")) return &c->adjoint_atomics;
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
     if (!std::strcmp(key, "vm_residual_fused")) return &c->vm_residual_fused;
+    if (!std::strcmp(key, "consumer_overwrite")) return &c->consumer_overwrite;
     if (!std::strcmp(key, "operand_cell")) return &c->operand_cell;
     if (!std::strcmp(key, "mc_part_points")) return &c->mc_part_points;
     if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;

@@ -38,6 +38,7 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
     dev = torch.device("cuda:0")
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("consumer_overwrite", 1)      # residual / matvec / diagonal calls SET their output vector (no memset before each)
     mesh = structured_mesh("triangle", (n_side, n_side), degree=2)
     dm = DeviceMesh.from_synthetic(mesh, ctx=ctx)
     G, d = 2, 4
@@ -60,7 +61,6 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
 
     def residual(Du):
         """(sigma, dp[, C_tang]) of the increment and the internal force of the returned stress on the free dofs"""
-        R.zero_()
         if tangent_array:
             dm.von_mises(prm, Du.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr(), mem=MEM_DEVICE)
             dm.adjoint("eps", G, sigma.data_ptr(), R.data_ptr())
@@ -69,7 +69,6 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
         return torch.where(free, R, torch.zeros_like(R))
 
     def K_times(v):
-        Kv.zero_()
         if tangent_array:
             dm.tangent_apply(C_tang.data_ptr(), v.data_ptr(), Kv.data_ptr())
         else:
@@ -80,7 +79,6 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
 
     def cg(b, tol=1e-10, maxit=4000):
         """Jacobi-preconditioned conjugate gradients; diag(K) comes from dxo_tangent_diagonal, also matrix-free."""
-        diag.zero_()
         if tangent_array:
             dm.tangent_diagonal(C_tang.data_ptr(), diag.data_ptr())
         else:

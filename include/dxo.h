@@ -453,7 +453,9 @@ int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* 
  *   dxo_operand_adjoint : out[dof] += sum_q w_q |det J_q| B_q^T s_q   for a quadrature field s of the operand's shape
  *                         (kind EPS_MANDEL with s = sigma: the internal force; GRAD with s = q: the heat residual)
  *   dxo_tangent_apply   : out[dof] += sum_q w_q |det J_q| B_q^T C_tang_q B_q v   (eps / Mandel, bs = gdim), K never formed
- * `out` is ACCUMULATED into (zero it first); S / C_tang are laid out like the operator outputs, (n_cells, nq, ...).
+ * `out` is ACCUMULATED into (zero it first) — unless option "consumer_overwrite" = 1, with which these calls (and
+ * dxo_tangent_*_vm, dxo_tangent_diagonal, dxo_von_mises_residual) SET out to the assembled vector: a Krylov matvec then needs no
+ * memset and the node sums no read of out. S / C_tang are laid out like the operator outputs, (n_cells, nq, ...).
  * Full-mesh calls write element vectors and add them per node in the fixed order of the transposed dofmap (no atomics,
  * bit-reproducible); entity subsets, or option "adjoint_atomics" = 1, add with fp64 hardware atomics instead
  * (reproducible to rounding only). Option "adjoint_cell" = 0 switches off the lane-per-cell kernel that the internal

@@ -141,3 +141,57 @@ def test_residual_in_one_call_equals_field_then_adjoint(ctx, cell, n, degree):
     finally:
         ctx.set_option("vm_residual_fused", 0)
         dm.close()
+
+
+@pytest.mark.parametrize("cell,n", [("hexahedron", (4, 3, 3)), ("triangle", (7, 6))])
+def test_consumer_overwrite_sets_instead_of_adding(ctx, cell, n):
+    """Option consumer_overwrite = 1: the consumer-side calls SET `out` (no memset needed before a Krylov matvec): same bits as
+    accumulating into zeros, for the two-pass form, the atomics form and an entity subset (whose other dofs become zero)."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh
+    from tools.synthetic import structured_mesh
+
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=4)
+    G, d = m.gdim, 4 if m.gdim == 2 else 6
+    nn, npts = m.node_x.shape[0], m.num_cells * m.nq
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    prm = VmParams(E, NU, 250.0, H)
+    rng = np.random.Generator(np.random.PCG64(12))
+    S = torch.from_numpy(rng.normal(0.0, 100.0, size=npts * d)).cuda()
+    dpv = torch.from_numpy(np.abs(rng.normal(0.0, 1e-3, size=npts)) * (rng.random(npts) < 0.5)).cuda()
+    A = rng.normal(size=(npts, d, d))
+    Ct = torch.from_numpy((A @ A.transpose(0, 2, 1) + np.eye(d)).reshape(-1)).cuda()
+    v = torch.from_numpy(rng.normal(size=nn * G)).cuda()
+    sub = torch.from_numpy(np.arange(0, m.num_cells, 3, dtype=np.int32)).cuda()
+    S_sub = S.reshape(m.num_cells, -1)[::3].contiguous().reshape(-1)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    calls = {"force": lambda o: dm.adjoint("eps", G, S.data_ptr(), o.data_ptr()),
+             "force_subset": lambda o: dm.adjoint("eps", G, S_sub.data_ptr(), o.data_ptr(), n_cells=int(sub.numel()), cells_ptr=sub.data_ptr()),
+             "apply": lambda o: dm.tangent_apply(Ct.data_ptr(), v.data_ptr(), o.data_ptr()),
+             "diag": lambda o: dm.tangent_diagonal(Ct.data_ptr(), o.data_ptr()),
+             "apply_vm": lambda o: dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), o.data_ptr()),
+             "diag_vm": lambda o: dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), o.data_ptr())}
+    try:
+        for atomics in (0, 1):
+            ctx.set_option("adjoint_atomics", atomics)
+            for name, fn in calls.items():
+                ctx.set_option("consumer_overwrite", 0)
+                ref = torch.zeros(nn * G, dtype=torch.float64, device="cuda")
+                fn(ref)
+                twice = ref.clone()
+                fn(twice)                                                  # default: accumulates
+                ctx.set_option("consumer_overwrite", 1)
+                out = torch.from_numpy(rng.normal(size=nn * G)).cuda()   # garbage that must not survive
+                fn(out)
+                torch.cuda.synchronize()
+                scale = float(ref.abs().max())
+                assert float((twice - 2 * ref).abs().max()) <= 1e-12 * scale, (name, atomics)
+                if atomics == 0 and name != "force_subset":
+                    assert torch.equal(out, ref), (name, atomics)           # two-pass form: the same bits
+                else:
+                    assert float((out - ref).abs().max()) <= 1e-12 * scale, (name, atomics)
+    finally:
+        ctx.set_option("consumer_overwrite", 0)
+        ctx.set_option("adjoint_atomics", 0)
+        dm.close()

@@ -29,15 +29,15 @@ def _geo_bytes(m):
 
 
 def loop_bytes(m, bs, d):
-    """Algorithmic HBM bytes per call (every array once; `out` of an accumulating call is read and written)."""
+    """Algorithmic HBM bytes per call (every array once; `out` is written only: the legs run with option consumer_overwrite = 1)."""
     npts = m.num_cells * m.nq
     vec = m.node_x.shape[0] * bs * 8
     geo = _geo_bytes(m)
     return {
         "von_mises_field_state": vec + geo + m.dofmap.nbytes + npts * (d + 1) * 8 + npts * (d * d + d + 1) * 8,
-        "internal_force": npts * d * 8 + geo + m.dofmap.nbytes + 2 * vec,
-        "tangent_apply": npts * d * d * 8 + geo + m.dofmap.nbytes + vec + 2 * vec,
-        "tangent_diagonal": npts * d * d * 8 + geo + m.dofmap.nbytes + 2 * vec,
+        "internal_force": npts * d * 8 + geo + m.dofmap.nbytes + vec,
+        "tangent_apply": npts * d * d * 8 + geo + m.dofmap.nbytes + vec + vec,
+        "tangent_diagonal": npts * d * d * 8 + geo + m.dofmap.nbytes + vec,
         "state_commit": npts * (2 * d + 3) * 8,     # read sigma, dp, p; write sigma_n, p  (sigma_n is overwritten, not read)
     }
 
@@ -60,6 +60,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
     mesh_s = time.perf_counter() - t0
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     st = None
+    ctx.set_option("consumer_overwrite", 1)     # the consumer-side calls SET their output vector: no memset in front of a matvec
     try:
         bs = m.gdim
         d = 4 if bs == 2 else 6
@@ -86,15 +87,12 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
             st.call_field(prm, dm._h, MEM_DEVICE, u.data_ptr(), Ct.data_ptr())
 
         def force():
-            R.zero_()
             dm.adjoint("eps", bs, ptr["sigma"], R.data_ptr())
 
         def matvec():
-            Kv.zero_()
             dm.tangent_apply(Ct.data_ptr(), v.data_ptr(), Kv.data_ptr())
 
         def diag():
-            Kv.zero_()
             dm.tangent_diagonal(Ct.data_ptr(), Kv.data_ptr())
 
         def iteration():
@@ -107,11 +105,9 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
             st.call_field(prm, dm._h, MEM_DEVICE, u.data_ptr(), None)
 
         def matvec_vm():
-            Kv.zero_()
             dm.tangent_apply_vm(prm, ptr["sigma"], ptr["dp"], v.data_ptr(), Kv.data_ptr())
 
         def diag_vm():
-            Kv.zero_()
             dm.tangent_diagonal_vm(prm, ptr["sigma"], ptr["dp"], Kv.data_ptr())
 
         def iteration_vm():
@@ -132,8 +128,8 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
                            "roofline": {**_hbm(by[name], ms), "algorithmic_bytes_per_call": by[name], "bytes_per_qp": by[name] / npts}}
         vec_b = nn * bs * 8
         by_vm = {"von_mises_field_state_no_tangent": by["von_mises_field_state"] - npts * d * d * 8,
-                 "tangent_apply_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + 3 * vec_b,
-                 "tangent_diagonal_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + 2 * vec_b}
+                 "tangent_apply_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + 2 * vec_b,
+                 "tangent_diagonal_vm": npts * (d + 1) * 8 + _geo_bytes(m) + m.dofmap.nbytes + vec_b}
         matvec()
         ref_Kv = Kv.clone()
         matvec_vm()
@@ -163,7 +159,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
                "iteration_ms": ms_it, "dtype": "f64", "plastic_fraction": plastic, "mesh_build_s": mesh_s, "calls": calls,
                "roofline": {**_hbm(it_bytes, ms_it), "algorithmic_bytes_per_iteration": it_bytes, "bytes_per_qp": it_bytes / npts,
                             "note": "sum of the three calls' algorithmic bytes over the iteration's time; each call has its own roofline under `calls`"},
-               "pcie_bytes_per_iteration": 0,
+               "pcie_bytes_per_iteration": 0, "consumer_overwrite": 1,
                "without_tangent_array": {
                    "meaning": "the same iteration with the von Mises tangent's action formed from the returned (sigma, dp) (dxo_tangent_apply_vm): "
                               "the fused operator runs with C_tang = NULL, a Krylov matvec reads 56 instead of 288 bytes per point",
@@ -173,6 +169,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
             out["cpu_baseline"] = _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm)
         return out
     finally:
+        ctx.set_option("consumer_overwrite", 0)
         if st is not None:
             st.close()
         dm.close()
