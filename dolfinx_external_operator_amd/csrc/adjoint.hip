@@ -342,6 +342,12 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
 #ifndef DXO_NS_WIDE
 #define DXO_NS_WIDE 1    // node_sum: 16-byte index and element-vector loads
 #endif
+#ifndef DXO_TA_VM_UT
+#define DXO_TA_VM_UT 1      // node groups of the register scatter in flight in tangent_apply<..., VM>
+#endif
+#ifndef DXO_C8_ADJ_UT
+#define DXO_C8_ADJ_UT 1     // the same in operand_adjoint_c8
+#endif
 typedef uint32_t NodeEnt4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef double NodeF64x2 __attribute__((ext_vector_type(2), aligned(8)));
 
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8(OperandDev m, co
                 T[i][k] = has_point ? scale * tt : 0.0;       // lanes without a point: zero vertices, singular J
             }
         const int64_t cell = c0 + c_l;
-        c8_scatter<ND>(L, T, [&](int a, const double (&o)[3]) {
+        c8_scatter<ND, DXO_C8_ADJ_UT>(L, T, [&](int a, const double (&o)[3]) {
             if (!has_point) return;
             if (fe) {
 #pragma unroll
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
                     T[i][k] = scale * tt;          // scale = 0 and gh = 0 for lanes without a point
                 }
             const int64_t cell = c0 + (lane >> 3);
-            c8_scatter<ND_CT>(L8, T, [&](int a, const double (&o)[3]) {
+            c8_scatter<ND_CT, VM ? DXO_TA_VM_UT : 1>(L8, T, [&](int a, const double (&o)[3]) {
                 if (!active) return;
                 if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) return;
                 if (fe) {

@@ -176,9 +176,10 @@ __device__ __forceinline__ void c8_forward(const C8Lane& L, const double (&U4)[4
 
 // transpose: T[i][k] of this lane's point (zero for lanes without one) -> element vector of the cell, entries of the lane's
 // own nodes, written to fe[node][cell][i] (two-pass form) or added to out through the dofmap (atomics)
-template <int ND, typename Store>
+// UT: how many of the four node groups are in flight together (each holds 8 table rows + 8 partials: 64 registers)
+template <int ND, int UT = 1, typename Store>
 __device__ __forceinline__ void c8_scatter(const C8Lane& L, const double (&T)[3][3], Store&& store) {
-#pragma unroll 1
+#pragma unroll UT
     for (int t = 0; t < 4; ++t) {
         double d[8][3];
 #pragma unroll

@@ -214,5 +214,44 @@ if all(dl_files.values()):
                 ratios[k]["lds_bank_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
     rec["sq_counters_sampled"] = sq
     rec["sq_ratios_of_wave_cycles"] = ratios
+    # fp64 arithmetic of the element kernels (their binding roof, not HBM): wave-instruction counts of the largest-grid dispatches,
+    # flop = 64 x (ADD + MUL + 2 FMA) with masked lanes counted, over the kernel's duration in the kernel trace of the bench run
+    fl = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in (out / "dl_flop").rglob("*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                n = short(r["Kernel_Name"])
+                key = next((k + n.split(k, 1)[1].split("(")[0] for k in names if k in n), None)
+                if key:
+                    fl[key][r["Counter_Name"]].append((int(r.get("Grid_Size", 0)), float(r["Counter_Value"])))
+    dur = {}
+    if trace:
+        for name, ds in disp.items():
+            big = max(d[2] for d in ds)
+            sel = [d[1] for d in ds if d[2] == big]
+            dur[name] = sum(sel) / len(sel) / 1e6            # ms
+    fp64 = {}
+    for k, cs in fl.items():
+        if "SQ_INSTS_VALU_FMA_F64" not in cs:
+            continue
+        def at_largest(c):
+            vals = cs.get(c, [])
+            if not vals:
+                return 0.0
+            big = max(g for g, _ in vals)
+            sel = [v for g, v in vals if g == big]
+            return sum(sel) / len(sel)
+        flop = 64.0 * (at_largest("SQ_INSTS_VALU_ADD_F64") + at_largest("SQ_INSTS_VALU_MUL_F64") + 2.0 * at_largest("SQ_INSTS_VALU_FMA_F64"))
+        if flop <= 0:
+            continue
+        e = {"fp64_flop_per_launch": flop, "trans_f64_wave_instructions": at_largest("SQ_INSTS_VALU_TRANS_F64")}
+        ms = next((v for n, v in dur.items() if n.startswith(k)), None)
+        if ms:
+            e.update({"kernel_ms_in_bench_trace": ms, "TFLOP_per_s": flop / ms / 1e9, "frac_of_78.6_TFLOP_per_s_fp64_vector_peak": flop / ms / 1e9 / 78.6})
+        fp64[k] = e
+    if fp64:
+        rec["fp64_issued"] = fp64
+        rec["fp64_note"] = ("flop = 64 x (ADD + MUL + 2 FMA) fp64 wave-instructions of the kernel's largest-grid dispatches (masked lanes counted: an upper bound on "
+                            "useful work); duration = the kernel's mean in the kernel trace of the bench run (stats/), same sizes")
     (out / f"{tag}_device_loop_pmc.json").write_text(json.dumps(rec, indent=1))
     print("== device loop:", json.dumps(rec["hbm_bytes_per_call"]), json.dumps(ratios))
