@@ -44,6 +44,8 @@ for path in libs:
     L._lib = L.load_library(path)
     ctx = Context(0)
     ctx.set_stream(stream.cuda_stream)
+    if __import__("os").environ.get("AB_ATOMICS") == "1":      # fp64 atomics into the dof vector instead of element vectors + node sums
+        ctx.set_option("adjoint_atomics", 1)
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     outs = {k: torch.zeros(nn * bs, dtype=torch.float64, device=dev) for k in ("apply", "diag", "force", "apply_vm", "diag_vm")}
     fns = {"apply": lambda dm=dm, o=outs["apply"]: (o.zero_(), dm.tangent_apply(Ct.data_ptr(), v.data_ptr(), o.data_ptr())),
