@@ -508,7 +508,7 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
     constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
     // cells of 8 points and at most 32 nodes (launched so only for nq = 8): the scatter phase runs in registers, a DPP
     // reduce-scatter over the cell's 8 lanes (cell8_dpp.h) instead of parked tensors and 96 LDS reads per (cell, node) pair
-    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES;
+    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
