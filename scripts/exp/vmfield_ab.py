@@ -44,6 +44,8 @@ for path in libs:
     ctx = Context(0)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("operand_cell", 0)
+    if os.environ.get("VMF_NT") is not None:
+        ctx.set_option("nontemporal", int(os.environ["VMF_NT"]))
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     if not runs:
         shared_out = ctx.vm_output_tensors(npts, d)   # ONE block for every variant (calibrated with vm_tile: the fused kernel stores in the same pattern)

@@ -188,13 +188,14 @@ def test_weights_are_required(ctx):
         dm.close()
 
 
-@pytest.mark.parametrize("tangent_array", [False, True])
-def test_device_newton_krylov_converges_quadratically(tangent_array):
+@pytest.mark.parametrize("tangent_array,graph", [(False, False), (True, False), (False, True)])
+def test_device_newton_krylov_converges_quadratically(tangent_array, graph):
     """examples/device_newton_krylov.py: load stepping with the fused constitutive kernel, the internal force and the
     matrix-free tangent, all on the device. Newton only converges quadratically if the tangent IS the derivative of the
     stress that the residual is built from — the kernel-level version of the reference's Taylor test
     (demo_plasticity_mohr_coulomb.py:1149-1235). Both forms of the tangent: acting from the returned (sigma, dp) with no
-    tangent array at all (the default), and read from the C_tang block the operator wrote."""
+    tangent array at all (the default), and read from the C_tang block the operator wrote; graph: the CG iteration (library call +
+    torch vector updates) captured once in a HIP graph and replayed — the device entry points are capture-safe after their first call."""
     import importlib.util
     import pathlib
 
@@ -202,7 +203,7 @@ def test_device_newton_krylov_converges_quadratically(tangent_array):
     spec = importlib.util.spec_from_file_location("nk_example", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    rep = mod.main(20, verbose=False, tangent_array=tangent_array)
+    rep = mod.main(20, verbose=False, tangent_array=tangent_array, graph=graph)
     assert rep["steps"][0]["newton_residuals"][-1] <= 1e-8 * rep["steps"][0]["newton_residuals"][0]
     assert len(rep["steps"][0]["newton_residuals"]) == 2                       # elastic step: one linear solve
     last = rep["steps"][-1]
