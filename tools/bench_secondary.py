@@ -261,6 +261,56 @@ def von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu):
     return out
 
 
+def von_mises_demo_host(torch, ctx, cpu):
+    """The von Mises operator at the size the reference's OWN demo runs it, through the drop-in factory with host arrays: Mandel d = 4,
+    3 points per P2 triangle (demo_plasticity_von_mises.py:230, 245, 295), 5 000 cells = 15 000 points — a call is latency, not
+    bandwidth. Microseconds per `external_function((1,))(deps)` call (NumPy in, three NumPy arrays out) beside the C port of the
+    reference's Numba kernel on ONE core (the reference's kernel is a serial Numba loop, :309-324) and on the host's cores."""
+    from dolfinx_external_operator_amd import make_von_mises
+
+    nc, nq, d = 5000, 3, 4
+    n = nc * nq
+    rng = np.random.Generator(np.random.PCG64(7))
+    deps = rng.normal(0.0, 3e-3, size=(nc, nq, d))
+    deps[..., 3:] *= 2.0 ** 0.5
+    sigma_n = rng.normal(0.0, 100.0, size=(n, d))
+    p = np.abs(rng.normal(0.0, 1e-3, size=n))
+    reps = 3 if QUICK else 300
+    out = {"workload": f"von Mises return map + tangent at the reference demo's own size: {nc} P2 triangles x {nq} points = {n} points, d = {d}, "
+                       "NumPy in / NumPy out through make_von_mises (one call = evaluate_external_operators' call of the (1,) derivative)",
+           "points": n, "unit": "qp/s", "dtype": "f64"}
+    for key, kw in (("us_per_call", {}), ("us_per_call_reuse_outputs", {"reuse_outputs": True})):
+        ext = make_von_mises(sigma_n, p, ctx=ctx, **kw)
+        f = ext((1,))
+        for _ in range(3):
+            res = f(deps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = f(deps)
+        out[key] = (time.perf_counter() - t0) / reps * 1e6
+        del res
+    out["value"] = n / (out["us_per_call"] * 1e-6)
+    if cpu:
+        from oracle import load_oracle
+
+        o = load_oracle()
+        h = (deps.reshape(n, d), sigma_n, p)
+        outb = (np.zeros((n, d, d)), np.zeros((n, d)), np.zeros(n))
+        scan = {}
+        for nt in (1, 8, min(32, _avail())):
+            o.von_mises(*h, nthreads=nt, out=outb)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                o.von_mises(*h, nthreads=nt, out=outb)
+            scan[nt] = (time.perf_counter() - t0) / reps * 1e6
+        best = min(scan, key=scan.get)
+        out["cpu_baseline"] = {"value": n / (scan[1] * 1e-6), "unit": "qp/s", "cores": 1, "kind": "port", "us_per_call": scan[1],
+                               "us_per_call_by_threads": scan, "best_threads": best,
+                               "sample": f"the same {n} points x {reps} calls, oracle/dxo_oracle.c (outputs preallocated); one core = what the "
+                                         "reference's serial Numba loop has"}
+    return out
+
+
 def vm_field_q2(torch, ctx, stream, cells_per_side, prm, cpu=False):
     from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh
     from tools.synthetic import structured_mesh
@@ -489,7 +539,7 @@ def von_mises_cfg2_1e6(torch, ctx, stream, prm, cpu):
     return out
 
 
-ALL_LEGS = ("heat_cfg1", "mohr_coulomb_cfg4", "icnn_cfg5", "isihara", "von_mises_d4_nq3", "von_mises_cfg2_1e6", "vm_field_q2",
+ALL_LEGS = ("heat_cfg1", "mohr_coulomb_cfg4", "icnn_cfg5", "isihara", "von_mises_d4_nq3", "von_mises_demo_host", "von_mises_cfg2_1e6", "vm_field_q2",
             "device_loop_q2hex", "device_loop_p2tri", "assign_cg")
 P2TRI_SIDE = 1291     # 1291^2 boxes x 2 triangles x 3 points = 10^7 points (the reference demos' element, demo_plasticity_von_mises.py:230,245,295)
 
@@ -504,6 +554,7 @@ def secondary_block(torch, ctx, stream, prm, n=10_000_000, cpu=True, field_cells
            "icnn_cfg5": lambda: icnn_cfg5(torch, ctx, stream, n, cpu),
            "von_mises_d4_nq3": lambda: von_mises_d4_nq3(torch, ctx, stream, n, prm, cpu),
            "von_mises_cfg2_1e6": lambda: von_mises_cfg2_1e6(torch, ctx, stream, prm, cpu),
+           "von_mises_demo_host": lambda: von_mises_demo_host(torch, ctx, cpu),
            "vm_field_q2": lambda: vm_field_q2(torch, ctx, stream, field_cells, prm, cpu),
            "device_loop_q2hex": lambda: dl.device_loop(torch, ctx, stream, prm, "hexahedron", (field_cells,) * 3, cpu),
            "device_loop_p2tri": lambda: dl.device_loop(torch, ctx, stream, prm, "triangle", (P2TRI_SIDE if field_cells >= 100 else 8 * field_cells,) * 2, cpu),
