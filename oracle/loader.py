@@ -47,6 +47,11 @@ class _IcnnWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("W0", "b0", "W1", "S1", "c1", "W2", "S2", "c2", "W3", "S3")]
 
 
+class _OracleMesh(C.Structure):
+    _fields_ = [("gdim", C.c_int), ("nd", C.c_int), ("ng", C.c_int), ("nq", C.c_int), ("x_cols", C.c_int), ("dofmap", C.c_void_p),
+                ("geom_dofmap", C.c_void_p), ("x", C.c_void_p), ("dphi", C.c_void_p), ("dpsi", C.c_void_p), ("w", C.c_void_p)]
+
+
 _ICNN_KEYS = ("layers__0__weight", "layers__0__bias", "layers__1__weights", "skip_layers__1__weight", "skip_layers__1__bias",
               "layers__2__weights", "skip_layers__2__weight", "skip_layers__2__bias", "layers__3__weights", "skip_layers__3__weights")
 
@@ -86,6 +91,58 @@ class OracleLib:
         if rc != 0:
             raise ValueError(f"oracle_icnn rc={rc}")
         return dP, P, H
+
+    # ---- oracle/operand_oracle_c.c: the consumer-side steps for the eps / Mandel operand, compiled and threaded
+    def _mesh(self, m, cells, with_weights):
+        """m: a tools.synthetic mesh (or anything with dofmap, geom_dofmap, x | node_x, dphi, dpsi, weights)."""
+        keep = {"dofmap": np.ascontiguousarray(m.dofmap[:cells], dtype=np.int32), "geom": np.ascontiguousarray(m.geom_dofmap[:cells], dtype=np.int32),
+                "x": np.ascontiguousarray(m.x, dtype=np.float64), "dphi": np.ascontiguousarray(m.dphi, dtype=np.float64),
+                "dpsi": np.ascontiguousarray(m.dpsi, dtype=np.float64), "w": np.ascontiguousarray(m.weights, dtype=np.float64)}
+        nq, nd, G = keep["dphi"].shape
+        desc = _OracleMesh(G, nd, keep["dpsi"].shape[1], nq, keep["x"].shape[1], keep["dofmap"].ctypes.data, keep["geom"].ctypes.data,
+                           keep["x"].ctypes.data, keep["dphi"].ctypes.data, keep["dpsi"].ctypes.data, keep["w"].ctypes.data if with_weights else None)
+        return desc, keep
+
+    def operand_eps(self, m, u, *, cells=None, nthreads=1):
+        """eps(u) in Mandel form at the quadrature points of the first `cells` cells -> (cells, nq, d)."""
+        nc = m.dofmap.shape[0] if cells is None else int(cells)
+        desc, keep = self._mesh(m, nc, False)
+        G = desc.gdim
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        e = np.empty((nc, desc.nq, 4 if G == 2 else 6))
+        self.lib.oracle_operand_eps.restype = C.c_int
+        self.lib.oracle_operand_eps.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        rc = self.lib.oracle_operand_eps(C.byref(desc), nc, _dp(u), _dp(e), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_operand_eps rc={rc}")
+        return e
+
+    def operand_eps_adjoint(self, m, S, n_nodes, *, cells=None, nthreads=1):
+        """sum_q w |det J| B^T S over the first `cells` cells -> (n_nodes * gdim,)."""
+        nc = m.dofmap.shape[0] if cells is None else int(cells)
+        desc, keep = self._mesh(m, nc, True)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        out = np.zeros(n_nodes * desc.gdim)
+        self.lib.oracle_operand_eps_adjoint.restype = C.c_int
+        self.lib.oracle_operand_eps_adjoint.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        rc = self.lib.oracle_operand_eps_adjoint(C.byref(desc), nc, _dp(S), _dp(out), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_operand_eps_adjoint rc={rc}")
+        return out
+
+    def tangent_apply(self, m, C_tang, v, n_nodes, *, cells=None, nthreads=1):
+        """K v over the first `cells` cells, K never formed -> (n_nodes * gdim,)."""
+        nc = m.dofmap.shape[0] if cells is None else int(cells)
+        desc, keep = self._mesh(m, nc, True)
+        C_tang = np.ascontiguousarray(C_tang, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.zeros(n_nodes * desc.gdim)
+        self.lib.oracle_tangent_apply.restype = C.c_int
+        self.lib.oracle_tangent_apply.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        rc = self.lib.oracle_tangent_apply(C.byref(desc), nc, _dp(C_tang), _dp(v), _dp(out), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_tangent_apply rc={rc}")
+        return out
 
     def max_threads(self) -> int:
         return int(self.lib.oracle_max_threads())

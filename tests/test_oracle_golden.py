@@ -118,3 +118,35 @@ def test_icnn_c_port_matches_golden_and_numpy_oracle(oracle, golden):
     assert np.allclose(H, h_correction(w), rtol=0, atol=1e-9) and np.allclose(H, g["H"], rtol=0, atol=1e-6)
     one = oracle.icnn(g["F"], w, nthreads=1)
     assert np.array_equal(one[0], dP) and np.array_equal(one[1], P)                                  # threads do not change the result
+
+
+@pytest.mark.parametrize("cell,n", [("triangle", (6, 5)), ("quadrilateral", (4, 4)), ("tetrahedron", (2, 3, 2)), ("hexahedron", (3, 2, 3))])
+@pytest.mark.parametrize("degree", [1, 2])
+def test_compiled_consumer_oracle_equals_the_numpy_one(cell, n, degree):
+    """oracle/operand_oracle_c.c (the threaded CPU baseline of the device-resident Newton iteration) against oracle/operand_oracle.py:
+    strain at the points, internal force, matrix-free tangent action — same sums in another order."""
+    from oracle import load_oracle
+    from oracle.operand_oracle import EPS_MANDEL, eval_operand, operand_adjoint, tangent_apply
+    from tools.synthetic import structured_mesh
+
+    o = load_oracle()
+    m = structured_mesh(cell, n, degree, distort=0.2, seed=6)
+    G, nn = m.gdim, m.node_x.shape[0]
+    d = 4 if G == 2 else 6
+    rng = np.random.Generator(np.random.PCG64(1))
+    u = rng.normal(size=nn * G)
+    args = (m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+    for nt in (1, 3):
+        e, e_ref = o.operand_eps(m, u, nthreads=nt), eval_operand(EPS_MANDEL, G, u, *args)
+        assert np.abs(e - e_ref).max() <= 1e-13 * np.abs(e_ref).max()
+        S = rng.normal(size=e.shape)
+        f, f_ref = o.operand_eps_adjoint(m, S, nn, nthreads=nt), operand_adjoint(EPS_MANDEL, G, S, m.weights, *args, nn)
+        assert np.abs(f - f_ref).max() <= 1e-13 * np.abs(f_ref).max()
+        A = rng.normal(size=(e.shape[0], e.shape[1], d, d))
+        Ct = A @ A.transpose(0, 1, 3, 2)
+        k, k_ref = o.tangent_apply(m, Ct, u, nn, nthreads=nt), tangent_apply(Ct, u, m.weights, *args, nn)
+        assert np.abs(k - k_ref).max() <= 1e-13 * np.abs(k_ref).max()
+    # a prefix of the cells: what the bench's bounded sample uses
+    half = m.num_cells // 2
+    e_half = o.operand_eps(m, u, cells=half, nthreads=2)
+    assert np.array_equal(e_half, o.operand_eps(m, u, nthreads=1)[:half])

@@ -182,36 +182,52 @@ def _view(torch, ptr, n, dev):
     return torch.as_tensor(_CudaArrayView(None, int(ptr), int(n), "<f8"), device=dev)
 
 
-def _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm, cells=40_000):
-    """The same three steps with the checkers on the first `cells` cells: NumPy operand oracle -> C return map (OpenMP) ->
-    NumPy adjoint oracle (internal force) and tangent action. ~10-30 s of CPU work."""
+def _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm, cells=1_000_000):
+    """The same three steps in compiled, threaded C on the first `cells` cells of the same mesh: oracle/operand_oracle_c.c (strain at the
+    points, internal force, tangent action; OpenMP over cells) and oracle/dxo_oracle.c (return map). The reference's own code for these
+    steps is compiled too (DOLFINx / FFCx behind Expression.eval and assemble_vector, the Numba kernel). A few seconds of CPU work: the
+    thread counts are scanned and the fastest is reported."""
     from oracle import load_oracle
-    from oracle.operand_oracle import EPS_MANDEL, eval_operand, operand_adjoint, tangent_apply
 
     o = load_oracle()
     nc = min(cells, m.num_cells)
-    sel = np.arange(nc)
     nq = m.nq
-    dofmap, geom = m.dofmap[:nc], m.geom_dofmap[:nc]
     s_h = sig0[: nc * nq * d].cpu().numpy().reshape(nc * nq, d)
     p_h = p0[: nc * nq].cpu().numpy()
     v_h = v.cpu().numpy()
     nn = m.node_x.shape[0]
-    nt = min(32, _avail())
-    t0 = time.perf_counter()
-    deps = eval_operand(EPS_MANDEL, bs, u_h, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, sel)
-    t1 = time.perf_counter()
-    C, s, dp = o.von_mises(deps.reshape(-1, d), s_h, p_h, E=prm.E, nu=prm.nu, sigma_0=prm.sigma_0, H=prm.H, nthreads=nt)
-    t2 = time.perf_counter()
-    operand_adjoint(EPS_MANDEL, bs, s.reshape(nc, nq, d), m.weights, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, nn, sel)
-    t3 = time.perf_counter()
-    tangent_apply(C, v_h, m.weights, dofmap, geom, m.x, m.phi, m.dphi, m.dpsi, nn)
-    t4 = time.perf_counter()
     n = nc * nq
-    return {"value": n / (t4 - t0), "unit": "qp/s per Newton iteration (1 matvec)", "cores": nt, "kind": "port",
-            "seconds": {"operand": t1 - t0, "return_map": t2 - t1, "internal_force": t3 - t2, "tangent_apply": t4 - t3},
-            "sample": f"first {nc} cells ({n} points) of the same mesh: oracle/operand_oracle.py (NumPy einsum, BLAS threads as configured) for "
-                      f"the operand, internal force and tangent action, oracle/dxo_oracle.c with {nt} OpenMP threads for the return map"}
+    best = None
+    scan = {}
+    for nt in sorted({1, 8, min(32, _avail()), min(64, _avail())}):
+        if nt == 1 and nc > 100_000:
+            sub = 100_000                                  # one core: a tenth of the sample is enough for a rate
+        else:
+            sub = nc
+        outb = tuple(np.full(shape, 0.5) for shape in ((sub * nq, d, d), (sub * nq, d), (sub * nq,)))      # written once: page faults stay out of the timing
+        w = min(sub, 2000)                                  # warm-up of every step on a few cells (thread pool, instruction cache)
+        dw = o.operand_eps(m, u_h, cells=w, nthreads=nt)
+        Cw, sw, _ = o.von_mises(dw.reshape(-1, d), s_h[: w * nq], p_h[: w * nq], E=prm.E, nu=prm.nu, sigma_0=prm.sigma_0, H=prm.H, nthreads=nt)
+        o.operand_eps_adjoint(m, sw.reshape(w, nq, d), nn, cells=w, nthreads=nt)
+        o.tangent_apply(m, Cw, v_h, nn, cells=w, nthreads=nt)
+        t0 = time.perf_counter()
+        deps = o.operand_eps(m, u_h, cells=sub, nthreads=nt)
+        t1 = time.perf_counter()
+        C, s, dp = o.von_mises(deps.reshape(-1, d), s_h[: sub * nq], p_h[: sub * nq], E=prm.E, nu=prm.nu, sigma_0=prm.sigma_0, H=prm.H, nthreads=nt, out=outb)
+        t2 = time.perf_counter()
+        o.operand_eps_adjoint(m, s.reshape(sub, nq, d), nn, cells=sub, nthreads=nt)
+        t3 = time.perf_counter()
+        o.tangent_apply(m, C, v_h, nn, cells=sub, nthreads=nt)
+        t4 = time.perf_counter()
+        rate = sub * nq / (t4 - t0)
+        scan[nt] = rate
+        if best is None or rate > best[0]:
+            best = (rate, nt, {"operand": t1 - t0, "return_map": t2 - t1, "internal_force": t3 - t2, "tangent_apply": t4 - t3}, sub)
+    rate, nt, secs, sub = best
+    return {"value": rate, "unit": "qp/s per Newton iteration (1 matvec)", "cores": nt, "kind": "port", "value_1core": scan.get(1), "thread_scan": scan,
+            "seconds": secs,
+            "sample": f"first {sub} cells ({sub * nq} points) of the same mesh: oracle/operand_oracle_c.c (strain, internal force, tangent action; "
+                      f"OpenMP over cells, atomic adds into the dof vector) and oracle/dxo_oracle.c (return map), fastest of the scanned thread counts"}
 
 
 def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):

@@ -350,24 +350,26 @@ def vm_field_q2(torch, ctx, stream, cells_per_side, prm, cpu=False):
                             "algorithmic_bytes_per_launch": in_bytes + out_bytes,
                             "output_memory": {k: C.dxo_block.info[k] for k in ("mode", "chosen_kind", "chosen_GBps", "candidates", "probe")},
                             "note": "algorithmic bytes = dof vector, coordinates and both dofmaps read once + (sigma_n, p) + the three outputs"}}
-        if cpu:     # the demo's pair on the host: operand oracle (NumPy) then the C return map (OpenMP), first 40 000 cells
+        if cpu:     # the demo's pair on the host in compiled, threaded C: strain at the points (operand_oracle_c.c), then the return map
             from oracle import load_oracle
-            from oracle.operand_oracle import EPS_MANDEL, eval_operand
 
             o = load_oracle()
-            nc = min(40_000, m.num_cells)
+            nc = min(1_000_000, m.num_cells)
             sh = sig[: nc * 8 * d].cpu().numpy().reshape(-1, d)
             ph = pp[: nc * 8].cpu().numpy()
             nt = min(32, _avail())
+            outb = tuple(np.full(shape, 0.5) for shape in ((nc * 8, d, d), (nc * 8, d), (nc * 8,)))
+            ew = o.operand_eps(m, u_h, cells=2000, nthreads=nt)                      # warm-up (thread pool)
+            o.von_mises(ew.reshape(-1, d), sh[:16000], ph[:16000], nthreads=nt)
             t0 = time.perf_counter()
-            e = eval_operand(EPS_MANDEL, bs, u_h, m.dofmap[:nc], m.geom_dofmap[:nc], m.x, m.phi, m.dphi, m.dpsi, np.arange(nc))
+            e = o.operand_eps(m, u_h, cells=nc, nthreads=nt)
             t1 = time.perf_counter()
-            o.von_mises(e.reshape(-1, d), sh, ph, nthreads=nt)
+            o.von_mises(e.reshape(-1, d), sh, ph, nthreads=nt, out=outb)
             t2 = time.perf_counter()
             out["cpu_baseline"] = {"value": nc * 8 / (t2 - t0), "unit": "qp/s", "cores": nt, "kind": "port",
                                    "seconds": {"operand": t1 - t0, "return_map": t2 - t1},
-                                   "sample": f"first {nc} cells ({nc * 8} points) of the same mesh: oracle/operand_oracle.py (NumPy einsum, BLAS threads "
-                                             f"as configured) + oracle/dxo_oracle.c with {nt} OpenMP threads"}
+                                   "sample": f"first {nc} cells ({nc * 8} points) of the same mesh: oracle/operand_oracle_c.c + oracle/dxo_oracle.c, "
+                                             f"{nt} OpenMP threads"}
         return out
     finally:
         dm.close()
