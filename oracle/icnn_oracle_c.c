@@ -158,3 +158,34 @@ int oracle_icnn(const oracle_icnn_weights* w, int64_t n, const double* F, double
     free(Wp2);
     return 0;
 }
+
+/* Analytic Isihara model (doc/demo/demo_hyperelasticity.py:686-703, a UFL form in the reference): W = c1 K1 + c2 K2 + c3 K1^2 + c4 K3 with
+ * the (K1, K2, K3) of `features`; P = dW/dF, dP = d2W/dF2 by the chain rule — the per-point form of oracle/icnn_oracle.py::isihara_stress_tangent
+ * (:122-141), OpenMP over points. det F <= 0: NaN, as there. */
+int oracle_isihara(const double* c, int64_t n, const double* F, double* dP, double* P, int nthreads) {
+    if (!c || n < 0 || (n > 0 && (!F || !dP || !P))) return -1;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t p = 0; p < n; ++p) {
+        const double* Fp = F + p * 4;
+        if (Fp[0] * Fp[3] - Fp[1] * Fp[2] <= 0.0) {
+            for (int i = 0; i < 4; ++i) P[p * 4 + i] = NAN;
+            for (int i = 0; i < 16; ++i) dP[p * 16 + i] = NAN;
+            continue;
+        }
+        double K[3], dK[3][4], d2K[3][4][4];
+        features(Fp, K, dK, d2K);
+        const double dy[3] = {c[0] + 2.0 * c[2] * K[0], c[1], c[3]};
+        for (int i = 0; i < 4; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += dy[k] * dK[k][i];
+            P[p * 4 + i] = s;
+            for (int j = 0; j < 4; ++j) {
+                double t = 2.0 * c[2] * dK[0][i] * dK[0][j];
+                for (int k = 0; k < 3; ++k) t += dy[k] * d2K[k][i][j];
+                dP[(p * 4 + i) * 4 + j] = t;
+            }
+        }
+    }
+    return 0;
+}

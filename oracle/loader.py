@@ -92,6 +92,19 @@ class OracleLib:
             raise ValueError(f"oracle_icnn rc={rc}")
         return dP, P, H
 
+    def isihara(self, F, c=(0.5, 1.0, 1.0, 1.5), *, nthreads=1):
+        """oracle/icnn_oracle_c.c::oracle_isihara: the compiled, threaded form of icnn_oracle.isihara_stress_tangent -> dP (N,4,4), P (N,4)."""
+        self.lib.oracle_isihara.restype = C.c_int
+        self.lib.oracle_isihara.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 4)
+        cc = np.asarray(c, dtype=np.float64)
+        n = F.shape[0]
+        dP, P = np.empty((n, 4, 4)), np.empty((n, 4))
+        rc = self.lib.oracle_isihara(_dp(cc), n, _dp(F), _dp(dP), _dp(P), int(nthreads))
+        if rc != 0:
+            raise ValueError(f"oracle_isihara rc={rc}")
+        return dP, P
+
     # ---- oracle/operand_oracle_c.c: the consumer-side steps for the eps / Mandel operand, compiled and threaded
     def _mesh(self, m, cells, with_weights):
         """m: a tools.synthetic mesh (or anything with dofmap, geom_dofmap, x | node_x, dphi, dpsi, weights)."""

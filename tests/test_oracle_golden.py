@@ -150,3 +150,24 @@ def test_compiled_consumer_oracle_equals_the_numpy_one(cell, n, degree):
     half = m.num_cells // 2
     e_half = o.operand_eps(m, u, cells=half, nthreads=2)
     assert np.array_equal(e_half, o.operand_eps(m, u, nthreads=1)[:half])
+
+
+def test_compiled_isihara_oracle_equals_the_numpy_one_and_the_golden(golden):
+    """oracle/icnn_oracle_c.c::oracle_isihara (the threaded CPU baseline of the Isihara leg) against icnn_oracle.isihara_stress_tangent and
+    against the torch-differentiated golden (tests/golden/isihara_analytic.npz)."""
+    from oracle import load_oracle
+    from oracle.icnn_oracle import isihara_stress_tangent
+
+    o = load_oracle()
+    g = golden("isihara_analytic.npz")
+    dP, P = o.isihara(g["F"], nthreads=2)
+    assert np.abs(P - g["P"].reshape(P.shape)).max() <= 1e-12 * np.abs(g["P"]).max()
+    assert np.abs(dP - g["dP"].reshape(dP.shape)).max() <= 1e-11 * np.abs(g["dP"]).max()
+    rng = np.random.Generator(np.random.PCG64(3))
+    F = rng.normal(size=(3000, 4)) * 0.1 + np.array([1.0, 0.0, 0.0, 1.0])
+    F[7] = [1.0, 2.0, 3.0, 4.0]                       # det F < 0: NaN in both
+    dP, P = o.isihara(F, nthreads=3)
+    dPr, Pr = isihara_stress_tangent(F)
+    ok = ~np.isnan(Pr[:, 0])
+    assert np.isnan(P[~ok]).all() and np.isnan(dP[~ok]).all() and (~ok).sum() == 1
+    assert np.abs(P[ok] - Pr[ok]).max() <= 1e-13 * np.abs(Pr[ok]).max() and np.abs(dP[ok] - dPr[ok]).max() <= 1e-13 * np.abs(dPr[ok]).max()
