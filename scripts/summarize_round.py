@@ -250,6 +250,15 @@ if all(dl_files.values()):
             e.update({"kernel_ms_in_bench_trace": ms, "TFLOP_per_s": flop / ms / 1e9, "frac_of_78.6_TFLOP_per_s_fp64_vector_peak": flop / ms / 1e9 / 78.6})
         fp64[k] = e
     if fp64:
+        # unversioned copy for tools/bench_device_loop.py (as mc_flop.json for the Mohr-Coulomb leg): the bench prices the consumer-side calls
+        # with these counts when its meshes have the sizes they were counted on
+        sizes = {}
+        bjs = out / "bench.json"
+        if bjs.exists() and bjs.read_text().strip():
+            sec = json.loads(bjs.read_text()).get("secondary", {})
+            sizes = {k: sec[k].get("points") for k in ("device_loop_q2hex", "device_loop_p2tri") if isinstance(sec.get(k), dict)}
+        (out / "consumer_flop.json").write_text(json.dumps({"fp64_issued": fp64, "points": sizes, "measured": f"{tag}: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 "
+                                                           "around tools/bench_secondary.py --child (pass dl_flop of scripts/profile_round.sh); masked lanes counted"}, indent=1))
         rec["fp64_issued"] = fp64
         rec["fp64_note"] = ("flop = 64 x (ADD + MUL + 2 FMA) fp64 wave-instructions of the kernel's largest-grid dispatches (masked lanes counted: an upper bound on "
                             "useful work); duration = the kernel's mean in the kernel trace of the bench run (stats/), same sizes")

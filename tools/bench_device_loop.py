@@ -165,6 +165,7 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
                               "the fused operator runs with C_tang = NULL, a Krylov matvec reads 56 instead of 288 bytes per point",
                    "iteration_ms": ms_it_vm, "value": npts / ms_it_vm * 1e3, "calls": calls_vm,
                    "matvec_max_rel_diff_vs_tangent_array": vm_err}}
+        _attach_fp64(out, "device_loop_q2hex" if cell == "hexahedron" else "device_loop_p2tri", bs)
         if cpu:
             out["cpu_baseline"] = _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm)
         return out
@@ -173,6 +174,46 @@ def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
         if st is not None:
             st.close()
         dm.close()
+
+
+FP64_PEAK_TFLOPS = 78.6      # fp64 vector peak of the MI355X (MI355X_MICROARCH.md)
+
+
+def _attach_fp64(out, leg, bs):
+    """The element kernels of the consumer side are bound by fp64 arithmetic, not by HBM: next to every call's HBM roofline goes the fp64 work
+    the kernel ISSUES per launch (counted on the kernel itself by scripts/profile_round.sh, profiles/consumer_flop.json: masked lanes included)
+    over the call's measured time — a lower bound of the kernel's own rate, since the call also contains node_sum — and the kernel-only
+    fraction of the profile run. Only when this mesh has the size the counts were taken on."""
+    import json
+
+    from tools.bench_secondary import _name_has
+
+    f = ROOT / "profiles" / "consumer_flop.json"
+    if not f.exists():
+        return
+    rec = json.loads(f.read_text())
+    if rec.get("points", {}).get(leg) != out["points"]:
+        return
+    g = "3, 27, 8" if bs == 3 else "2, 0, 0"
+    gd = "3, 27" if bs == 3 else "2, 0"
+    keys = {("calls", "von_mises_field_state"): f"vm_field<{bs},*, 0>", ("calls", "tangent_apply"): f"tangent_apply<{g}, false>",
+            ("calls", "tangent_diagonal"): f"tangent_diag<{gd}, false>",
+            ("calls", "internal_force"): "operand_adjoint_c8<" if bs == 3 else "adjoint_cell_eps<2,",
+            ("without_tangent_array", "calls", "von_mises_field_state_no_tangent"): f"vm_field<{bs},*, 1>",
+            ("without_tangent_array", "calls", "tangent_apply_vm"): f"tangent_apply<{g}, true>",
+            ("without_tangent_array", "calls", "tangent_diagonal_vm"): f"tangent_diag<{gd}, true>"}
+    for path, key in keys.items():
+        e = next((v for k, v in rec["fp64_issued"].items() if _name_has(key, k)), None)
+        call = out
+        for p_ in path:
+            call = call.get(p_, {}) if isinstance(call, dict) else {}
+        if not e or "ms_per_call" not in call:
+            continue
+        tf = e["fp64_flop_per_launch"] / call["ms_per_call"] / 1e9
+        call["roofline"]["fp64_valu"] = {"bound": "fp64_valu", "flop_per_launch_issued": e["fp64_flop_per_launch"], "achieved_over_call": tf, "unit": "TFLOP/s",
+                                         "peak": FP64_PEAK_TFLOPS, "frac_over_call": tf / FP64_PEAK_TFLOPS,
+                                         "kernel_only_frac_in_profile_run": e.get("frac_of_78.6_TFLOP_per_s_fp64_vector_peak"),
+                                         "source": "profiles/consumer_flop.json (" + rec.get("measured", "") + ")"}
 
 
 def _view(torch, ptr, n, dev):
