@@ -4,6 +4,7 @@
   <tag>_kernel_stats.csv         rocprofv3 --stats rows of the library's kernels (name, calls, total / average / min / max ns)
   <tag>_pmc_summary.txt          HBM counters of the headline kernel + traffic.json
   <tag>_mc_pmc.json, mc_flop.json   Mohr-Coulomb counters; flop per plastic point for bench.py's secondary roofline
+  <tag>_device_loop_pmc.json, consumer_flop.json   consumer-side kernels: HBM bytes, SQ ratios, issued fp64 work (the bench reads the latter)
   <tag>_icnn_pmc.json, <tag>_field_pmc.json
 usage: summarize_round.py gpurun_out/<tag> <tag>"""
 import collections
