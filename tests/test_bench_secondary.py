@@ -71,3 +71,27 @@ def test_new_legs_small(ctx):
         assert 0.0 < rec["plastic_fraction"] < 1.0 and rec["iteration_ms"] > 0
     assert out["assign_cg"]["last_writer_spot_check"] == "ok"
     assert out["von_mises_cfg2_1e6"]["points"] == 1_000_000
+
+
+def test_fp64_roofline_is_attached_only_at_the_counted_size():
+    """tools/bench_device_loop._attach_fp64: the issued-flop figures of profiles/consumer_flop.json price a call only when the leg's mesh has
+    the size they were counted on."""
+    import json
+
+    from tools import bench_device_loop as dl
+
+    rec = json.loads((bs.ROOT / "profiles" / "consumer_flop.json").read_text())
+    pts = rec["points"]["device_loop_q2hex"]
+
+    def leg(points):
+        return {"points": points, "calls": {"tangent_apply": {"ms_per_call": 1.0, "roofline": {}}, "internal_force": {"ms_per_call": 0.5, "roofline": {}}},
+                "without_tangent_array": {"calls": {"tangent_apply_vm": {"ms_per_call": 1.0, "roofline": {}}}}}
+
+    a = leg(pts)
+    dl._attach_fp64(a, "device_loop_q2hex", 3)
+    f = a["without_tangent_array"]["calls"]["tangent_apply_vm"]["roofline"]["fp64_valu"]
+    assert f["flop_per_launch_issued"] > 1e10 and f["frac_over_call"] == pytest.approx(f["flop_per_launch_issued"] / 1e9 / 78.6)
+    assert "fp64_valu" in a["calls"]["internal_force"]["roofline"] and "fp64_valu" in a["calls"]["tangent_apply"]["roofline"]
+    b = leg(pts + 8)
+    dl._attach_fp64(b, "device_loop_q2hex", 3)
+    assert "fp64_valu" not in b["calls"]["tangent_apply"]["roofline"]
