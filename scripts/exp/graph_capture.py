@@ -8,7 +8,6 @@ import time
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from dolfinx_external_operator_amd import Context, DeviceMesh, VmParams  # noqa: E402
