@@ -342,6 +342,9 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
 #ifndef DXO_NS_WIDE
 #define DXO_NS_WIDE 1    // node_sum: 16-byte index and element-vector loads
 #endif
+#ifndef DXO_TA_VM_BLOCKS_PER_CU
+#define DXO_TA_VM_BLOCKS_PER_CU 12     // persistent grid of tangent_apply<..., VM>; 2 / 4 / 8 / 12 / 24 / 48 workgroups per CU: hexahedra 0.954 / 0.970 / 0.975 / 0.956 / 0.999 / 1.054 ms, triangles 0.459 / 0.460 / 0.422 / 0.415 / 0.429 / 0.457
+#endif
 #ifndef DXO_TA_VM_UT
 #define DXO_TA_VM_UT 1      // node groups of the register scatter in flight in tangent_apply<..., VM>
 #endif
@@ -1211,7 +1214,7 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * (vs ? 12 : 8);
+    const int64_t cap = (int64_t)ctx->compute_units * (vs ? DXO_TA_VM_BLOCKS_PER_CU : 8);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     const VmStateSrc none{};
