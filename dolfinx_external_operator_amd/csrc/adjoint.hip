@@ -342,6 +342,10 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
 #ifndef DXO_NS_WIDE
 #define DXO_NS_WIDE 1    // node_sum: 16-byte index and element-vector loads
 #endif
+#ifndef DXO_NS_BLOCKS_PER_CU
+#define DXO_NS_BLOCKS_PER_CU 1024   // node_sum grid: in effect one thread per node. 4 / 8 / 16 / 32 / 64 / uncapped workgroups per CU, state-based matvec:
+                                    // hexahedra 0.959 / 0.956 / 0.936 / 0.929 / 0.948 / 0.922 ms, triangles 0.395 / 0.402 / 0.400 / 0.402 / 0.395 / 0.388
+#endif
 #ifndef DXO_TA_VM_BLOCKS_PER_CU
 #define DXO_TA_VM_BLOCKS_PER_CU 12     // persistent grid of tangent_apply<..., VM>; 2 / 4 / 8 / 12 / 24 / 48 workgroups per CU: hexahedra 0.954 / 0.970 / 0.975 / 0.956 / 0.999 / 1.054 ms, triangles 0.459 / 0.460 / 0.422 / 0.415 / 0.429 / 0.457
 #endif
@@ -1053,7 +1057,7 @@ int clear_for_atomics(dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out, cons
 
 void launch_node_sum(const dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out, hipStream_t s) {
     int64_t blocks = (m->num_field_nodes + DXO_BLOCK - 1) / DXO_BLOCK;
-    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    const int64_t cap = (int64_t)ctx->compute_units * DXO_NS_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (bs == 1) hipLaunchKernelGGL(node_sum<1>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
