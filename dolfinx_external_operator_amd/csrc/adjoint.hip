@@ -342,6 +342,18 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint(OperandDev m, const
 #ifndef DXO_NS_WIDE
 #define DXO_NS_WIDE 1    // node_sum: 16-byte index and element-vector loads
 #endif
+#ifndef DXO_C8_ADJ_BLOCKS_PER_CU
+#define DXO_C8_ADJ_BLOCKS_PER_CU 32   // operand_adjoint_c8 grid; 4 / 8 / 16 / 32 / 64 / uncapped workgroups per CU: 0.780 / 0.754 / 0.742 / 0.718 / 0.725 / 0.818 ms per call
+#endif
+#ifndef DXO_TD_VM_BLOCKS_PER_CU
+#define DXO_TD_VM_BLOCKS_PER_CU 8    // tangent_diag<..., VM>: 4 / 8 / 16 make no difference (0.999-1.013 ms hexahedra, 0.339-0.346 triangles)
+#endif
+#ifndef DXO_TD_BLOCKS_PER_CU
+#define DXO_TD_BLOCKS_PER_CU 8
+#endif
+#ifndef DXO_TA_BLOCKS_PER_CU
+#define DXO_TA_BLOCKS_PER_CU 8
+#endif
 #ifndef DXO_NS_BLOCKS_PER_CU
 #define DXO_NS_BLOCKS_PER_CU 1024   // node_sum grid: in effect one thread per node. 4 / 8 / 16 / 32 / 64 / uncapped workgroups per CU, state-based matvec:
                                     // hexahedra 0.959 / 0.956 / 0.936 / 0.929 / 0.948 / 0.922 ms, triangles 0.395 / 0.402 / 0.400 / 0.402 / 0.395 / 0.388
@@ -1135,7 +1147,7 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
         // hexahedra with the 2x2x2 rule: contraction across the cell's lanes, nothing staged in LDS (operand_adjoint_c8)
         const int64_t n_groups = (n_cells + 7) / 8;
         int64_t blocks = (n_groups + 3) / 4;
-        const int64_t cap = (int64_t)ctx->compute_units * 16;
+        const int64_t cap = (int64_t)ctx->compute_units * DXO_C8_ADJ_BLOCKS_PER_CU;
         if (blocks > cap) blocks = cap;
         blocks = (blocks + 7) / 8 * 8;
         const size_t shm = (size_t)C8_LDS * sizeof(double);
@@ -1179,7 +1191,7 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    const int64_t cap = (int64_t)ctx->compute_units * (vs ? DXO_TD_VM_BLOCKS_PER_CU : DXO_TD_BLOCKS_PER_CU);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     const VmStateSrc none{};
@@ -1218,7 +1230,7 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * (vs ? DXO_TA_VM_BLOCKS_PER_CU : 8);
+    const int64_t cap = (int64_t)ctx->compute_units * (vs ? DXO_TA_VM_BLOCKS_PER_CU : DXO_TA_BLOCKS_PER_CU);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;
     const VmStateSrc none{};

@@ -212,10 +212,13 @@ inline bool launch_tangent_cell(const dxo_ctx* ctx, const dxo_mesh* m, const dou
 }
 
 // launches the specialised kernel if the mesh's element is one of the instantiated ones; returns false otherwise
+#ifndef DXO_AC_BLOCKS_PER_CU
+#define DXO_AC_BLOCKS_PER_CU 128   // adjoint_cell_eps grid; 1 / 8 / 32 / 128 workgroups per CU on P2 triangles: 0.302 / 0.306 / 0.293 / 0.290 ms per call
+#endif
 inline bool launch_adjoint_cell_eps(const dxo_ctx* ctx, const dxo_mesh* m, const double* S, double* fe, hipStream_t s) {
     const OperandDev& v = m->dev;
     int64_t blocks = (m->num_cells + DXO_BLOCK - 1) / DXO_BLOCK;
-    const int64_t cap = (int64_t)ctx->compute_units * 8;
+    const int64_t cap = (int64_t)ctx->compute_units * DXO_AC_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
 #define DXO_CELL_CASE(G_, ND_, NQ_, NG_)                                                                                 \
     if (m->gdim == G_ && v.ndofs == ND_ && v.nq == NQ_ && v.ngeom == NG_) {                                               \
