@@ -46,6 +46,10 @@ namespace {
 #ifndef DXO_VMF_KO
 #define DXO_VMF_KO 0    // knock-out experiments (wrong results): 1 no stores, 2 no state loads, 4 no dof gather
 #endif
+#ifndef DXO_VMF_STATE_BLOCKS_PER_CU
+#define DXO_VMF_STATE_BLOCKS_PER_CU 8     // grid of the (sigma, dp)-only launch (arithmetic-bound, unlike the full one): 8 against 16 / 32 / 64 workgroups per CU:
+                                          // hexahedra 0.456 / 0.465 / 0.483 / 0.501 ms, triangles 0.239 / 0.254 / 0.262 / 0.296; 3 - 12 within the noise of each other
+#endif
 #ifndef DXO_VMF_BLOCKS_PER_CU
 #define DXO_VMF_BLOCKS_PER_CU 16
 #endif
@@ -264,7 +268,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");
     const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = (int64_t)ctx->compute_units * DXO_VMF_BLOCKS_PER_CU;
+    const int64_t cap = (int64_t)ctx->compute_units * ((C_tang || fe) ? DXO_VMF_BLOCKS_PER_CU : DXO_VMF_STATE_BLOCKS_PER_CU);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;      // whole rounds over the 8 XCDs (xcd_group_walk)
     const bool nt = ctx->nontemporal != 0;
