@@ -20,8 +20,11 @@ the >= 70 %-of-HBM-roofline target on (config 2's 10^6 points is 448 MB, of whic
 in the 256 MB Infinity Cache between steps; scripts/bench_extra.py reports it). Scaling is weak: with N > 1 every
 rank owns its own cell block of 1.25*10^7 points (BASELINE config 3: 10^8 points over 8 GPUs).
 
-Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (contract: task statement). Under torch.distributed (N > 1)
-a second, final line repeats it with `gather_check` (the verdict of libdxo's own RCCL path, run after the result) filled in.
+stdout carries the contract line (rank 0): a BOUNDED extract (tools/bench_line.py, <= 6 000 bytes) of the full record, which goes
+to `bench_full.json` beside this file and to stderr. With one GPU the line is written as soon as the timed region is over and
+again — a superset each time — when `cpu_baseline` + the live HBM-counter passes are in and when the end_to_end / secondary legs
+are done; the LAST line is the result. Under torch.distributed (N > 1) the line is written once and repeated with
+`gather_check` (the verdict of libdxo's own RCCL path, run after the result) filled in.
 """
 from __future__ import annotations
 
@@ -384,6 +387,10 @@ def main():
                     help="skip the `secondary` block (BASELINE configs 4 and 5, the reference's d = 4 layout, the fused operand + "
                          "return-map kernel: tools/bench_secondary.py)")
     ap.add_argument("--secondary-points", type=int, default=10_000_000)
+    ap.add_argument("--secondary-budget", type=float, default=70.0,
+                    help="seconds of wall the secondary legs (and their counter passes) may use: a leg that would start after the deadline is skipped and "
+                         "named in secondary.skipped (the default run must finish well inside the driver's patience)")
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of timed passes of the headline's cpu_baseline leg")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--blocks-per-cu", type=int, default=-1)
@@ -396,7 +403,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
-    # stdout carries exactly ONE line, the result. Libraries that write to fd 1 on their own (RCCL prints a version
+    # stdout carries nothing but result lines (see the module docstring). Libraries that write to fd 1 on their own (RCCL prints a version
     # banner when its first communicator comes up) are sent to stderr: fd 1 is pointed at fd 2 for the whole run and
     # the JSON line is written to a saved copy of the real stdout at the end.
     sys.stdout.flush()
@@ -611,32 +618,26 @@ def main():
     emitted = threading.Lock()
     last_result = {}
 
+    def write_line(result, stage):
+        """Rank 0: the bounded contract line (tools/bench_line.py, <= 6 000 bytes) to the real stdout; the full record to
+        bench_full.json beside this file (and, at the final stage, to stderr)."""
+        from tools.bench_line import compact_line
+
+        os.write(real_stdout, (compact_line(result, stage) + "\n").encode())
+        try:
+            (ROOT / "bench_full.json").write_text(json.dumps({**result, "line": stage}) + "\n")
+        except OSError as exc:
+            log(f"bench: bench_full.json not written: {exc!r}")
+
     def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True, degraded=False, mode=None):
-        """Rank 0: build the result line and write it to the real stdout, once."""
+        """Rank 0: build the result and write its line to the real stdout. With one GPU the line is written THREE times, each a
+        complete contract line and each a superset of the one before: (1) `headline` as soon as the timed region is over,
+        (2) `headline+cpu+traffic` once the CPU port and the live HBM-counter passes are in, (3) `final` = the same with one
+        short record per end_to_end / secondary leg. A reader takes the last line; a run cut short still leaves a valid one."""
         if rank != 0 or not emitted.acquire(blocking=False):
             return
         mode = mode or args.gather_mode
-        # HBM traffic of this kernel is NOT measured in this run (PMC counters need rocprofv3 around the process): the
-        # stored result of the last counter pass over the same launch shape is quoted with its source, `traffic` is null.
-        traffic_from_profile = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            try:
-                tj = json.loads(tfile.read_text())
-                # the counter pass records the launch's grid size in threads = points rounded up to whole workgroups
-                if 0 <= tj.get("grid_threads", -1) - n < 256 and tj.get("d") == d:
-                    traffic_from_profile = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"), "file": "profiles/traffic.json",
-                                            "measured": tj.get("measured", "earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                                                           "(scripts/gpu_check.sh), not this run")}
-            except Exception:
-                traffic_from_profile = None
         achieved = bytes_per_launch / (kernel_ms_ * 1e-3) / 1e9
-        traffic, traffic_detail = None, None
-        if extras and world == 1 and not args.no_traffic:
-            try:
-                traffic, traffic_detail = measure_traffic(n, d)
-            except Exception as exc:   # noqa: BLE001 — a counter pass must never cost the line
-                traffic, traffic_detail = None, repr(exc)
         result = {
             "metric": "quadrature-points/sec (von Mises return-map + tangent)",
             "value": total_points * K / elapsed_, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -670,8 +671,7 @@ def main():
                                          if gather_on else None),
                 "rccl_ranks": world if dist_on else 0,
                 "collective_backend": (dist.get_backend() if dist_on else None),
-                # what sharding.all_gather_in_place decided at its first call, on all ranks together (RCCL in-place form on the
-                # aliasing view, or the cloned send buffer every rank falls back to when any rank's in-place call raised)
+                # what sharding.all_gather_in_place was told to do (decided before any rank issues a collective)
                 "gather_in_place": (in_place_status() if gather_on else None),
                 "mode_status": ({m: ("timed" if (m == mode or m in other_) else "failed or skipped: see stderr") for m in MODES} if gather_on else None),
                 "placement_candidates_requested": args.placement, "placement_candidates_probed": placement.get("candidates"),
@@ -681,9 +681,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
-                "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
-                "traffic_from_profile": traffic_from_profile,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_detail": None,
+                "traffic_over_algorithmic": None,
                 "kernel": f"vm_tile<{d}>" if args.variant else f"vm_point<{d}>",
                 "kernel_ms_avg": kernel_ms_, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "bytes_per_qp": BYTES_PER_QP[d],
@@ -696,28 +695,73 @@ def main():
             },
             "kernel_only_value": total_points / (kernel_ms_ * 1e-3),
         }
-        if extras and world == 1 and not args.no_e2e:
-            result["end_to_end"] = end_to_end(ctx, prm, d)
-        if extras and world == 1 and not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(d, 2_000_000)
-        if extras and world == 1 and not args.no_secondary:
-            # the other BASELINE configs, each with its own roofline and cpu_baseline (never `value`)
-            from tools.bench_secondary import secondary_block
-
-            result["secondary"] = secondary_block(torch, ctx, stream, prm, n=args.secondary_points, cpu=not args.no_cpu)
         if dist_on:
             result["gather_check"] = ({"status": "skipped", "why": "dry_collective: libdxo's own RCCL path needs one GPU per rank"} if args.dry_collective
                                       else {"status": "skipped", "why": "--no-library-gather"} if args.no_library_gather
                                       else {"status": "pending", "why": "runs after this line; a second, final line repeats this one with the verdict"})
         last_result.update(result)
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        single = extras and world == 1
+        t_extras = time.perf_counter()
+        if not single:
+            write_line(result, "final")
+            return
+        write_line(result, "headline")      # (1) the contract line exists from here on
+        # the live HBM-counter passes (two child runs of this script under rocprofv3 --pmc: GPU work of OTHER processes, counters
+        # only, nothing timed) run beside the CPU port's timed passes (host cores only) — neither measures what the other uses
+        traffic_box = {}
+
+        def _traffic():
+            try:
+                traffic_box["r"] = measure_traffic(n, d)
+            except Exception as exc:   # noqa: BLE001 — a side leg must never cost the line
+                traffic_box["r"] = (None, repr(exc))
+
+        tt = None
+        if not args.no_traffic:
+            tt = threading.Thread(target=_traffic, daemon=True)
+            tt.start()
+        if not args.no_cpu:
+            try:
+                result["cpu_baseline"] = cpu_baseline(d, 2_000_000, budget_s=args.cpu_budget)
+            except Exception as exc:   # noqa: BLE001
+                log(f"bench: cpu_baseline failed: {exc!r}")
+        if tt is not None:
+            tt.join(200.0)
+            traffic, traffic_detail = traffic_box.get("r", (None, "counter passes did not come back in time"))
+            result["roofline"].update(traffic=traffic, traffic_detail=traffic_detail,
+                                      traffic_over_algorithmic=(traffic / bytes_per_launch) if traffic else None)
+        write_line(result, "headline+cpu+traffic")      # (2)
+        result["wall_s"] = {"cpu_and_traffic": round(time.perf_counter() - t_extras, 1)}
+        if not args.no_e2e:
+            t_leg = time.perf_counter()
+            try:
+                result["end_to_end"] = end_to_end(ctx, prm, d)
+            except SystemExit:
+                raise
+            except Exception as exc:   # noqa: BLE001
+                log(f"bench: end_to_end failed: {exc!r}")
+            result["wall_s"]["end_to_end"] = round(time.perf_counter() - t_leg, 1)
+        if not args.no_secondary:
+            # the other BASELINE configs, each with its own roofline and cpu_baseline (never `value`)
+            t_leg = time.perf_counter()
+            try:
+                from tools.bench_secondary import secondary_block
+
+                result["secondary"] = secondary_block(torch, ctx, stream, prm, n=args.secondary_points, cpu=not args.no_cpu,
+                                                      deadline=time.perf_counter() + args.secondary_budget)
+            except Exception as exc:   # noqa: BLE001
+                log(f"bench: secondary block failed: {exc!r}")
+            result["wall_s"]["secondary"] = round(time.perf_counter() - t_leg, 1)
+        last_result.update(result)
+        log(json.dumps(result))      # the full record: stderr + bench_full.json
+        write_line(result, "final")      # (3)
 
     def emit_gather_check(rec):
         """Rank 0: the second, final line = the first with the verdict of the library's own RCCL path."""
         if rank != 0 or not last_result:
             return
         last_result["gather_check"] = rec
-        os.write(real_stdout, (json.dumps(last_result) + "\n").encode())
+        write_line(last_result, "final+gather_check")
 
     # the other gather modes, same protocol, reported beside the headline (never as `value`). They are comparison figures:
     # if one of them — or the reduction of the times behind them — does not come back (a collective that hangs), rank 0

@@ -134,53 +134,70 @@ def all_gather_flat_into(out, local, group=None, async_op: bool = False):
     return dist.all_gather(chunks, local, group=group, async_op=async_op)
 
 
-_IN_PLACE: dict = {}   # (backend, id(group)) -> {"ok": bool, "why": str}: decided ONCE, by all ranks together
+_IN_PLACE: dict = {}   # (backend, id(group)) -> {"ok": bool, "why": str}: a RULE every rank evaluates alike, never a trial
 
 
 def in_place_status(group=None) -> dict | None:
-    """What `all_gather_in_place` decided for this group at its first call ({"ok": bool, "why": ...}), None before it."""
+    """The form `all_gather_in_place` uses on this group ({"ok": bool, "why": ...}), None before its first call."""
     import torch.distributed as dist
 
     return _IN_PLACE.get((dist.get_backend(group), id(group)))
 
 
+def _in_place_rule(backend: str, try_in_place: bool | None) -> dict:
+    """Which send buffer the gather uses — decided from things EVERY rank sees alike (argument, environment, backend name),
+    before any rank issues a collective. There is no trial and no fallback: ranks that took different forms, or a rank that
+    skipped a collective the others had already enqueued, would leave mismatched collective sequences on the communicator
+    (a hang or silent corruption). A raise out of the chosen form is therefore fatal and propagates."""
+    import os
+
+    env = os.environ.get("DXO_GATHER_IN_PLACE", "")
+    if try_in_place is not None:
+        ok, why = bool(try_in_place), "try_in_place argument"
+    elif env in ("0", "1"):
+        ok, why = env == "1", f"DXO_GATHER_IN_PLACE={env}"
+    else:
+        ok, why = backend == "nccl", f"backend {backend}"
+    return {"ok": ok, "why": why + (": in-place all_gather_into_tensor on the aliasing view (sendbuff == recvbuff + rank*count)" if ok
+                                    else ": cloned send buffer")}
+
+
+def refuse_chunk_backed(*tensors) -> None:
+    """Arena blocks backed by 2 MB virtual-memory chunks (ctx option placement_vmm) cannot be exported with hipIpcGetMemHandle,
+    which RCCL may use for peer access: handing one to a collective is undefined behaviour, so it is refused here. The arena
+    tags its tensors (`dxo_block`); a view carries its base. DXO_ALLOW_VMM_COLLECTIVE=1 lifts the refusal (experiments)."""
+    import os
+
+    if os.environ.get("DXO_ALLOW_VMM_COLLECTIVE") == "1":
+        return
+    for t in tensors:
+        for cand in (t, getattr(t, "_base", None)):
+            blk = getattr(cand, "dxo_block", None) if cand is not None else None
+            kind = (getattr(blk, "info", None) or {}).get("chosen_kind") if blk is not None else None
+            if kind == "2MB_chunks":
+                raise ValueError("this tensor lives in a chunk-backed (virtual-memory) block of the output arena, which must not be handed "
+                                 "to RCCL / IPC: set ctx option placement_vmm = 0 before allocating outputs that go into a collective")
+
+
 def all_gather_in_place(full, rank: int, group=None, *, try_in_place: bool | None = None):
     """All-gather where every rank has already written its block into `full` at [rank*m, (rank+1)*m).
 
-    With RCCL the send buffer is that view itself (NCCL's in-place all-gather: sendbuff == recvbuff + rank*count),
-    so the kernel's output is never copied locally; other backends (gloo in the tests) get a clone of the block.
-    The in-place form has never met RCCL with more than one rank on this project's hardware, so the FIRST call on a group is a
-    trial: if the aliased call raises on any rank, an all-reduce of the failure flags makes EVERY rank fall back — once and for
-    good — to a cloned send buffer (`in_place_status` reports it; bench.py puts it into config.gather_in_place).
-    `try_in_place` overrides the backend rule (tests)."""
-    import torch
+    With RCCL the send buffer is that view itself (NCCL's documented in-place all-gather: sendbuff == recvbuff + rank*count —
+    the form torch's own FSDP uses), so the kernel's output is never copied locally; other backends (gloo in the tests) get
+    a clone of the block. The form is fixed by `_in_place_rule` before the first collective (argument > DXO_GATHER_IN_PLACE >
+    backend name) and reported by `in_place_status`; a raise from the collective is fatal, not a reason to try another form."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     if full.numel() % world:
         raise ValueError(f"gather buffer of {full.numel()} elements does not split into {world} equal blocks")
+    refuse_chunk_backed(full)
     m = full.numel() // world
     local = full[rank * m:(rank + 1) * m]
     key = (dist.get_backend(group), id(group))
     st = _IN_PLACE.get(key)
-    if st is None:
-        want = (key[0] == "nccl") if try_in_place is None else bool(try_in_place)
-        if not want:
-            st = _IN_PLACE[key] = {"ok": False, "why": f"backend {key[0]}: cloned send buffer"}
-        else:
-            failed, why, work = 0, "in-place all_gather_into_tensor on the aliasing view", None
-            try:
-                work = all_gather_flat_into(full, local, group)
-            except Exception as exc:   # noqa: BLE001 — any refusal of the aliased call is a reason to fall back, together
-                failed, why = 1, f"in-place form raised on rank {rank}: {exc!r}; every rank uses a cloned send buffer"
-            flag = torch.tensor([failed], dtype=torch.int32, device=full.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            ok = int(flag.item()) == 0
-            if not ok and not failed:
-                why = "in-place form raised on another rank; every rank uses a cloned send buffer"
-            st = _IN_PLACE[key] = {"ok": ok, "why": why}
-            if ok:
-                return work
+    if st is None or try_in_place is not None:
+        st = _IN_PLACE[key] = _in_place_rule(key[0], try_in_place)
     if not st["ok"]:
         local = local.clone()
     return all_gather_flat_into(full, local, group)
@@ -198,6 +215,7 @@ def _check_full(C_tang_full, sigma_full, dp_full, world: int, d: int) -> int:
     m = dp_full.numel() // world
     if dp_full.numel() != m * world or sigma_full.numel() != m * world * d or C_tang_full.numel() != m * world * d * d:
         raise ValueError("full buffers do not hold world equal blocks of (C_tang, sigma, dp)")
+    refuse_chunk_backed(sigma_full, dp_full, C_tang_full)
     return m
 
 
@@ -293,6 +311,7 @@ def exchange_blocks_direct(full, rank: int, group=None) -> None:
         raise ValueError(f"gather buffer of {full.numel()} elements does not split into {world} equal blocks")
     if world == 1:
         return
+    refuse_chunk_backed(full)
     m = full.numel() // world
     own = full[rank * m:(rank + 1) * m]
     ops = []
@@ -320,5 +339,5 @@ def gather_von_mises_compact_direct(C_tang_full, sigma_full, dp_full, rank: int,
         clear_marks(dp_full, world * m)
 
 
-__all__ = ["CellBlockPartition", "in_place_status", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
+__all__ = ["CellBlockPartition", "in_place_status", "refuse_chunk_backed", "exchange_blocks_direct", "gather_von_mises_compact_direct", "all_gather_flat", "all_gather_flat_into", "all_gather_in_place",
            "remote_point_ranges", "gather_von_mises_compact", "gather_von_mises_compact_pipelined", "WAVE_TILE"]

@@ -247,7 +247,7 @@ def test_gloo_compact_gather_rebuilds_tangents_nan_exact_and_replica_identical(o
         assert len({v[1] for v in got.values()}) == 1, "replicas differ between ranks"
 
 
-def _worker_in_place_fallback(rank, world, port, ret, fail_rank):
+def _worker_in_place_real(rank, world, port, ret):
     import torch
     import torch.distributed as dist
 
@@ -256,44 +256,50 @@ def _worker_in_place_fallback(rank, world, port, ret, fail_rank):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("DXO_GATHER_IN_PLACE", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         real = sharding.all_gather_flat_into
         calls = {"aliased": 0, "cloned": 0}
 
-        def picky(out, local, group=None, async_op=False):
+        def counting(out, local, group=None, async_op=False):     # every rank REALLY issues the collective it was told to
             aliased = out.data_ptr() <= local.data_ptr() < out.data_ptr() + out.numel() * out.element_size()
             calls["aliased" if aliased else "cloned"] += 1
-            if aliased and rank == fail_rank:
-                raise RuntimeError("backend refuses an input that aliases the output")
-            if aliased:   # a rank on which the trial "works" has completed a collective the failing rank never entered: with a
-                return None   # real backend that call would be pending; here it is simply not issued (gloo would deadlock)
             return real(out, local, group, async_op)
 
-        sharding.all_gather_flat_into = picky
+        sharding.all_gather_flat_into = counting
         m = 96
         full = torch.zeros(world * m, dtype=torch.float64)
-        for it in range(3):
+        forms = []
+        for it, force in enumerate((None, True, True, False)):
             full.zero_()
             full[rank * m:(rank + 1) * m] = torch.arange(m, dtype=torch.float64) + 1000 * rank + it
-            sharding.all_gather_in_place(full, rank, try_in_place=True)
-            if it == 0 and fail_rank is not None:
-                # the trial round: ranks that did not raise skipped the (mock) aliased collective; everyone redoes it cloned
-                pass
+            sharding.all_gather_in_place(full, rank, try_in_place=force)
             want = torch.cat([torch.arange(m, dtype=torch.float64) + 1000 * r + it for r in range(world)])
-            if fail_rank is None and it == 0:
-                continue        # mock "success" issues nothing: only the decision is checked in that configuration
             assert torch.equal(full, want), (rank, it)
-        st = sharding.in_place_status()
-        ret[rank] = (st["ok"], calls["aliased"], calls["cloned"], "cloned send buffer" in st["why"])
+            forms.append(sharding.in_place_status()["ok"])
+        # a raise out of the chosen form is fatal: it propagates, and NO second collective is issued in its place
+        def refusing(out, local, group=None, async_op=False):
+            calls["aliased"] += 1
+            raise RuntimeError("backend refuses an input that aliases the output")
+
+        sharding.all_gather_flat_into = refusing
+        before = dict(calls)
+        try:
+            sharding.all_gather_in_place(full, rank, try_in_place=True)
+            raised = False
+        except RuntimeError:
+            raised = True
+        ret[rank] = (forms, calls["aliased"] - before["aliased"], calls["cloned"] - before["cloned"], raised, before)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_in_place_gather_falls_back_on_every_rank_when_one_rank_refuses(world):
-    """First call = trial of the aliased (RCCL in-place) form; rank 1 refuses it -> the all-reduced flag makes ALL ranks use a
-    cloned send buffer from then on (one trial only), and the gathered vectors are right."""
+def test_in_place_form_is_a_rule_all_ranks_share_and_a_raise_is_fatal(world):
+    """The send-buffer form is decided from things every rank sees alike (argument > DXO_GATHER_IN_PLACE > backend) BEFORE any
+    collective: gloo -> cloned by default; forced in-place, every rank really issues the aliased collective and the result is
+    right; a raise propagates on the spot — no fallback collective that the other ranks would not match."""
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
@@ -301,12 +307,52 @@ def test_in_place_gather_falls_back_on_every_rank_when_one_rank_refuses(world):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker_in_place_fallback, args=(r, world, port, ret, 1)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_in_place_real, args=(r, world, port, ret)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
         pr.join(timeout=180)
         assert pr.exitcode == 0
     for r in range(world):
-        ok, aliased, cloned, says = ret[r]
-        assert ok is False and aliased == 1 and cloned == 3 and says
+        forms, aliased_after, cloned_after, raised, before = ret[r]
+        assert forms == [False, True, True, False]
+        assert before == {"aliased": 2, "cloned": 2}
+        assert raised and aliased_after == 1 and cloned_after == 0
+
+
+def test_in_place_rule_precedence(monkeypatch):
+    from dolfinx_external_operator_amd.sharding import _in_place_rule
+
+    monkeypatch.delenv("DXO_GATHER_IN_PLACE", raising=False)
+    assert _in_place_rule("nccl", None)["ok"] is True and _in_place_rule("gloo", None)["ok"] is False
+    monkeypatch.setenv("DXO_GATHER_IN_PLACE", "0")
+    assert _in_place_rule("nccl", None)["ok"] is False and "DXO_GATHER_IN_PLACE=0" in _in_place_rule("nccl", None)["why"]
+    assert _in_place_rule("nccl", True)["ok"] is True          # the argument wins
+    monkeypatch.setenv("DXO_GATHER_IN_PLACE", "1")
+    assert _in_place_rule("gloo", None)["ok"] is True and _in_place_rule("gloo", False)["ok"] is False
+
+
+def test_chunk_backed_arena_tensors_are_refused_by_the_collectives(monkeypatch):
+    """operators.make_von_mises documents that chunk-backed arena outputs must not go to RCCL / IPC and that sharding refuses
+    them: the refusal, on the tagged tensor and on views of it."""
+    import torch
+
+    from dolfinx_external_operator_amd import sharding
+
+    class Block:
+        def __init__(self, kind):
+            self.info = {"chosen_kind": kind}
+
+    monkeypatch.delenv("DXO_ALLOW_VMM_COLLECTIVE", raising=False)
+    t = torch.zeros(128, dtype=torch.float64)
+    t.dxo_block = Block("2MB_chunks")
+    for bad in (t, t[:64], t.view(2, 64)):
+        with pytest.raises(ValueError, match="chunk-backed"):
+            sharding.refuse_chunk_backed(bad)
+    ok = torch.zeros(128, dtype=torch.float64)
+    ok.dxo_block = Block("hipMalloc")
+    sharding.refuse_chunk_backed(ok, ok[:64], torch.zeros(4))
+    with pytest.raises(ValueError, match="chunk-backed"):
+        sharding._check_full(torch.zeros(2 * 36), t[:2 * 6], torch.zeros(2), 1, 6)
+    monkeypatch.setenv("DXO_ALLOW_VMM_COLLECTIVE", "1")
+    sharding.refuse_chunk_backed(t)

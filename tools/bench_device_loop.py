@@ -52,11 +52,11 @@ def field_dofs(m, rng):
 
 def device_loop(torch, ctx, stream, prm, cell, n, cpu=True, launches=10):
     from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh
-    from tools.synthetic import structured_mesh
+    from tools.synthetic import structured_mesh_cached
 
     dev = torch.device("cuda", ctx.device)
     t0 = time.perf_counter()
-    m = structured_mesh(cell, n, 2, distort=0.2, seed=0)
+    m = structured_mesh_cached(cell, n, 2, distort=0.2, seed=0)
     mesh_s = time.perf_counter() - t0
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     st = None
@@ -276,10 +276,10 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
     node) scattered with NumPy's last-writer-wins rule (external_operator.py:286-287 with get_unrolled_dofmap :18-26).
     Algorithmic bytes: flat_dofs (int32) + values read once, coefficient written once."""
     from dolfinx_external_operator_amd import AssignDesc
-    from tools.synthetic import structured_mesh
+    from tools.synthetic import structured_mesh_cached
 
     dev = torch.device("cuda", ctx.device)
-    m = structured_mesh("hexahedron", (cells_per_side,) * 3, 2)
+    m = structured_mesh_cached("hexahedron", (cells_per_side,) * 3, 2, distort=0.2, seed=0)     # the device_loop leg's mesh: same dofmap
     nc, npt = m.dofmap.shape
     size = m.node_x.shape[0]
     dofs = torch.from_numpy(np.ascontiguousarray(m.dofmap.reshape(-1))).to(dev)

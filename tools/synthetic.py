@@ -112,6 +112,21 @@ class SyntheticMesh:
         return np.einsum("qv,cvj->cqj", psi, self.x[self.geom_dofmap])
 
 
+_MESH_CACHE: dict = {}
+
+
+def structured_mesh_cached(cell: str, n: tuple[int, ...], degree: int = 2, distort: float = 0.0, seed: int = 0) -> SyntheticMesh:
+    """`structured_mesh`, the last few results kept (bench legs that share the 108^3 Q2 mesh build it once: 3 s each time).
+    The legs treat a mesh as read-only."""
+    key = (cell, tuple(int(k) for k in n), degree, float(distort), seed)
+    m = _MESH_CACHE.get(key)
+    if m is None:
+        if len(_MESH_CACHE) >= 3:
+            _MESH_CACHE.pop(next(iter(_MESH_CACHE)))
+        m = _MESH_CACHE[key] = structured_mesh(cell, n, degree, distort, seed)
+    return m
+
+
 def structured_mesh(cell: str, n: tuple[int, ...], degree: int = 2, distort: float = 0.0, seed: int = 0) -> SyntheticMesh:
     """Unit square / cube split into n[0] x n[1] (x n[2]) boxes; triangles: 2 per box, tetrahedra: 6 per box.
 
