@@ -10,6 +10,9 @@ SRCS    := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 FLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 
+# icnn.hip: no SLP re-packing of the neuron-pair fp32 arithmetic into v_pk_*_f32 (see the comment at icnn_f2 there)
+$(OBJDIR)/icnn.o: FLAGS += -fno-slp-vectorize
+
 all: $(LIB)
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/dxo.h

@@ -42,13 +42,18 @@ def hip_flags() -> list[str]:
             f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
+# per-file flags on top of hip_flags(). icnn.hip: the SLP vectoriser must not re-pack the neuron-pair fp32 arithmetic into
+# v_pk_*_f32 (a packed fp32 instruction beside a running MFMA stalls ~20 cycles, see the comment at icnn_f2)
+EXTRA_FLAGS = {"icnn.hip": ["-fno-slp-vectorize"]}
+
+
 def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
     """Compile every HIP translation unit for gfx950 and link libdxo_hip.so next to this file."""
     srcs = [CSRC / s for s in HIP_SOURCES]
     deps = srcs + sorted(CSRC.glob("*.h")) + [INCLUDE / "dxo.h"]
     flags = hip_flags()
     stamp_file = PKG / ".libdxo_hip.stamp"
-    stamp = _stamp(deps, flags)
+    stamp = _stamp(deps, flags + [f"{k}:{' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items())])
     if not force and LIB.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
         return LIB
     hipcc = _hipcc()
@@ -58,7 +63,7 @@ def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
     procs = []
     for src in srcs:
         obj = objdir / (src.stem + ".o")
-        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

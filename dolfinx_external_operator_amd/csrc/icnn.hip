@@ -438,7 +438,20 @@ __device__ __forceinline__ f32x16 icnn_mfma_bf16(icnn_u32x4 a, icnn_u32x4 b, f32
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(icnn_bf16x8, a), __builtin_bit_cast(icnn_bf16x8, b), c, 0, 0, 0);
 }
 
-typedef float icnn_f2 __attribute__((ext_vector_type(2)));
+// A neuron PAIR's two fp32 values. A plain struct with scalar operators, NOT an ext_vector_type: <2 x float> arithmetic becomes
+// v_pk_{fma,mul,add}_f32, and a packed fp32 instruction issued beside a running MFMA stalls ~20 cycles
+// (profiles/r05_mfma_gap_probe.txt: one v_pk_fma_f32 per 32-cycle MFMA gap: 52 cycles per MFMA; six v_fma_f32: 37;
+// MI355X_MICROARCH.md: "packed f32 VALU ... an anti-lever beside MFMAs"). The arithmetic is identical (IEEE fp32 either way);
+// this translation unit is built with -fno-slp-vectorize so that the compiler does not re-pack adjacent scalar operations
+// (_build.py, Makefile).
+struct icnn_f2 {
+    float x, y;
+};
+__device__ __forceinline__ icnn_f2 operator+(icnn_f2 a, icnn_f2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ icnn_f2 operator-(icnn_f2 a, icnn_f2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ icnn_f2 operator*(icnn_f2 a, icnn_f2 b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ icnn_f2 operator+(icnn_f2 a, float b) { return {a.x + b, a.y + b}; }
+__device__ __forceinline__ icnn_f2 operator*(icnn_f2 a, float b) { return {a.x * b, a.y * b}; }
 
 __device__ __forceinline__ IcnnSplit icnn_pack(const IcnnSplitW& w) {
     IcnnSplit o;
@@ -474,7 +487,7 @@ __device__ __forceinline__ void softplus3_pk(icnn_f2 a, icnn_f2& sp, icnn_f2& s1
     s2 = s1 * r;
 }
 
-__device__ __forceinline__ icnn_f2 icnn_fma2(icnn_f2 a, icnn_f2 b, icnn_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ icnn_f2 icnn_fma2(icnn_f2 a, icnn_f2 b, icnn_f2 c) { return {__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 
 // c0, c1 += A[jt] (split) x B (split): the six products with a weight above 2^-24, smallest first, accumulators alternating
 __device__ __forceinline__ void icnn_mma6(const IcnnSplit (&A)[2], const IcnnSplit& B, f32x16& c0, f32x16& c1) {
@@ -486,7 +499,8 @@ __device__ __forceinline__ void icnn_mma6(const IcnnSplit (&A)[2], const IcnnSpl
     c0 = icnn_mfma_bf16(A[0].h, B.h, c0); c1 = icnn_mfma_bf16(A[1].h, B.h, c1);
 }
 
-#define DXO_ICNN_PIN2(x) asm volatile("" : "+v"(x));
+// not `volatile`: a volatile asm orders every LDS read around it and would pin the table reads between the pins
+#define DXO_ICNN_PIN2(PAIR_) asm("" : "+v"((PAIR_).x), "+v"((PAIR_).y));
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const float* __restrict__ wT1, const float* __restrict__ wW2,

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1
 pass() {
   local name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o ic -- python3 scripts/bench_icnn.py --launches 2 > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o ic -- python3 scripts/bench_icnn.py --launches 2 --variant ${ICNN_VARIANT:-2} > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
 }
 pass p1 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE
 pass p2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
