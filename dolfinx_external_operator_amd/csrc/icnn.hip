@@ -505,9 +505,272 @@ __device__ __forceinline__ void icnn_mma6(const IcnnSplit (&A)[2], const IcnnSpl
 #define DXO_ICNN_PIPE_AGPR false
 #endif
 
+// ------------------------------------------------------------------ split-bf16 kernel, phases in sequence, PACKED fp32 vector arithmetic (icnn_variant = 2, the default)
+// Rounds 3-4's kernel, unchanged: two waves per SIMD, every neuron pair's arithmetic as v_pk_{fma,mul,add}_f32. A packed fp32
+// instruction cannot run beside an MFMA (profiles/r05_mfma_gap_probe.txt: it waits for the MFMA in flight and ~16 cycles more),
+// so this kernel's half-tile costs the SUM of its matrix-pipe and vector cycles — but its vector work is 1 770 instructions
+// where the scalar form below needs 2 850, which is why it is still the faster of the two (profiles/NOTES_icnn.md).
+typedef float icnn_f2p __attribute__((ext_vector_type(2)));
+
+// one B-fragment dword (two consecutive k: the neuron pair) of each part from a pair of fp32 values
+__device__ __forceinline__ void icnn_split_pair_p(icnn_f2p v, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned vx = __float_as_uint(v.x), vy = __float_as_uint(v.y);
+    h = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    const icnn_f2p vh = {__uint_as_float(vx & 0xffff0000u), __uint_as_float(vy & 0xffff0000u)};
+    const icnn_f2p r = v - vh;
+    const unsigned rx = __float_as_uint(r.x), ry = __float_as_uint(r.y);
+    m = __builtin_amdgcn_perm(ry, rx, 0x07060302u);
+    const icnn_f2p rh = {__uint_as_float(rx & 0xffff0000u), __uint_as_float(ry & 0xffff0000u)};
+    const icnn_f2p q = r - rh;
+    l = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
+}
+
+
+// softplus, softplus', softplus'' of two pre-activations: softplus3_mfma's operations, the multiplies and adds as packed fp32
+__device__ __forceinline__ void softplus3_p(icnn_f2p a, icnn_f2p& sp, icnn_f2p& s1, icnn_f2p& s2) {
+    const icnn_f2p am = {fminf(a.x, 80.0f), fminf(a.y, 80.0f)};
+    const icnn_f2p t = am * 1.4426950408889634f;
+    const icnn_f2p e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const icnn_f2p ope = e + 1.0f;
+    const icnn_f2p r = {__builtin_amdgcn_rcpf(ope.x), __builtin_amdgcn_rcpf(ope.y)};
+    const icnn_f2p l = icnn_f2p{__builtin_amdgcn_logf(ope.x), __builtin_amdgcn_logf(ope.y)} * 0.6931471805599453f;
+    sp = icnn_f2p{fmaxf(l.x, a.x), fmaxf(l.y, a.y)};
+    s1 = e * r;
+    s2 = s1 * r;
+}
+
+
+__device__ __forceinline__ icnn_f2p icnn_fma2_p(icnn_f2p a, icnn_f2p b, icnn_f2p c) { return __builtin_elementwise_fma(a, b, c); }
+
+#define DXO_ICNN_PINP(x) asm volatile("" : "+v"(x));
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3_packed(const float* __restrict__ wT1, const float* __restrict__ wW2,
+                                                        const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
+                                                        const double* __restrict__ F, double* __restrict__ dP,
+                                                        double* __restrict__ P) {
+    constexpr int BLOCK = WAVES * 64;
+    constexpr int FRAG = 64 * 8;   // bf16 per fragment (64 lanes x 8)
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    // A fragments, [matrix][t][step][part][lane] x 8 bf16 (one 16-byte read per lane and fragment). Forward matrices:
+    //   c = 0: W2p / 12 (meets h1 = softplus^2);  c = 1..3: W2p[j][i] / 12 * 2 A1[i][c - 1] (meets u = softplus softplus'):
+    // the layer-1 input weights ride in the A operand, so all three gradient GEMMs share ONE B operand.
+    __shared__ __attribute__((aligned(16))) unsigned short sA3[4 * 2 * 4 * 3 * FRAG];
+    __shared__ __attribute__((aligned(16))) unsigned short sAT3[2 * 4 * 3 * FRAG];   // beta GEMM: W2p transposed
+    // per neuron PAIR (rows 2 r, 2 r + 1; the two values of a quantity adjacent: operands of the packed fp32 instructions)
+    __shared__ __attribute__((aligned(16))) float sP1[32 * 8];    // A1x A1y A1z d1
+    __shared__ __attribute__((aligned(16))) float sP3[32 * 12];   // the six products A1_k A1_l / 6
+    __shared__ __attribute__((aligned(16))) float sP2[32 * 12];   // S2x S2y S2z c2 w3/6, 0
+    __shared__ float sMine[WAVES * 9 * 64];
+    float* minep = sMine + wave * (9 * 64) + lane;
+    for (int e = threadIdx.x; e < 2 * 4 * 64 * 8; e += BLOCK) {
+        const int i = e & 7, l = (e >> 3) & 63, st = (e >> 9) & 3, t = e >> 11;
+        const int row = icnn_row(st >> 1, 8 * (st & 1) + i) + 4 * (l >> 5);
+        const float wf = wW2[(32 * t + (l & 31)) * NH + row] * (1.0f / 12.0f);   // forward GEMMs: A[j = 32 t + p][k -> neuron row]
+        const float wb = wW2[row * NH + 32 * t + (l & 31)];                      // beta GEMM:     A[i = 32 t + p][k -> neuron row (a j)]
+        const int base = ((t * 4 + st) * 3) * FRAG + l * 8 + i;
+        unsigned hb, mb, lb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            icnn_split1(c == 0 ? wf : wf * wT1[row * 16 + 3 + c], hb, mb, lb);
+            unsigned short* d = sA3 + c * (2 * 4 * 3 * FRAG) + base;
+            d[0] = (unsigned short)(hb >> 16); d[FRAG] = (unsigned short)(mb >> 16); d[2 * FRAG] = (unsigned short)(lb >> 16);
+        }
+        icnn_split1(wb, hb, mb, lb);
+        sAT3[base] = (unsigned short)(hb >> 16); sAT3[base + FRAG] = (unsigned short)(mb >> 16); sAT3[base + 2 * FRAG] = (unsigned short)(lb >> 16);
+    }
+    for (int e = threadIdx.x; e < NH * 4; e += BLOCK) {
+        const int row = e >> 2, k = e & 3;
+        sP1[(row >> 1) * 8 + 2 * k + (row & 1)] = wT1[row * 16 + k];
+    }
+    for (int e = threadIdx.x; e < NH * 6; e += BLOCK) {
+        const int row = e / 6, k = e % 6;
+        sP3[(row >> 1) * 12 + 2 * k + (row & 1)] = wT1[row * 16 + 8 + k];
+        sP2[(row >> 1) * 12 + 2 * k + (row & 1)] = k < 5 ? wT2[row * 8 + k] : 0.0f;
+    }
+    __syncthreads();
+    const icnn_u32x4* A_l = reinterpret_cast<const icnn_u32x4*>(sA3) + lane;     // fragment (c, t, st, part) at (((c*2+t)*4+st)*3+part)*64
+    const icnn_u32x4* AT_l = reinterpret_cast<const icnn_u32x4*>(sAT3) + lane;
+    // the lane's neurons are rows icnn_row(t, q) + 4 h: pair index (icnn_row(t, q) >> 1) + 2 h for even q
+    const float* P1_h = sP1 + 2 * h * 8;
+    const float* P3_h = sP3 + 2 * h * 12;
+    const float* P2_h = sP2 + 2 * h * 12;
+
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t tile_step = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    dxo_f64x2 f01n{1.0, 0.0}, f23n{0.0, 1.0};
+    if (tile < n_tiles) {
+        const int64_t pl0 = tile * 64 + lane < n ? tile * 64 + lane : n - 1;
+        f01n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[0];
+        f23n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[1];
+    }
+    for (; tile < n_tiles; tile += tile_step) {
+        const int64_t pidx = tile * 64 + lane;
+        const dxo_f64x2 f01 = f01n, f23 = f23n;
+        float x0, x1, x2;
+        {
+            const double Fv[4] = {f01.x, f01.y, f23.x, f23.y};   // tail lanes recompute the last point, never store
+            const double t = Fv[0] * Fv[0] + Fv[1] * Fv[1] + Fv[2] * Fv[2] + Fv[3] * Fv[3];
+            const double D = Fv[0] * Fv[3] - Fv[1] * Fv[2];
+            const double aD = fabs(D);
+            const double m = hyper_pow_m23(aD), nn = m * m;
+            x0 = (float)((t + 1.0) * m - 3.0); x1 = (float)((t + D * D) * nn - 3.0); x2 = (float)((aD - 1.0) * (aD - 1.0));
+        }
+        if (tile + tile_step < n_tiles) {
+            const int64_t pn = (tile + tile_step) * 64 + lane;
+            const int64_t pln = pn < n ? pn : n - 1;
+            f01n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[0];
+            f23n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[1];
+        }
+        const float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
+#pragma unroll 1
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool own = (tt == h);
+            const float xs0 = own ? x0 : xp0, xs1 = own ? x1 : xp1, xs2 = own ? x2 : xp2;
+            asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads inside the loop (see icnn_mfma_f32)
+            icnn_f2p res[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) res[q] = icnn_f2p{0.f, 0.f};
+            icnn_f2p cph[16];
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[jt][c][q] = 0.f;
+            // ---- phase 1: four K-steps of 16 layer-1 neurons (eight per lane, as four pairs)
+            //      [a2 | g0 | g1 | g2] += [A_0 h1 | A_1 u | A_2 u | A_3 u]
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                IcnnSplitW Bhw, Buw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pr = icnn_row(st >> 1, 8 * (st & 1) + 2 * k) >> 1;
+                    const float4 ta = *reinterpret_cast<const float4*>(P1_h + pr * 8);       // A1x pair, A1y pair
+                    const float4 tb = *reinterpret_cast<const float4*>(P1_h + pr * 8 + 4);   // A1z pair, d1 pair
+                    const icnn_f2p a = icnn_fma2_p(icnn_f2p{ta.x, ta.y}, icnn_f2p{xs0, xs0},
+                                                icnn_fma2_p(icnn_f2p{ta.z, ta.w}, icnn_f2p{xs1, xs1},
+                                                          icnn_fma2_p(icnn_f2p{tb.x, tb.y}, icnn_f2p{xs2, xs2}, icnn_f2p{tb.z, tb.w})));
+                    icnn_f2p sp, s1, s2;
+                    softplus3_p(a, sp, s1, s2);
+                    const icnn_f2p hv = sp * sp, uv = sp * s1;
+                    cph[st * 4 + k] = icnn_fma2_p(sp, s2, s1 * s1);   // phi''(a1) * 6: the 1/6 sits in the table of products (phase 3)
+                    DXO_ICNN_PINP(cph[st * 4 + k])
+                    icnn_split_pair_p(hv, Bhw.h[k], Bhw.m[k], Bhw.l[k]);
+                    icnn_split_pair_p(uv, Buw.h[k], Buw.m[k], Buw.l[k]);
+                }
+                const IcnnSplit Bh = icnn_pack(Bhw), Bu = icnn_pack(Buw);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    IcnnSplit A[2];
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt) {
+                        A[jt].h = A_l[(((c * 2 + jt) * 4 + st) * 3 + 0) * 64];
+                        A[jt].m = A_l[(((c * 2 + jt) * 4 + st) * 3 + 1) * 64];
+                        A[jt].l = A_l[(((c * 2 + jt) * 4 + st) * 3 + 2) * 64];
+                    }
+                    icnn_mma6(A, c == 0 ? Bh : Bu, acc[0][c], acc[1][c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase 2: layer-2 neurons in groups of eight (four pairs); each group's deltas are one B fragment of the beta GEMM
+            f32x16 bacc[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jt = g >> 1;
+                IcnnSplitW Bdw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = 8 * (g & 1) + 2 * k;
+                    const int pr = icnn_row(jt, q) >> 1;
+                    const float4 ta = *reinterpret_cast<const float4*>(P2_h + pr * 12);       // S2x pair, S2y pair
+                    const float4 tb = *reinterpret_cast<const float4*>(P2_h + pr * 12 + 4);   // S2z pair, c2 pair
+                    const float2 tw = *reinterpret_cast<const float2*>(P2_h + pr * 12 + 8);   // w3 / 6 pair
+                    const icnn_f2p S2x = {ta.x, ta.y}, S2y = {ta.z, ta.w}, S2z = {tb.x, tb.y}, w6 = {tw.x, tw.y};
+                    const icnn_f2p a2 = icnn_f2p{acc[jt][0][q], acc[jt][0][q + 1]} +
+                                       icnn_fma2_p(S2x, icnn_f2p{xs0, xs0}, icnn_fma2_p(S2y, icnn_f2p{xs1, xs1}, icnn_fma2_p(S2z, icnn_f2p{xs2, xs2}, icnn_f2p{tb.z, tb.w})));
+                    const icnn_f2p g0 = icnn_f2p{acc[jt][1][q], acc[jt][1][q + 1]} + S2x;
+                    const icnn_f2p g1 = icnn_f2p{acc[jt][2][q], acc[jt][2][q + 1]} + S2y;
+                    const icnn_f2p g2 = icnn_f2p{acc[jt][3][q], acc[jt][3][q + 1]} + S2z;
+                    icnn_f2p sp, s1, s2;
+                    softplus3_p(a2, sp, s1, s2);
+                    const icnn_f2p dl = w6 * sp * s1;
+                    const icnn_f2p curv = w6 * icnn_fma2_p(sp, s2, s1 * s1);
+                    icnn_split_pair_p(dl, Bdw.h[k], Bdw.m[k], Bdw.l[k]);
+                    const icnn_f2p cg0 = curv * g0, cg1 = curv * g1, cg2 = curv * g2;
+                    res[0] = icnn_fma2_p(dl, g0, res[0]); res[1] = icnn_fma2_p(dl, g1, res[1]); res[2] = icnn_fma2_p(dl, g2, res[2]);
+                    res[3] = icnn_fma2_p(cg0, g0, res[3]); res[4] = icnn_fma2_p(cg0, g1, res[4]); res[5] = icnn_fma2_p(cg0, g2, res[5]);
+                    res[6] = icnn_fma2_p(cg1, g1, res[6]); res[7] = icnn_fma2_p(cg1, g2, res[7]); res[8] = icnn_fma2_p(cg2, g2, res[8]);
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) DXO_ICNN_PINP(res[r])
+                }
+                IcnnSplit A[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    A[it].h = AT_l[((it * 4 + g) * 3 + 0) * 64];
+                    A[it].m = AT_l[((it * 4 + g) * 3 + 1) * 64];
+                    A[it].l = AT_l[((it * 4 + g) * 3 + 2) * 64];
+                }
+                icnn_mma6(A, icnn_pack(Bdw), bacc[0], bacc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase 3: second Hessian term, beta_i (accumulator registers) x phi''(a1_i) (cph) x A1_i A1_i^T / 6 (table)
+#pragma unroll
+            for (int ip = 0; ip < 16; ++ip) {
+                const int it = ip >> 3, q = 2 * (ip & 7);
+                const int pr = icnn_row(it, q) >> 1;
+                const float4 pa = *reinterpret_cast<const float4*>(P3_h + pr * 12);
+                const float4 pb = *reinterpret_cast<const float4*>(P3_h + pr * 12 + 4);
+                const float4 pc = *reinterpret_cast<const float4*>(P3_h + pr * 12 + 8);
+                const icnn_f2p c = icnn_f2p{bacc[it][q], bacc[it][q + 1]} * cph[ip];
+                res[3] = icnn_fma2_p(c, icnn_f2p{pa.x, pa.y}, res[3]); res[4] = icnn_fma2_p(c, icnn_f2p{pa.z, pa.w}, res[4]);
+                res[5] = icnn_fma2_p(c, icnn_f2p{pb.x, pb.y}, res[5]); res[6] = icnn_fma2_p(c, icnn_f2p{pb.z, pb.w}, res[6]);
+                res[7] = icnn_fma2_p(c, icnn_f2p{pc.x, pc.y}, res[7]); res[8] = icnn_fma2_p(c, icnn_f2p{pc.z, pc.w}, res[8]);
+#pragma unroll
+                for (int r = 3; r < 9; ++r) DXO_ICNN_PINP(res[r])
+            }
+            // both half-waves hold partial sums of the SAME 32 points: add them, keep the tile this lane owns
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float part = res[q].x + res[q].y;
+                const float tot = part + xor32(part);
+                if (own) minep[q * 64] = tot;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (pidx < n) {
+            // the fp64 feature derivatives are formed here, after the GEMM phases (they would occupy 18 registers through them)
+            const double Fk[4] = {f01.x, f01.y, f23.x, f23.y};
+            const double t = Fk[0] * Fk[0] + Fk[1] * Fk[1] + Fk[2] * Fk[2] + Fk[3] * Fk[3];
+            const double D = Fk[0] * Fk[3] - Fk[1] * Fk[2];
+            const double aD = fabs(D), sg = D < 0.0 ? -1.0 : 1.0, iD = 1.0 / D;
+            const double m = hyper_pow_m23(aD), nn = m * m;
+            float mine[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) mine[q] = minep[q * 64];
+            const double kt[3] = {m, nn, 0.0};
+            const double kD[3] = {(t + 1.0) * (-2.0 / 3.0) * m * iD, 2.0 * D * nn + (t + D * D) * (-4.0 / 3.0) * nn * iD,
+                                  2.0 * (aD - 1.0) * sg};
+            const double ktD[3] = {(-2.0 / 3.0) * m * iD, (-4.0 / 3.0) * nn * iD, 0.0};
+            const double kDD[3] = {(t + 1.0) * (10.0 / 9.0) * m * iD * iD,
+                                   -(10.0 / 3.0) * nn + (28.0 / 9.0) * (t + D * D) * nn * iD * iD, 2.0};
+            const float y1f[3] = {mine[0] + small.s3[0], mine[1] + small.s3[1], mine[2] + small.s3[2]};
+            icnn_chain(Fk, kt, kD, ktD, kDD, y1f, mine + 3, small.H, dP + pidx * 16, P + pidx * 4);
+        }
+    }
+}
+
+
 // ---- the phases of one half-tile (32 points, both half-waves on the same points, each on half of the neurons) as device
-// functions: icnn_mfma_bf16x3 runs them one after the other, icnn_mfma_bf16x3_pipe runs phase 1 of the NEXT half-tile beside
-// phases 2 of this one. The arithmetic (operations and their order per accumulator) is the same in both, bit for bit.
+// functions with SCALAR fp32 arithmetic, for icnn_mfma_bf16x3_pipe, which runs phase 1 of the NEXT half-tile beside phases 2 of
+// this one. The arithmetic (operations and their order per accumulator) is that of icnn_mfma_bf16x3_packed, bit for bit.
 struct IcnnTabs {
     const icnn_u32x4* A_l;    // fragment (c, t, st, part) at (((c*2+t)*4+st)*3+part)*64, this lane's 16 bytes
     const icnn_u32x4* AT_l;   // beta GEMM: (t, g, part) at ((t*4+g)*3+part)*64
@@ -804,91 +1067,7 @@ __device__ __forceinline__ void icnn_fill_lds(const float* __restrict__ wT1, con
     }
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3(const float* __restrict__ wT1, const float* __restrict__ wW2,
-                                                        const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
-                                                        const double* __restrict__ F, double* __restrict__ dP,
-                                                        double* __restrict__ P) {
-    constexpr int BLOCK = WAVES * 64;
-    constexpr int FRAG = 64 * 8;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
-    // A fragments, [matrix][t][step][part][lane] x 8 bf16 (one 16-byte read per lane and fragment). Forward matrices:
-    //   c = 0: W2p / 12 (meets h1 = softplus^2);  c = 1..3: W2p[j][i] / 12 * 2 A1[i][c - 1] (meets u = softplus softplus'):
-    // the layer-1 input weights ride in the A operand, so all three gradient GEMMs share ONE B operand.
-    __shared__ __attribute__((aligned(16))) unsigned short sA3[4 * 2 * 4 * 3 * FRAG];
-    __shared__ __attribute__((aligned(16))) unsigned short sAT3[2 * 4 * 3 * FRAG];   // beta GEMM: W2p transposed
-    // per neuron PAIR (rows 2 r, 2 r + 1; the two values of a quantity adjacent)
-    __shared__ __attribute__((aligned(16))) float sP1[32 * 8];    // A1x A1y A1z d1
-    __shared__ __attribute__((aligned(16))) float sP3[32 * 12];   // the six products A1_k A1_l / 6
-    __shared__ __attribute__((aligned(16))) float sP2[32 * 12];   // S2x S2y S2z c2 w3/6, 0
-    __shared__ float sMine[WAVES * 9 * 64];
-    float* minep = sMine + wave * (9 * 64) + lane;
-    icnn_fill_lds<BLOCK>(wT1, wW2, wT2, sA3, sAT3, sP1, sP3, sP2);
-    __syncthreads();
-    // the lane's neurons are rows icnn_row(t, q) + 4 h: pair index (icnn_row(t, q) >> 1) + 2 h for even q
-    const IcnnTabs T = {reinterpret_cast<const icnn_u32x4*>(sA3) + lane, reinterpret_cast<const icnn_u32x4*>(sAT3) + lane, sP1 + 2 * h * 8,
-                        sP2 + 2 * h * 12, sP3 + 2 * h * 12};
-
-    const int64_t n_tiles = (n + 63) / 64;
-    const int64_t tile_step = (int64_t)gridDim.x * WAVES;
-    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
-    dxo_f64x2 f01n{1.0, 0.0}, f23n{0.0, 1.0};
-    if (tile < n_tiles) {
-        const int64_t pl0 = tile * 64 + lane < n ? tile * 64 + lane : n - 1;
-        f01n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[0];
-        f23n = reinterpret_cast<const dxo_f64x2*>(F + pl0 * 4)[1];
-    }
-    for (; tile < n_tiles; tile += tile_step) {
-        const int64_t pidx = tile * 64 + lane;
-        const dxo_f64x2 f01 = f01n, f23 = f23n;   // tail lanes recompute the last point, never store
-        float x0, x1, x2;
-        icnn_features(f01, f23, x0, x1, x2);
-        if (tile + tile_step < n_tiles) {
-            const int64_t pn = (tile + tile_step) * 64 + lane;
-            const int64_t pln = pn < n ? pn : n - 1;
-            f01n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[0];
-            f23n = reinterpret_cast<const dxo_f64x2*>(F + pln * 4)[1];
-        }
-        const float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
-#pragma unroll 1
-        for (int tt = 0; tt < 2; ++tt) {
-            const bool own = (tt == h);
-            const float xs0 = own ? x0 : xp0, xs1 = own ? x1 : xp1, xs2 = own ? x2 : xp2;
-            asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads inside the loop (see icnn_mfma_f32)
-            icnn_f2 res[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) res[q] = icnn_f2{0.f, 0.f};
-            icnn_f2 cph[16];
-            f32x16 acc[2][4];
-            icnn_zero(acc);
-            // ---- phase 1: four K-steps of 16 layer-1 neurons (eight per lane, as four pairs)
-            IcnnSplit Bh, Bu;
-            icnn_p1_operands<0>(T, xs0, xs1, xs2, cph, Bh, Bu); icnn_p1_mfma<0>(T, Bh, Bu, acc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p1_operands<1>(T, xs0, xs1, xs2, cph, Bh, Bu); icnn_p1_mfma<1>(T, Bh, Bu, acc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p1_operands<2>(T, xs0, xs1, xs2, cph, Bh, Bu); icnn_p1_mfma<2>(T, Bh, Bu, acc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p1_operands<3>(T, xs0, xs1, xs2, cph, Bh, Bu); icnn_p1_mfma<3>(T, Bh, Bu, acc); __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 2: layer-2 neurons in groups of eight (four pairs); each group's deltas are one B fragment of the beta GEMM
-            f32x16 bacc[2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
-            IcnnSplit Bd;
-            icnn_p2_operands<0>(T, xs0, xs1, xs2, acc, res, Bd); icnn_p2_mfma<0>(T, Bd, bacc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p2_operands<1>(T, xs0, xs1, xs2, acc, res, Bd); icnn_p2_mfma<1>(T, Bd, bacc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p2_operands<2>(T, xs0, xs1, xs2, acc, res, Bd); icnn_p2_mfma<2>(T, Bd, bacc); __builtin_amdgcn_sched_barrier(0);
-            icnn_p2_operands<3>(T, xs0, xs1, xs2, acc, res, Bd); icnn_p2_mfma<3>(T, Bd, bacc); __builtin_amdgcn_sched_barrier(0);
-            // ---- phase 3
-            icnn_p3(T, bacc, cph, res);
-            icnn_reduce_store(res, own, minep);
-        }
-        asm volatile("" ::: "memory");
-        if (pidx < n) icnn_finish(f01, f23, minep, small, dP, P, pidx);   // (the fp64 feature derivatives would occupy 18 registers through the GEMM phases)
-    }
-}
-
-// ------------------------------------------------------------------ the same, software-pipelined over half-tiles (icnn_variant = 3)
+// ------------------------------------------------------------------ SCALAR fp32 vector arithmetic, software-pipelined over half-tiles (icnn_variant = 3)
 // profiles/r05_mfma_gap_probe.txt (hand-placed streams, s_memtime): a v_mfma_f32_32x32x16_bf16 occupies the matrix pipe for 32
 // cycles and up to SIX plain vector instructions issued behind it are free (37 cycles per MFMA with six v_fma_f32, 41 with
 // seven, +4 each beyond; a transcendental counts double; one packed-fp32 instruction costs +20) — with one wave per SIMD or
@@ -1141,7 +1320,7 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
             if (mp > ctx->compute_units) mp = ctx->compute_units;
             hipLaunchKernelGGL((icnn_mfma_bf16x3_pipe<4>), dim3((int)mp), dim3(256), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
         } else if (ctx->icnn_variant != 1)   // 2: the same products phase after phase, two waves per SIMD; 1: fp32-input MFMA
-            hipLaunchKernelGGL((icnn_mfma_bf16x3<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
+            hipLaunchKernelGGL((icnn_mfma_bf16x3_packed<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
         else
             hipLaunchKernelGGL((icnn_mfma_f32<8>), dim3((int)mb), dim3(512), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
         return DXO_OK;

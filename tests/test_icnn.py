@@ -124,7 +124,33 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 20_001, 300_000])
+def test_pipelined_kernel_is_bit_identical_to_the_default(ctx, weights, n):
+    """icnn_variant 3 (scalar fp32 arithmetic, phase 1 of the next half-tile issued between the vector instructions of this one's
+    phases 2, one wave per SIMD) runs the same operations in the same order per accumulator as the default kernel (packed fp32,
+    phases in sequence): same bits, at sizes with one tile per wave, ragged tails and several tiles per wave."""
+    from dolfinx_external_operator_amd import MEM_HOST
+
+    rng = np.random.default_rng(21)
+    F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
+    model = ctx.icnn_create(state_dict(weights))
+    out = {}
+    try:
+        for variant in (2, 3):
+            ctx.set_option("icnn_variant", variant)
+            dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
+            ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
+            assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
+            out[variant] = (dP, P)
+    finally:
+        ctx.set_option("icnn_variant", 2)
+        ctx.icnn_destroy(model)
+    assert np.array_equal(out[2][0], out[3][0]) and np.array_equal(out[2][1], out[3][1])
+    assert np.all(np.isfinite(out[3][0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant):
     """The MFMA kernels evaluate 64 points per wave through shared matrix products: a point is one COLUMN of every product, so
     a NaN / inf / singular deformation gradient must poison its own 20 outputs and nothing else — the other points come out
