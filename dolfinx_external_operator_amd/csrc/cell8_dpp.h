@@ -201,4 +201,29 @@ __device__ __forceinline__ void c8_scatter(const C8Lane& L, const double (&T)[3]
     }
 }
 
+// the same with a store every lane calls for every node group t (the patch form adds into LDS in passes that need uniform
+// control flow; the store masks the lanes without a node itself)
+template <int ND, typename Store>
+__device__ __forceinline__ void c8_scatter_all(const C8Lane& L, const double (&T)[3][3], Store&& store) {
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        double d[8][3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* r = L.row(j, t);
+            const dxo_f64x2 a = *reinterpret_cast<const dxo_f64x2*>(r);
+            d[j][0] = a.x; d[j][1] = a.y; d[j][2] = r[2];
+        }
+        double o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = T[i][0] * d[j][0] + T[i][1] * d[j][1] + T[i][2] * d[j][2];
+            o[i] = c8_reduce_scatter(p);
+        }
+        store(t, o);
+    }
+}
+
 }  // namespace

@@ -244,6 +244,10 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     const int32_t* bi = reinterpret_cast<const int32_t*>(v.x + n_x);
     v.dofmap = bi; v.geom_dofmap = bi + n_dm;
     if (n_dm) m->h_dofmap.assign(d->dofmap, d->dofmap + n_dm);
+    m->h_cell_xyz.assign((size_t)d->num_cells * 3, 0.0f);      // vertex mean of every cell: orders the wave groups (adjoint_patch.h)
+    for (int64_t c = 0; c < d->num_cells; ++c)
+        for (int v2 = 0; v2 < d->ngeom; ++v2)
+            for (int j = 0; j < G; ++j) m->h_cell_xyz[(size_t)c * 3 + j] += (float)(hx[(int64_t)d->geom_dofmap[c * d->ngeom + v2] * G + j] / d->ngeom);
     *out = m;
     return DXO_OK;
 }
@@ -264,6 +268,8 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_node_ptr) (void)hipFree(m->d_node_ptr);
     if (m->d_node_ent) (void)hipFree(m->d_node_ent);
     if (m->d_fe) (void)hipFree(m->d_fe);
+    if (m->patch.blob) (void)hipFree(m->patch.blob);
+    if (m->patch.dev.bpart) (void)hipFree(m->patch.dev.bpart);
     delete m;
     return DXO_OK;
 }

@@ -360,6 +360,43 @@ __device__ __forceinline__ bool operand_point(const OperandDev& m, const double*
 
 }  // namespace
 
+#ifndef DXO_PATCH_WAVES
+#define DXO_PATCH_WAVES 4     // waves of a patch workgroup = wave groups per iteration
+#endif
+constexpr int PATCH_WAVES = DXO_PATCH_WAVES;
+constexpr int PATCH_BLOCK = PATCH_WAVES * DXO_WAVE;
+
+// what the kernels read (device pointers, owned by dxo_mesh::patch)
+struct PatchDev {
+    int32_t n_patches = 0;
+    int32_t R = 0;                       // wave groups per wave and patch
+    int32_t max_priv = 0;                // largest number of nodes in one wave's accumulator
+    int32_t max_local = 0;               // largest number of nodes of a patch
+    const int32_t* groups = nullptr;     // [n_patches][PATCH_WAVES][R] wave group, -1: none
+    const int32_t* node_off = nullptr;   // [n_patches + 1] offsets of the patches' nodes (= slots of bpart)
+    const uint32_t* gnode = nullptr;     // [n_slots] global node of a patch node; bit 31: shared with another patch
+    const uint16_t* mmap = nullptr;      // [n_slots][PATCH_WAVES] the node's entry in wave w's accumulator, 0xffff: none
+    const uint16_t* lnode = nullptr;     // [num_cells][ndofs] entry of (cell, local dof) in the accumulator of the wave that owns the cell
+    const uint8_t* cellcol = nullptr;    // [num_cells] colour of the cell within its wave group
+    const uint8_t* grp_ncol = nullptr;   // [n_groups] number of cell colours of the group
+    double* bpart = nullptr;             // [n_slots][bs] partials of the shared nodes (slots of unshared nodes unused)
+    // second pass
+    int64_t n_bnodes = 0;
+    const int32_t* bnode = nullptr;      // [n_bnodes] shared (or untouched) nodes
+    const int64_t* bptr = nullptr;       // [n_bnodes + 1]
+    const uint32_t* bent = nullptr;      // slots of the node's partials, ascending patch order (+ 3 entries of padding)
+};
+
+struct PatchSet {
+    bool built = false, usable = false;
+    int cpw = 0, bs_cap = 0;
+    PatchDev dev;
+    void* blob = nullptr;                // one device allocation for the index arrays
+    size_t bpart_cap = 0;
+    int64_t n_slots = 0;
+    double shared_fraction = 0.0;        // shared patch nodes / (cell, node) incidences: what still travels through HBM
+};
+
 struct dxo_mesh {
     int gdim = 0;
     OperandDev dev{};
@@ -383,4 +420,7 @@ struct dxo_mesh {
     uint32_t* d_node_ent = nullptr;    // [num_cells * ndofs], values a * num_cells + cell (index into d_fe), fixed order per node
     double* d_fe = nullptr;            // [ndofs][num_cells][bs] element vectors of the last adjoint call
     size_t fe_cap = 0;
+    // adjoint kernels, patch form (adjoint_patch.h): a representative point per cell for the Morton order of the wave groups
+    std::vector<float> h_cell_xyz;     // [num_cells][3]
+    PatchSet patch;
 };

@@ -197,6 +197,20 @@ class DeviceMesh:
             raise ValueError(f"{w.size} weights for {self.nq} quadrature points")
         self.ctx.check(self.ctx.lib.dxo_mesh_set_weights(self.ctx._h, self._h, w.ctypes.data), "dxo_mesh_set_weights")
 
+
+    def patch_info(self) -> dict:
+        """The patches of the full-mesh consumer-side calls (dxo_mesh_patch_info; built on first use)."""
+        import numpy as np
+
+        info = np.zeros(8, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.dxo_mesh_patch_info(self.ctx._h, self._h, info.ctypes.data), "dxo_mesh_patch_info")
+        keys = ("patches", "groups_per_wave", "wave_groups", "max_patch_nodes", "patch_nodes", "shared_nodes", "shared_entry_ppm", "waves_per_patch")
+        out = dict(zip(keys, (int(x) for x in info)))
+        out["max_wave_nodes"] = out["groups_per_wave"] >> 32
+        out["groups_per_wave"] &= 0xFFFFFFFF
+        out["schedule_fill"] = out["wave_groups"] / max(1, out["patches"] * out["waves_per_patch"] * out["groups_per_wave"])
+        return out
+
     def adjoint(self, kind: str, bs: int, S_ptr: int, out_ptr: int, n_cells: int | None = None, cells_ptr: int | None = None) -> None:
         """out += sum_q w |det J| B^T S (DEVICE pointers): the assembled vector of inner(S, operand(v)) dx."""
         rc = self.ctx.lib.dxo_operand_adjoint(self.ctx._h, self._h, KINDS[kind], int(bs), C.c_void_p(S_ptr),

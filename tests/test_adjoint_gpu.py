@@ -272,3 +272,41 @@ def test_lane_per_cell_kernel_equals_wave_group_kernel(ctx, cell, n, degree):
         assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max()
     finally:
         dm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n, overwrite", [((5, 4, 3), 0), ((12, 9, 7), 1), ((20, 20, 20), 1)])
+def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overwrite):
+    """Option adjoint_patch = 1 (csrc/adjoint_patch.h, an opt-in experiment): the element-vector entries of Q2 hexahedra are added in
+    LDS patch by patch and only patch-border partials go through HBM. Same sums in another (fixed) order: equal to the two-pass form
+    to rounding, identical bits run to run, untouched entries handled like the two-pass form does (accumulate / overwrite)."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh
+    from tools.synthetic import structured_mesh
+
+    m = structured_mesh("hexahedron", n, 2, distort=0.2, seed=3)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
+    S = torch.randn(npts * 6, generator=g, device=dev, dtype=torch.float64)
+    saved = (ctx.get_option("adjoint_patch"), ctx.get_option("consumer_overwrite"))
+    try:
+        ctx.set_option("consumer_overwrite", overwrite)
+        outs = []
+        for mode in (0, 1, 1):
+            ctx.set_option("adjoint_patch", mode)
+            out = torch.full((nn * 3,), 2.5, dtype=torch.float64, device=dev)
+            dm.adjoint("eps", 3, S.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            outs.append(out)
+        info = dm.patch_info()
+    finally:
+        ctx.set_option("adjoint_patch", saved[0])
+        ctx.set_option("consumer_overwrite", saved[1])
+    scale = float(outs[0].abs().max())
+    assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale
+    assert torch.equal(outs[1], outs[2])
+    assert info["patches"] >= 1 and info["wave_groups"] == -(-m.num_cells // 8) and 0 < info["schedule_fill"] <= 1.0
