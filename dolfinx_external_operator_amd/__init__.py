@@ -4,7 +4,7 @@
 Product path: `operators.make_*` -> ctypes (`_lib`) -> libdxo_hip.so (hand-written HIP, include/dxo.h).
 There is no CPU fallback; `oracle/` is test infrastructure and is never imported from here.
 """
-from ._lib import GATHER_COMPACT, GATHER_FULL, GATHER_NONE, MEM_DEVICE, MEM_HOST, AssignDesc, AssignPlan, Context, MultiGpu, DxoError, IsiharaParams, McParams, VmParams, default_context, load_library
+from ._lib import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, GATHER_FULL, GATHER_NONE, MEM_DEVICE, MEM_HOST, AssignDesc, AssignPlan, Context, MultiGpu, DxoError, IsiharaParams, McParams, VmParams, default_context, load_library
 from .evaluation import (
     Coefficient,
     MixedExternalOperator,
@@ -25,5 +25,5 @@ __all__ = [
     "make_von_mises", "make_heat", "make_conductivity", "make_mohr_coulomb", "make_icnn", "make_isihara", "McParams", "IsiharaParams", "von_mises_commit_state",
     "QuadratureExternalOperator", "MixedExternalOperator", "Operand", "Coefficient",
     "evaluate_operands", "evaluate_external_operators", "get_unrolled_dofmap", "DeviceMesh", "DeviceOperand", "LazyOperand", "AssignDesc",
-    "MultiGpu", "GATHER_NONE", "GATHER_FULL", "GATHER_COMPACT",
+    "MultiGpu", "GATHER_NONE", "GATHER_FULL", "GATHER_COMPACT", "GATHER_COMPACT_DIRECT", "GATHER_COMPACT_PIPELINED",
 ]

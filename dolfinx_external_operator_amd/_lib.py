@@ -760,7 +760,7 @@ class _CudaArrayView:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
 
 
-GATHER_NONE, GATHER_FULL, GATHER_COMPACT = 0, 1, 2
+GATHER_NONE, GATHER_FULL, GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED = 0, 1, 2, 3, 4
 MGPU_ID_BYTES = 128
 
 

@@ -82,6 +82,7 @@ struct dxo_ctx {
     int64_t consumer_overwrite = 0;     // dxo_operand_adjoint / dxo_tangent_apply* / dxo_tangent_diagonal* / dxo_von_mises_residual: 1 = out is SET to the
                                         // assembled vector instead of added to (a Krylov matvec needs no memset and node_sum no read of out)
     int64_t adjoint_patch = 0;          // internal force on hexahedra, whole mesh: 1 = patch form (entries meet in LDS, adjoint_patch.h; measured SLOWER, profiles/r05_patch_form.txt), 0 = element vectors + node sums
+    int64_t mgpu_chunks = 4;            // DXO_GATHER_COMPACT_PIPELINED: pieces of a rank's block (kernel of piece k + 1 beside the exchange of piece k)
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and

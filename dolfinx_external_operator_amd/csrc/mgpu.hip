@@ -45,6 +45,10 @@ struct dxo_mgpu {
     std::vector<bool> own_ctx;
     std::vector<ncclComm_t> comm;
     bool local_only = false;       // dxo_mgpu_create_local: contexts without a communicator (host-sharded calls only)
+    // DXO_GATHER_COMPACT_PIPELINED: the exchange runs on its own stream per local device, beside the kernels of later chunks
+    std::vector<hipStream_t> xstream;
+    std::vector<hipEvent_t> ev_kernel, ev_arrived;      // [local device][chunk], made on first use
+    int ev_chunks = 0;
     std::string err;
 };
 
@@ -59,6 +63,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -88,6 +94,8 @@ Rccl* rccl() {
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return r.why.empty() ? &r : nullptr;
@@ -110,6 +118,13 @@ int nccl_fail(dxo_mgpu* g, ncclResult_t r, const char* where) {
         ncclResult_t r_ = (call);                                     \
         if (r_ != ncclSuccess) return nccl_fail((g), r_, #call);      \
     } while (0)
+
+// HIP errors are positive hipError_t codes (as everywhere in the C ABI)
+int mg_hip_fail(dxo_mgpu* g, const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (g) g->err = std::string(what) + ": " + hipGetErrorString(e) + " (hipError " + std::to_string((int)e) + ")";
+    return (int)e > 0 ? (int)e : 999;
+}
 
 int need_rccl(dxo_mgpu* g) {
     if (g->local_only)
@@ -148,7 +163,10 @@ int dxo_mgpu_destroy(dxo_mgpu* g) {
             (void)hipStreamSynchronize(dxo_launch_stream(g->ctx[i]));
         }
         if (R && i < g->comm.size() && g->comm[i]) (void)R->CommDestroy(g->comm[i]);
+        if (i < g->xstream.size() && g->xstream[i]) (void)hipStreamDestroy(g->xstream[i]);
     }
+    for (hipEvent_t e : g->ev_kernel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_arrived) (void)hipEventDestroy(e);
     for (size_t i = 0; i < g->ctx.size(); ++i)
         if (g->own_ctx[i] && g->ctx[i]) (void)dxo_ctx_destroy(g->ctx[i]);
     delete g;
@@ -349,6 +367,74 @@ static int mg_all_gather_bytes(dxo_mgpu* g, void* const* buf, size_t bytes_per_r
     return DXO_OK;
 }
 
+// The same result as the in-place all-gather, as point-to-point traffic (SURVEY.md 8e prefers it on a fully connected xGMI
+// node: one link per GPU pair, so every block travels on its own link at once whatever algorithm RCCL's all-gather would pick for
+// the message size). Piece [off, off + len) ELEMENTS of every rank's block (block = count_per_rank elements of elem_bytes bytes;
+// rank r's block at element r * count_per_rank of the full-length array): each local device sends its own piece to every peer
+// and receives each peer's piece straight into place; all 2 (world - 1) operations of all local devices in ONE group. Peer order
+// staggered by rank (at step s everybody talks to rank + s / rank - s: disjoint pairs).
+static int mg_exchange_direct(dxo_mgpu* g, void* const* buf, size_t elem_bytes, size_t count_per_rank, size_t off, size_t len,
+                              const std::vector<hipStream_t>* streams) {
+    const int rc0 = need_rccl(g);
+    if (rc0 != DXO_OK) return rc0;
+    if (len == 0 || g->world == 1) return DXO_OK;
+    Rccl* R = rccl();
+    if (!R->Send || !R->Recv) return mg_fail(g, DXO_E_NODEVICE, "this RCCL has no ncclSend / ncclRecv");
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        if (!buf[i]) return mg_fail(g, DXO_E_NULL, "dxo_mgpu exchange: NULL buffer");
+        if (dxo_arena_is_vmm(g->ctx[i], buf[i]))
+            return mg_fail(g, DXO_E_MEM, "dxo_mgpu exchange: the buffer lies in an arena block backed by 2 MB physical chunks, which peers cannot "
+                                         "access; allocate it with option placement_vmm = 0 (the group's contexts have it set)");
+    }
+    DXO_NCCL(g, R->GroupStart());
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        char* b = static_cast<char*>(buf[i]);
+        const int me = g->rank[i];
+        hipStream_t st = streams ? (*streams)[i] : dxo_launch_stream(g->ctx[i]);
+        const char* mine = b + ((size_t)me * count_per_rank + off) * elem_bytes;
+        for (int step = 1; step < g->world; ++step) {
+            const int to = (me + step) % g->world, from = (me - step + g->world) % g->world;
+            ncclResult_t r = R->Send(mine, len * elem_bytes, ncclChar, to, g->comm[i], st);
+            if (r == ncclSuccess) r = R->Recv(b + ((size_t)from * count_per_rank + off) * elem_bytes, len * elem_bytes, ncclChar, from, g->comm[i], st);
+            if (r != ncclSuccess) {
+                (void)R->GroupEnd();
+                return nccl_fail(g, r, "ncclSend / ncclRecv");
+            }
+        }
+    }
+    DXO_NCCL(g, R->GroupEnd());
+    return DXO_OK;
+}
+
+// the exchange streams and the per-chunk events of DXO_GATHER_COMPACT_PIPELINED, made once per group
+static int mg_pipeline_resources(dxo_mgpu* g, int chunks) {
+    const size_t L = g->ctx.size();
+    if (g->xstream.size() != L) {
+        g->xstream.assign(L, nullptr);
+        for (size_t i = 0; i < L; ++i) {
+            if (hipSetDevice(g->ctx[i]->device) != hipSuccess || hipStreamCreateWithFlags(&g->xstream[i], hipStreamNonBlocking) != hipSuccess) {
+                return mg_hip_fail(g, "dxo_mgpu: could not create the exchange stream");
+            }
+        }
+    }
+    if (g->ev_chunks < chunks) {
+        for (hipEvent_t e : g->ev_kernel) (void)hipEventDestroy(e);
+        for (hipEvent_t e : g->ev_arrived) (void)hipEventDestroy(e);
+        g->ev_kernel.assign(L * (size_t)chunks, nullptr);
+        g->ev_arrived.assign(L * (size_t)chunks, nullptr);
+        for (size_t i = 0; i < L; ++i) {
+            (void)hipSetDevice(g->ctx[i]->device);
+            for (int k = 0; k < chunks; ++k)
+                if (hipEventCreateWithFlags(&g->ev_kernel[i * chunks + k], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&g->ev_arrived[i * chunks + k], hipEventDisableTiming) != hipSuccess) {
+                    return mg_hip_fail(g, "dxo_mgpu: could not create the pipeline events");
+                }
+        }
+        g->ev_chunks = chunks;
+    }
+    return DXO_OK;
+}
+
 int dxo_mgpu_all_gather(dxo_mgpu* g, double* const* buf, int64_t count_per_rank) {
     if (!g || !buf) return DXO_E_NULL;
     if (count_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_all_gather: negative count");
@@ -472,47 +558,124 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
     if (!prm || !deps || !sigma_n || !p || !C_tang || !sigma || !dp) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL argument");
     if (d != 4 && d != 6) return mg_fail(g, DXO_E_DIM, "dxo_mgpu_von_mises: d must be 4 or 6");
     if (n_per_rank < 0) return mg_fail(g, DXO_E_SIZE, "dxo_mgpu_von_mises: n_per_rank < 0");
-    if (gather < DXO_GATHER_NONE || gather > DXO_GATHER_COMPACT) return mg_fail(g, DXO_E_MEM, "dxo_mgpu_von_mises: bad gather mode");
+    if (gather < DXO_GATHER_NONE || gather > DXO_GATHER_COMPACT_PIPELINED) return mg_fail(g, DXO_E_MEM, "dxo_mgpu_von_mises: bad gather mode");
     if (gather != DXO_GATHER_NONE && (n_per_rank % 2)) return mg_fail(g, DXO_E_ALIGN, "dxo_mgpu_von_mises: with a gather n_per_rank must be even (16-byte aligned blocks)");
     const size_t n = (size_t)n_per_rank, L = g->ctx.size();
-    const bool compact = gather == DXO_GATHER_COMPACT;
-    // 1. every local device: return map of its own cell block, written into its slice of the full-length outputs. COMPACT:
-    //    (sigma, dp) only, with the 0/0 point marked in the sign bit of dp — every tangent is rebuilt in step 3
-    for (size_t i = 0; i < L; ++i) {
-        const size_t off = gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n;
-        if (compact && (!C_tang[i] || !sigma[i] || !dp[i])) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL output array");
-        int rc;
-        {   // option switch, call and restore as ONE unit under the context's (recursive) lock: another thread calling
-            // dxo_von_mises on the same borrowed context never sees marks it did not ask for
-            DXO_LOCK(g->ctx[i]);
-            const int64_t saved_mark = g->ctx[i]->vm_mark_indeterminate;
-            if (compact) g->ctx[i]->vm_mark_indeterminate = 1;
-            rc = dxo_von_mises(g->ctx[i], prm, d, n_per_rank, DXO_MEM_DEVICE, deps[i], sigma_n[i], p[i],
-                               compact ? nullptr : (C_tang[i] ? C_tang[i] + off * d * d : nullptr),
-                               sigma[i] ? sigma[i] + off * d : nullptr, dp[i] ? dp[i] + off : nullptr);
-            g->ctx[i]->vm_mark_indeterminate = saved_mark;
+    const bool compact = gather >= DXO_GATHER_COMPACT;
+    if (compact)
+        for (size_t i = 0; i < L; ++i)
+            if (!C_tang[i] || !sigma[i] || !dp[i]) return mg_fail(g, DXO_E_NULL, "dxo_mgpu_von_mises: NULL output array");
+    // the return map of points [b, e) of every local device's block, written into its slice of the full-length outputs. COMPACT
+    // forms: (sigma, dp) only, with the 0/0 point marked in the sign bit of dp — every tangent is rebuilt afterwards
+    auto kernels = [&](size_t b, size_t e) -> int {
+        for (size_t i = 0; i < L; ++i) {
+            const size_t off = (gather == DXO_GATHER_NONE ? 0 : (size_t)g->rank[i] * n) + b;
+            int rc;
+            {   // option switch, call and restore as ONE unit under the context's (recursive) lock: another thread calling
+                // dxo_von_mises on the same borrowed context never sees marks it did not ask for
+                DXO_LOCK(g->ctx[i]);
+                const int64_t saved_mark = g->ctx[i]->vm_mark_indeterminate;
+                if (compact) g->ctx[i]->vm_mark_indeterminate = 1;
+                rc = dxo_von_mises(g->ctx[i], prm, d, (int64_t)(e - b), DXO_MEM_DEVICE, deps[i] + b * d, sigma_n[i] + b * d, p[i] + b,
+                                   compact ? nullptr : (C_tang[i] ? C_tang[i] + off * d * d : nullptr),
+                                   sigma[i] ? sigma[i] + off * d : nullptr, dp[i] ? dp[i] + off : nullptr);
+                g->ctx[i]->vm_mark_indeterminate = saved_mark;
+            }
+            if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
         }
-        if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
-    }
-    // 2. the exchange step (a world of one has none; COMPACT still owes the tangent of its only block)
-    if (gather == DXO_GATHER_NONE || n == 0) return DXO_OK;
-    int rc = DXO_OK;
-    if (g->world > 1) {
-        rc = dxo_mgpu_all_gather(g, sigma, n_per_rank * d);
-        if (rc == DXO_OK) rc = dxo_mgpu_all_gather(g, dp, n_per_rank);
+        return DXO_OK;
+    };
+    // the tangents of points [b, e) of EVERY rank's block from the gathered state, on each local device's launch stream
+    auto rebuild = [&](size_t b, size_t e) -> int {
+        for (size_t i = 0; i < L; ++i)
+            for (int r = 0; r < g->world; ++r) {
+                const size_t o = (size_t)r * n + b;
+                const int rc = dxo_vm_expand_tangent(g->ctx[i], prm, d, (int64_t)(e - b), DXO_MEM_DEVICE, sigma[i] + o * d, dp[i] + o, C_tang[i] + o * d * d);
+                if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+            }
+        return DXO_OK;
+    };
+    auto clear_marks = [&]() -> int {
+        for (size_t i = 0; i < L; ++i) {
+            const int rc = dxo_vm_clear_marks(g->ctx[i], (int64_t)((size_t)g->world * n), dp[i]);
+            if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
+        }
+        return DXO_OK;
+    };
+    int rc;
+    if (gather == DXO_GATHER_COMPACT_PIPELINED && n > 0) {
+        // the block in `chunks` pieces on 64-point borders; the kernel of piece k + 1 runs while piece k is on the
+        // links (exchange stream), and piece k's tangents are rebuilt while later pieces are still travelling
+        int64_t chunks = g->ctx[0]->mgpu_chunks;
+        if (chunks < 1) chunks = 1;
+        if (chunks > 64) chunks = 64;
+        size_t step = (n + (size_t)chunks - 1) / (size_t)chunks;
+        step = (step + DXO_WAVE - 1) / DXO_WAVE * DXO_WAVE;
+        const int nk = (int)((n + step - 1) / step);
+        rc = mg_pipeline_resources(g, nk);
         if (rc != DXO_OK) return rc;
-        if (gather == DXO_GATHER_FULL) return dxo_mgpu_all_gather(g, C_tang, n_per_rank * d * d);
+        for (int k = 0; k < nk; ++k) {
+            const size_t b = (size_t)k * step, e = b + step < n ? b + step : n;
+            rc = kernels(b, e);
+            if (rc != DXO_OK) return rc;
+            if (g->world == 1) continue;
+            for (size_t i = 0; i < L; ++i) {
+                (void)hipSetDevice(g->ctx[i]->device);
+                if (hipEventRecord(g->ev_kernel[i * g->ev_chunks + k], dxo_launch_stream(g->ctx[i])) != hipSuccess ||
+                    hipStreamWaitEvent(g->xstream[i], g->ev_kernel[i * g->ev_chunks + k], 0) != hipSuccess) {
+                    return mg_hip_fail(g, "dxo_mgpu_von_mises: event record / wait failed");
+                }
+            }
+            rc = mg_exchange_direct(g, (void* const*)sigma, sizeof(double) * (size_t)d, n, b, e - b, &g->xstream);
+            if (rc == DXO_OK) rc = mg_exchange_direct(g, (void* const*)dp, sizeof(double), n, b, e - b, &g->xstream);
+            if (rc != DXO_OK) return rc;
+            for (size_t i = 0; i < L; ++i) {
+                (void)hipSetDevice(g->ctx[i]->device);
+                if (hipEventRecord(g->ev_arrived[i * g->ev_chunks + k], g->xstream[i]) != hipSuccess) {
+                    return mg_hip_fail(g, "dxo_mgpu_von_mises: event record failed");
+                }
+            }
+        }
+        for (int k = 0; k < nk; ++k) {
+            const size_t b = (size_t)k * step, e = b + step < n ? b + step : n;
+            if (g->world > 1)
+                for (size_t i = 0; i < L; ++i) {
+                    (void)hipSetDevice(g->ctx[i]->device);
+                    if (hipStreamWaitEvent(dxo_launch_stream(g->ctx[i]), g->ev_arrived[i * g->ev_chunks + k], 0) != hipSuccess) {
+                        return mg_hip_fail(g, "dxo_mgpu_von_mises: event wait failed");
+                    }
+                }
+            rc = rebuild(b, e);
+            if (rc != DXO_OK) return rc;
+        }
+        return clear_marks();
+    }
+    // 1. every local device: return map of its own cell block
+    rc = kernels(0, n);
+    if (rc != DXO_OK) return rc;
+    // 2. the exchange step (a world of one has none; the COMPACT forms still owe the tangent of the only block)
+    if (gather == DXO_GATHER_NONE || n == 0) return DXO_OK;
+    if (g->world > 1) {
+        if (gather == DXO_GATHER_COMPACT_DIRECT) {
+            rc = mg_exchange_direct(g, (void* const*)sigma, sizeof(double) * (size_t)d, n, 0, n, nullptr);
+            if (rc == DXO_OK) rc = mg_exchange_direct(g, (void* const*)dp, sizeof(double), n, 0, n, nullptr);
+            if (rc != DXO_OK) return rc;
+        } else {
+            rc = dxo_mgpu_all_gather(g, sigma, n_per_rank * d);
+            if (rc == DXO_OK) rc = dxo_mgpu_all_gather(g, dp, n_per_rank);
+            if (rc != DXO_OK) return rc;
+            if (gather == DXO_GATHER_FULL) return dxo_mgpu_all_gather(g, C_tang, n_per_rank * d * d);
+        }
     }
     if (!compact) return DXO_OK;
-    // 3. COMPACT: the tangent of EVERY block (own block included) from the gathered state, on each device's stream
-    //    behind its gathers: one launch over the full range, then the marks are cleared
+    // 3. COMPACT forms: the tangent of EVERY block (own block included) from the gathered state, on each device's stream
+    //    behind its exchange: one launch over the full range, then the marks are cleared
     for (size_t i = 0; i < L; ++i) {
         const int64_t all = (int64_t)((size_t)g->world * n);
         rc = dxo_vm_expand_tangent(g->ctx[i], prm, d, all, DXO_MEM_DEVICE, sigma[i], dp[i], C_tang[i]);
-        if (rc == DXO_OK) rc = dxo_vm_clear_marks(g->ctx[i], all, dp[i]);
         if (rc != DXO_OK) return mg_fail(g, rc, dxo_last_error(g->ctx[i]));
     }
-    return DXO_OK;
+    return clear_marks();
 }
 
 }  // extern "C"

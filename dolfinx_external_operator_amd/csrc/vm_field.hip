@@ -40,6 +40,9 @@ namespace {
 #ifndef DXO_VMF_STATE2D_WAVES
 #define DXO_VMF_STATE2D_WAVES 4   // (sigma, dp)-only launch in 2-D: 132 registers at three waves per SIMD
 #endif
+#ifndef DXO_VMF_STATE3D_WAVES
+#define DXO_VMF_STATE3D_WAVES 3   // (sigma, dp)-only launch in 3-D: waves per SIMD its register budget is set for (see profiles/r05_vm_field_state.txt)
+#endif
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
@@ -59,7 +62,7 @@ namespace {
 // MODE 0: (C_tang, sigma, dp). MODE 1: (sigma, dp) only — its own instantiation, so that the profiler's kernel names tell the two
 // launches apart (the arithmetic of the stores that remain is the same). MODE 2: RES.
 template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, int MODE = 0>
-__global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE == 1 && G == 2) ? DXO_VMF_STATE2D_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
+__global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE == 1 && G == 2) ? DXO_VMF_STATE2D_WAVES : (MODE == 1) ? DXO_VMF_STATE3D_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
                                                          const double* __restrict__ p, double* __restrict__ C_tang,
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
             X2[lane * T::CH_VEC + k] = dxo_f64x2{sig[2 * k], sig[2 * k + 1]};
-            if constexpr (!RES) Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};
+            if constexpr (MODE == 0) Y2[lane * (T::ST / 2) + k] = dxo_f64x2{nrm[2 * k], nrm[2 * k + 1]};     // the tangent walk's inputs: only where a tangent is written
         }
-        if constexpr (!RES) Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
+        if constexpr (MODE == 0) Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
         wave_lds_fence();
         if ((DXO_VMF_KO & 1) && dp != 1.2345e300) { wave_lds_fence(); continue; }
         if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);

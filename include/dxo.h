@@ -584,6 +584,14 @@ int dxo_isihara_field(dxo_ctx* ctx, const dxo_isihara_params* prm, dxo_mesh* mes
 #define DXO_GATHER_NONE 0
 #define DXO_GATHER_FULL 1
 #define DXO_GATHER_COMPACT 2
+/* DXO_GATHER_COMPACT with the exchange of (sigma, dp) as ONE group of ncclSend / ncclRecv pairs (every rank's block straight to
+ * every peer: on a fully connected xGMI node each block travels on its own link at once) instead of RCCL's
+ * all-gather — same arrays afterwards, bit for bit. dxo_mgpu_von_mises only. */
+#define DXO_GATHER_COMPACT_DIRECT 3
+/* ... and with the block cut into option "mgpu_chunks" (default 4) pieces on 64-point borders: the kernel of piece k + 1 runs
+ * while piece k is on the links (the library's own exchange stream per device), and piece k's tangents are rebuilt while later
+ * pieces still travel (SURVEY.md 8e iii). Same arrays afterwards, bit for bit. dxo_mgpu_von_mises only. */
+#define DXO_GATHER_COMPACT_PIPELINED 4
 typedef struct dxo_mgpu dxo_mgpu;
 int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out);
 /* Contexts only, no communicator and no RCCL: for dxo_mgpu_von_mises_host, whose data path has no exchange step. The

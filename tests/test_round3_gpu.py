@@ -152,6 +152,47 @@ def test_mgpu_compact_reproduces_the_nan_tangent_and_clears_the_marks(ctx, form,
         g.close()
 
 
+@pytest.mark.parametrize("form", ["single_process", "rank"])
+def test_mgpu_direct_and_pipelined_exchange_forms_world_of_one(ctx, form, d=6):
+    """DXO_GATHER_COMPACT_DIRECT / _PIPELINED (round 5: the exchange forms sharding.py has, inside libdxo for C / MPI callers). A
+    world of one has nobody to talk to, so what runs here is everything around the exchange: the (sigma, dp)-only kernel in pieces
+    on 64-point borders (ragged last piece), the library's exchange stream and events, the per-piece rebuild of the tangents and the
+    clearing of the marks — the arrays come out bit for bit as DXO_GATHER_COMPACT leaves them, NaN tangents included."""
+    import torch
+
+    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, MultiGpu
+
+    n, where = 10_000, (5, 64, 2559, 2560, 9999)     # 10 000 = 156 tiles of 64 + 16: pieces of 2 560 with mgpu_chunks = 4, the last one short
+    _, sigma_0, deps, sigma_n, p = _batch_with_indeterminate_points(ctx, d, n, 32, where)
+    prm = VmParams(E, NU, sigma_0, H)
+    mg = MultiGpu(devices=[0]) if form == "single_process" else MultiGpu.from_rank(ctx, MultiGpu.unique_id(), 0, 1)
+    try:
+        mg.set_stream(0, torch.cuda.current_stream().cuda_stream)
+        t_in = [_dev(a) for a in (deps, sigma_n, p)]
+        out = {}
+        for gather, chunks in ((GATHER_COMPACT, 4), (GATHER_COMPACT_DIRECT, 4), (GATHER_COMPACT_PIPELINED, 4), (GATHER_COMPACT_PIPELINED, 1),
+                               (GATHER_COMPACT_PIPELINED, 7)):
+            mg.set_option("mgpu_chunks", chunks)
+            C = torch.full((n * d * d,), -5.0, dtype=torch.float64, device="cuda:0")
+            s = torch.full((n * d,), -5.0, dtype=torch.float64, device="cuda:0")
+            dp = torch.full((n,), -5.0, dtype=torch.float64, device="cuda:0")
+            mg.von_mises(prm, d, n, gather, [t_in[0]], [t_in[1]], [t_in[2]], [C], [s], [dp])
+            mg.synchronize()
+            out[(gather, chunks)] = (C, s, dp)
+        ref = out[(GATHER_COMPACT, 4)]
+        for i in where:
+            assert bool(torch.isnan(ref[0][i * d * d:(i + 1) * d * d]).all())
+        assert not bool(torch.signbit(ref[2]).any())
+        for key, (C, s, dp) in out.items():
+            assert torch.equal(C.view(torch.int64), ref[0].view(torch.int64)), key     # NaN-safe bit comparison
+            assert torch.equal(s, ref[1]) and torch.equal(dp.view(torch.int64), ref[2].view(torch.int64)), key
+        with pytest.raises(ValueError):
+            mg.von_mises(prm, d, n, 5, [t_in[0]], [t_in[1]], [t_in[2]], [ref[0]], [ref[1]], [ref[2]])      # no such gather mode
+    finally:
+        mg.set_option("mgpu_chunks", 4)
+        mg.close()
+
+
 def test_collectives_refuse_chunk_backed_arena_blocks(hip_library):
     """A virtual range backed by 2 MB physical chunks is accessible from its own device only and cannot be exported to a
     peer: dxo_mgpu_all_gather returns DXO_E_MEM for a pointer inside such an arena block instead of handing it to RCCL."""

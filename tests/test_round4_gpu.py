@@ -195,3 +195,4 @@ def test_consumer_overwrite_sets_instead_of_adding(ctx, cell, n):
         ctx.set_option("consumer_overwrite", 0)
         ctx.set_option("adjoint_atomics", 0)
         dm.close()
+
