@@ -266,7 +266,7 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     ends the process with exit code 3 (a rank that has touched the GPU and gives up must not report success)."""
     import threading
 
-    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_FULL, MultiGpu
+    from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, GATHER_FULL, MultiGpu
 
     done = threading.Event()
 
@@ -285,7 +285,7 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     sigma_n = torch.empty(n, d, dtype=torch.float64, device=device).normal_(0.0, 100.0, generator=g)
     p = torch.empty(n, dtype=torch.float64, device=device).normal_(0.0, 1e-3, generator=g).abs_()
     out = {}
-    for mode, name in ((GATHER_FULL, "full"), (GATHER_COMPACT, "compact")):
+    for mode, name in ((GATHER_FULL, "full"), (GATHER_COMPACT, "compact"), (GATHER_COMPACT_DIRECT, "direct"), (GATHER_COMPACT_PIPELINED, "pipelined")):
         C = torch.zeros(world * n * d * d, dtype=torch.float64, device=device)
         s = torch.zeros(world * n * d, dtype=torch.float64, device=device)
         dp = torch.zeros(world * n, dtype=torch.float64, device=device)
@@ -310,13 +310,18 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     identical = bool((lo == hi).all())
+    # the direct and the pipelined form leave the SAME arrays as compact, bit for bit (NaN-safe: compared as integers)
+    same_forms = all(bool(torch.equal(out[k]["C"].view(torch.int64), out["compact"]["C"].view(torch.int64))) and
+                     bool(torch.equal(out[k]["s"], out["compact"]["s"])) and bool(torch.equal(out[k]["dp"].view(torch.int64), out["compact"]["dp"].view(torch.int64)))
+                     for k in ("direct", "pipelined"))
     mg.close()
     done.set()
-    ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13 and identical
+    ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13 and identical and same_forms
     rec = {"library_gather_check": "ok" if ok else "MISMATCH", "rank": rank, "rccl_ranks_in_libdxo": world, "points_per_rank": n,
            "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
+           "direct_ms_per_step": out["direct"]["ms_per_step"], "overlap_ms_per_step": out["pipelined"]["ms_per_step"],
            "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C,
-           "compact_replicas_bit_identical": identical}
+           "compact_replicas_bit_identical": identical, "direct_and_pipelined_equal_compact_bitwise": same_forms}
     log(json.dumps(rec))
     return rec
 
@@ -557,8 +562,28 @@ def main():
     ptrs_state_only = (*ptrs[:3], None, ptrs[4], ptrs[5])
     rebuild = dict(identical=True, clear_marks=clear_marks)
 
+    # libdxo's own exchange forms (dxo_mgpu_von_mises with RCCL inside the library: what a C / MPI caller gets), timed beside the
+    # torch.distributed ones whenever there is a real communicator (not in the gloo dry run)
+    LIB_MODES = {}
+    mg = None
+    if gather_on and dist_on and not args.dry_collective and not args.no_library_gather:
+        from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, MultiGpu
+
+        uid = [MultiGpu.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        mg = MultiGpu.from_rank(ctx, uid[0], rank, world)
+        LIB_MODES = {"library_compact": GATHER_COMPACT, "library_direct": GATHER_COMPACT_DIRECT, "library_pipelined": GATHER_COMPACT_PIPELINED}
+
     def make_step(mode):
         compact = gather_on and mode.startswith("compact")
+        if mode in LIB_MODES:
+            def lib_step(ev=None, g_=LIB_MODES[mode]):
+                if ev is not None:
+                    ev[0].record(stream)
+                mg.von_mises(prm, d, n, g_, [deps], [sigma_n], [p], [C_full], [sigma_full], [dp_full])
+                if ev is not None:
+                    ev[1].record(stream)
+            return lib_step
 
         def step(ev=None):
             if ev is not None:
@@ -614,7 +639,7 @@ def main():
         kernel_ms_avg = bytes_per_launch_of(d, n) / time_kernel(ptrs[3:], K) / 1e6
     total_points = n * world
     bytes_per_launch = BYTES_PER_QP[d] * n
-    MODES = ("compact", "compact_pipelined", "compact_direct", "full")
+    MODES = ("compact", "compact_pipelined", "compact_direct", "full", *LIB_MODES)
     emitted = threading.Lock()
     last_result = {}
 
@@ -667,7 +692,9 @@ def main():
                                                      "reference's NaN tangent at f_el == 0 carried by the sign bit of dp, cleared afterwards)",
                                           "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic",
                                           "compact_direct": "compact with (sigma, dp) exchanged as ONE batch of point-to-point sends / receives "
-                                                            "(every block on its own xGMI link at once) instead of the library's all-gather"}
+                                                            "(every block on its own xGMI link at once) instead of the library's all-gather",
+                                          "library_*": "the same three compact forms through libdxo's own RCCL path (dxo_mgpu_von_mises with "
+                                                       "DXO_GATHER_COMPACT / _COMPACT_DIRECT / _COMPACT_PIPELINED): what a C / MPI caller gets"}
                                          if gather_on else None),
                 "rccl_ranks": world if dist_on else 0,
                 "collective_backend": (dist.get_backend() if dist_on else None),
@@ -879,6 +906,8 @@ def main():
         except Exception as exc:   # noqa: BLE001
             log(f"bench rank {rank}: library_gather_check failed: {exc!r}")
             emit_gather_check({"status": "error", "why": repr(exc)})
+    if mg is not None:
+        mg.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,15 +7,26 @@
 // step is what forces the 16/36-double tangents across PCIe. Its arithmetic is the ADJOINT of the operand evaluation:
 //   operand      e_q   = B_q u          (gather dofs, contract with grad phi, push forward, shape)      operand.hip
 //   virtual work f     = sum_q w_q |det J_q| B_q^T s_q                                                  dxo_operand_adjoint
-//   tangent      K v   = sum_q w_q |det J_q| B_q^T C_q B_q v   (never forming K)                        dxo_tangent_apply
-// so with these two entry points a Newton-Krylov solver can keep sigma and C_tang in HBM and move only dof vectors.
+//   tangent      K v   = sum_q w_q |det J_q| B_q^T C_q B_q v   (never forming K)                        dxo_tangent_apply[_vm]
+//   its diagonal                                                                                        dxo_tangent_diagonal[_vm]
+// so with these entry points a Newton-Krylov solver can keep sigma and C_tang in HBM and move only dof vectors.
 //
-// Kernel shape (both): a wave owns floor(64/nq) consecutive cells. Phase 1, lane = (cell, point): J^-1 and det J from
-// the gathered vertices, the point's dual tensor pulled back to reference gradients T_q[i][k] = w|detJ| sum_j G_ij K[k][j]
-// (G = the stress-like quantity unpacked from Mandel / row-major form), parked in the wave's LDS slice. Phase 2, lane =
-// (cell, node): f_a,i = sum_q sum_k T_q[i][k] dphi_a,k(xi_q) (+ the value part), one fp64 atomic add per dof into the
-// global vector (global_atomic_add_f64; nodes are shared between cells, the order of the additions is not fixed, so
-// results are reproducible to rounding, not bit for bit).
+// Shape of every call (whole mesh): TWO PASSES, no atomics, bit-reproducible.
+//   pass 1, element kernel: a wave owns floor(64 / nq) consecutive cells, lane = (cell, point). J^-1 and det J from the
+//     gathered vertices; the point's dual tensor pulled back to reference gradients T_q[i][k] = w |det J| sum_j G_ij K[k][j];
+//     the element-vector entries f_a,i = sum_q sum_k T_q[i][k] dphi_a,k(xi_q) are written to fe[local node][cell][i].
+//     Q2 / Q1 hexahedra with the 2x2x2 rule keep everything in registers and reduce-scatter the entries over a cell's 8 lanes
+//     with DPP moves (cell8_dpp.h: operand_adjoint_c8, the scatter of tangent_apply<3, 27, 8>); the other elements park T_q in the
+//     wave's LDS slice and let lane = (cell, node) form the entries (adjoint_scatter); P2 triangles' internal force has a
+//     lane = cell form (adjoint_cell.h). tangent_apply requests its tangent rows lane-linear and passes them through LDS
+//     (TangentRows); the *_vm forms rebuild the tangent's action from the returned (sigma, dp) instead (VmStateSrc).
+//   pass 2, node_sum: one thread per node adds the node's entries in the fixed order of the transposed dofmap (built once per
+//     mesh) — or SETS the vector to the sums with option consumer_overwrite (no memset before a Krylov matvec).
+// Entity subsets, or option adjoint_atomics = 1, add with fp64 hardware atomics into the dof vector instead (one pass,
+// reproducible to rounding only). Option adjoint_patch = 1: the hexahedral internal force with the entries added in LDS patch by
+// patch (adjoint_patch.h — an experiment, measured slower; profiles/r05_patch_form.txt).
+// Kernel variants that were measured and not shipped (contraction across the lanes as well, lane = cell tangent action) live in
+// scripts/exp/adjoint_variants.h and are compiled only with -DDXO_EXPERIMENTS.
 #include "dxo_common.h"
 #include "operand_core.h"
 #include "adjoint_cell.h"
@@ -41,20 +52,22 @@
 #ifndef DXO_TA_WAVES
 #define DXO_TA_WAVES 2
 #endif
-#ifndef DXO_TA_KO
-#define DXO_TA_KO 0          // knock-out experiments (wrong results!): 1 no element-vector stores, 2 no tangent loads, 4 no dof gather
-#endif
 #ifndef DXO_TA_RS
 #define DXO_TA_RS 1          // Q2 hexahedra: scatter phase in registers with a DPP reduce-scatter (scatter_rs)
 #endif
+#ifdef DXO_EXPERIMENTS       // variants that were measured and not shipped (scripts/exp/adjoint_variants.h)
 #ifndef DXO_TA_C8_FORWARD
-#define DXO_TA_C8_FORWARD 0  // experiment: tangent_apply_c8 (contraction across the lanes as well); slower, see the kernel's comment
+#define DXO_TA_C8_FORWARD 0  // tangent_apply_c8 (contraction across the lanes as well)
 #endif
 #ifndef DXO_TANGENT_CELL
-#define DXO_TANGENT_CELL 0   // experiment: lane = cell tangent action on P2 triangles (slower, see dxo_tangent_apply)
+#define DXO_TANGENT_CELL 0   // lane = cell tangent action on P2 triangles
 #endif
 #ifndef DXO_C8_EARLY_C
 #define DXO_C8_EARLY_C 0     // tangent_apply_c8: 0 = the tangent rows are requested after the contraction (72 registers the pass does not have)
+#endif
+#else
+#define DXO_TA_C8_FORWARD 0
+#define DXO_TANGENT_CELL 0
 #endif
 #ifndef DXO_TA_VM_WAVES
 #define DXO_TA_VM_WAVES 2    // waves per SIMD of the state-based tangent action (3: 45 registers spilled on hexahedra)
@@ -97,7 +110,7 @@ struct TangentRows {
 #pragma unroll
             for (int k = 0; k < LPC; ++k) {
                 const int u = c * TR_PC * CV + k * DXO_WAVE + lane;
-                r[c][k] = (u < npts * CV && !(DXO_TA_KO & 2)) ? ta_load<DXO_TA_NT != 0>(base + u) : dxo_f64x2{1.0, 0.5};
+                r[c][k] = u < npts * CV ? ta_load<DXO_TA_NT != 0>(base + u) : dxo_f64x2{1.0, 0.5};
             }
     }
     // t = C_row e for this lane's point straight from the staged rows (the row never sits in registers)
@@ -252,7 +265,6 @@ __device__ __forceinline__ void adjoint_scatter(const OperandDev& m, const doubl
             }
         }
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
-        if ((DXO_TA_KO & 1) && acc[0] != 1.2345e300) continue;
         if (fe) {        // two-pass form: the element vector entry, summed per node afterwards (node_sum).
             // Layout fe[a][cell][i]: the cells of a wave group are consecutive, so each local node's entries leave as one
             // contiguous run per group, and in node_sum neighbouring nodes (same local role in neighbouring cells) read
@@ -647,11 +659,6 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
         pipe_load_values<G, G>(m, pf, v);
         pipe_load_indices<G, G>(m, pf, (grp + stride) * cpw, cells_in(grp + stride), lane);
     }
-#if DXO_TA_KO & 4
-#define DXO_TA_SKIP_GATHER 1
-#else
-#define DXO_TA_SKIP_GATHER 0
-#endif
     const int q_l = lane - (lane / m.nq) * m.nq;
     const double w_l = lane < cpw * m.nq ? wq[q_l] : 0.0;
     for (; grp < walk.end; grp += stride) {
@@ -676,10 +683,8 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
 #endif
         if (piped) {
             pipe_commit<G, G>(m, pf, W, ncell, lane);
-            if (!DXO_TA_SKIP_GATHER) {
-                pipe_load_values<G, G>(m, pf, v);
-                pipe_load_indices<G, G>(m, pf, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
-            }
+            pipe_load_values<G, G>(m, pf, v);
+            pipe_load_indices<G, G>(m, pf, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
         } else {
             operand_gather<G, G>(m, W, v, nullptr, c0, ncell, lane);
         }
@@ -751,7 +756,6 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
             const int64_t cell = c0 + (lane >> 3);
             c8_scatter<ND_CT, VM ? DXO_TA_VM_UT : 1>(L8, T, [&](int a, const double (&o)[3]) {
                 if (!active) return;
-                if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) return;
                 if (fe) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
@@ -767,109 +771,9 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
     }
 }
 
-// EXPERIMENT, not launched by default (-DDXO_TA_C8_FORWARD=1): the same operator with the strain contraction ALSO across the lanes
-// — NO gather buffer in LDS, dof values and vertex coordinates go from global memory into the registers of the lane that owns
-// them and are all-gathered over the cell's 8 lanes (cell8_dpp.h). Correct (tests/test_adjoint_gpu.py passes on it) but slower
-// than the shipped hybrid (LDS gather + contraction, DPP scatter): 1.65 against 1.31 ms per 10^7 points — the all-gather is 210
-// dependent DPP moves per lane and group that the two resident waves per SIMD do not cover, while LDS reads are asynchronous;
-// it also needs the tangent rows requested late (they do not fit beside the contraction's registers: 23 spilled otherwise).
-template <int ND>
-__global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_apply_c8(OperandDev m, const double* __restrict__ wq,
-                                                                 const double* __restrict__ C_tang, const double* __restrict__ v,
-                                                                 int64_t n_cells, double* __restrict__ out, double* __restrict__ fe) {
-    constexpr int D = 6;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    c8_fill_tables(m, lds);
-    __syncthreads();
-    const int lane = threadIdx.x & (DXO_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
-    double* W = lds + C8_LDS + wave * TangentRows<D>::LDS_DOUBLES;
-    const C8Lane L(lds, lane);
-    constexpr int cpw = 8;
-    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
-    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
-    const int64_t stride = walk.stride;
-    auto cells_in = [&](int64_t g) -> int {
-        if (g >= walk.end) return 0;
-        const int64_t left = n_cells - g * cpw;
-        return left < cpw ? (int)left : cpw;
-    };
-    C8Pipe pf;
-    int64_t grp = walk.first;
-    c8_load_indices<ND>(m, pf, L, grp * cpw, cells_in(grp), lane);
-    c8_load_values(m, pf, v);
-    c8_load_indices<ND>(m, pf, L, (grp + stride) * cpw, cells_in(grp + stride), lane);
-    const double w_l = wq[lane & 7];
-    for (; grp < walk.end; grp += stride) {
-        const int64_t c0 = grp * cpw;
-        const int ncell = cells_in(grp);
-        const bool has_point = (lane >> 3) < ncell;
-        TangentRows<D> rows;
-#if DXO_C8_EARLY_C
-        rows.request(C_tang, c0 * 8, ncell * 8, lane);
+#ifdef DXO_EXPERIMENTS
+#include "../../scripts/exp/adjoint_variants.h"      // tangent_apply_c8 (measured, not shipped)
 #endif
-        // pf.ud / pf.xd hold THIS group's values (requested during the last iteration), pf.un / pf.xn the next group's indices
-        double K[3][3], gref[3][3];
-        const double det = c8_geometry(L, pf.xd, K);
-        c8_forward(L, pf.ud, gref);
-        // consumed in place: now the next group's values (indices have been here for an iteration) and the indices of the one after;
-        // their latency runs under the tangent product and the scatter phase of this group and the geometry of the next
-        c8_load_values(m, pf, v);
-        c8_load_indices<ND>(m, pf, L, (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
-        double e[D];
-        {
-            double val[3] = {0.0, 0.0, 0.0}, g[3][3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) sacc += gref[i][k] * K[k][j];
-                    g[i][j] = sacc;
-                }
-            shape_operand<3, 3, DXO_OPERAND_EPS_MANDEL>(val, g, e);
-        }
-        if (!has_point) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) e[k] = 0.0;
-        }
-#if !DXO_C8_EARLY_C
-        __builtin_amdgcn_sched_barrier(0);     // keep the 18 row loads (72 registers) below the contraction
-        rows.request(C_tang, c0 * 8, ncell * 8, lane);
-#endif
-        double t6[D];
-        rows.times(W, lane, e, t6);
-        double T[3][3];
-        {
-            double vh[3], gh[3][3];
-            dual_tensor<3, 3, DXO_OPERAND_EPS_MANDEL>(t6, vh, gh);
-            const double scale = w_l * fabs(det);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    double tt = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
-                    T[i][k] = has_point ? scale * tt : 0.0;      // lanes without a point: zero vertices, singular J
-                }
-        }
-        const int64_t cell = c0 + (lane >> 3);
-        c8_scatter<ND>(L, T, [&](int a, const double (&o)[3]) {
-            if (!has_point) return;
-            if ((DXO_TA_KO & 1) && o[0] != 1.2345e300) return;
-            if (fe) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) fe[((int64_t)a * m.num_cells_fe + cell) * 3 + i] = o[i];
-            } else {
-                const int64_t node = m.dofmap[cell * ND + a];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
-            }
-        });
-    }
-}
 
 // diag(K) without K, for a Jacobi preconditioner: K_(a,i),(a,i) = sum_q w|detJ| e_(a,i)^T C_q e_(a,i) with e_(a,i) the Mandel
 // strain of the unit dof (local node a, component i). With g = K^T dphi_a (physical gradient of the node's basis function) that
@@ -1433,13 +1337,14 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     const VmStateSrc none{};
     const VmStateSrc& src = vs ? *vs : none;
 #define DXO_APPLY_LAUNCH(...) hipLaunchKernelGGL((tangent_apply<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, v, mesh->num_cells, out, fe)
+#ifdef DXO_EXPERIMENTS
     if (!vs && DXO_TANGENT_CELL && fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {
-        // EXPERIMENT (-DDXO_TANGENT_CELL=1): lane = cell form (adjoint_cell.h) for P2 triangles — correct, but 0.61 against 0.55-0.58 ms
-        // per 10^7 points for the wave-group kernel: a lane's three 128-byte tangent rows arrive as 24 sixteen-byte pieces of lines
-        // that 64 lanes touch at a 384-byte stride
+        // lane = cell form for P2 triangles — correct, but 0.61 against 0.55-0.58 ms per 10^7 points for the wave-group kernel
     } else if (c8)
         hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
-    else if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
+    else
+#endif
+    if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
     else if (rs)              { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true); else DXO_APPLY_LAUNCH(3, 27, 8, false); }   // Q2 hexahedra, 2x2x2 rule: compile-time trip counts, scatter in registers
     else                      { if (vs) DXO_APPLY_LAUNCH(3, 0, 0, true); else DXO_APPLY_LAUNCH(3, 0, 0, false); }
 #undef DXO_APPLY_LAUNCH

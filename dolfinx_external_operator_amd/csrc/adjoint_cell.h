@@ -81,6 +81,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void adjoint_cell_eps(const double* __re
     }
 }
 
+#ifdef DXO_EXPERIMENTS      // measured, not shipped (profiles/r04_adjoint_experiments.txt)
 // lane = cell form of the matrix-free tangent action K v (dxo_tangent_apply) for small simplicial elements: the cell's dof values
 // of v, its vertices and the pulled-back tensors of all its points in registers, tables as scalar operands, no LDS; the lane reads
 // the D*D tangent entries of each of its points as 16-byte pieces of its own contiguous row block. On P2 triangles (the
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(DXO_BLOCK) void tangent_cell(const double* __restri
         }
     }
 }
+#endif
 
+#ifdef DXO_EXPERIMENTS
 inline bool launch_tangent_cell(const dxo_ctx* ctx, const dxo_mesh* m, const double* C_tang, const double* v, double* fe, hipStream_t s) {
     const OperandDev& d = m->dev;
     int64_t blocks = (m->num_cells + DXO_BLOCK - 1) / DXO_BLOCK;
@@ -210,6 +213,7 @@ inline bool launch_tangent_cell(const dxo_ctx* ctx, const dxo_mesh* m, const dou
     }
     return false;
 }
+#endif
 
 // launches the specialised kernel if the mesh's element is one of the instantiated ones; returns false otherwise
 #ifndef DXO_AC_BLOCKS_PER_CU

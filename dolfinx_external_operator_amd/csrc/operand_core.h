@@ -20,9 +20,6 @@ struct OperandDev {
     const double* x;               // [num_geom_nodes][G]
 };
 
-#ifndef DXO_OP_KO_GEO
-#define DXO_OP_KO_GEO 0     // knock-out experiments (wrong results): 1 no Jacobian arithmetic, 2 no vertex gather either
-#endif
 
 namespace {
 
@@ -204,7 +201,7 @@ __device__ __forceinline__ void pipe_load_indices(const OperandDev& m, OperandPi
     for (int it = 0; it < OP_XI; ++it) {
         const int idx = it * DXO_WAVE + lane;
         pf.xn[it] = -1;
-        if (idx < ncell * ng && DXO_OP_KO_GEO < 2) pf.xn[it] = m.geom_dofmap[c0 * ng + idx];
+        if (idx < ncell * ng) pf.xn[it] = m.geom_dofmap[c0 * ng + idx];
     }
 }
 
@@ -287,14 +284,6 @@ __device__ __forceinline__ bool operand_compute_geo(const OperandDev& m, const d
                 for (int k = 0; k < G; ++k) J[j][k] += Xc[v * G + j] * dpsi[v * G + k];
         }
         detJ = invert<G>(J, K);
-#if DXO_OP_KO_GEO
-        // knock-out experiment (wrong results): what the geometry costs — identity Jacobian, nothing computed from the vertices
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-#pragma unroll
-            for (int k = 0; k < G; ++k) K[j][k] = j == k ? 1.0 : 0.0;
-        detJ = 1.0;
-#endif
         double val[BS], gref[BS][G];
 #pragma unroll
         for (int i = 0; i < BS; ++i) {

@@ -46,9 +46,6 @@ namespace {
 #ifndef DXO_VMF_FULL
 #define DXO_VMF_FULL 1   // guard-free tangent stores for full groups: -0.5 % (0.812 vs 0.816 ms); grid of 8 / 16 / 32 / 64 workgroups per CU: 0.819 / 0.816 / 0.827 / 0.867
 #endif
-#ifndef DXO_VMF_KO
-#define DXO_VMF_KO 0    // knock-out experiments (wrong results): 1 no stores, 2 no state loads, 4 no dof gather
-#endif
 #ifndef DXO_VMF_STATE_BLOCKS_PER_CU
 #define DXO_VMF_STATE_BLOCKS_PER_CU 8     // grid of the (sigma, dp)-only launch (arithmetic-bound, unlike the full one): 8 against 16 / 32 / 64 workgroups per CU:
                                           // hexahedra 0.456 / 0.465 / 0.483 / 0.501 ms, triangles 0.239 / 0.254 / 0.262 / 0.296; 3 - 12 within the noise of each other
@@ -131,10 +128,8 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
         double sK22 = 0.0;                  // RES only
         if (piped) {
             pipe_commit<G, G>(m, pf, W, ncell, lane);
-            if (!(DXO_VMF_KO & 4)) {
-                pipe_load_values<G, G>(m, pf, u);
-                pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
-            }
+            pipe_load_values<G, G>(m, pf, u);
+            pipe_load_indices<G, G>(m, pf, cell0 + (grp + 2 * stride) * cpw, cells_in(grp + 2 * stride), lane);
             if constexpr (RES) {
                 double Kinv[G][G], detJ;
                 active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e, Kinv, detJ);
@@ -163,9 +158,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
             const int idx = k * DXO_WAVE + lane;
-            N2[idx] = (idx < nvec && !(DXO_VMF_KO & 2)) ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
+            N2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
         }
-        const double p_l = (lane < npts && !(DXO_VMF_KO & 2)) ? p[p0 + lane] : 0.0;
+        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
 #endif
         wave_lds_fence();
         double sn[D];
@@ -189,7 +184,6 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
         }
         if constexpr (MODE == 0) Y2[lane * (T::ST / 2) + T::CH_VEC] = dxo_f64x2{a, b};
         wave_lds_fence();
-        if ((DXO_VMF_KO & 1) && dp != 1.2345e300) { wave_lds_fence(); continue; }
         if (lane < npts) store8<NT>(dp_out + p0 + lane, dp);
         dxo_f64x2* g_o = reinterpret_cast<dxo_f64x2*>(sigma + p0 * D);
 #pragma unroll

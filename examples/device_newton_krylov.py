@@ -85,13 +85,18 @@ def main(n_side: int = 64, steps=(0.0012, 0.0024, 0.0036, 0.0048), verbose: bool
     captured = {}
 
     def cg_iteration():
+        # The convergence test runs only every `check_every` iterations, so up to check_every - 1 iterations run on a system that
+        # has already converged: there r . z and p . K p reach 0 and the two quotients would be 0 / 0. Both are guarded ON THE
+        # DEVICE (a zero step / no new direction instead of NaN in xk and u); the captured graph replays the same guarded body.
         Ap.copy_(K_times(pk))
-        alpha = rz / torch.dot(pk, Ap)
+        pAp = torch.dot(pk, Ap)
+        alpha = torch.where(pAp > 0, rz / pAp, torch.zeros_like(rz))
         xk.add_(alpha * pk)
         r.sub_(alpha * Ap)
         torch.mul(minv, r, out=z)
         rz_new = torch.dot(r, z).reshape(1)
-        pk.mul_(rz_new / rz).add_(z)
+        beta = torch.where(rz > 0, rz_new / rz, torch.zeros_like(rz))
+        pk.mul_(beta).add_(z)
         rz.copy_(rz_new)
 
     def capture():
