@@ -727,7 +727,7 @@ def main():
                                       else {"status": "skipped", "why": "--no-library-gather"} if args.no_library_gather
                                       else {"status": "pending", "why": "runs after this line; a second, final line repeats this one with the verdict"})
         last_result.update(result)
-        single = extras and world == 1
+        single = extras and world == 1 and not dist_on      # under torch.distributed (also a world of one) the line is written once, then once more with gather_check
         t_extras = time.perf_counter()
         if not single:
             write_line(result, "final")
