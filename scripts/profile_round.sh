@@ -1,7 +1,8 @@
 #!/bin/bash
 # One gpurun call that produces every file profiles/ needs for a round (GPU box, repo root):
 #   bash scripts/profile_round.sh <tag> [quick]
-#     bench.json                 the default `python3 bench.py` line (headline + end_to_end + cpu_baseline + secondary)
+#     bench.json                 the full record of the default `python3 bench.py` run (bench_full.json); bench_stdout.txt = the bounded lines the
+#                                driver sees, <tag>_bench_line.json = the last of them
 #     stats/                     rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-probe --no-e2e` (headline AND
 #                                secondary kernels: vm_tile, mc_fused, icnn_mfma_bf16x3 / icnn_mfma_f32, vm_field, ...)
 #     prof_fetch/, prof_write/   HBM counters of the headline kernel, separate --pmc passes (--no-secondary)
@@ -14,7 +15,10 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.build()" > "$OUT/build.log" 2>&1 || { echo BUILD FAILED; tail -30 "$OUT/build.log"; exit 1; }
-timeout 900 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+S0=$(date +%s)
+timeout 900 python3 bench.py > "$OUT/bench_stdout.txt" 2> "$OUT/bench.err"; echo "bench rc=$? wall=$(( $(date +%s) - S0 )) s, stdout $(wc -c < "$OUT/bench_stdout.txt") bytes in $(wc -l < "$OUT/bench_stdout.txt") lines"
+cp bench_full.json "$OUT/bench.json" 2>/dev/null        # the full record (the stdout lines are bounded extracts of it)
+tail -1 "$OUT/bench_stdout.txt" > "$OUT/${TAG}_bench_line.json"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e --no-traffic > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
