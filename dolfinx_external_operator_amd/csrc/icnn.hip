@@ -1287,6 +1287,212 @@ __global__ __launch_bounds__(WAVES * 64, 1) void icnn_mfma_bf16x3_pipe(const flo
     }
 }
 
+// ------------------------------------------------------------------ HYBRID (icnn_variant = 4): scalar operands inside the MFMAs of phase 1, packed phases 2 and 3
+// What the gap probe allows (profiles/r05_mfma_gap_probe.txt) and what the two kernels above each get half of: plain vector
+// instructions ride free behind an MFMA (<= 6 per 32 cycles), packed ones never do but need ~40 % fewer instructions. Per half-tile:
+//   phase 1  192 MFMAs; the ~900 SCALAR instructions that form the operands of the NEXT K-step (for the last K-step: K-step 0 of the
+//            next half-tile) sit at tick points between them, ~4.7 per MFMA — hidden; fragments and table rows requested a chunk ahead
+//   phases 2, 3  the default kernel's PACKED statements, with no MFMA in flight except the 12 beta MFMAs that end each group
+// One wave per SIMD (a packed instruction of a second wave would wait behind this wave's MFMAs). Same operations in the same order
+// per accumulator as the other two kernels: bit-identical outputs.
+template <int ST, int K>
+struct IcnnTickH {      // chunk (ST, K) of phase 1: the 12 MFMAs of K-step ST, matrix K, over the 8 tick points of one scalar pair
+    const IcnnTabs& T;
+    const IcnnSplit (&A)[2];
+    IcnnSplit (&An)[2];
+    IcnnRow1& r1n;
+    const IcnnSplit& B;
+    f32x16& c0;
+    f32x16& c1;
+    template <int P>
+    __device__ __forceinline__ void at() {
+        constexpr int j0 = (P / 2) * 3 + (P % 2) * 2;        // MFMAs per point: 2, 1, 2, 1, 2, 1, 2, 1
+        icnn_mma6_j<j0, ST == 0>(A, B, c0, c1);
+        if constexpr (P % 2 == 0) icnn_mma6_j<j0 + 1, ST == 0>(A, B, c0, c1);
+        // the next chunk: (ST, K + 1) or (ST + 1, 0); its vector work is pair K' of K-step ST' + 1 (of the next half-tile's K-step 0 for ST' = 3)
+        constexpr int STn = K < 3 ? ST : ST + 1, Kn = (K + 1) & 3;
+        if constexpr (STn < 4) {
+            if constexpr (P == 2) r1n = icnn_row1<(STn < 3 ? STn + 1 : 0), Kn>(T);
+            if constexpr (P == 4) icnn_load_A(T, STn, Kn, An);
+        }
+        DXO_ICNN_TICK_FENCE
+    }
+};
+
+// phases 2 and 3 of a half-tile with packed fp32 arithmetic: the statements of icnn_mfma_bf16x3_packed
+__device__ __forceinline__ void icnn_p23_packed(const IcnnTabs& T, float xs0, float xs1, float xs2, const f32x16 (&acc)[2][4], const icnn_f2 (&cph)[16],
+                                                icnn_f2p (&res)[9]) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) res[q] = icnn_f2p{0.f, 0.f};
+    f32x16 bacc[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bacc[it][q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int jt = g >> 1;
+        IcnnSplitW Bdw;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 8 * (g & 1) + 2 * k;
+            const int pr = icnn_row(jt, q) >> 1;
+            const float4 ta = *reinterpret_cast<const float4*>(T.P2_h + pr * 12);       // S2x pair, S2y pair
+            const float4 tb = *reinterpret_cast<const float4*>(T.P2_h + pr * 12 + 4);   // S2z pair, c2 pair
+            const float2 tw = *reinterpret_cast<const float2*>(T.P2_h + pr * 12 + 8);   // w3 / 6 pair
+            const icnn_f2p S2x = {ta.x, ta.y}, S2y = {ta.z, ta.w}, S2z = {tb.x, tb.y}, w6 = {tw.x, tw.y};
+            const icnn_f2p a2 = icnn_f2p{acc[jt][0][q], acc[jt][0][q + 1]} +
+                               icnn_fma2_p(S2x, icnn_f2p{xs0, xs0}, icnn_fma2_p(S2y, icnn_f2p{xs1, xs1}, icnn_fma2_p(S2z, icnn_f2p{xs2, xs2}, icnn_f2p{tb.z, tb.w})));
+            const icnn_f2p g0 = icnn_f2p{acc[jt][1][q], acc[jt][1][q + 1]} + S2x;
+            const icnn_f2p g1 = icnn_f2p{acc[jt][2][q], acc[jt][2][q + 1]} + S2y;
+            const icnn_f2p g2 = icnn_f2p{acc[jt][3][q], acc[jt][3][q + 1]} + S2z;
+            icnn_f2p sp, s1, s2;
+            softplus3_p(a2, sp, s1, s2);
+            const icnn_f2p dl = w6 * sp * s1;
+            const icnn_f2p curv = w6 * icnn_fma2_p(sp, s2, s1 * s1);
+            icnn_split_pair_p(dl, Bdw.h[k], Bdw.m[k], Bdw.l[k]);
+            const icnn_f2p cg0 = curv * g0, cg1 = curv * g1, cg2 = curv * g2;
+            res[0] = icnn_fma2_p(dl, g0, res[0]); res[1] = icnn_fma2_p(dl, g1, res[1]); res[2] = icnn_fma2_p(dl, g2, res[2]);
+            res[3] = icnn_fma2_p(cg0, g0, res[3]); res[4] = icnn_fma2_p(cg0, g1, res[4]); res[5] = icnn_fma2_p(cg0, g2, res[5]);
+            res[6] = icnn_fma2_p(cg1, g1, res[6]); res[7] = icnn_fma2_p(cg1, g2, res[7]); res[8] = icnn_fma2_p(cg2, g2, res[8]);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) DXO_ICNN_PINP(res[r])
+        }
+        IcnnSplit A[2];
+        icnn_load_AT(T, g, A);
+        icnn_mma6(A, icnn_pack(Bdw), bacc[0], bacc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ip = 0; ip < 16; ++ip) {
+        const int it = ip >> 3, q = 2 * (ip & 7);
+        const int pr = icnn_row(it, q) >> 1;
+        const float4 pa = *reinterpret_cast<const float4*>(T.P3_h + pr * 12);
+        const float4 pb = *reinterpret_cast<const float4*>(T.P3_h + pr * 12 + 4);
+        const float4 pc = *reinterpret_cast<const float4*>(T.P3_h + pr * 12 + 8);
+        const icnn_f2p c = icnn_f2p{bacc[it][q], bacc[it][q + 1]} * icnn_f2p{cph[ip].x, cph[ip].y};
+        res[3] = icnn_fma2_p(c, icnn_f2p{pa.x, pa.y}, res[3]); res[4] = icnn_fma2_p(c, icnn_f2p{pa.z, pa.w}, res[4]);
+        res[5] = icnn_fma2_p(c, icnn_f2p{pb.x, pb.y}, res[5]); res[6] = icnn_fma2_p(c, icnn_f2p{pb.z, pb.w}, res[6]);
+        res[7] = icnn_fma2_p(c, icnn_f2p{pc.x, pc.y}, res[7]); res[8] = icnn_fma2_p(c, icnn_f2p{pc.z, pc.w}, res[8]);
+#pragma unroll
+        for (int r = 3; r < 9; ++r) DXO_ICNN_PINP(res[r])
+    }
+}
+
+// K-step ST of phase 1 in four chunks: matrix K's 12 MFMAs inside pair K of the next operands (VST = the K-step whose operands these
+// are; `cphn` where their phi'' go). Bh, Bu: this K-step's operands on entry, the next one's on exit.
+template <int ST>
+__device__ __forceinline__ void icnn_hybrid_step(const IcnnTabs& T, float nx0, float nx1, float nx2, icnn_f2* cphn, f32x16 (&acc)[2][4], IcnnSplit& Bh,
+                                                 IcnnSplit& Bu, IcnnSplit (&A0)[2], IcnnSplit (&A1)[2], IcnnRow1& r1a, IcnnRow1& r1b) {
+    IcnnSplitW Bhw, Buw;
+    constexpr int VST = ST < 3 ? ST + 1 : 0;
+#define DXO_ICNN_HCHUNK(K_, ACUR_, ANXT_, RCUR_, RNXT_)                                                                           \
+    {                                                                                                                               \
+        IcnnTickH<ST, K_> tk{T, ACUR_, ANXT_, RNXT_, K_ == 0 ? Bh : Bu, acc[0][K_], acc[1][K_]};                                     \
+        icnn_p1_pair<VST, K_, 0>(RCUR_, nx0, nx1, nx2, cphn[K_], Bhw, Buw, tk);                                                      \
+    }
+    DXO_ICNN_HCHUNK(0, A0, A1, r1a, r1b)
+    DXO_ICNN_HCHUNK(1, A1, A0, r1b, r1a)
+    DXO_ICNN_HCHUNK(2, A0, A1, r1a, r1b)
+    DXO_ICNN_HCHUNK(3, A1, A0, r1b, r1a)
+#undef DXO_ICNN_HCHUNK
+    Bh = icnn_pack(Bhw);
+    Bu = icnn_pack(Buw);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void icnn_mfma_bf16x3_hybrid(const float* __restrict__ wT1, const float* __restrict__ wW2,
+                                                                        const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
+                                                                        const double* __restrict__ F, double* __restrict__ dP,
+                                                                        double* __restrict__ P) {
+    constexpr int BLOCK = WAVES * 64;
+    constexpr int FRAG = 64 * 8;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned short sA3[4 * 2 * 4 * 3 * FRAG];
+    __shared__ __attribute__((aligned(16))) unsigned short sAT3[2 * 4 * 3 * FRAG];
+    __shared__ __attribute__((aligned(16))) float sP1[32 * 8];
+    __shared__ __attribute__((aligned(16))) float sP3[32 * 12];
+    __shared__ __attribute__((aligned(16))) float sP2[32 * 12];
+    __shared__ float sMine[WAVES * 9 * 64];
+    float* minep = sMine + wave * (9 * 64) + lane;
+    icnn_fill_lds<BLOCK>(wT1, wW2, wT2, sA3, sAT3, sP1, sP3, sP2);
+    __syncthreads();
+    const IcnnTabs T = {reinterpret_cast<const icnn_u32x4*>(sA3) + lane, reinterpret_cast<const icnn_u32x4*>(sAT3) + lane, sP1 + 2 * h * 8,
+                        sP2 + 2 * h * 12, sP3 + 2 * h * 12};
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t tile_step = (int64_t)gridDim.x * WAVES;
+    int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    if (tile >= n_tiles) return;
+    auto load_F = [&](int64_t tl, dxo_f64x2& a, dxo_f64x2& b) {   // a tile past the end repeats the last one (never stored)
+        const int64_t tc = tl < n_tiles ? tl : n_tiles - 1;
+        const int64_t pl = tc * 64 + lane < n ? tc * 64 + lane : n - 1;
+        a = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[0];
+        b = reinterpret_cast<const dxo_f64x2*>(F + pl * 4)[1];
+    };
+    dxo_f64x2 f01, f23, f01n, f23n;
+    load_F(tile, f01, f23);
+    load_F(tile + tile_step, f01n, f23n);
+    float x0, x1, x2;
+    icnn_features(f01, f23, x0, x1, x2);
+    float xp0 = xor32(x0), xp1 = xor32(x1), xp2 = xor32(x2);
+    // the half-tile in flight: its inputs, its phi'' and its accumulators; `nxt*`: what the last K-step stages for the one after it
+    float xs0 = (h == 0) ? x0 : xp0, xs1 = (h == 0) ? x1 : xp1, xs2 = (h == 0) ? x2 : xp2;
+    icnn_f2 cph[16], cph0n[4];
+    f32x16 acc[2][4];
+    IcnnSplit Bh, Bu, A0[2], A1[2];
+    IcnnRow1 r1a, r1b;
+    icnn_p1_operands<0>(T, xs0, xs1, xs2, cph, Bh, Bu);       // prologue: K-step 0 of (tile, 0), nothing to hide behind
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (; tile < n_tiles; tile += tile_step) {
+        const int64_t pidx = tile * 64 + lane;
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads inside the loop
+        const dxo_f64x2 f01c = f01, f23c = f23;
+        // the next tile's features (its F was requested a tile ago); request the one after
+        float y0, y1, y2;
+        f01 = f01n; f23 = f23n;
+        load_F(tile + 2 * tile_step, f01n, f23n);
+        icnn_features(f01, f23, y0, y1, y2);
+        const float yp0 = xor32(y0), yp1 = xor32(y1), yp2 = xor32(y2);
+#pragma unroll 1
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool own = (tt == h);
+            // the half-tile after this one: (tile, 1) after (tile, 0), (tile + step, 0) after (tile, 1)
+            const bool nown = tt == 0 ? (h == 1) : (h == 0);
+            const float bx0 = tt == 0 ? x0 : y0, bx1 = tt == 0 ? x1 : y1, bx2 = tt == 0 ? x2 : y2;
+            const float bp0 = tt == 0 ? xp0 : yp0, bp1 = tt == 0 ? xp1 : yp1, bp2 = tt == 0 ? xp2 : yp2;
+            const float nx0 = nown ? bx0 : bp0, nx1 = nown ? bx1 : bp1, nx2 = nown ? bx2 : bp2;
+            // ---- phase 1
+            icnn_load_A(T, 0, 0, A0);
+            r1a = icnn_row1<1, 0>(T);
+            __builtin_amdgcn_sched_barrier(0);
+            icnn_hybrid_step<0>(T, xs0, xs1, xs2, cph + 4, acc, Bh, Bu, A0, A1, r1a, r1b);
+            icnn_hybrid_step<1>(T, xs0, xs1, xs2, cph + 8, acc, Bh, Bu, A0, A1, r1a, r1b);
+            icnn_hybrid_step<2>(T, xs0, xs1, xs2, cph + 12, acc, Bh, Bu, A0, A1, r1a, r1b);
+            icnn_hybrid_step<3>(T, nx0, nx1, nx2, cph0n, acc, Bh, Bu, A0, A1, r1a, r1b);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phases 2 and 3, packed
+            icnn_f2p res[9];
+            icnn_p23_packed(T, xs0, xs1, xs2, acc, cph, res);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float part = res[q].x + res[q].y;
+                const float tot = part + xor32(part);
+                if (own) minep[q * 64] = tot;
+            }
+            // the staged half-tile becomes the current one
+            xs0 = nx0; xs1 = nx1; xs2 = nx2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cph[k] = cph0n[k];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        x0 = y0; x1 = y1; x2 = y2; xp0 = yp0; xp1 = yp1; xp2 = yp2;
+        asm volatile("" ::: "memory");
+        if (pidx < n) icnn_finish(f01c, f23c, minep, small, dP, P, pidx);
+    }
+}
+
 template <typename T>
 void launch_icnn(const IcnnDev<T>& m, int blocks, hipStream_t s, int64_t n, const double* F, double* dP, double* P) {
     IcnnSmall<T> small;
@@ -1315,7 +1521,11 @@ int icnn_launch(dxo_ctx* ctx, const IcnnLaunch& L, int64_t n, const double* F, d
         for (int k = 0; k < 4; ++k) small.H[k] = L.m->f32.H[k];
         int64_t mb = (n + 8 * 64 - 1) / (8 * 64);
         if (mb > ctx->compute_units) mb = ctx->compute_units;
-        if (ctx->icnn_variant == 3) {   // split-bf16 products, software-pipelined over half-tiles: one 4-wave workgroup per CU (one wave per SIMD)
+        if (ctx->icnn_variant == 4) {   // scalar operands inside phase 1's MFMAs, packed phases 2 and 3: one 4-wave workgroup per CU
+            int64_t mp = (n + 4 * 64 - 1) / (4 * 64);
+            if (mp > ctx->compute_units) mp = ctx->compute_units;
+            hipLaunchKernelGGL((icnn_mfma_bf16x3_hybrid<4>), dim3((int)mp), dim3(256), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);
+        } else if (ctx->icnn_variant == 3) {   // split-bf16 products, software-pipelined over half-tiles: one 4-wave workgroup per CU (one wave per SIMD)
             int64_t mp = (n + 4 * 64 - 1) / (4 * 64);
             if (mp > ctx->compute_units) mp = ctx->compute_units;
             hipLaunchKernelGGL((icnn_mfma_bf16x3_pipe<4>), dim3((int)mp), dim3(256), 0, s, L.m->f32.T1, L.m->f32.W2, L.m->f32.T2, small, n, F, dP, P);

@@ -18,7 +18,7 @@ det = F[:, 0] * F[:, 3] - F[:, 1] * F[:, 2]
 F[det <= 0.2] = torch.tensor([1.0, 0, 0, 1.0], device=dev, dtype=torch.float64)
 dP = torch.empty(n * 16, device=dev, dtype=torch.float64); P = torch.empty(n * 4, device=dev, dtype=torch.float64)
 run = lambda: ctx.icnn_eval(model, 0, n, MEM_DEVICE, F.data_ptr(), dP.data_ptr(), P.data_ptr())
-for variant in (2, 3):
+for variant in (2, 3, 4):
     ctx.set_option("icnn_variant", variant)
     dP.zero_(); P.zero_()
     for _ in range(3):

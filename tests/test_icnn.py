@@ -4,6 +4,8 @@ import pytest
 
 from oracle.icnn_oracle import features, icnn_stress_tangent
 
+DEFAULT_VARIANT = 2     # ctx option icnn_variant as the library ships it (restored by the tests that switch kernels)
+
 # The reference runs the network in fp32 (`.float()`, demo_hyperelasticity.py:286); two correct fp32
 # implementations differ by summation order. Tolerances are relative to max|dP| resp. max|P| of the batch.
 RTOL_FP32 = 2e-6
@@ -114,7 +116,7 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
             assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
             out[variant] = (dP[: n * 16], P[: n * 4])
     finally:
-        ctx.set_option("icnn_variant", 2)
+        ctx.set_option("icnn_variant", DEFAULT_VARIANT)
         ctx.icnn_destroy(model)
     dPo, Po = icnn_stress_tangent(F, weights)
     for variant in (1, 2):
@@ -125,10 +127,11 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 20_001, 300_000])
-def test_pipelined_kernel_is_bit_identical_to_the_default(ctx, weights, n):
+def test_pipelined_and_hybrid_kernels_are_bit_identical_to_the_packed_one(ctx, weights, n):
     """icnn_variant 3 (scalar fp32 arithmetic, phase 1 of the next half-tile issued between the vector instructions of this one's
-    phases 2, one wave per SIMD) runs the same operations in the same order per accumulator as the default kernel (packed fp32,
-    phases in sequence): same bits, at sizes with one tile per wave, ragged tails and several tiles per wave."""
+    phases 2, one wave per SIMD) and 4 (scalar operands inside phase 1's MFMAs, packed phases 2 and 3) run the same operations in
+    the same order per accumulator as variant 2 (packed fp32, phases in sequence): same bits, at sizes with one tile per wave,
+    ragged tails and several tiles per wave."""
     from dolfinx_external_operator_amd import MEM_HOST
 
     rng = np.random.default_rng(21)
@@ -136,21 +139,22 @@ def test_pipelined_kernel_is_bit_identical_to_the_default(ctx, weights, n):
     model = ctx.icnn_create(state_dict(weights))
     out = {}
     try:
-        for variant in (2, 3):
+        for variant in (2, 3, 4):
             ctx.set_option("icnn_variant", variant)
             dP, P = np.full(n * 16 + 4, -7.0), np.full(n * 4 + 4, -7.0)
             ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
             assert np.all(dP[n * 16:] == -7.0) and np.all(P[n * 4:] == -7.0)
             out[variant] = (dP, P)
     finally:
-        ctx.set_option("icnn_variant", 2)
+        ctx.set_option("icnn_variant", DEFAULT_VARIANT)
         ctx.icnn_destroy(model)
-    assert np.array_equal(out[2][0], out[3][0]) and np.array_equal(out[2][1], out[3][1])
-    assert np.all(np.isfinite(out[3][0]))
+    for variant in (3, 4):
+        assert np.array_equal(out[2][0], out[variant][0]) and np.array_equal(out[2][1], out[variant][1]), variant
+    assert np.all(np.isfinite(out[4][0]))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant):
     """The MFMA kernels evaluate 64 points per wave through shared matrix products: a point is one COLUMN of every product, so
     a NaN / inf / singular deformation gradient must poison its own 20 outputs and nothing else — the other points come out
@@ -174,7 +178,7 @@ def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant):
             ctx.icnn_eval(model, 0, n, MEM_HOST, Fx, dP, P)
             out.append((dP.reshape(n, 16), P.reshape(n, 4)))
     finally:
-        ctx.set_option("icnn_variant", 2)
+        ctx.set_option("icnn_variant", DEFAULT_VARIANT)
         ctx.icnn_destroy(model)
     good = np.ones(n, dtype=bool)
     good[list(bad)] = False
@@ -236,7 +240,7 @@ def test_kernels_with_random_weights(ctx, weights, seed, scale, rtol):
             ctx.icnn_eval(model, 0, n, MEM_HOST, F, dP, P)
             out[variant] = (dP, P)
     finally:
-        ctx.set_option("icnn_variant", 2)
+        ctx.set_option("icnn_variant", DEFAULT_VARIANT)
         ctx.icnn_destroy(model)
     dPo, Po = icnn_stress_tangent(F, w)
     assert np.all(np.isfinite(dPo)) and np.max(np.abs(dPo)) > 0

@@ -549,8 +549,8 @@ def von_mises_cfg2_1e6(torch, ctx, stream, prm, cpu):
 
 
 # in order of importance: with a deadline (bench.py --secondary-budget) the legs at the end are the ones that get skipped
-ALL_LEGS = ("mohr_coulomb_cfg4", "icnn_cfg5", "device_loop_q2hex", "device_loop_p2tri", "vm_field_q2", "heat_cfg1", "isihara", "von_mises_d4_nq3",
-            "von_mises_cfg2_1e6", "assign_cg", "von_mises_demo_host")
+ALL_LEGS = ("mohr_coulomb_cfg4", "icnn_cfg5", "device_loop_q2hex", "device_loop_p2tri", "vm_field_q2", "heat_cfg1", "von_mises_demo_host", "isihara",
+            "von_mises_d4_nq3", "von_mises_cfg2_1e6", "assign_cg")
 TRAFFIC_PASS_S = 30.0     # what the two counter child runs take on a fresh box (r04: 35.5 s before the mesh cache)
 P2TRI_SIDE = 1291     # 1291^2 boxes x 2 triangles x 3 points = 10^7 points (the reference demos' element, demo_plasticity_von_mises.py:230,245,295)
 
