@@ -1401,7 +1401,7 @@ __device__ __forceinline__ void icnn_hybrid_step(const IcnnTabs& T, float nx0, f
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void icnn_mfma_bf16x3_hybrid(const float* __restrict__ wT1, const float* __restrict__ wW2,
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void icnn_mfma_bf16x3_hybrid(const float* __restrict__ wT1, const float* __restrict__ wW2,
                                                                         const float* __restrict__ wT2, IcnnSmall<float> small, int64_t n,
                                                                         const double* __restrict__ F, double* __restrict__ dP,
                                                                         double* __restrict__ P) {
