@@ -223,7 +223,7 @@ def _view(torch, ptr, n, dev):
     return torch.as_tensor(_CudaArrayView(None, int(ptr), int(n), "<f8"), device=dev)
 
 
-def _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm, cells=1_000_000):
+def _cpu_iteration(m, bs, d, u_h, sig0, p0, v, prm, cells=500_000):
     """The same three steps in compiled, threaded C on the first `cells` cells of the same mesh: oracle/operand_oracle_c.c (strain at the
     points, internal force, tangent action; OpenMP over cells) and oracle/dxo_oracle.c (return map). The reference's own code for these
     steps is compiled too (DOLFINx / FFCx behind Expression.eval and assemble_vector, the Numba kernel). A few seconds of CPU work: the

@@ -133,10 +133,10 @@ def mohr_coulomb_cfg4(torch, ctx, stream, n, cpu):
         t0 = time.perf_counter()
         o.mohr_coulomb(h1d, h1s, nthreads=1)
         one = len(h1d) / (time.perf_counter() - t0)
-        m = 200_000
+        m = 100_000      # a bounded sample: the whole default bench run has to stay inside the driver's patience
         hd, hs = deps[:m].cpu().numpy(), sn[:m].cpu().numpy()
         scan = {1: one}
-        nt = 8
+        nt = 16 if avail >= 16 else 8
         while nt <= avail:
             t0 = time.perf_counter()
             o.mohr_coulomb(hd, hs, nthreads=nt)
