@@ -5,7 +5,7 @@
 // the hot path). Between jobs a worker first SPINS on the generation counter for up to DXO_POOL_SPIN_US and only then
 // sleeps on the condition variable: the pipeline hands over a chunk every few hundred microseconds, and waking 31
 // sleeping threads through the futex cost more than rebuilding the chunk (measured on the GPU box's 2 x EPYC 9575F,
-// 10^7 points, 32 threads: 23-30 ms as 153 jobs of 2^16 points against 12 ms as one job — scripts/exp/host_rebuild_bench.hip).
+// 10^7 points, 32 threads: 23-30 ms as 153 jobs of 2^16 points against 12 ms as one job — scripts/exp/archive/host_rebuild_bench.hip).
 // Every worker checks in for every job, so when dxo_pool_parallel_for returns no thread is inside fn or can still read
 // the job's fields.
 #pragma once

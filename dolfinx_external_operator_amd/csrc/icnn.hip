@@ -207,11 +207,11 @@ __device__ __forceinline__ void icnn_lds_fence() {   // wave-private LDS: only t
 // lane-private slots for what is only needed after both half-tiles; no accumulator parking, no fences. Round 2's kernel
 // spent 36 % of a wave's cycles in vector-only phases (accumulator parking, 128 + 128 LDS accesses per lane and half-tile,
 // 32 repeated softplus) and ran at 0.46 of the fp32 MFMA peak; this one issues 6.8 instead of 11.7 vector instructions per
-// MFMA and runs at 0.60. What bounds it (scripts/exp/mfma32_valu_probe.hip, profiles/r03_mfma32_valu_probe.txt): on gfx950
-// vector work placed between MFMAs does not hide under them at this density — every v_fma_f32 between two
-// v_mfma_f32_32x32x2_f32 adds ~2.5-3 cycles to the 64 of the MFMA, every v_exp / v_log / v_rcp ~12.5, with one or two waves
-// per SIMD alike (the bf16 pipe behaves the same way) — so the time of a half-tile is the SUM of its 320 MFMAs (20.5 k
-// cycles) and of its vector instructions, not the maximum; see DESIGN.md 8.
+// MFMA and runs at 0.60. What bounds it: the kernel's stream is [vector instructions of a K-step][its MFMAs], a wave issues
+// in order, and its two waves per SIMD run in lock step, so the half-tile costs the SUM of its 320 MFMAs (20.5 k cycles) and
+// of its vector instructions. (Round 3 read that sum as a hardware property — "vector work does not hide under MFMAs" — from a
+// probe whose fillers the compiler had moved behind the MFMAs; the hand-placed probe of round 5, profiles/r05_mfma_gap_probe.txt,
+// shows six plain vector instructions riding free behind a 32-cycle MFMA. See DESIGN.md 8.)
 __device__ __forceinline__ constexpr int icnn_row(int t, int q) { return 32 * t + (q & 3) + 8 * (q >> 2); }   // + 4 h
 
 // softplus with first and second derivative for icnn_mfma_f32: the exponent is clamped at 80 (e^80 is finite in fp32), so that
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void icnn_fill_lds(const float* __restrict__ wT1, con
 // seven, +4 each beyond; a transcendental counts double; one packed-fp32 instruction costs +20) — with one wave per SIMD or
 // two. A wave issues in order, so the vector work has to sit BETWEEN the MFMAs in the instruction stream: icnn_mfma_bf16x3
 // above runs [200 vector instructions][48 MFMAs] per K-step, and its half-tile costs the sum of both (two waves per SIMD run in
-// lock step: started half a period apart they measure the same, scripts/exp/icnn_skew.py). Here ONE wave per SIMD (512
+// lock step: started half a period apart they measure the same, scripts/exp/archive/icnn_skew.py). Here ONE wave per SIMD (512
 // registers: two sets of accumulators) runs phase 1 of half-tile k + 1 (192 MFMAs) in the same instruction stream as phases 2
 // of half-tile k (1 300 vector instructions + 48 MFMAs), slice by slice (K-step st beside group g = st), and the operands of
 // K-step st + 1 are formed beside the MFMAs of K-step st.

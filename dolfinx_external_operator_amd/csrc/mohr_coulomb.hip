@@ -344,7 +344,7 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_newton(mc::Const k, const 
 //     the stores before it): 0.825 against 0.806 ms. Neither the load latency nor the store acknowledgements are what the
 //     mix waits for.
 #ifndef DXO_MC_PROF
-#define DXO_MC_PROF 0   // 1: instrumented build for scripts/exp/mc_phase_profile.py only (it corrupts dlambda)
+#define DXO_MC_PROF 0   // 1: instrumented build for scripts/exp/archive/mc_phase_profile.py only (it corrupts dlambda)
 #endif
 constexpr int MC_QCAP = 128;   // plastic point indices waiting per wave: at most 63 + 64 from one more tile
 constexpr int MC_STASH = 64;   // of which the newest keep their inputs in LDS
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(DXO_BLOCK, MINW) void mc_fused(mc::Const k, int64_t
         if (dlambda) dlambda[idx] = L.dl;
     };
 #if DXO_MC_PROF
-    // EXPERIMENT ONLY (scripts/exp/mc_phase_profile.py): cycles per wave in classification / refill / Newton pass, number of passes
+    // EXPERIMENT ONLY (scripts/exp/archive/mc_phase_profile.py): cycles per wave in classification / refill / Newton pass, number of passes
     long long prof[4] = {0, 0, 0, 0};
     const long long prof_t0 = __builtin_readcyclecounter();
     long long prof_t = prof_t0;

@@ -197,7 +197,7 @@ int dxo_output_alloc_probed(dxo_ctx* ctx, int64_t bytes, dxo_probe_launch launch
  * ITSELF: every candidate is timed running vm_tile on synthetic inputs of the reference's distribution, in two launch
  * shapes (one tile per wave, 32 persistent workgroups per CU), and the block that makes the kernel fastest is kept
  * together with its shape (probe_kind 2). Generic sweeps rank blocks for ONE access pattern: blocks that topped a
- * store-stream or six-stream ranking ran the kernel anywhere between 5.3 and 6.4 TB/s (scripts/exp/arena_eval.hip).
+ * store-stream or six-stream ranking ran the kernel anywhere between 5.3 and 6.4 TB/s (scripts/exp/archive/arena_eval.hip).
  * C_tang is the base of the block (pass it to dxo_output_free / dxo_output_info); sigma and dp start on 256-byte borders
  * behind it. Same options as dxo_output_alloc; blocks below "placement_min_bytes" are plain hipMalloc. */
 int dxo_vm_output_alloc(dxo_ctx* ctx, int d, int64_t n, double** C_tang, double** sigma, double** dp);

@@ -2,7 +2,7 @@
 // worth having? NH hipMalloc blocks and NV blocks backed by 2 MB chunks (virtual-memory API), all alive side by side;
 // for each: one store stream, the 2-stream mix (one input + one output stream), the 6-stream mix of arena.hip, and
 // dxo_von_mises itself (d = 6, 10^7 points, device pointers) through libdxo_hip.so.
-// build: hipcc --offload-arch=gfx950 -O3 -Iinclude scripts/exp/arena_eval.hip -o scripts/exp/arena_eval \
+// build: hipcc --offload-arch=gfx950 -O3 -Iinclude scripts/exp/archive/arena_eval.hip -o scripts/exp/arena_eval \
 //        -Ldolfinx_external_operator_amd -ldxo_hip -Wl,-rpath,$PWD/dolfinx_external_operator_amd
 #include <hip/hip_runtime.h>
 

@@ -29,5 +29,5 @@ build base                               # same flags as the product (sanity: mu
 #   -DDXO_MC_CLASSIFY_MINW=4 / 5 (mc_classify at <= 128 / <= 96 registers)        1.28-1.31 / 1.46 ms (1: 1.18-1.26)
 # round 3, single persistent Mohr-Coulomb kernel (mc_variant 2): tiles classified per visit
 for k in 0 1; do build mcpf$k -DDXO_MC_PREFETCH=$k; done
-# instrumented Mohr-Coulomb kernel for scripts/exp/mc_phase_profile.py (cycle counters per phase; its dlambda output is overwritten)
+# instrumented Mohr-Coulomb kernel for scripts/exp/archive/mc_phase_profile.py (cycle counters per phase; its dlambda output is overwritten)
 build mcprof -DDXO_MC_PROF=1

@@ -1,6 +1,6 @@
 // Host half of the DXO_MEM_HOST pipeline on its own: vm_host_rebuild_range<6> over n points with the context's worker
 // pool, threads x grain sweep, on (a) malloc'd memory first-touched by the workers, (b) hipHostMalloc memory.
-// build: hipcc -O3 -std=c++17 -Idolfinx_external_operator_amd/csrc scripts/exp/host_rebuild_bench.hip -o scripts/exp/host_rebuild_bench -lpthread
+// build: hipcc -O3 -std=c++17 -Idolfinx_external_operator_amd/csrc scripts/exp/archive/host_rebuild_bench.hip -o scripts/exp/host_rebuild_bench -lpthread
 #include <hip/hip_runtime.h>
 
 #include <chrono>

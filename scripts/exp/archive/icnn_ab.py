@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ICNN A/B on the GPU box: the round-4 library (scripts/exp/bin/libdxo_hip_r04.so, built from the r04 sources) against the
 current one, each in its own child process (DXO_HIP_LIBRARY) on the same fixed-seed batch: sha256 of (dP, P) and kernel time.
-usage: python3 scripts/exp/icnn_ab.py [--n 10000000]"""
+usage: python3 scripts/exp/archive/icnn_ab.py [--n 10000000]"""
 import argparse, hashlib, json, os, pathlib, statistics, subprocess, sys
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 ap = argparse.ArgumentParser()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment driver: Mohr-Coulomb call time against the plastic fraction of the batch, per kernel variant (GPU box).
-usage: python3 scripts/exp/mc_fraction.py [--n 10000000] [--variants 1,2]"""
+usage: python3 scripts/exp/archive/mc_fraction.py [--n 10000000] [--variants 1,2]"""
 import argparse, json, pathlib, statistics, sys, time
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))

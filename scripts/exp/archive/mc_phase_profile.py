@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment driver: where the waves of mc_fused spend their cycles. Needs a build with -DDXO_MC_PROF=1 (scripts/exp/build_variants.sh:
 the kernel then overwrites the head of `dlambda` with per-wave cycle counts: classification, refill, Newton pass, passes, total).
-usage: DXO_HIP_LIBRARY=.../libdxo_mcprof.so python3 scripts/exp/mc_phase_profile.py"""
+usage: DXO_HIP_LIBRARY=.../libdxo_mcprof.so python3 scripts/exp/archive/mc_phase_profile.py"""
 import json, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dxo_von_mises_residual on Q2 hexahedra (108^3 cells): the fused kernel against the two calls (option vm_residual_fused), one process,
-interleaved rounds. usage: python scripts/exp/residual_ab.py [lib.so ...]"""
+interleaved rounds. usage: python scripts/exp/archive/residual_ab.py [lib.so ...]"""
 import json
 import pathlib
 import statistics

@@ -1,5 +1,5 @@
 // vm_exp.hip — standalone A/B harness for von Mises d=6 kernel structure experiments (not product code).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/exp/vm_exp.hip -o scripts/exp/vm_exp
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/exp/archive/vm_exp.hip -o scripts/exp/vm_exp
 // run  : scripts/exp/vm_exp [n_points] [rounds] [launches]
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Call latency of the drop-in factories at the reference's demo sizes, copy path vs zero-copy path (option
-host_zero_copy_bytes): python3 scripts/exp/zero_copy_latency.py"""
+host_zero_copy_bytes): python3 scripts/exp/archive/zero_copy_latency.py"""
 import json
 import pathlib
 import statistics
