@@ -186,8 +186,12 @@ int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out) {
     for (int i = 0; i < n_dev; ++i) {
         devs[(size_t)i] = devices ? devices[i] : i;
         if (devs[(size_t)i] < 0 || devs[(size_t)i] >= count) return DXO_E_NODEVICE;
+        // one rank per physical device (RCCL refuses anything else). TEST HOOK: with DXO_MGPU_TEST_SHARE_DEVICE=1 in the environment
+        // several ranks may share a device — only a mock transport (tests/mock_rccl) can carry that; it lets the N > 1 data path run
+        // on a one-GPU box.
+        const char* share = std::getenv("DXO_MGPU_TEST_SHARE_DEVICE");
         for (int j = 0; j < i; ++j)
-            if (devs[(size_t)j] == devs[(size_t)i]) return DXO_E_SIZE;   // one rank per physical device
+            if (devs[(size_t)j] == devs[(size_t)i] && !(share && share[0] == '1')) return DXO_E_SIZE;
     }
     if (!rccl()) return DXO_E_NODEVICE;
     dxo_mgpu* g = new dxo_mgpu();
