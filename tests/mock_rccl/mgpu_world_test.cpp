@@ -112,6 +112,61 @@ int main(int argc, char** argv) {
         std::printf("%s %s world %d n_per_rank %lld: %ld bytes moved\n", form_bad ? "MISMATCH" : "ok", f.name, world, (long long)n, moved);
         bad += form_bad;
     }
+    // ---- another operator through the same split + all-gather: Mohr-Coulomb, five output arrays of three element sizes (16, 4
+    // doubles, an int32 and two doubles per point), one of them not requested (NULL pointer array)
+    {
+        const double phi = 0.5235987755982988;
+        const dxo_mc_params mc = {6778.0, 0.25, 3.45, phi, phi, 26.0 * 3.141592653589793 / 180.0, 0.26 * 3.45 / std::tan(phi), 1e-8, 200, 0};
+        const int64_t m = n - (n % 4);
+        std::vector<std::vector<double>> e(world), s0(world);
+        for (int r = 0; r < world; ++r) {
+            e[r].resize(m * 4); s0[r].resize(m * 4);
+            for (int64_t i = 0; i < m; ++i) {
+                const double load = (i % 3 == 0) ? 2e-3 : 1e-5;         // a third of the points yield
+                for (int k = 0; k < 4; ++k) { e[r][i * 4 + k] = load * lcg(seed); s0[r][i * 4 + k] = (k < 3 ? -1.0 : 0.1) * std::fabs(lcg(seed)); }
+            }
+        }
+        std::vector<double*> me(world), ms(world), mC(world), mS(world), mY(world), mL(world);
+        std::vector<int32_t*> mI(world);
+        const size_t M = (size_t)world * m;
+        for (int r = 0; r < world; ++r) {
+            dxo_ctx* c = dxo_mgpu_ctx(g, r);
+            me[r] = dev_alloc(c, m * 32, e[r].data()); ms[r] = dev_alloc(c, m * 32, s0[r].data());
+            mC[r] = dev_alloc(c, M * 128, nullptr); mS[r] = dev_alloc(c, M * 32, nullptr); mY[r] = dev_alloc(c, M * 8, nullptr); mL[r] = dev_alloc(c, M * 8, nullptr);
+            mI[r] = reinterpret_cast<int32_t*>(dev_alloc(c, M * 4, nullptr));
+        }
+        double *oe = dev_alloc(c1, m * 32, nullptr), *os = dev_alloc(c1, m * 32, nullptr), *oC = dev_alloc(c1, m * 128, nullptr), *oS = dev_alloc(c1, m * 32, nullptr);
+        double *oY = dev_alloc(c1, m * 8, nullptr), *oL = dev_alloc(c1, m * 8, nullptr);
+        int32_t* oI = reinterpret_cast<int32_t*>(dev_alloc(c1, m * 4, nullptr));
+        std::vector<double> rC(M * 16), rS(M * 4), rY(M), rL(M), gC(M * 16), gS(M * 4), gY(M), gL(M);
+        std::vector<int32_t> rI(M), gI(M);
+        for (int r = 0; r < world; ++r) {
+            if (dxo_copy(c1, oe, e[r].data(), m * 32, DXO_COPY_H2D) || dxo_copy(c1, os, s0[r].data(), m * 32, DXO_COPY_H2D)) return 1;
+            int rc = dxo_mohr_coulomb(c1, &mc, m, DXO_MEM_DEVICE, oe, os, oC, oS, oI, oY, nullptr, oL);
+            if (rc || dxo_ctx_synchronize(c1)) { std::fprintf(stderr, "Mohr-Coulomb reference: %d\n", rc); return 1; }
+            if (dxo_copy(c1, rC.data() + (size_t)r * m * 16, oC, m * 128, DXO_COPY_D2H) || dxo_copy(c1, rS.data() + (size_t)r * m * 4, oS, m * 32, DXO_COPY_D2H) ||
+                dxo_copy(c1, rI.data() + (size_t)r * m, oI, m * 4, DXO_COPY_D2H) || dxo_copy(c1, rY.data() + (size_t)r * m, oY, m * 8, DXO_COPY_D2H) ||
+                dxo_copy(c1, rL.data() + (size_t)r * m, oL, m * 8, DXO_COPY_D2H)) return 1;
+        }
+        std::vector<const double*> a(me.begin(), me.end()), b(ms.begin(), ms.end());
+        CHECK(dxo_mgpu_mohr_coulomb(g, &mc, m, DXO_GATHER_FULL, a.data(), b.data(), mC.data(), mS.data(), mI.data(), mY.data(), nullptr, mL.data()));
+        CHECK(dxo_mgpu_synchronize(g));
+        int mc_bad = 0;
+        long plastic = 0;
+        for (size_t i = 0; i < M; ++i) plastic += rY[i] > 0.0;
+        for (int r = 0; r < world; ++r) {
+            dxo_ctx* cx = dxo_mgpu_ctx(g, r);
+            if (dxo_copy(cx, gC.data(), mC[r], M * 128, DXO_COPY_D2H) || dxo_copy(cx, gS.data(), mS[r], M * 32, DXO_COPY_D2H) || dxo_copy(cx, gI.data(), mI[r], M * 4, DXO_COPY_D2H) ||
+                dxo_copy(cx, gY.data(), mY[r], M * 8, DXO_COPY_D2H) || dxo_copy(cx, gL.data(), mL[r], M * 8, DXO_COPY_D2H)) return 1;
+            if (std::memcmp(gC.data(), rC.data(), M * 128) || std::memcmp(gS.data(), rS.data(), M * 32) || std::memcmp(gI.data(), rI.data(), M * 4) ||
+                std::memcmp(gY.data(), rY.data(), M * 8) || std::memcmp(gL.data(), rL.data(), M * 8)) {
+                std::fprintf(stderr, "mohr_coulomb full gather: rank %d differs from the block-by-block reference\n", r);
+                mc_bad = 1;
+            }
+        }
+        std::printf("%s mohr_coulomb_full world %d n_per_rank %lld: %ld of %zu points plastic\n", mc_bad ? "MISMATCH" : "ok", world, (long long)m, plastic, M);
+        bad += mc_bad;
+    }
     dxo_mgpu_destroy(g);
     dxo_mgpu_destroy(one);
     return bad ? 1 : 0;

@@ -7,7 +7,8 @@ and no torch): `world` ranks of one process share device 0, collectives and send
 at ncclGroupEnd. What is checked is WHICH bytes land WHERE: for every gather form (all-gather of everything, compact, compact
 as direct send / receive pairs, compact in 1 / 4 / 7 overlapped pieces) the full-length (C_tang, sigma, dp) of EVERY rank must
 equal, bit for bit, the blocks computed one at a time by a world-of-one group, and the transport must have carried exactly
-world x (world - 1) x n x bytes-per-point bytes. The reference has no counterpart (it never gathers:
+world x (world - 1) x n x bytes-per-point bytes; the Mohr-Coulomb entry point (five outputs of three element sizes, one not
+requested) goes through the same split and all-gather. The reference has no counterpart (it never gathers:
 src/dolfinx_external_operator/external_operator.py:365-371, 445); north_star's design asks for the exchange.
 """
 import os
@@ -48,4 +49,4 @@ def test_every_gather_form_leaves_the_block_by_block_result_on_every_rank(driver
     r = subprocess.run([str(driver / "mgpu_world_test"), str(world), str(n)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("ok", "MISMATCH"))]
-    assert len(lines) == 6 and all(ln.startswith("ok") for ln in lines), r.stdout
+    assert len(lines) == 7 and all(ln.startswith("ok") for ln in lines), r.stdout      # six von Mises forms + the Mohr-Coulomb full gather
