@@ -15,8 +15,11 @@
 //   pass 1, element kernel: a wave owns floor(64 / nq) consecutive cells, lane = (cell, point). J^-1 and det J from the
 //     gathered vertices; the point's dual tensor pulled back to reference gradients T_q[i][k] = w |det J| sum_j G_ij K[k][j];
 //     the element-vector entries f_a,i = sum_q sum_k T_q[i][k] dphi_a,k(xi_q) are written to fe[local node][cell][i].
-//     Q2 / Q1 hexahedra with the 2x2x2 rule keep everything in registers and reduce-scatter the entries over a cell's 8 lanes
-//     with DPP moves (cell8_dpp.h: operand_adjoint_c8, the scatter of tangent_apply<3, 27, 8>); the other elements park T_q in the
+//     Q2 / Q1 hexahedra with the 2x2x2 rule form the entries of a wave's 8 cells on the fp64 matrix pipe, f[a][(c, i)] =
+//     D[a][(q, k)] T[(q, k)][(c, i)] as 24 v_mfma_f64_16x16x4_f64 (c8m_contract: operand_adjoint_c8_mfma, tangent_apply<3, 27, 8, .., MF>;
+//     option adjoint_mfma = 0: the round-4 form, everything in registers and a DPP reduce-scatter over a cell's 8 lanes, cell8_dpp.h:
+//     operand_adjoint_c8, tangent_apply<3, 27, 8>; round 5, Q2 hexahedra 108^3: state-based action 0.88 -> 0.80 ms, C_tang rows 1.13 ->
+//     1.10, internal force 0.61 -> 0.59); the other elements park T_q in the
 //     wave's LDS slice and let lane = (cell, node) form the entries (adjoint_scatter); P2 triangles' internal force has a
 //     lane = cell form (adjoint_cell.h). tangent_apply requests its tangent rows lane-linear and passes them through LDS
 //     (TangentRows); the *_vm forms rebuild the tangent's action from the returned (sigma, dp) instead (VmStateSrc).
@@ -68,6 +71,9 @@
 #else
 #define DXO_TA_C8_FORWARD 0
 #define DXO_TANGENT_CELL 0
+#endif
+#ifndef DXO_TA_VM_MF_WAVES
+#define DXO_TA_VM_MF_WAVES 2 // the same with the MFMA scatter (option adjoint_mfma)
 #endif
 #ifndef DXO_TA_VM_WAVES
 #define DXO_TA_VM_WAVES 2    // waves per SIMD of the state-based tangent action (3: 45 registers spilled on hexahedra)
@@ -523,6 +529,189 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8(OperandDev m, co
     }
 }
 
+// operand_adjoint_c8 with the element-vector contraction on the f64 MATRIX pipe (option adjoint_mfma). The scatter
+//   f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) * T_(c,q)[i][k]          a: 27 nodes, (c, i): 8 cells x 3, (q, k): 8 points x 3
+// is a 27 x 24 x 24 product per wave group: 24 v_mfma_f64_16x16x4_f64 (two 16-row tiles of nodes, two 16-column tiles of (cell,
+// component), six K-steps) instead of 288 FMAs and 250 DPP moves / adds per lane. The table fragments A[a][(q, k)] are constants
+// of the kernel and stay in registers (12 doubles per lane); a lane's T goes through the wave's LDS slice once (9 writes, 12
+// fragment reads) to reach the B layout (lane l: row 4 s + l / 16, column l % 16). The matrix pipe gives no more flops than the
+// vector pipe on gfx950 (a 16x16x4 f64 MFMA takes ~64 cycles for 1 024 FMAs) — what it gives is ISSUE SLOTS: the kernel was bound by
+// the issue of ~900 vector instructions per group, a third of its lanes' work being data movement.
+// Results: the same sums in another (fixed) order — equal to the DPP form to rounding, bit-reproducible run to run.
+constexpr int C8M_CS = 34;                 // column stride of the staged T (doubles): column-major, 34 = 2 mod 32, so the 16 columns x 2 rows a 32-lane
+                                           // half reads land on 32 different 8-byte banks
+constexpr int C8M_WAVE = 24 * C8M_CS;      // doubles per wave (816: fits the gather buffer of tangent_apply<3, 27, 8>, 848)
+typedef double c8m_d4 __attribute__((ext_vector_type(4)));
+
+// A fragments of the scatter: lane l holds dphi of node mt * 16 + l % 16 at (point, direction) index r = 4 s + l / 16 (r = 3 q + k)
+template <int ND>
+__device__ __forceinline__ void c8m_load_A(const OperandDev& m, int lane, double (&Afr)[2][6]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int a = mt * 16 + (lane & 15), r = 4 * s + (lane >> 4);
+            Afr[mt][s] = a < ND ? m.dphi[((r / 3) * m.ndofs + a) * 3 + r % 3] : 0.0;
+        }
+}
+
+// the same fragments as a lane-linear LDS table [mt * 6 + s][lane] (12 x 64 doubles, filled by the whole workgroup): 24 registers less
+template <int ND>
+__device__ __forceinline__ void c8m_fill_A(const OperandDev& m, double* Atab) {
+    for (int e = threadIdx.x; e < 12 * DXO_WAVE; e += blockDim.x) {
+        const int f = e / DXO_WAVE, lane = e - f * DXO_WAVE, mt = f / 6, s = f - mt * 6;
+        const int a = mt * 16 + (lane & 15), r = 4 * s + (lane >> 4);
+        Atab[e] = a < ND ? m.dphi[((r / 3) * m.ndofs + a) * 3 + r % 3] : 0.0;
+    }
+}
+
+// f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) T_(c,q)[i][k] for the wave's 8 cells as 24 f64 MFMAs. `Tl`: the wave's staging slice,
+// 24 rows of NS doubles (only columns 0..23 are touched). Every lane ends up with 16 entries: acc[mt][nt][r] belongs to node
+// mt * 16 + 4 r + l / 16 and column n = nt * 16 + l % 16 = 3 c + i (D layout of v_mfma_f64_16x16x4_f64: scripts/exp/mfma64_probe.hip).
+// ALDS: the A fragments come from the table of c8m_fill_A (`Atab`) instead of from `Afr`.
+template <bool ALDS = false>
+__device__ __forceinline__ void c8m_contract(double* Tl, int lane, const double (&T)[3][3], const double (&Afr)[2][6], c8m_d4 (&acc)[2][2],
+                                             const double* Atab = nullptr) {
+    const int c_l = lane >> 3, q_l = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Tl[(c_l * 3 + i) * C8M_CS + q_l * 3 + k] = T[i][k];
+    op_fence();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = c8m_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nt * 16 + (lane & 15);
+            const double b = n < 24 ? Tl[n * C8M_CS + 4 * st + (lane >> 4)] : 0.0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                double a;
+                if constexpr (ALDS) a = Atab[(mt * 6 + st) * DXO_WAVE + lane];
+                else a = Afr[mt][st];
+                acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    op_fence();                                   // the slice is free again
+}
+
+#if defined(DXO_EXPERIMENTS) && defined(DXO_C8M_FORWARD) && DXO_C8M_FORWARD
+#define DXO_C8M_FWD 1
+#include "../../scripts/exp/adjoint_mfma_forward.h"      // c8m_forward_eps: the strain contraction as MFMAs too (measured, not shipped)
+#else
+#define DXO_C8M_FWD 0
+constexpr int C8M_FTAB = 0;
+#endif
+
+// the lane's 16 entries to the element-vector array fe[node][cell][component] (or, fe == nullptr, added to `out` with atomics)
+template <int ND>
+__device__ __forceinline__ void c8m_store(const OperandDev& m, int lane, const c8m_d4 (&acc)[2][2], int64_t c0, int ncell, double* __restrict__ fe,
+                                          double* __restrict__ out) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 16 + (lane & 15), c = n / 3, i = n - 3 * c;
+        if (n < 24 && c < ncell) {
+            const int64_t cell = c0 + c;
+            if (fe) {
+                // node a = mt * 16 + 4 r + l / 16: a running pointer instead of sixteen 64-bit index products
+                const int64_t step = m.num_cells_fe * 3;
+                double* p = fe + ((int64_t)(lane >> 4) * m.num_cells_fe + cell) * 3 + i;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = mt * 16 + 4 * r + (lane >> 4);
+                        if (a < ND) p[(int64_t)(mt * 16 + 4 * r) * step] = acc[mt][nt][r];
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = mt * 16 + 4 * r + (lane >> 4);
+                        if (a < ND) unsafeAtomicAdd(out + (int64_t)m.dofmap[cell * ND + a] * 3 + i, acc[mt][nt][r]);
+                    }
+            }
+        }
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8_mfma(OperandDev m, const double* __restrict__ wq, const double* __restrict__ S,
+                                                                     int64_t n_cells, double* __restrict__ out, double* __restrict__ fe) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    // geometry rows only (the dphi table lives in the A fragments): [q][vertex][dpsi_x, dpsi_y, dpsi_z, 0] at the offset C8Lane expects
+    for (int e = threadIdx.x; e < C8_GEO; e += blockDim.x) {
+        const int k = e & 3, v = (e >> 2) & 7, q = e >> 5;
+        lds[C8_TAB + e] = k < 3 ? m.dpsi[(q * 8 + v) * 3 + k] : 0.0;
+    }
+    const int lane = threadIdx.x & (DXO_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    double* Tl = lds + C8_LDS + wave * C8M_WAVE;
+    __syncthreads();
+    const C8Lane L(lds, lane);
+    constexpr int cpw = 8;
+    double Afr[2][6];
+    c8m_load_A<ND>(m, lane, Afr);
+    const int64_t n_groups = (n_cells + cpw - 1) / cpw;
+    const GroupWalk walk = xcd_group_walk(n_groups, DXO_BLOCK / DXO_WAVE, wave);
+    const int64_t stride = walk.stride;
+    auto cells_in = [&](int64_t g) -> int {
+        if (g >= walk.end) return 0;
+        const int64_t left = n_cells - g * cpw;
+        return left < cpw ? (int)left : cpw;
+    };
+    const double w_l = wq[lane & 7];
+    const int c_l = lane >> 3, q_l = lane & 7;
+    auto vertex_index = [&](int64_t g) -> int32_t { return c_l < cells_in(g) ? m.geom_dofmap[(g * cpw + c_l) * 8 + q_l] : -1; };
+    auto vertex = [&](int32_t xn, double (&xv)[3]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[j] = xn >= 0 ? m.x[(int64_t)xn * 3 + j] : 0.0;
+    };
+    int64_t grp = walk.first;
+    int32_t xn = vertex_index(grp);
+    double xv[3];
+    vertex(xn, xv);
+    xn = vertex_index(grp + stride);
+    for (; grp < walk.end; grp += stride) {
+        const int64_t c0 = grp * cpw;
+        const int ncell = cells_in(grp);
+        const bool has_point = c_l < ncell;
+        dxo_f64x2 s2[3];
+        {
+            const dxo_f64x2* Sp = reinterpret_cast<const dxo_f64x2*>(S + (c0 * 8 + lane) * 6);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s2[k] = has_point ? Sp[k] : dxo_f64x2{0.0, 0.0};
+        }
+        double K[3][3];
+        const double det = c8_geometry(L, xv, K);
+        vertex(xn, xv);                              // the next group's vertex (its index has been here for an iteration)
+        xn = vertex_index(grp + 2 * stride);
+        const double s[6] = {s2[0].x, s2[0].y, s2[1].x, s2[1].y, s2[2].x, s2[2].y};
+        double vh[3], gh[3][3];
+        dual_tensor<3, 3, DXO_OPERAND_EPS_MANDEL>(s, vh, gh);
+        const double scale = w_l * fabs(det);
+        double T[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double tt = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
+                T[i][k] = has_point ? scale * tt : 0.0;       // lanes without a point: zero vertices, singular J
+            }
+        c8m_d4 acc[2][2];
+        c8m_contract(Tl, lane, T, Afr, acc);
+        c8m_store<ND>(m, lane, acc, c0, ncell, fe, out);
+    }
+}
+
 // operand_adjoint_c8 in the PATCH form (adjoint_patch.h): one workgroup per patch, its waves take one wave group per iteration
 // (groups of an iteration share no node), the element-vector entries are added into the patch's LDS accumulator, and only the
 // nodes shared with another patch leave a partial in HBM. Same arithmetic per entry as operand_adjoint_c8; a node's entries are
@@ -621,8 +810,9 @@ __global__ __launch_bounds__(PATCH_BLOCK) void operand_adjoint_c8_patch(OperandD
 // requested at the top of the iteration, 16 bytes per load, and is consumed after the contraction has hidden its latency,
 // (iii) the parked tensors have an odd stride (adjoint_scatter). ND_CT / NG_CT as in operand_compute_geo.
 // VM: the tangent's action comes from the von Mises state (VmStateSrc) instead of from C_tang rows.
-template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false>
-__global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
+// MF (option adjoint_mfma, Q2 hexahedra): the scatter's contraction as f64 MFMAs (c8m_contract) instead of the DPP reduce-scatter.
+template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false, bool MF = false>
+__global__ __launch_bounds__(DXO_BLOCK, VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_VM_WAVES) : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                               const double* __restrict__ C_tang, VmStateSrc vs,
                                                               const double* __restrict__ v, int64_t n_cells,
                                                               double* __restrict__ out, double* __restrict__ fe) {
@@ -635,7 +825,11 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
     double* tab = lds;
     operand_load_tables<G>(m, tab);
     double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;     // behind the waves' regions (RS only)
-    if constexpr (RS) c8_fill_tables(m, tabP);
+    if constexpr (RS && !MF) c8_fill_tables(m, tabP);
+    if constexpr (RS && MF) c8m_fill_A<ND_CT>(m, tabP);      // 768 of the C8_LDS doubles
+#if DXO_C8M_FWD
+    if constexpr (RS && MF) c8m_fill_F<ND_CT>(m, tabP + 12 * DXO_WAVE);
+#endif
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -693,7 +887,12 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int j = 0; j < G; ++j) K[i][j] = 0.0;
-        const bool active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e, K, det);
+        bool active;
+#if DXO_C8M_FWD
+        if constexpr (RS && MF) active = c8m_forward_eps<ND_CT>(m, tab, tabP + 12 * DXO_WAVE, W, ncell, lane, e, K, det);
+        else
+#endif
+        active = operand_compute_geo<G, G, DXO_OPERAND_EPS_MANDEL, ND_CT, NG_CT>(m, tab, W, ncell, lane, e, K, det);
         double vh[G], gh[G][G], scale = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -753,6 +952,13 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? DXO_TA_VM_WAVES : DXO_TA_WAVES) voi
                     for (int j = 0; j < 3; ++j) tt += gh[i][j] * K[k][j];
                     T[i][k] = scale * tt;          // scale = 0 and gh = 0 for lanes without a point
                 }
+            if constexpr (MF) {
+                c8m_d4 acc[2][2];
+                const double none[2][6] = {};
+                c8m_contract<true>(W, lane, T, none, acc, tabP);       // compute_geo / rows.times have fenced: the gather buffer is free
+                c8m_store<ND_CT>(m, lane, acc, c0, ncell, fe, out);
+                continue;
+            }
             const int64_t cell = c0 + (lane >> 3);
             c8_scatter<ND_CT, VM ? DXO_TA_VM_UT : 1>(L8, T, [&](int a, const double (&o)[3]) {
                 if (!active) return;
@@ -1251,8 +1457,11 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
         const int64_t cap = (int64_t)ctx->compute_units * DXO_C8_ADJ_BLOCKS_PER_CU;
         if (blocks > cap) blocks = cap;
         blocks = (blocks + 7) / 8 * 8;
-        const size_t shm = (size_t)C8_LDS * sizeof(double);
-        if (mesh->dev.ndofs == 27) hipLaunchKernelGGL((operand_adjoint_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
+        const size_t shm = (size_t)(C8_LDS + (ctx->adjoint_mfma ? (DXO_BLOCK / DXO_WAVE) * C8M_WAVE : 0)) * sizeof(double);
+        if (ctx->adjoint_mfma) {      // the contraction on the f64 matrix pipe
+            if (mesh->dev.ndofs == 27) hipLaunchKernelGGL((operand_adjoint_c8_mfma<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
+            else                       hipLaunchKernelGGL((operand_adjoint_c8_mfma<8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
+        } else if (mesh->dev.ndofs == 27) hipLaunchKernelGGL((operand_adjoint_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
         else                       hipLaunchKernelGGL((operand_adjoint_c8<8>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, S, n_cells, out, fe);
         if (fe) launch_node_sum(ctx, mesh, bs, out, s);
         return dxo_device_end(ctx, s);
@@ -1320,7 +1529,7 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     const int wd = rs ? (vs ? ((mesh->dev.cells_per_wave * (op_odd(mesh->dev.ndofs * 3) + op_odd(mesh->dev.ngeom * 3)) + 1) & ~1) : apply_rs_lds_wave(mesh))
                       : adjoint_lds_wave(mesh);
     const size_t shm = c8 ? (size_t)(C8_LDS + 4 * TangentRows<6>::LDS_DOUBLES) * sizeof(double)
-                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
+                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (ctx->adjoint_mfma ? 12 * DXO_WAVE + C8M_FTAB : C8_LDS) : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1345,6 +1554,7 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     else
 #endif
     if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
+    else if (rs && ctx->adjoint_mfma) { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true, true); else DXO_APPLY_LAUNCH(3, 27, 8, false, true); }
     else if (rs)              { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true); else DXO_APPLY_LAUNCH(3, 27, 8, false); }   // Q2 hexahedra, 2x2x2 rule: compile-time trip counts, scatter in registers
     else                      { if (vs) DXO_APPLY_LAUNCH(3, 0, 0, true); else DXO_APPLY_LAUNCH(3, 0, 0, false); }
 #undef DXO_APPLY_LAUNCH

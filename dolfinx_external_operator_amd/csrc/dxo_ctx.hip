@@ -143,6 +143,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "icnn_variant")) return &c->icnn_variant;
     if (!std::strcmp(key, "adjoint_atomics")) return &c->adjoint_atomics;
     if (!std::strcmp(key, "adjoint_patch")) return &c->adjoint_patch;
+    if (!std::strcmp(key, "adjoint_mfma")) return &c->adjoint_mfma;
     if (!std::strcmp(key, "mgpu_chunks")) return &c->mgpu_chunks;
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
     if (!std::strcmp(key, "vm_residual_fused")) return &c->vm_residual_fused;

@@ -459,7 +459,10 @@ int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* 
  * Full-mesh calls write element vectors and add them per node in the fixed order of the transposed dofmap (no atomics,
  * bit-reproducible); entity subsets, or option "adjoint_atomics" = 1, add with fp64 hardware atomics instead
  * (reproducible to rounding only). Option "adjoint_cell" = 0 switches off the lane-per-cell kernel that the internal
- * force (kind EPS_MANDEL) uses on the standard elements.
+ * force (kind EPS_MANDEL) uses on the standard elements. On hexahedra with the 2x2x2 rule (8 or 27 nodes) the element vectors
+ * f_a = sum_q dphi_a(xi_q) . T_q of a wave's 8 cells are formed on the fp64 matrix pipe, [32 x 24] x [24 x 24] as 24
+ * v_mfma_f64_16x16x4_f64 (option "adjoint_mfma", default 1; 0 = the round-4 DPP reduce-scatter over a cell's 8 lanes; both are
+ * bit-reproducible, they differ from each other in the last bits: a different order of the 8-point sum).
  * C_tang of dxo_tangent_apply / dxo_tangent_diagonal must be 16-byte aligned (the operator kernels' outputs are).
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);

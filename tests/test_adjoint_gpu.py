@@ -310,3 +310,50 @@ def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overw
     assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale
     assert torch.equal(outs[1], outs[2])
     assert info["patches"] >= 1 and info["wave_groups"] == -(-m.num_cells // 8) and 0 < info["schedule_fill"] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n, degree, atomics", [((5, 4, 3), 2, 0), ((12, 9, 7), 2, 0), ((7, 5, 3), 1, 0), ((6, 5, 5), 2, 1), ((20, 20, 21), 2, 0)])
+def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree, atomics):
+    """Option adjoint_mfma (default 1): on hexahedra with the 2x2x2 rule the element vectors of a wave's 8 cells are formed by 24
+    v_mfma_f64_16x16x4_f64 (csrc/adjoint.hip c8m_contract) instead of the DPP reduce-scatter (0). The same sums in another fixed order:
+    equal to rounding, identical bits run to run; cell counts that are not a multiple of 8, Q1 and Q2, the atomics form."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh, VmParams
+    from tools.synthetic import structured_mesh
+
+    m = structured_mesh("hexahedron", n, degree, distort=0.2, seed=4)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
+    S = torch.randn(npts * 6, generator=g, device=dev, dtype=torch.float64)
+    CT = torch.randn(npts, 36, generator=g, device=dev, dtype=torch.float64)
+    v = torch.randn(nn * 3, generator=g, device=dev, dtype=torch.float64)
+    dpv = (torch.randn(npts, generator=g, device=dev, dtype=torch.float64) * 1e-3).clamp_(min=0.0)
+    prm = VmParams(70e3, 0.3, 250.0, 70e3 * 700.0 / (70e3 - 700.0))
+    calls = {"force": lambda o: dm.adjoint("eps", 3, S.data_ptr(), o.data_ptr()),
+             "apply": lambda o: dm.tangent_apply(CT.data_ptr(), v.data_ptr(), o.data_ptr()),
+             "apply_vm": lambda o: dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), o.data_ptr())}
+    assert ctx.get_option("adjoint_mfma") == 1
+    saved = ctx.get_option("adjoint_atomics")
+    try:
+        ctx.set_option("adjoint_atomics", atomics)
+        for name, f in calls.items():
+            outs = []
+            for mode in (0, 1, 1):
+                ctx.set_option("adjoint_mfma", mode)
+                out = torch.full((nn * 3,), 0.5, dtype=torch.float64, device=dev)
+                f(out)
+                torch.cuda.synchronize()
+                outs.append(out)
+            scale = float(outs[0].abs().max())
+            assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale, name
+            if not atomics:
+                assert torch.equal(outs[1], outs[2]), name
+    finally:
+        ctx.set_option("adjoint_mfma", 1)
+        ctx.set_option("adjoint_atomics", saved)
+        dm.close()
