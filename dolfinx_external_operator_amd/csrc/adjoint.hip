@@ -565,11 +565,26 @@ __device__ __forceinline__ void c8m_fill_A(const OperandDev& m, double* Atab) {
     }
 }
 
+// tangent_diag: K_(a,i),(a,i) = sum_q sum_(k <= kk) dphi_a,k dphi_a,kk N_(c,q)[i][(k, kk)] — the same product with 48 rows (q, (k, kk)),
+// as two passes of 24: pass p covers the pairs 3 p .. 3 p + 2 of (00, 01, 02, 11, 12, 22). Two tables [p][mt * 6 + s][lane].
+template <int ND>
+__device__ __forceinline__ void c8m_fill_A2(const OperandDev& m, double* Atab) {
+    for (int e = threadIdx.x; e < 2 * 12 * DXO_WAVE; e += blockDim.x) {
+        const int p = e / (12 * DXO_WAVE), e1 = e - p * 12 * DXO_WAVE;
+        const int f = e1 / DXO_WAVE, lane = e1 - f * DXO_WAVE, mt = f / 6, s = f - mt * 6;
+        const int a = mt * 16 + (lane & 15), r = 4 * s + (lane >> 4), q = r / 3, slot = 3 * p + r % 3;
+        const int k = slot < 3 ? 0 : (slot < 5 ? 1 : 2), kk = slot < 3 ? slot : (slot < 5 ? slot - 2 : 2);
+        const double* d = m.dphi + (q * m.ndofs + a) * 3;
+        Atab[e] = a < ND ? d[k] * d[kk] : 0.0;
+    }
+}
+
 // f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) T_(c,q)[i][k] for the wave's 8 cells as 24 f64 MFMAs. `Tl`: the wave's staging slice,
 // 24 rows of NS doubles (only columns 0..23 are touched). Every lane ends up with 16 entries: acc[mt][nt][r] belongs to node
 // mt * 16 + 4 r + l / 16 and column n = nt * 16 + l % 16 = 3 c + i (D layout of v_mfma_f64_16x16x4_f64: scripts/exp/mfma64_probe.hip).
-// ALDS: the A fragments come from the table of c8m_fill_A (`Atab`) instead of from `Afr`.
-template <bool ALDS = false>
+// ALDS: the A fragments come from the table of c8m_fill_A (`Atab`) instead of from `Afr`. ACCUM: `acc` is added to, not cleared
+// (tangent_diag: 48 rows as two passes of 24).
+template <bool ALDS = false, bool ACCUM = false>
 __device__ __forceinline__ void c8m_contract(double* Tl, int lane, const double (&T)[3][3], const double (&Afr)[2][6], c8m_d4 (&acc)[2][2],
                                              const double* Atab = nullptr) {
     const int c_l = lane >> 3, q_l = lane & 7;
@@ -578,10 +593,12 @@ __device__ __forceinline__ void c8m_contract(double* Tl, int lane, const double 
 #pragma unroll
         for (int k = 0; k < 3; ++k) Tl[(c_l * 3 + i) * C8M_CS + q_l * 3 + k] = T[i][k];
     op_fence();
+    if constexpr (!ACCUM) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = c8m_d4{0.0, 0.0, 0.0, 0.0};
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = c8m_d4{0.0, 0.0, 0.0, 0.0};
+    }
 #pragma unroll
     for (int st = 0; st < 6; ++st) {
 #pragma unroll
@@ -991,7 +1008,7 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_V
 // dphi_k dphi_k' NS_i[kk'] over the cell's points. Before, phase 2 read the 36 entries of C_q from global memory for every
 // (node, point) pair — 27 times each on Q2 hexahedra: 4.5 ms per 10^7 points, 2.3 matvecs' worth; now see profiles/README.md.
 // ND_CT > 0 (launched for cells of 8 points, at most 32 nodes): phase 2 in registers with the DPP reduce-scatter of cell8_dpp.h.
-template <int G, int ND_CT = 0, bool VM = false>
+template <int G, int ND_CT = 0, bool VM = false, bool MF = false>
 __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                             const double* __restrict__ C_tang, VmStateSrc vs, int64_t n_cells,
                                                             double* __restrict__ out, double* __restrict__ fe) {
@@ -1005,7 +1022,8 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
     double* tab = lds;
     operand_load_tables<G>(m, tab);
     double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;
-    if constexpr (RS) c8_fill_tables(m, tabP);
+    if constexpr (RS && !MF) c8_fill_tables(m, tabP);
+    if constexpr (RS && MF) c8m_fill_A2<ND_CT>(m, tabP);
     __syncthreads();
     const OperandLayout<G> L(m);
     const int lane = threadIdx.x & (DXO_WAVE - 1);
@@ -1118,6 +1136,23 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
         if constexpr (RS) {
             // phase 2 in registers: every lane forms its point's partial of K_(a,i),(a,i) for 8 nodes at a time and the cell's 8
             // lanes reduce-scatter them (cell8_dpp.h); the lane ends up with the entries of its own four nodes
+            if constexpr (MF) {
+                // the same sums on the matrix pipe: rows (q, pair) of the two passes against the product tables (c8m_fill_A2)
+                c8m_d4 acc[2][2];
+                const double none[2][6] = {};
+                double T[3][3];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) T[i][k] = NSr[i * NS1 + 3 * p + k];
+                    if (p == 0) c8m_contract<true, false>(Pm, lane, T, none, acc, tabP);
+                    else c8m_contract<true, true>(Pm, lane, T, none, acc, tabP + 12 * DXO_WAVE);
+                }
+                c8m_store<ND_CT>(m, lane, acc, c0, ncell, fe, out);
+                continue;      // c8m_contract has fenced: the staging slice (Pm) is free for the next group's tangent rows
+            }
             const int64_t cell = c0 + (lane >> 3);
 #pragma unroll 1
             for (int t = 0; t < 4; ++t) {
@@ -1489,8 +1524,11 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
         return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang / sigma must be 16-byte aligned");
     (void)who;
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
-    const int wd = diag_lds_wave(mesh);
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? C8_LDS : 0)) * sizeof(double);
+    // MFMA form (state-based only: with the staging space of the tangent rows the product tables would not fit 64 KB): the wave's slice is
+    // the vertex buffer + the staged matrices of c8m_contract
+    const bool mf = rs && ctx->adjoint_mfma && vs;
+    const int wd = mf ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1508,6 +1546,7 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     const VmStateSrc& src = vs ? *vs : none;
 #define DXO_DIAG_LAUNCH(...) hipLaunchKernelGGL((tangent_diag<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, mesh->num_cells, out, fe)
     if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
+    else if (mf)         { DXO_DIAG_LAUNCH(3, 27, true, true); }
     else if (rs)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true); else DXO_DIAG_LAUNCH(3, 27, false); }
     else                 { if (vs) DXO_DIAG_LAUNCH(3, 0, true); else DXO_DIAG_LAUNCH(3, 0, false); }
 #undef DXO_DIAG_LAUNCH

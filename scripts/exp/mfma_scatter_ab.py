@@ -25,6 +25,7 @@ dm = DeviceMesh.from_synthetic(m, ctx=ctx)
 out = torch.zeros(nn * 3, dtype=torch.float64, device=dev)
 CT = torch.randn(npts, 36, generator=g, device=dev, dtype=torch.float64)
 calls = {"apply": lambda: dm.tangent_apply(CT.data_ptr(), v.data_ptr(), out.data_ptr()),
+         "diag": lambda: dm.tangent_diagonal(CT.data_ptr(), out.data_ptr()),
          "force": lambda: dm.adjoint("eps", 3, S.data_ptr(), out.data_ptr()),
          "apply_vm": lambda: dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), out.data_ptr()),
          "diag_vm": lambda: dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), out.data_ptr())}
