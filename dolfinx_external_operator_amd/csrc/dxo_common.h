@@ -77,8 +77,8 @@ struct dxo_ctx {
     int64_t icnn_variant = 2;           // fp32 network: 0 VALU lane-per-point kernel; wave-per-64-points MFMA kernels: 1 fp32-input MFMA, 2 split-bf16 MFMA
     int64_t adjoint_cell = 1;           // virtual work of eps on the standard elements: lane = cell kernel (0: wave-group kernel)
     int64_t operand_cell = 1;           // dxo_eval_operand, eps on the 2-D standard elements: lane = cell kernel (operand_cell.h); 0: wave-group kernel
-    int64_t vm_residual_fused = 0;      // dxo_von_mises_residual on Q2 hexahedra: 1 = one kernel (stress scattered from registers; measured no faster:
-                                        // 1.19 against 1.16-1.19 ms per 10^7 points, profiles/r04_adjoint_experiments.txt), 0 = field + adjoint calls
+    int64_t vm_residual_fused = 0;      // dxo_von_mises_residual on Q2 hexahedra: 1 = one kernel (stress scattered from registers, cell8_mfma.h; round 5: 1.11 against
+                                        // 1.14-1.16 ms per 10^7 points, profiles/r05_mfma_scatter.txt; R differs from the two calls in the last bits), 0 = field + adjoint calls
     int64_t consumer_overwrite = 0;     // dxo_operand_adjoint / dxo_tangent_apply* / dxo_tangent_diagonal* / dxo_von_mises_residual: 1 = out is SET to the
                                         // assembled vector instead of added to (a Krylov matvec needs no memset and node_sum no read of out)
     int64_t adjoint_patch = 0;          // internal force on hexahedra, whole mesh: 1 = patch form (entries meet in LDS, adjoint_patch.h; measured SLOWER, profiles/r05_patch_form.txt), 0 = element vectors + node sums

@@ -17,6 +17,7 @@
 #include "vm_core.h"
 #include "vm_host.h"
 #include "cell8_dpp.h"
+#include "cell8_mfma.h"
 
 namespace {
 
@@ -32,6 +33,9 @@ namespace {
 #ifndef DXO_VMF_ROWS
 #define DXO_VMF_ROWS 0   // 1: tangent rows built per lane and turned to output order through LDS (vm_store_tangent_rows: ~90 instead of ~650 vector
                          // instructions per tile, bit-identical output) — 0.836 against 0.832 ms: the walk's arithmetic is not what the kernel waits for
+#endif
+#ifndef DXO_VMF_RES_MFMA
+#define DXO_VMF_RES_MFMA 1   // residual form: the scatter on the matrix pipe (cell8_mfma.h) instead of the DPP reduce-scatter
 #endif
 #ifndef DXO_VMF_RES_WAVES
 #define DXO_VMF_RES_WAVES 2   // residual form: 224 registers. Three waves per SIMD spill 136 registers even with w|J|J^-1 parked in LDS (1.80 ms
@@ -53,7 +57,7 @@ namespace {
 #ifndef DXO_VMF_BLOCKS_PER_CU
 #define DXO_VMF_BLOCKS_PER_CU 16
 #endif
-// RES (hexahedra with the 2x2x2 rule, cell8_dpp.h; EXPERIMENT, option vm_residual_fused, off by default): the kernel also forms the internal force of the stress it has just returned —
+// RES (hexahedra with the 2x2x2 rule, cell8_mfma.h; option vm_residual_fused, off by default): the kernel also forms the internal force of the stress it has just returned —
 // element vectors fe[node][cell][i] = sum_q w|J| B^T sigma, reduce-scattered over the cell's 8 lanes while sigma, J^-1 and |J| are
 // still in registers (dxo_von_mises_residual; node_sum follows). No tangent is written in this form.
 // MODE 0: (C_tang, sigma, dp). MODE 1: (sigma, dp) only — its own instantiation, so that the profiler's kernel names tell the two
@@ -73,7 +77,10 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
     double* tab = lds;
     operand_load_tables<G>(m, tab);
     double* tab8 = lds + m.table_doubles + T::WAVES * wave_doubles;     // RES: the padded dphi rows c8_scatter reads
-    if constexpr (RES) c8_fill_tables(m, tab8);
+    if constexpr (RES) {
+        if constexpr (DXO_VMF_RES_MFMA) c8m_fill_A<ND_CT>(m, tab8);
+        else c8_fill_tables(m, tab8);
+    }
     __syncthreads();
     const int lane = threadIdx.x & (DXO_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -209,6 +216,14 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
                     for (int j = 0; j < 3; ++j) tt += gh[i][j] * sK[k][j];
                     Tq[i][k] = has_point ? tt : 0.0;
                 }
+            if constexpr (DXO_VMF_RES_MFMA) {
+                wave_lds_fence();           // the stress rows have left X, w|J|J^-1 has left Y: the whole slice stages T
+                c8m_d4 acc[2][2];
+                const double none[2][6] = {};
+                c8m_contract<true>(W, lane, Tq, none, acc, tab8);
+                c8m_store<ND_CT>(m, lane, acc, cell0 + c0, ncell, fe, nullptr);
+                continue;
+            }
             const C8Lane L8(tab8, lane);
             const int64_t cell = cell0 + c0 + (lane >> 3);
             c8_scatter<ND_CT>(L8, Tq, [&](int a, const double (&o)[3]) {

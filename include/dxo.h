@@ -495,8 +495,8 @@ int dxo_tangent_diagonal_vm(dxo_ctx* ctx, dxo_mesh* mesh, const dxo_vm_params* p
  * by the assembly of inner(sigma, eps(v)) dx, :266): (sigma, dp) = return map of (eps(u), sigma_n, p) exactly as dxo_von_mises_field
  * returns them with C_tang = NULL, and R[dof] += sum_q w|J| B^T sigma as dxo_operand_adjoint(EPS_MANDEL) adds it: the two launches back to
  * back on the context's stream. Option "vm_residual_fused" = 1 selects, on Q2 hexahedra with the 2x2x2 rule, ONE kernel that scatters the
- * stress from the registers it was returned in (measured no faster than the two launches — both halves are bound by arithmetic, not by
- * the stress's trip through HBM — hence off by default). sigma_n, sigma 16-byte aligned. */
+ * stress from the registers it was returned in (round 5, with the scatter on the matrix pipe: 1.11 against 1.14-1.16 ms per 10^7 points;
+ * R then differs from the two launches' in the last bits — another order of the Jacobian's sums — hence off by default). sigma_n, sigma 16-byte aligned. */
 int dxo_von_mises_residual(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* mesh, const double* u, const double* sigma_n,
                            const double* p, double* sigma, double* dp, double* R);
 /* out[dof] += K_(dof,dof): the diagonal of the same operator (Jacobi preconditioner of a matrix-free Krylov solve). */
