@@ -48,7 +48,7 @@ if [ -z "$QUICK" ]; then
   pass dl_write $DL -- WRITE_SIZE
   pass dl_sq1 $DL -- SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
   pass dl_sq2 $DL -- SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-  pass dl_flop $DL -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64     # fp64 work of the consumer-side kernels
+  pass dl_flop $DL -- SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64     # fp64 work of the consumer-side kernels
   OP="scripts/bench_operand.py --launches 2 --case 0 --operand-cell 0"
   pass field_fetch $OP -- FETCH_SIZE
   pass field_write $OP -- WRITE_SIZE

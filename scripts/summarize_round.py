@@ -204,7 +204,7 @@ if all(dl_files.values()):
         fb, wb = bs._pick(f.get(key), which), bs._pick(w.get(key), which)
         if fb is not None and wb is not None:
             rec["hbm_bytes_per_call"][leg + ":" + "/".join(path[:-1] or ("call",))] = {"kernel": key, "fetch_corrected": fb, "write": wb, "total": fb + wb}
-    names = ("tangent_apply<", "tangent_diag<", "tangent_cell<", "operand_adjoint_c8<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
+    names = ("tangent_apply<", "tangent_diag<", "tangent_cell<", "operand_adjoint_c8_mfma<", "operand_adjoint_c8<", "adjoint_cell_eps<", "node_sum<", "vm_field<", "vm_commit", "assign_owner", "assign_store", "assign_apply")
     sq = counters(["dl_sq1", "dl_sq2"], lambda n: next((k + n.split(k, 1)[1].split("(")[0] for k in names if k in n), None))
     ratios = {}
     for k, c in sq.items():
@@ -246,6 +246,9 @@ if all(dl_files.values()):
         if flop <= 0:
             continue
         e = {"fp64_flop_per_launch": flop, "trans_f64_wave_instructions": at_largest("SQ_INSTS_VALU_TRANS_F64")}
+        mops = at_largest("SQ_INSTS_VALU_MFMA_MOPS_F64")          # the scatter of the hexahedral kernels on the matrix pipe (cell8_mfma.h): units of 512 flop,
+        if mops > 0:                                               # padding rows / columns of the 16x16x4 tiles counted; NOT part of the vector-pipe figure above
+            e["fp64_mfma_flop_per_launch"] = 512.0 * mops
         ms = next((v for n, v in dur.items() if n.startswith(k)), None)
         if ms:
             e.update({"kernel_ms_in_bench_trace": ms, "TFLOP_per_s": flop / ms / 1e9, "frac_of_78.6_TFLOP_per_s_fp64_vector_peak": flop / ms / 1e9 / 78.6})

@@ -18,15 +18,15 @@ def _csv(tmp_path, counter, rows):
 
 def test_counter_parser_attributes_followers_and_halves(tmp_path):
     rows = [("void at::native::vectorized_elementwise_kernel<4, FillFunctor>", 10, 7),
-            ("operand_adjoint_c8<27>(OperandDev, ...)", 100, 1000), ("node_sum<3>(long, ...)", 50, 500),
-            ("tangent_apply<3, 27, 8, false>(OperandDev, ...)", 100, 3000), ("node_sum<3>(long, ...)", 50, 500),
+            ("operand_adjoint_c8_mfma<27>(OperandDev, ...)", 100, 1000), ("node_sum<3>(long, ...)", 50, 500),
+            ("tangent_apply<3, 27, 8, false, true>(OperandDev, ...)", 100, 3000), ("node_sum<3>(long, ...)", 50, 500),
             ("vm_commit(long, long, double*, ...)", 40, 10), ("vm_commit(long, long, double*, ...)", 40, 10),
             ("vm_field<2, true, 0, 0, 0>(VmConst, ...)", 64, 5), ("vm_field<2, true, 0, 0, 0>(VmConst, ...)", 640, 50),
             ("vm_field<2, true, 0, 0, 1>(VmConst, ...)", 640, 9),
             ("vm_commit(long, long, double*, ...)", 40, 30), ("vm_commit(long, long, double*, ...)", 40, 30)]
     got = bs.parse_counter_csv([_csv(tmp_path, "FETCH_SIZE", rows)], "FETCH_SIZE")
-    assert got["operand_adjoint_c8<"] == [[100, 1500 * 1024.0]]          # node_sum added to the call that launched it; gather kernels: x1
-    assert got["tangent_apply<3, 27, 8, false>"] == [[100, (2 * 3000 + 500) * 1024.0]]  # streaming kernel x2, its node_sum x1
+    assert got["operand_adjoint_c8"] == [[100, 1500 * 1024.0]]          # node_sum added to the call that launched it; gather kernels: x1
+    assert got["tangent_apply<3, 27, 8, false*>"] == [[100, (2 * 3000 + 500) * 1024.0]]  # streaming kernel x2, its node_sum x1
     assert bs._pick(got["vm_commit("], "first_half") == 20 * 1024.0 and bs._pick(got["vm_commit("], "second_half") == 60 * 1024.0
     assert bs._pick(got["vm_field<2,*, 0>("]) == 100 * 1024.0             # largest grid only (small set-up dispatches ignored)
     assert bs._pick(got["vm_field<2,*, 1>("]) == 18 * 1024.0              # the (sigma, dp)-only launch is its own kernel name
