@@ -40,6 +40,8 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <atomic>
+
 // experiment switches (scripts/exp/ab_adjoint.py builds variants with -D...)
 #ifndef DXO_TA_NT
 #define DXO_TA_NT 0          // non-temporal loads of the tangent rows
@@ -1405,12 +1407,21 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
         return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_diagonal: C_tang / sigma must be 16-byte aligned");
     (void)who;
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
-    // MFMA form (state-based only: with the staging space of the tangent rows the product tables would not fit 64 KB): the wave's slice is
-    // the vertex buffer + the staged matrices of c8m_contract
-    const bool mf = rs && ctx->adjoint_mfma && vs;
-    const int wd = mf ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
+    // MFMA form: the wave's slice is the vertex buffer + the staged matrices of c8m_contract (state-based), or the staging space of the
+    // tangent rows, which also holds them (C_tang rows: 66 KB per workgroup with the product tables — above the 64 KB a launch gets without asking)
+    const bool mf = rs && ctx->adjoint_mfma;
+    const int wd = (mf && vs) ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
     const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : 0)) * sizeof(double);
-    if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
+    if (shm > (mf ? 80 : 64) * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
+    if (mf && !vs && shm > 64 * 1024) {
+        static std::atomic<uint64_t> raised{0};           // one bit per device: the attribute belongs to the device's copy of the kernel
+        const uint64_t bit = 1ull << (ctx->device & 63);
+        if (!(raised.load() & bit)) {
+            DXO_HIP(ctx, hipSetDevice(ctx->device));
+            DXO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&tangent_diag<3, 27, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            raised.fetch_or(bit);
+        }
+    }
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
@@ -1427,7 +1438,7 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     const VmStateSrc& src = vs ? *vs : none;
 #define DXO_DIAG_LAUNCH(...) hipLaunchKernelGGL((tangent_diag<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, mesh->num_cells, out, fe)
     if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
-    else if (mf)         { DXO_DIAG_LAUNCH(3, 27, true, true); }
+    else if (mf)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true, true); else DXO_DIAG_LAUNCH(3, 27, false, true); }
     else if (rs)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true); else DXO_DIAG_LAUNCH(3, 27, false); }
     else                 { if (vs) DXO_DIAG_LAUNCH(3, 0, true); else DXO_DIAG_LAUNCH(3, 0, false); }
 #undef DXO_DIAG_LAUNCH

@@ -214,6 +214,8 @@ def _attach_fp64(out, leg, bs):
                                          "peak": FP64_PEAK_TFLOPS, "frac_over_call": tf / FP64_PEAK_TFLOPS,
                                          "kernel_only_frac_in_profile_run": e.get("frac_of_78.6_TFLOP_per_s_fp64_vector_peak"),
                                          "source": "profiles/consumer_flop.json (" + rec.get("measured", "") + ")"}
+        if e.get("fp64_mfma_flop_per_launch"):      # the scatter on the matrix pipe (cell8_mfma.h): beside, not part of, the vector-pipe figure
+            call["roofline"]["fp64_valu"]["mfma_flop_per_launch_issued"] = e["fp64_mfma_flop_per_launch"]
 
 
 def _view(torch, ptr, n, dev):
