@@ -569,14 +569,23 @@ def main():
     if gather_on and dist_on and not args.dry_collective and not args.no_library_gather:
         from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, MultiGpu
 
-        uid = [MultiGpu.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        mg = MultiGpu.from_rank(ctx, uid[0], rank, world)
         LIB_MODES = {"library_compact": GATHER_COMPACT, "library_direct": GATHER_COMPACT_DIRECT, "library_pipelined": GATHER_COMPACT_PIPELINED}
+
+    def library_communicator():
+        """libdxo's own RCCL communicator, created AFTER the headline has been timed (inside the comparison loop's try / watchdog): a
+        failure or a hang here costs the library modes, never the line."""
+        nonlocal mg
+        if mg is None:
+            uid = [MultiGpu.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            mg = MultiGpu.from_rank(ctx, uid[0], rank, world)
+        return mg
 
     def make_step(mode):
         compact = gather_on and mode.startswith("compact")
         if mode in LIB_MODES:
+            library_communicator()
+
             def lib_step(ev=None, g_=LIB_MODES[mode]):
                 if ev is not None:
                     ev[0].record(stream)
