@@ -30,6 +30,11 @@ namespace {
 #ifndef DXO_VMF_PRELOAD
 #define DXO_VMF_PRELOAD 0   // request sigma_n / p before the strain is formed: no gain (0.844 vs 0.844 ms with two waves per SIMD, 1.00 with three: spills)
 #endif
+#ifndef DXO_VMF_DMA
+#define DXO_VMF_DMA 1     // sigma_n of the group lands in a slice of its own by global_load_lds (lane-linear, no registers) while the strain is formed:
+                          // Q2 hexahedra, (sigma, dp)-only launch 0.467 -> 0.414 ms, with tangent 0.935 -> 0.924 (one lease, scripts/exp/vmfield_ab.py); 0 = the
+                          // loads are issued after the contraction and awaited at once (in registers ahead of it they cost the third wave: DXO_VMF_PRELOAD)
+#endif
 #ifndef DXO_VMF_ROWS
 #define DXO_VMF_ROWS 0   // 1: tangent rows built per lane and turned to output order through LDS (vm_store_tangent_rows: ~90 instead of ~650 vector
                          // instructions per tile, bit-identical output) — 0.836 against 0.832 ms: the walk's arithmetic is not what the kernel waits for
@@ -70,6 +75,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
                                                          double* __restrict__ sigma, double* __restrict__ dp_out,
                                                          const double* __restrict__ wq, double* __restrict__ fe) {
     constexpr bool RES = MODE == 2;
+    // the stress tile by global_load_lds (DXO_VMF_DMA) — not in the one instantiation that sits exactly at its register budget (Q2 hexahedra with
+    // tangent: 168 registers; the two address pairs the copies need spill there and cost 2 %)
+    constexpr bool DMA = DXO_VMF_DMA && !DXO_VMF_PRELOAD && !(MODE == 0 && ND_CT == 27);
     static_assert(!RES || (G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8), "the residual form is the eight-point hexahedron's");
     constexpr int D = G == 2 ? 4 : 6;
     using T = VmTile<D>;
@@ -90,6 +98,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
     dxo_f64x2* X2 = reinterpret_cast<dxo_f64x2*>(X);
     dxo_f64x2* Y2 = reinterpret_cast<dxo_f64x2*>(Y);
     dxo_f64x2* N2 = RES ? X2 : Y2;      // where sigma_n turns from lane-linear to point-per-lane (RES keeps w|J|J^-1 in Y)
+    // landing slice of the wave (X_DOUBLES + 64 doubles behind every wave's region and the RES tables)
+    dxo_f64x2* L2 = reinterpret_cast<dxo_f64x2*>(lds + m.table_doubles + T::WAVES * wave_doubles + (RES ? C8_LDS : 0) + wave * (T::X_DOUBLES + DXO_WAVE));
+    uint32_t* P32 = reinterpret_cast<uint32_t*>(L2 + T::X_DOUBLES / 2);      // 64 doubles behind the stress slice
     const double w_l = RES ? wq[lane & 7] : 0.0;
     const int cpw = m.cells_per_wave;
     const int64_t n_groups = (n_cells + cpw - 1) / cpw;
@@ -129,6 +140,21 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
         }
         const double p_l = lane < npts ? p[p0 + lane] : 0.0;
 #endif
+        if constexpr (DMA) {
+            // chunk q of the tile (16 bytes) goes to slot q of the slice: the wave's uniform base + lane x 16, as the instruction writes it. Lanes
+            // beyond the tile's chunks are masked and leave their slots as they were: only idle lanes read those, and their results are never stored
+            const dxo_f64x2* g_s0 = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
+#pragma unroll
+            for (int k = 0; k < T::CH_VEC; ++k)
+                if (k * DXO_WAVE + lane < nvec)
+                    __builtin_amdgcn_global_load_lds(g_s0 + k * DXO_WAVE + lane, (__attribute__((address_space(3))) void*)(L2 + k * DXO_WAVE), 16, 0, 0);
+            // p the same way, as its two 32-bit halves (the instruction moves 4, 12 or 16 bytes per lane): [low words of the 64 points | high words]
+            if (lane < npts) {
+                const uint32_t* g_p = reinterpret_cast<const uint32_t*>(p + p0 + lane);
+                __builtin_amdgcn_global_load_lds(g_p, (__attribute__((address_space(3))) void*)P32, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(g_p + 1, (__attribute__((address_space(3))) void*)(P32 + DXO_WAVE), 4, 0, 0);
+            }
+        }
         // ---- A1: strain increment of this lane's point from the displacement dofs
         double e[D];
         bool active;
@@ -162,18 +188,29 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
         for (int k = 0; k < T::CH_VEC; ++k) N2[k * DXO_WAVE + lane] = sreg[k];
 #else
         const dxo_f64x2* g_s = reinterpret_cast<const dxo_f64x2*>(sigma_n + p0 * D);
+        double p_l = 0.0;
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int k = 0; k < T::CH_VEC; ++k) {
-            const int idx = k * DXO_WAVE + lane;
-            N2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
+            for (int k = 0; k < T::CH_VEC; ++k) {
+                const int idx = k * DXO_WAVE + lane;
+                N2[idx] = idx < nvec ? g_s[idx] : dxo_f64x2{1.0 + lane, 0.5};
+            }
+            p_l = lane < npts ? p[p0 + lane] : 0.0;
         }
-        const double p_l = lane < npts ? p[p0 + lane] : 0.0;
 #endif
+        const dxo_f64x2* S2 = DMA ? L2 : N2;
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile has landed (the strain's arithmetic ran meanwhile)
+            if (lane < npts) {
+                const uint32_t lo = P32[lane], hi = P32[DXO_WAVE + lane];
+                p_l = __hiloint2double((int)hi, (int)lo);
+            }
+        }
         wave_lds_fence();
         double sn[D];
 #pragma unroll
         for (int k = 0; k < T::CH_VEC; ++k) {
-            const dxo_f64x2 b2 = N2[lane * T::CH_VEC + k];
+            const dxo_f64x2 b2 = S2[lane * T::CH_VEC + k];
             sn[2 * k] = b2.x;
             sn[2 * k + 1] = b2.y;
         }
@@ -276,7 +313,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
 #endif
     if (wd < tile) wd = tile;
     wd = (wd + 1) & ~1;
-    const size_t shm = (size_t)(m.table_doubles + 4 * wd + (fe ? C8_LDS : 0)) * sizeof(double);
+    const size_t shm = (size_t)(m.table_doubles + 4 * wd + (fe ? C8_LDS : 0) + (DXO_VMF_DMA ? 4 * DXO_WAVE * (D + 1) : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");
     const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
