@@ -1409,19 +1409,23 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
     // MFMA form: the wave's slice is the vertex buffer + the staged matrices of c8m_contract (state-based), or the staging space of the
     // tangent rows, which also holds them (C_tang rows: 66 KB per workgroup with the product tables — above the 64 KB a launch gets without asking)
-    const bool mf = rs && ctx->adjoint_mfma;
+    bool mf = rs && ctx->adjoint_mfma;
+    if (mf && !vs) {
+        // the C_tang-rows form needs the raised launch limit of its one instantiation; a runtime that refuses it gets the DPP form
+        static std::atomic<uint64_t> raised{0}, refused{0};           // one bit per device: the attribute belongs to the device's copy of the kernel
+        const uint64_t bit = 1ull << (ctx->device & 63);
+        if (!((raised.load() | refused.load()) & bit)) {
+            DXO_HIP(ctx, hipSetDevice(ctx->device));
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tangent_diag<3, 27, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e == hipSuccess) raised.fetch_or(bit);
+            else { (void)hipGetLastError(); refused.fetch_or(bit); }
+        }
+        if (refused.load() & bit) mf = false;
+    }
     const int wd = (mf && vs) ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
     const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : 0)) * sizeof(double);
-    if (shm > (mf ? 80 : 64) * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
-    if (mf && !vs && shm > 64 * 1024) {
-        static std::atomic<uint64_t> raised{0};           // one bit per device: the attribute belongs to the device's copy of the kernel
-        const uint64_t bit = 1ull << (ctx->device & 63);
-        if (!(raised.load() & bit)) {
-            DXO_HIP(ctx, hipSetDevice(ctx->device));
-            DXO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&tangent_diag<3, 27, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            raised.fetch_or(bit);
-        }
-    }
+    if (shm > (mf && !vs ? 80 : 64) * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
