@@ -13,8 +13,8 @@ namespace {
 //   f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) * T_(c,q)[i][k]          a: 27 nodes, (c, i): 8 cells x 3, (q, k): 8 points x 3
 // is a 27 x 24 x 24 product per wave group: 24 v_mfma_f64_16x16x4_f64 (two 16-row tiles of nodes, two 16-column tiles of (cell,
 // component), six K-steps) instead of 288 FMAs and 250 DPP moves / adds per lane. The table fragments A[a][(q, k)] are constants
-// of the kernel and stay in registers (12 doubles per lane); a lane's T goes through the wave's LDS slice once (9 writes, 12
-// fragment reads) to reach the B layout (lane l: row 4 s + l / 16, column l % 16). The matrix pipe gives no more flops than the
+// of the kernel (12 doubles per lane in registers, or a lane-linear LDS table); a lane's T goes through the wave's LDS slice once (9 writes,
+// 12 fragment reads) to reach the B layout (lane l: row 4 s + l / 16, column l % 16). The matrix pipe gives no more flops than the
 // vector pipe on gfx950 (a 16x16x4 f64 MFMA takes ~64 cycles for 1 024 FMAs) — what it gives is ISSUE SLOTS: the kernel was bound by
 // the issue of ~900 vector instructions per group, a third of its lanes' work being data movement.
 // Results: the same sums in another (fixed) order — equal to the DPP form to rounding, bit-reproducible run to run.
@@ -59,8 +59,8 @@ __device__ __forceinline__ void c8m_fill_A2(const OperandDev& m, double* Atab) {
     }
 }
 
-// f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) T_(c,q)[i][k] for the wave's 8 cells as 24 f64 MFMAs. `Tl`: the wave's staging slice,
-// 24 rows of NS doubles (only columns 0..23 are touched). Every lane ends up with 16 entries: acc[mt][nt][r] belongs to node
+// f[a][(c, i)] = sum over (q, k) of dphi_a,k(xi_q) T_(c,q)[i][k] for the wave's 8 cells as 24 f64 MFMAs. `Tl`: the wave's staging slice
+// (C8M_WAVE doubles: column (c, i) at n * C8M_CS, row (q, k) inside it). Every lane ends up with 16 entries: acc[mt][nt][r] belongs to node
 // mt * 16 + 4 r + l / 16 and column n = nt * 16 + l % 16 = 3 c + i (D layout of v_mfma_f64_16x16x4_f64: scripts/exp/mfma64_probe.hip).
 // ALDS: the A fragments come from the table of c8m_fill_A (`Atab`) instead of from `Afr`. ACCUM: `acc` is added to, not cleared
 // (tangent_diag: 48 rows as two passes of 24).
