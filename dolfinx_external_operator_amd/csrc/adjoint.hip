@@ -35,6 +35,7 @@
 #include "adjoint_cell.h"
 #include "cell8_dpp.h"
 #include "cell8_mfma.h"
+#include "scatter_mfma.h"
 #include "vm_core.h"
 #include "adjoint_patch.h"
 
@@ -74,6 +75,10 @@
 #else
 #define DXO_TA_C8_FORWARD 0
 #define DXO_TANGENT_CELL 0
+#endif
+#ifndef DXO_TA_GM_WAVES
+#define DXO_TA_GM_WAVES 2    // P2 tetrahedra / triangles with the MFMA scatter (scatter_mfma.h). Tetrahedra: 196 registers; at three waves per SIMD 13 are
+                             // spilled and the matvec takes 0.683 instead of 0.661 ms (LDS form 0.74-0.76); triangles fit three waves either way (148)
 #endif
 #ifndef DXO_TA_VM_MF_WAVES
 #define DXO_TA_VM_MF_WAVES 2 // the same with the MFMA scatter (option adjoint_mfma)
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(PATCH_BLOCK) void operand_adjoint_c8_patch(OperandD
 // VM: the tangent's action comes from the von Mises state (VmStateSrc) instead of from C_tang rows.
 // MF (option adjoint_mfma, Q2 hexahedra): the scatter's contraction as f64 MFMAs (c8m_contract) instead of the DPP reduce-scatter.
 template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false, bool MF = false>
-__global__ __launch_bounds__(DXO_BLOCK, VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_VM_WAVES) : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
+__global__ __launch_bounds__(DXO_BLOCK, (MF && ND_CT != 27) ? DXO_TA_GM_WAVES : VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_VM_WAVES) : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                               const double* __restrict__ C_tang, VmStateSrc vs,
                                                               const double* __restrict__ v, int64_t n_cells,
                                                               double* __restrict__ out, double* __restrict__ fe) {
@@ -721,10 +726,14 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_V
     // cells of 8 points and at most 32 nodes (launched so only for nq = 8): the scatter phase runs in registers, a DPP
     // reduce-scatter over the cell's 8 lanes (cell8_dpp.h) instead of parked tensors and 96 LDS reads per (cell, node) pair
     constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8;
+    // MF on the other standard elements (scatter_mfma.h): P2 tetrahedra with the 4-point rule, P2 triangles with the 3-point rule
+    constexpr bool GMF = MF && !RS && ND_CT > 0;
+    constexpr int NQ_GM = G == 3 ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
-    double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;     // behind the waves' regions (RS only)
+    double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;     // behind the waves' regions (RS, GMF)
+    if constexpr (GMF) gm_fill_A<G, ND_CT, NQ_GM>(m, tabP);
     if constexpr (RS && !MF) c8_fill_tables(m, tabP);
     if constexpr (RS && MF) c8m_fill_A<ND_CT>(m, tabP);      // 768 of the C8_LDS doubles
 #if DXO_C8M_FWD
@@ -871,6 +880,18 @@ __global__ __launch_bounds__(DXO_BLOCK, VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_V
                     for (int i = 0; i < 3; ++i) unsafeAtomicAdd(out + node * 3 + i, o[i]);
                 }
             });
+        } else if constexpr (GMF) {
+            double T[G][G];
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    double tt = 0.0;
+#pragma unroll
+                    for (int j = 0; j < G; ++j) tt += gh[i][j] * K[k][j];
+                    T[i][k] = scale * tt;          // scale = 0 and gh = 0 for lanes without a point
+                }
+            gm_scatter<G, ND_CT, NQ_GM>(m, tabP, W, lane, T, c0, ncell, fe, out);      // compute_geo / rows.times have fenced: the wave's region is free
         } else {
             adjoint_scatter<G, G>(m, tab, Tm, active, lane, vh, gh, K, scale, c0, ncell, nullptr, out, fe);
         }
@@ -1463,8 +1484,13 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     // the state form stages nothing: its wave region is the gather buffer (and the parked tensors where the scatter uses them)
     const int wd = rs ? (vs ? ((mesh->dev.cells_per_wave * (op_odd(mesh->dev.ndofs * 3) + op_odd(mesh->dev.ngeom * 3)) + 1) & ~1) : apply_rs_lds_wave(mesh))
                       : adjoint_lds_wave(mesh);
+    // scatter_mfma.h: P2 tetrahedra (4-point rule) and P2 triangles (3-point rule), state-based form (with the tangent rows' registers on top the
+    // compile-time element costs more than the scatter gains: 0.511 against 0.503 ms on triangles, 1.135 / 1.106 on tetrahedra)
+    const bool gm_tet = vs && ctx->adjoint_mfma && mesh->gdim == 3 && mesh->dev.ndofs == 10 && mesh->dev.ngeom == 4 && mesh->dev.nq == 4;
+    const bool gm_tri = vs && ctx->adjoint_mfma && mesh->gdim == 2 && mesh->dev.ndofs == 6 && mesh->dev.ngeom == 3 && mesh->dev.nq == 3;
+    const int gm_tab = gm_tet ? GmShape<3, 10, 4>::ATAB : gm_tri ? GmShape<2, 6, 3>::ATAB : 0;
     const size_t shm = c8 ? (size_t)(C8_LDS + 4 * TangentRows<6>::LDS_DOUBLES) * sizeof(double)
-                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (ctx->adjoint_mfma ? 12 * DXO_WAVE + C8M_FTAB : C8_LDS) : 0)) * sizeof(double);
+                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (ctx->adjoint_mfma ? 12 * DXO_WAVE + C8M_FTAB : C8_LDS) : gm_tab)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1488,7 +1514,9 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
         hipLaunchKernelGGL((tangent_apply_c8<27>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, C_tang, v, mesh->num_cells, out, fe);
     else
 #endif
-    if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
+    if (gm_tri)               { DXO_APPLY_LAUNCH(2, 6, 3, true, true); }
+    else if (gm_tet)          { DXO_APPLY_LAUNCH(3, 10, 4, true, true); }
+    else if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
     else if (rs && ctx->adjoint_mfma) { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true, true); else DXO_APPLY_LAUNCH(3, 27, 8, false, true); }
     else if (rs)              { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true); else DXO_APPLY_LAUNCH(3, 27, 8, false); }   // Q2 hexahedra, 2x2x2 rule: compile-time trip counts, scatter in registers
     else                      { if (vs) DXO_APPLY_LAUNCH(3, 0, 0, true); else DXO_APPLY_LAUNCH(3, 0, 0, false); }

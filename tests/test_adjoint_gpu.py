@@ -360,3 +360,46 @@ def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree,
         ctx.set_option("adjoint_mfma", 1)
         ctx.set_option("adjoint_atomics", saved)
         dm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell, n, atomics", [("triangle", (7, 5), 0), ("triangle", (40, 33), 0), ("tetrahedron", (3, 2, 2), 0), ("tetrahedron", (9, 7, 6), 0),
+                                              ("tetrahedron", (4, 3, 3), 1), ("triangle", (11, 9), 1)])
+def test_matrix_pipe_scatter_on_p2_triangles_and_tetrahedra(ctx, cell, n, atomics):
+    """scatter_mfma.h: on P2 triangles (3-point rule) and P2 tetrahedra (4-point rule) the state-based tangent action forms the element vectors
+    of a wave's 21 / 16 cells as 6 / 9 v_mfma_f64_16x16x4_f64 (option adjoint_mfma = 1, the default) instead of the lane = (cell, node) loop
+    over tensors parked in LDS (0): equal to rounding, identical bits run to run, ragged last groups, the atomics form."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh, VmParams
+    from tools.synthetic import structured_mesh
+
+    m = structured_mesh(cell, n, 2, distort=0.2, seed=7)
+    G, d = m.gdim, 4 if m.gdim == 2 else 6
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
+    S = torch.randn(npts * d, generator=g, device=dev, dtype=torch.float64)
+    v = torch.randn(nn * G, generator=g, device=dev, dtype=torch.float64)
+    dpv = (torch.randn(npts, generator=g, device=dev, dtype=torch.float64) * 1e-3).clamp_(min=0.0)
+    prm = VmParams(70e3, 0.3, 250.0, 70e3 * 700.0 / (70e3 - 700.0))
+    saved = ctx.get_option("adjoint_atomics")
+    try:
+        ctx.set_option("adjoint_atomics", atomics)
+        outs = []
+        for mode in (0, 1, 1):
+            ctx.set_option("adjoint_mfma", mode)
+            out = torch.full((nn * G,), 0.25, dtype=torch.float64, device=dev)
+            dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            outs.append(out)
+        scale = float(outs[0].abs().max())
+        assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale
+        if not atomics:
+            assert torch.equal(outs[1], outs[2])
+    finally:
+        ctx.set_option("adjoint_mfma", 1)
+        ctx.set_option("adjoint_atomics", saved)
+        dm.close()
