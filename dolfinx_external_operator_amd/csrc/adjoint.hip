@@ -921,13 +921,18 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
     constexpr int NS1 = G * (G + 1) / 2;            // unique entries of one symmetrised matrix
     constexpr int PT = (G * NS1) | 1;               // odd per-point stride (bank spread across cells)
     constexpr double r2 = 0.70710678118654752440;
-    constexpr bool RS = DXO_TA_RS && G == 3 && ND_CT > 0 && ND_CT <= C8_NODES;
+    constexpr bool RS = DXO_TA_RS && G == 3 && (ND_CT == 27 || ND_CT == 8);
+    // MF on P2 tetrahedra (4-point rule) / P2 triangles (3-point rule): scatter_mfma.h, rows (q, pair) in passes of three pairs
+    constexpr bool GMF = MF && !RS && ND_CT > 0;
+    constexpr int NQ_GM = G == 3 ? 4 : 3;
+    using GS = GmShape<G, GMF ? ND_CT : 1, NQ_GM, 3>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tab = lds;
     operand_load_tables<G>(m, tab);
     double* tabP = lds + m.table_doubles + (DXO_BLOCK / DXO_WAVE) * lds_wave;
     if constexpr (RS && !MF) c8_fill_tables(m, tabP);
     if constexpr (RS && MF) c8m_fill_A2<ND_CT>(m, tabP);
+    if constexpr (GMF) gm_fill_A2<G, ND_CT, NQ_GM>(m, tabP);
     __syncthreads();
     const OperandLayout<G> L(m);
     const int lane = threadIdx.x & (DXO_WAVE - 1);
@@ -1031,11 +1036,26 @@ __global__ __launch_bounds__(DXO_BLOCK, 2) void tangent_diag(OperandDev m, const
                             a += KM[k][jj] * K[kk][jj];
                             b += KM[kk][jj] * K[k][jj];
                         }
-                        if constexpr (RS) NSr[i * NS1 + slot] = scale * (k == kk ? a : a + b);
+                        if constexpr (RS || GMF) NSr[i * NS1 + slot] = scale * (k == kk ? a : a + b);
                         else Pm[lane * PT + i * NS1 + slot] = scale * (k == kk ? a : a + b);
                         ++slot;
                     }
             }
+        }
+        if constexpr (GMF) {
+            c8m_d4 acc[GS::MT][GS::NT];
+            double T[G][3];
+#pragma unroll
+            for (int p = 0; p < NS1 / 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) T[i][k] = NSr[i * NS1 + 3 * p + k];
+                if (p == 0) gm_contract<G, ND_CT, NQ_GM, 3, false>(tabP, Pm, lane, T, acc);
+                else gm_contract<G, ND_CT, NQ_GM, 3, true>(tabP + GS::ATAB, Pm, lane, T, acc);
+            }
+            gm_store<G, ND_CT, NQ_GM>(m, lane, acc, c0, ncell, fe, out);
+            continue;      // gm_contract has fenced: the staging slice (Pm) is free for the next group
         }
         if constexpr (RS) {
             // phase 2 in registers: every lane forms its point's partial of K_(a,i),(a,i) for 8 nodes at a time and the cell's 8
@@ -1430,6 +1450,9 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
     // MFMA form: the wave's slice is the vertex buffer + the staged matrices of c8m_contract (state-based), or the staging space of the
     // tangent rows, which also holds them (C_tang rows: 66 KB per workgroup with the product tables — above the 64 KB a launch gets without asking)
+    // scatter_mfma.h: P2 tetrahedra (4-point rule) and P2 triangles (3-point rule), state-based form
+    const bool gm_tet = vs && ctx->adjoint_mfma && mesh->gdim == 3 && mesh->dev.ndofs == 10 && mesh->dev.ngeom == 4 && mesh->dev.nq == 4;
+    const bool gm_tri = vs && ctx->adjoint_mfma && mesh->gdim == 2 && mesh->dev.ndofs == 6 && mesh->dev.ngeom == 3 && mesh->dev.nq == 3;
     bool mf = rs && ctx->adjoint_mfma;
     if (mf && !vs) {
         // the C_tang-rows form needs the raised launch limit of its one instantiation; a runtime that refuses it gets the DPP form
@@ -1444,8 +1467,14 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
         }
         if (refused.load() & bit) mf = false;
     }
-    const int wd = (mf && vs) ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : 0)) * sizeof(double);
+    int wd = (mf && vs) ? ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * 3) + 1) & ~1) + C8M_WAVE : diag_lds_wave(mesh);
+    const int gm_stage = gm_tet ? GmShape<3, 10, 4, 3>::STAGE : gm_tri ? GmShape<2, 6, 3, 3>::STAGE : 0;
+    const int gm_tab = gm_tet ? 2 * GmShape<3, 10, 4, 3>::ATAB : gm_tri ? GmShape<2, 6, 3, 3>::ATAB : 0;
+    if (gm_stage) {      // the staging slice behind the vertex buffer
+        const int need = ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * mesh->gdim) + 1) & ~1) + gm_stage;
+        if (wd < need) wd = (need + 1) & ~1;
+    }
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : gm_tab)) * sizeof(double);
     if (shm > (mf && !vs ? 80 : 64) * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1462,7 +1491,9 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     const VmStateSrc none{};
     const VmStateSrc& src = vs ? *vs : none;
 #define DXO_DIAG_LAUNCH(...) hipLaunchKernelGGL((tangent_diag<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, mesh->num_cells, out, fe)
-    if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
+    if (gm_tri)          { DXO_DIAG_LAUNCH(2, 6, true, true); }
+    else if (gm_tet)     { DXO_DIAG_LAUNCH(3, 10, true, true); }
+    else if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
     else if (mf)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true, true); else DXO_DIAG_LAUNCH(3, 27, false, true); }
     else if (rs)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true); else DXO_DIAG_LAUNCH(3, 27, false); }
     else                 { if (vs) DXO_DIAG_LAUNCH(3, 0, true); else DXO_DIAG_LAUNCH(3, 0, false); }

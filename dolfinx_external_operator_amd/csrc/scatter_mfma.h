@@ -10,10 +10,11 @@
 
 namespace {
 
-template <int G, int ND, int NQ>
+// RPQ: rows per quadrature point — G (the directions k of the scatter) or 3 (a pass of three (k, kk) pairs of the diagonal)
+template <int G, int ND, int NQ, int RPQ = G>
 struct GmShape {
     static constexpr int CPW = DXO_WAVE / NQ;                 // cells per wave (OperandDev::cells_per_wave of such a mesh)
-    static constexpr int ROWS = NQ * G, COLS = CPW * G;
+    static constexpr int ROWS = NQ * RPQ, COLS = CPW * G;
     static constexpr int MT = (ND + 15) / 16, KS = (ROWS + 3) / 4, NT = (COLS + 15) / 16;
     // column stride of the staged T: even with an odd half, so the 16 columns x 2 rows a 32-lane half reads fall on 32 different 8-byte banks
     static constexpr int CS = ROWS <= 18 ? 18 : 34;
@@ -33,24 +34,48 @@ __device__ __forceinline__ void gm_fill_A(const OperandDev& m, double* Atab) {
     }
 }
 
-// Tl: the wave's staging slice (S::STAGE doubles); T = w |det J| G_hat K^T of this lane's point (zero for lanes without one).
+// tangent_diag: rows (q, pair) with the products dphi_a,k dphi_a,kk of the pairs (k <= kk) 3 p .. 3 p + 2 of (00, 01, 02, 11, 12, 22) resp.
+// (00, 01, 11); PASSES tables of GmShape<G, ND, NQ, 3>::ATAB doubles
 template <int G, int ND, int NQ>
-__device__ __forceinline__ void gm_scatter(const OperandDev& m, const double* Atab, double* Tl, int lane, const double (&T)[G][G], int64_t c0, int ncell,
-                                           double* __restrict__ fe, double* __restrict__ out) {
-    using S = GmShape<G, ND, NQ>;
+__device__ __forceinline__ void gm_fill_A2(const OperandDev& m, double* Atab) {
+    using S = GmShape<G, ND, NQ, 3>;
+    constexpr int PASSES = G == 3 ? 2 : 1;
+    for (int e = threadIdx.x; e < PASSES * S::ATAB; e += blockDim.x) {
+        const int p = e / S::ATAB, e1 = e - p * S::ATAB;
+        const int f = e1 / DXO_WAVE, lane = e1 - f * DXO_WAVE, mt = f / S::KS, s = f - mt * S::KS;
+        const int a = mt * 16 + (lane & 15), r = 4 * s + (lane >> 4), q = r / 3, slot = 3 * p + r % 3;
+        int k, kk;
+        if (G == 3) { k = slot < 3 ? 0 : (slot < 5 ? 1 : 2); kk = slot < 3 ? slot : (slot < 5 ? slot - 2 : 2); }
+        else { k = slot < 2 ? 0 : 1; kk = slot < 1 ? 0 : 1; }
+        double v = 0.0;
+        if (a < ND && r < S::ROWS) {
+            const double* d = m.dphi + (q * m.ndofs + a) * G;
+            v = d[k] * d[kk];
+        }
+        Atab[e] = v;
+    }
+}
+
+// acc (+)= A x T for the wave's cells. Tl: the wave's staging slice (S::STAGE doubles); T[i][r]: this lane's point, component i, row r of the
+// point's RPQ (zero for lanes without a point).
+template <int G, int ND, int NQ, int RPQ, bool ACCUM>
+__device__ __forceinline__ void gm_contract(const double* Atab, double* Tl, int lane, const double (&T)[G][RPQ],
+                                            c8m_d4 (&acc)[GmShape<G, ND, NQ, RPQ>::MT][GmShape<G, ND, NQ, RPQ>::NT]) {
+    using S = GmShape<G, ND, NQ, RPQ>;
     const int c_l = lane / NQ, q_l = lane - c_l * NQ;
     if (c_l < S::CPW) {
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int k = 0; k < G; ++k) Tl[(c_l * G + i) * S::CS + q_l * G + k] = T[i][k];
+            for (int k = 0; k < RPQ; ++k) Tl[(c_l * G + i) * S::CS + q_l * RPQ + k] = T[i][k];
     }
     op_fence();
-    c8m_d4 acc[S::MT][S::NT];
+    if constexpr (!ACCUM) {
 #pragma unroll
-    for (int mt = 0; mt < S::MT; ++mt)
+        for (int mt = 0; mt < S::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < S::NT; ++nt) acc[mt][nt] = c8m_d4{0.0, 0.0, 0.0, 0.0};
+            for (int nt = 0; nt < S::NT; ++nt) acc[mt][nt] = c8m_d4{0.0, 0.0, 0.0, 0.0};
+    }
 #pragma unroll
     for (int st = 0; st < S::KS; ++st) {
         const int r = 4 * st + (lane >> 4);
@@ -64,7 +89,13 @@ __device__ __forceinline__ void gm_scatter(const OperandDev& m, const double* At
         }
     }
     op_fence();                                   // the slice is free again
-    // acc[mt][nt][r] of lane l = f[mt * 16 + 4 r + l / 16][nt * 16 + l % 16] (D layout of the instruction, scripts/exp/mfma64_probe.hip)
+}
+
+// acc[mt][nt][r] of lane l = f[mt * 16 + 4 r + l / 16][nt * 16 + l % 16] (D layout of the instruction, scripts/exp/mfma64_probe.hip)
+template <int G, int ND, int NQ>
+__device__ __forceinline__ void gm_store(const OperandDev& m, int lane, const c8m_d4 (&acc)[GmShape<G, ND, NQ>::MT][GmShape<G, ND, NQ>::NT], int64_t c0,
+                                         int ncell, double* __restrict__ fe, double* __restrict__ out) {
+    using S = GmShape<G, ND, NQ>;
 #pragma unroll
     for (int nt = 0; nt < S::NT; ++nt) {
         const int n = nt * 16 + (lane & 15), c = n / G, i = n - G * c;
@@ -82,6 +113,16 @@ __device__ __forceinline__ void gm_scatter(const OperandDev& m, const double* At
                 }
         }
     }
+}
+
+// Tl: the wave's staging slice (S::STAGE doubles); T = w |det J| G_hat K^T of this lane's point (zero for lanes without one).
+template <int G, int ND, int NQ>
+__device__ __forceinline__ void gm_scatter(const OperandDev& m, const double* Atab, double* Tl, int lane, const double (&T)[G][G], int64_t c0, int ncell,
+                                           double* __restrict__ fe, double* __restrict__ out) {
+    using S = GmShape<G, ND, NQ>;
+    c8m_d4 acc[S::MT][S::NT];
+    gm_contract<G, ND, NQ, G, false>(Atab, Tl, lane, T, acc);
+    gm_store<G, ND, NQ>(m, lane, acc, c0, ncell, fe, out);
 }
 
 }  // namespace

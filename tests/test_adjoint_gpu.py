@@ -366,7 +366,7 @@ def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree,
 @pytest.mark.parametrize("cell, n, atomics", [("triangle", (7, 5), 0), ("triangle", (40, 33), 0), ("tetrahedron", (3, 2, 2), 0), ("tetrahedron", (9, 7, 6), 0),
                                               ("tetrahedron", (4, 3, 3), 1), ("triangle", (11, 9), 1)])
 def test_matrix_pipe_scatter_on_p2_triangles_and_tetrahedra(ctx, cell, n, atomics):
-    """scatter_mfma.h: on P2 triangles (3-point rule) and P2 tetrahedra (4-point rule) the state-based tangent action forms the element vectors
+    """scatter_mfma.h: on P2 triangles (3-point rule) and P2 tetrahedra (4-point rule) the state-based tangent action and diagonal form the element vectors
     of a wave's 21 / 16 cells as 6 / 9 v_mfma_f64_16x16x4_f64 (option adjoint_mfma = 1, the default) instead of the lane = (cell, node) loop
     over tensors parked in LDS (0): equal to rounding, identical bits run to run, ragged last groups, the atomics form."""
     import torch
@@ -388,17 +388,20 @@ def test_matrix_pipe_scatter_on_p2_triangles_and_tetrahedra(ctx, cell, n, atomic
     saved = ctx.get_option("adjoint_atomics")
     try:
         ctx.set_option("adjoint_atomics", atomics)
-        outs = []
-        for mode in (0, 1, 1):
-            ctx.set_option("adjoint_mfma", mode)
-            out = torch.full((nn * G,), 0.25, dtype=torch.float64, device=dev)
-            dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), out.data_ptr())
-            torch.cuda.synchronize()
-            outs.append(out)
-        scale = float(outs[0].abs().max())
-        assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale
-        if not atomics:
-            assert torch.equal(outs[1], outs[2])
+        calls = {"apply_vm": lambda o: dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), o.data_ptr()),
+                 "diag_vm": lambda o: dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), o.data_ptr())}      # rows (q, pair) in passes of three pairs
+        for name, f in calls.items():
+            outs = []
+            for mode in (0, 1, 1):
+                ctx.set_option("adjoint_mfma", mode)
+                out = torch.full((nn * G,), 0.25, dtype=torch.float64, device=dev)
+                f(out)
+                torch.cuda.synchronize()
+                outs.append(out)
+            scale = float(outs[0].abs().max())
+            assert float((outs[1] - outs[0]).abs().max()) <= 1e-13 * scale, name
+            if not atomics:
+                assert torch.equal(outs[1], outs[2]), name
     finally:
         ctx.set_option("adjoint_mfma", 1)
         ctx.set_option("adjoint_atomics", saved)
