@@ -1453,7 +1453,8 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     // scatter_mfma.h: P2 tetrahedra (4-point rule) and P2 triangles (3-point rule), state-based form
     const bool gm_tet = vs && ctx->adjoint_mfma && mesh->gdim == 3 && mesh->dev.ndofs == 10 && mesh->dev.ngeom == 4 && mesh->dev.nq == 4;
     const bool gm_tri = vs && ctx->adjoint_mfma && mesh->gdim == 2 && mesh->dev.ndofs == 6 && mesh->dev.ngeom == 3 && mesh->dev.nq == 3;
-    bool mf = rs && ctx->adjoint_mfma;
+    const bool q1 = vs && ctx->adjoint_mfma && DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 8 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q1 hexahedra, state-based
+    bool mf = (rs || q1) && ctx->adjoint_mfma;
     if (mf && !vs) {
         // the C_tang-rows form needs the raised launch limit of its one instantiation; a runtime that refuses it gets the DPP form
         static std::atomic<uint64_t> raised{0}, refused{0};           // one bit per device: the attribute belongs to the device's copy of the kernel
@@ -1474,7 +1475,7 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
         const int need = ((mesh->dev.cells_per_wave * op_odd(mesh->dev.ngeom * mesh->gdim) + 1) & ~1) + gm_stage;
         if (wd < need) wd = (need + 1) & ~1;
     }
-    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : gm_tab)) * sizeof(double);
+    const size_t shm = (size_t)(mesh->dev.table_doubles + 4 * wd + ((rs || q1) ? (mf ? 2 * 12 * DXO_WAVE : C8_LDS) : gm_tab)) * sizeof(double);
     if (shm > (mf && !vs ? 80 : 64) * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_diagonal: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1494,6 +1495,7 @@ int tangent_diagonal_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, co
     if (gm_tri)          { DXO_DIAG_LAUNCH(2, 6, true, true); }
     else if (gm_tet)     { DXO_DIAG_LAUNCH(3, 10, true, true); }
     else if (mesh->gdim == 2) { if (vs) DXO_DIAG_LAUNCH(2, 0, true); else DXO_DIAG_LAUNCH(2, 0, false); }
+    else if (q1)         { DXO_DIAG_LAUNCH(3, 8, true, true); }
     else if (mf)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true, true); else DXO_DIAG_LAUNCH(3, 27, false, true); }
     else if (rs)         { if (vs) DXO_DIAG_LAUNCH(3, 27, true); else DXO_DIAG_LAUNCH(3, 27, false); }
     else                 { if (vs) DXO_DIAG_LAUNCH(3, 0, true); else DXO_DIAG_LAUNCH(3, 0, false); }
@@ -1512,16 +1514,19 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
         return dxo_fail(ctx, DXO_E_ALIGN, "dxo_tangent_apply: C_tang / sigma must be 16-byte aligned");
     const bool rs = DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 27 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;   // Q2 hexahedra, 2x2x2 rule
     const bool c8 = rs && DXO_TA_C8_FORWARD && !vs;
+    // Q1 hexahedra with the 2x2x2 rule, state-based form: the same kernel with 8 nodes (matrix-pipe scatter only)
+    const bool q1 = vs && ctx->adjoint_mfma && DXO_TA_RS && mesh->gdim == 3 && mesh->dev.ndofs == 8 && mesh->dev.ngeom == 8 && mesh->dev.nq == 8;
     // the state form stages nothing: its wave region is the gather buffer (and the parked tensors where the scatter uses them)
-    const int wd = rs ? (vs ? ((mesh->dev.cells_per_wave * (op_odd(mesh->dev.ndofs * 3) + op_odd(mesh->dev.ngeom * 3)) + 1) & ~1) : apply_rs_lds_wave(mesh))
-                      : adjoint_lds_wave(mesh);
+    int wd = (rs || q1) ? (vs ? ((mesh->dev.cells_per_wave * (op_odd(mesh->dev.ndofs * 3) + op_odd(mesh->dev.ngeom * 3)) + 1) & ~1) : apply_rs_lds_wave(mesh))
+                        : adjoint_lds_wave(mesh);
+    if (q1 && wd < C8M_WAVE) wd = C8M_WAVE;      // c8m_contract stages T in the wave's region
     // scatter_mfma.h: P2 tetrahedra (4-point rule) and P2 triangles (3-point rule), state-based form (with the tangent rows' registers on top the
     // compile-time element costs more than the scatter gains: 0.511 against 0.503 ms on triangles, 1.135 / 1.106 on tetrahedra)
     const bool gm_tet = vs && ctx->adjoint_mfma && mesh->gdim == 3 && mesh->dev.ndofs == 10 && mesh->dev.ngeom == 4 && mesh->dev.nq == 4;
     const bool gm_tri = vs && ctx->adjoint_mfma && mesh->gdim == 2 && mesh->dev.ndofs == 6 && mesh->dev.ngeom == 3 && mesh->dev.nq == 3;
     const int gm_tab = gm_tet ? GmShape<3, 10, 4>::ATAB : gm_tri ? GmShape<2, 6, 3>::ATAB : 0;
     const size_t shm = c8 ? (size_t)(C8_LDS + 4 * TangentRows<6>::LDS_DOUBLES) * sizeof(double)
-                          : (size_t)(mesh->dev.table_doubles + 4 * wd + (rs ? (ctx->adjoint_mfma ? 12 * DXO_WAVE + C8M_FTAB : C8_LDS) : gm_tab)) * sizeof(double);
+                          : (size_t)(mesh->dev.table_doubles + 4 * wd + ((rs || q1) ? (ctx->adjoint_mfma ? 12 * DXO_WAVE + C8M_FTAB : C8_LDS) : gm_tab)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1548,6 +1553,7 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     if (gm_tri)               { DXO_APPLY_LAUNCH(2, 6, 3, true, true); }
     else if (gm_tet)          { DXO_APPLY_LAUNCH(3, 10, 4, true, true); }
     else if (mesh->gdim == 2) { if (vs) DXO_APPLY_LAUNCH(2, 0, 0, true); else DXO_APPLY_LAUNCH(2, 0, 0, false); }
+    else if (q1)              { DXO_APPLY_LAUNCH(3, 8, 8, true, true); }
     else if (rs && ctx->adjoint_mfma) { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true, true); else DXO_APPLY_LAUNCH(3, 27, 8, false, true); }
     else if (rs)              { if (vs) DXO_APPLY_LAUNCH(3, 27, 8, true); else DXO_APPLY_LAUNCH(3, 27, 8, false); }   // Q2 hexahedra, 2x2x2 rule: compile-time trip counts, scatter in registers
     else                      { if (vs) DXO_APPLY_LAUNCH(3, 0, 0, true); else DXO_APPLY_LAUNCH(3, 0, 0, false); }

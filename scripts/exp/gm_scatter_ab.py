@@ -1,10 +1,15 @@
+#!/usr/bin/env python3
+"""The state-based consumer-side calls with the scatter on the fp64 matrix pipe (option adjoint_mfma = 1: csrc/scatter_mfma.h on P2 triangles / tetrahedra,
+cell8_mfma.h on Q1 hexahedra) against the generic kernels (0), 10^7 points, two interleaved rounds.
+usage: python scripts/exp/gm_scatter_ab.py tri|tet|hex1 apply_vm,diag_vm"""
 import json, statistics, sys
 sys.path.insert(0, ".")
 import torch
 from dolfinx_external_operator_amd import Context, DeviceMesh, VmParams
 from tools.synthetic import structured_mesh
 cell = sys.argv[1]
-m = structured_mesh("triangle", (1291, 1291), 2, distort=0.2, seed=0) if cell == "tri" else structured_mesh("tetrahedron", (75,) * 3, 2, distort=0.2, seed=0)
+m = (structured_mesh("triangle", (1291, 1291), 2, distort=0.2, seed=0) if cell == "tri" else structured_mesh("tetrahedron", (75,) * 3, 2, distort=0.2, seed=0) if cell == "tet"
+     else structured_mesh("hexahedron", (108,) * 3, 1, distort=0.2, seed=0))      # hex1: Q1 hexahedra
 dev = torch.device("cuda:0"); G = m.gdim; d = 4 if G == 2 else 6
 npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
 g = torch.Generator(device=dev); g.manual_seed(1)

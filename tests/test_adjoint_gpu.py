@@ -337,8 +337,9 @@ def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree,
     calls = {"force": lambda o: dm.adjoint("eps", 3, S.data_ptr(), o.data_ptr()),
              "apply": lambda o: dm.tangent_apply(CT.data_ptr(), v.data_ptr(), o.data_ptr()),
              "apply_vm": lambda o: dm.tangent_apply_vm(prm, S.data_ptr(), dpv.data_ptr(), v.data_ptr(), o.data_ptr())}
-    if degree == 2:      # the diagonal's 48-row product (two passes of c8m_contract against the tables of c8m_fill_A2), state-based form
-        calls["diag_vm"] = lambda o: dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), o.data_ptr())
+    # the diagonal's 48-row product (two passes of c8m_contract against the tables of c8m_fill_A2), state-based form; Q1: the same kernels with 8 nodes
+    calls["diag_vm"] = lambda o: dm.tangent_diagonal_vm(prm, S.data_ptr(), dpv.data_ptr(), o.data_ptr())
+    if degree == 2:
         calls["diag"] = lambda o: dm.tangent_diagonal(CT.data_ptr(), o.data_ptr())        # 66 KB of LDS per workgroup: the raised launch limit
     assert ctx.get_option("adjoint_mfma") == 1
     saved = ctx.get_option("adjoint_atomics")
