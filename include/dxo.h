@@ -462,7 +462,9 @@ int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* 
  * force (kind EPS_MANDEL) uses on the standard elements. On hexahedra with the 2x2x2 rule (8 or 27 nodes) the element vectors
  * f_a = sum_q dphi_a(xi_q) . T_q of a wave's 8 cells are formed on the fp64 matrix pipe, [32 x 24] x [24 x 24] as 24
  * v_mfma_f64_16x16x4_f64 (option "adjoint_mfma", default 1; 0 = the round-4 DPP reduce-scatter over a cell's 8 lanes; both are
- * bit-reproducible, they differ from each other in the last bits: a different order of the 8-point sum).
+ * bit-reproducible, they differ from each other in the last bits: a different order of the 8-point sum). The state-based forms
+ * (dxo_tangent_apply_vm, dxo_tangent_diagonal_vm) do the same on P2 triangles with the 3-point rule and P2 tetrahedra with the
+ * 4-point rule (6 / 9 instructions per wave group; 0 = the lane = (cell, node) loop over tensors parked in LDS).
  * C_tang of dxo_tangent_apply / dxo_tangent_diagonal must be 16-byte aligned (the operator kernels' outputs are).
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
