@@ -194,14 +194,14 @@ def _attach_fp64(out, leg, bs):
     rec = json.loads(f.read_text())
     if rec.get("points", {}).get(leg) != out["points"]:
         return
-    g = "3, 27, 8" if bs == 3 else "2, 0, 0"
-    gd = "3, 27" if bs == 3 else "2, 0"
-    keys = {("calls", "von_mises_field_state"): f"vm_field<{bs},*, 0>", ("calls", "tangent_apply"): f"tangent_apply<{g}, false*>",
-            ("calls", "tangent_diagonal"): f"tangent_diag<{gd}, false*>",
+    g = "3, 27, 8" if bs == 3 else "2, *"        # triangles: generic kernels <2, 0, 0, ..> or the matrix-pipe instantiation <2, 6, 3, ..>
+    gd = "3, 27" if bs == 3 else "2, *"
+    keys = {("calls", "von_mises_field_state"): f"vm_field<{bs},*, 0>", ("calls", "tangent_apply"): f"tangent_apply<{g}, false, *>",
+            ("calls", "tangent_diagonal"): f"tangent_diag<{gd}, false, *>",
             ("calls", "internal_force"): "operand_adjoint_c8" if bs == 3 else "adjoint_cell_eps<2,",
             ("without_tangent_array", "calls", "von_mises_field_state_no_tangent"): f"vm_field<{bs},*, 1>",
-            ("without_tangent_array", "calls", "tangent_apply_vm"): f"tangent_apply<{g}, true*>",
-            ("without_tangent_array", "calls", "tangent_diagonal_vm"): f"tangent_diag<{gd}, true*>"}
+            ("without_tangent_array", "calls", "tangent_apply_vm"): f"tangent_apply<{g}, true, *>",
+            ("without_tangent_array", "calls", "tangent_diagonal_vm"): f"tangent_diag<{gd}, true, *>"}
     for path, key in keys.items():
         e = next((v for k, v in rec["fp64_issued"].items() if _name_has(key, k)), None)
         call = out

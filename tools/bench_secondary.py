@@ -630,12 +630,12 @@ TRAFFIC_KEYS = {
     ("device_loop_q2hex", ("calls", "state_commit", "roofline")): ("vm_commit(", "first_half"),
     ("device_loop_q2hex", ("without_tangent_array", "calls", "tangent_apply_vm", "roofline")): ("tangent_apply<3, 27, 8, true*>", "all"),
     ("device_loop_q2hex", ("without_tangent_array", "calls", "tangent_diagonal_vm", "roofline")): ("tangent_diag<3, 27, true*>", "all"),
-    ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_apply_vm", "roofline")): ("tangent_apply<2, 0, 0, true*>", "all"),
-    ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_diagonal_vm", "roofline")): ("tangent_diag<2, 0, true*>", "all"),
+    ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_apply_vm", "roofline")): ("tangent_apply<2, *, true, *>", "all"),
+    ("device_loop_p2tri", ("without_tangent_array", "calls", "tangent_diagonal_vm", "roofline")): ("tangent_diag<2, *, true, *>", "all"),
     ("device_loop_p2tri", ("calls", "von_mises_field_state", "roofline")): ("vm_field<2,*, 0>(", "all"),
     ("device_loop_p2tri", ("calls", "internal_force", "roofline")): ("adjoint_cell_eps<2,", "all"),
-    ("device_loop_p2tri", ("calls", "tangent_apply", "roofline")): ("tangent_apply<2, 0, 0, false*>", "all"),
-    ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2, 0, false*>", "all"),
+    ("device_loop_p2tri", ("calls", "tangent_apply", "roofline")): ("tangent_apply<2, *, false, *>", "all"),
+    ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2, *, false, *>", "all"),
     ("device_loop_p2tri", ("calls", "state_commit", "roofline")): ("vm_commit(", "second_half"),
     ("assign_cg", ("roofline",)): ("assign_owner(", "all"),
     ("assign_cg", ("plan", "roofline")): ("assign_apply<", "all"),
