@@ -59,4 +59,5 @@ fi
 python3 scripts/summarize_round.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt"
 find "$OUT" -name "*.db" -delete
 find "$OUT" -name "*_agent_info.csv" -delete
+find "$OUT" -name "*counter_collection.csv" -size +1M -exec gzip -f {} \;      # gpurun brings back at most 64 MiB; the summaries above are what profiles/ keeps
 du -sh "$OUT"
