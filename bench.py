@@ -113,7 +113,7 @@ def cpu_baseline(d, n_sample, budget_s=10.0):
     }
 
 
-def measure_traffic(n, d, timeout_s=150):
+def measure_traffic(n, d, timeout_s=90):
     """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only — MI355X_MICROARCH.md "HBM"), 3 timed
     steps each on the same workload (plain allocation: counters do not depend on placement). bytes = counter x 1024, and
@@ -132,7 +132,7 @@ def measure_traffic(n, d, timeout_s=150):
     for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         with tempfile.TemporaryDirectory(prefix="dxo_pmc_", dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "t", "--", sys.executable, str(pathlib.Path(__file__).resolve()),
-                   "--steps", "3", "--warmup", "1", "--nqp", str(n), "--d", str(d), "--placement", "0", "--no-cpu", "--no-probe", "--no-e2e",
+                   "--steps", "3", "--warmup", "1", "--batches", "1", "--nqp", str(n), "--d", str(d), "--placement", "0", "--no-cpu", "--no-probe", "--no-e2e",
                    "--no-secondary", "--no-traffic"]
             try:
                 res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, cwd=tmp)
@@ -259,7 +259,7 @@ def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=2):
     return res
 
 
-def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 20, steps=5):
+def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 20, steps=5, n_full=0, steps_full=0):
     """After the result line is out: the same split + exchange through the C ABI's own RCCL path (dxo_mgpu_create_rank /
     dxo_mgpu_von_mises, csrc/mgpu.hip) on a small batch, compared with torch.distributed's all-gather of the same
     blocks. Reported on stderr only; the result line is already out when it starts. A collective that does not come back
@@ -271,8 +271,8 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     done = threading.Event()
 
     def watchdog():
-        if not done.wait(120.0):
-            log(f"bench rank {rank}: library_gather_check did not finish in 120 s — leaving with exit code 3 (the result line is already out)")
+        if not done.wait(170.0):
+            log(f"bench rank {rank}: library_gather_check did not finish in 170 s — leaving with exit code 3 (the result line is already out)")
             os._exit(3)
 
     threading.Thread(target=watchdog, daemon=True).start()
@@ -314,6 +314,35 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
     same_forms = all(bool(torch.equal(out[k]["C"].view(torch.int64), out["compact"]["C"].view(torch.int64))) and
                      bool(torch.equal(out[k]["s"], out["compact"]["s"])) and bool(torch.equal(out[k]["dp"].view(torch.int64), out["compact"]["dp"].view(torch.int64)))
                      for k in ("direct", "pipelined"))
+    # the same forms at the bench's own size (what `config.gather_modes` reports for the torch.distributed side): K steps each,
+    # one set of full-length arrays; times are this rank's, rank 0 reports the maximum over ranks
+    full_size = None
+    if n_full > 0 and steps_full > 0:
+        del C, s, dp
+        for v in out.values():
+            v.pop("C"), v.pop("s"), v.pop("dp")
+        torch.cuda.empty_cache()
+        g.manual_seed(100 + rank)
+        deps = torch.empty(n_full, d, dtype=torch.float64, device=device).normal_(0.0, 3e-3, generator=g)
+        sigma_n = torch.empty(n_full, d, dtype=torch.float64, device=device).normal_(0.0, 100.0, generator=g)
+        p = torch.empty(n_full, dtype=torch.float64, device=device).normal_(0.0, 1e-3, generator=g).abs_()
+        C = torch.empty(world * n_full * d * d, dtype=torch.float64, device=device)
+        s = torch.empty(world * n_full * d, dtype=torch.float64, device=device)
+        dp = torch.empty(world * n_full, dtype=torch.float64, device=device)
+        times = []
+        names = (("compact", GATHER_COMPACT), ("direct", GATHER_COMPACT_DIRECT), ("pipelined", GATHER_COMPACT_PIPELINED), ("full", GATHER_FULL))
+        for name, mode in names:
+            mg.von_mises(prm, d, n_full, mode, [deps], [sigma_n], [p], [C], [s], [dp])
+            mg.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps_full):
+                mg.von_mises(prm, d, n_full, mode, [deps], [sigma_n], [p], [C], [s], [dp])
+            mg.synchronize()
+            times.append((time.perf_counter() - t0) / steps_full * 1e3)
+        tt = torch.tensor(times, dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        full_size = {"points_per_rank": n_full, "steps": steps_full, **{name: float(tt[i]) for i, (name, _) in enumerate(names)}}
     mg.close()
     done.set()
     ok = err_s == 0.0 and err_cs == 0.0 and err_C < 1e-13 and identical and same_forms
@@ -321,7 +350,8 @@ def library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n=1 << 2
            "full_ms_per_step": out["full"]["ms_per_step"], "compact_ms_per_step": out["compact"]["ms_per_step"],
            "direct_ms_per_step": out["direct"]["ms_per_step"], "overlap_ms_per_step": out["pipelined"]["ms_per_step"],
            "sigma_vs_torch_all_gather_max_abs": err_s, "compact_vs_full_tangent_max_rel": err_C,
-           "compact_replicas_bit_identical": identical, "direct_and_pipelined_equal_compact_bitwise": same_forms}
+           "compact_replicas_bit_identical": identical, "direct_and_pipelined_equal_compact_bitwise": same_forms,
+           "library_full_size_ms_per_step": full_size}
     log(json.dumps(rec))
     return rec
 
@@ -361,6 +391,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batches", type=int, default=5,
+                    help="timed batches of --steps steps each, every batch between its own fences; value / ms_per_step are the median batch's "
+                         "(SURVEY.md 8d timing protocol)")
     ap.add_argument("--nqp", type=int, default=0,
                     help="quadrature points per GPU; default 10^7 at --gpus 1 (north_star's target size) and 1.25*10^7 at "
                          "--gpus N > 1 (BASELINE config 3: 10^8 points over 8 GPUs)")
@@ -382,7 +415,9 @@ def main():
                     help="skip the dxo_mgpu_* (RCCL inside libdxo_hip.so) cross-check that runs after the result line at N > 1")
     ap.add_argument("--gather-vmm", type=int, default=0,
                     help="1: let the gathered (RCCL send / receive) arrays live in a virtual range backed by 2 MB chunks too "
-                         "(experiment; default 0 = hipMalloc candidates only, see the comment at placement_vmm below)")
+                         "(experiment; default 0 = hipMalloc candidates only, see the comment at placement_vmm below); sets "
+                         "DXO_ALLOW_VMM_COLLECTIVE=1 on every rank, without which sharding.py refuses such buffers; libdxo's own "
+                         "forms (the cross-check after the line) refuse them always")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
@@ -405,6 +440,11 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.gather_vmm:
+        # the experiment this flag names hands chunk-backed arena blocks to the collectives, which sharding.py refuses by default
+        # (set here, before anything is imported, and inherited by the ranks a parent launches); libdxo's own forms refuse such
+        # buffers regardless (DXO_E_MEM), so the library cross-check after the line reports an error in this configuration
+        os.environ["DXO_ALLOW_VMM_COLLECTIVE"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -503,6 +543,8 @@ def main():
     sigma = sigma_full[own * n * d:(own + 1) * n * d]
     dp = dp_full[own * n:(own + 1) * n]
 
+    plain_GBps = factory_GBps = factory_fresh_GBps = None      # side figures, filled in after the timed batches
+
     def bytes_per_launch_of(d_, n_):
         return BYTES_PER_QP[d_] * n_
 
@@ -517,38 +559,7 @@ def main():
         torch.cuda.synchronize(device)
         return BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / launches * 1e-3) / 1e9
 
-    plain_GBps = None
-    if rank == 0 and not gather_on:
-        plain = torch.empty(n * per_pt, dtype=torch.float64, device=device)   # what an un-placed allocation gives
-        plain_GBps = time_kernel((plain.data_ptr(), plain.data_ptr() + n * d * d * 8, plain.data_ptr() + n * (d * d + d) * 8), 12)
-        del plain
-        torch.cuda.empty_cache()
-
     ptrs = (deps.data_ptr(), sigma_n.data_ptr(), p.data_ptr(), C_tang.data_ptr(), sigma.data_ptr(), dp.data_ptr())
-
-    # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
-    # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
-    # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
-    factory_GBps, factory_fresh_GBps = None, None
-    if rank == 0 and not gather_on and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
-        from dolfinx_external_operator_amd import make_von_mises
-
-        deps3 = deps.view(n // args.nq, args.nq, d)
-        rates = []
-        for kw in ({"device_outputs": "arena"}, {}):
-            ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
-            f = ext((1,))
-            f(deps3)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(12):
-                f(deps3)
-            e1.record(stream)
-            torch.cuda.synchronize(device)
-            rates.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
-            del ext, f
-            torch.cuda.empty_cache()
-        factory_GBps, factory_fresh_GBps = rates
 
     def expand(s_view, dp_view, C_view, npts):
         ctx.vm_expand_tangent(prm, d, npts, MEM_DEVICE, s_view.data_ptr(), dp_view.data_ptr(), C_view.data_ptr())
@@ -562,38 +573,8 @@ def main():
     ptrs_state_only = (*ptrs[:3], None, ptrs[4], ptrs[5])
     rebuild = dict(identical=True, clear_marks=clear_marks)
 
-    # libdxo's own exchange forms (dxo_mgpu_von_mises with RCCL inside the library: what a C / MPI caller gets), timed beside the
-    # torch.distributed ones whenever there is a real communicator (not in the gloo dry run)
-    LIB_MODES = {}
-    mg = None
-    if gather_on and dist_on and not args.dry_collective and not args.no_library_gather:
-        from dolfinx_external_operator_amd import GATHER_COMPACT, GATHER_COMPACT_DIRECT, GATHER_COMPACT_PIPELINED, MultiGpu
-
-        LIB_MODES = {"library_compact": GATHER_COMPACT, "library_direct": GATHER_COMPACT_DIRECT, "library_pipelined": GATHER_COMPACT_PIPELINED}
-
-    def library_communicator():
-        """libdxo's own RCCL communicator, created AFTER the headline has been timed (inside the comparison loop's try / watchdog): a
-        failure or a hang here costs the library modes, never the line."""
-        nonlocal mg
-        if mg is None:
-            uid = [MultiGpu.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            mg = MultiGpu.from_rank(ctx, uid[0], rank, world)
-        return mg
-
     def make_step(mode):
         compact = gather_on and mode.startswith("compact")
-        if mode in LIB_MODES:
-            library_communicator()
-
-            def lib_step(ev=None, g_=LIB_MODES[mode]):
-                if ev is not None:
-                    ev[0].record(stream)
-                mg.von_mises(prm, d, n, g_, [deps], [sigma_n], [p], [C_full], [sigma_full], [dp_full])
-                if ev is not None:
-                    ev[1].record(stream)
-            return lib_step
-
         def step(ev=None):
             if ev is not None:
                 ev[0].record(stream)
@@ -629,18 +610,68 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(W):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    fence()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(events[k])
-    fence()
-    elapsed = time.perf_counter() - t0
+    # Timing protocol: W warm-up steps, then B batches of EXACTLY K steps, each batch between its own
+    # pair of fences (synchronize + barrier + synchronize); `value` / `ms_per_step` are the MEDIAN batch's (under torch.distributed
+    # every batch time is first reduced with MAX over ranks). Every launch sits between two HIP events on the launch stream, so a
+    # batch whose wall time and kernel time disagree shows where the time went: `step_gap_us_max` is the largest interval between
+    # the end of one step's launch and the start of the next one's. Nothing is allocated or freed between warm-up and the last batch,
+    # Python's collector is off, and the events already exist (an event is created by its first record).
+    B = max(1, args.batches)
+    import gc
 
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    def run_batches(step_fn, warm):
+        """`warm` untimed steps, then B batches of K steps; returns this rank's batch wall times, the mean kernel-event time of every
+        batch and the step gaps (microseconds) of every batch."""
+        for _ in range(warm):
+            step_fn()
+        evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] for _ in range(B)]
+        for batch in evs:
+            for e_pair in batch:
+                e_pair[0].record(stream)
+                e_pair[1].record(stream)
+        gc.collect()
+        gc.disable()
+        try:
+            walls = []
+            for b_ in range(B):
+                fence()
+                t0 = time.perf_counter()
+                for k in range(K):
+                    step_fn(evs[b_][k])
+                fence()
+                walls.append(time.perf_counter() - t0)
+        finally:
+            gc.enable()
+        kern = [sum(a.elapsed_time(e) for a, e in batch) / K for batch in evs]
+        gaps = [[batch[k][1].elapsed_time(batch[k + 1][0]) * 1e3 for k in range(K - 1)] for batch in evs]
+        return walls, kern, gaps
+
+    def batch_record(walls, kern, gaps):
+        """The median batch and what the line says about all of them (walls: already the maximum over ranks under torch.distributed)."""
+        b_med = sorted(range(B), key=lambda b_: walls[b_])[B // 2]
+        gap_max = max(((g, b_, k) for b_, row in enumerate(gaps) for k, g in enumerate(row)), default=(0.0, 0, 0))
+        return b_med, {
+            "batches": B, "median_batch": b_med,
+            "ms_per_step_batches": [t / K * 1e3 for t in walls],
+            "kernel_ms_batches": kern,
+            "step_gap_us_max": gap_max[0], "step_gap_us_max_at": {"batch": gap_max[1], "after_step": gap_max[2]},
+            "step_gap_us_median": statistics.median([g for row in gaps for g in row]) if K > 1 else 0.0,
+            "step_gap_meaning": ("interval between the end of one step's kernel and the start of the next step's, from the launch stream's own events"
+                                 + (" (with the gather on it contains the exchange)" if gather_on else "")),
+        }
+
+    def reduce_walls(walls):
+        if not dist_on:     # one batch time for the job = the slowest rank's
+            return list(walls)
+        tb = torch.tensor(walls, dtype=torch.float64, device=device)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        return [float(x) for x in tb]
+
+    walls, kernel_ms_batches, step_gaps_us = run_batches(step, W)
+    walls = reduce_walls(walls)
+    b_med, batch_stats = batch_record(walls, kernel_ms_batches, step_gaps_us)
+    elapsed = walls[b_med]
+    kernel_ms_avg = kernel_ms_batches[b_med]
     if gather_on:
         # in the compact forms the step's own launch is the (sigma, dp)-only kernel; `roofline` and `kernel_only_value` are
         # about the FULL kernel (448 B/point), so with a gather on it is timed here, K launches back to back into this
@@ -648,7 +679,7 @@ def main():
         kernel_ms_avg = bytes_per_launch_of(d, n) / time_kernel(ptrs[3:], K) / 1e6
     total_points = n * world
     bytes_per_launch = BYTES_PER_QP[d] * n
-    MODES = ("compact", "compact_pipelined", "compact_direct", "full", *LIB_MODES)
+    MODES = ("compact", "compact_pipelined", "compact_direct", "full")
     emitted = threading.Lock()
     last_result = {}
 
@@ -663,10 +694,10 @@ def main():
         except OSError as exc:
             log(f"bench: bench_full.json not written: {exc!r}")
 
-    def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True, degraded=False, mode=None):
+    def emit_result(elapsed_, kernel_ms_, other_, probe_GBps=None, note=None, extras=True, degraded=False, mode=None, stats=None):
         """Rank 0: build the result and write its line to the real stdout. With one GPU the line is written THREE times, each a
         complete contract line and each a superset of the one before: (1) `headline` as soon as the timed region is over,
-        (2) `headline+cpu+traffic` once the CPU port and the live HBM-counter passes are in, (3) `final` = the same with one
+        (2) `headline+cpu`, then `headline+cpu+traffic` once the CPU port / the live HBM-counter passes are in, (3) `final` = the same with one
         short record per end_to_end / secondary leg. A reader takes the last line; a run cut short still leaves a valid one."""
         if rank != 0 or not emitted.acquire(blocking=False):
             return
@@ -676,6 +707,10 @@ def main():
             "metric": "quadrature-points/sec (von Mises return-map + tangent)",
             "value": total_points * K / elapsed_, "unit": "qp/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed_ / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "timing": {"protocol": f"{W} warm-up steps, then {B} batches of {K} steps, each batch between its own fences (synchronize + barrier); "
+                                   "value and ms_per_step are the median batch's (max over ranks per batch); HIP events around every launch",
+                       **{k: v for k, v in (stats or {}).items() if k not in ("batches", "ms_per_step_batches", "kernel_ms_batches", "step_gap_us_max")}},
+            **{k: (stats or {}).get(k) for k in ("batches", "ms_per_step_batches", "kernel_ms_batches", "step_gap_us_max")},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             **({"dry_collective": "NOT A MEASUREMENT: all ranks on one GPU, gloo collectives (logic check of the N > 1 path)"}
                if args.dry_collective else {}),
@@ -693,7 +728,8 @@ def main():
                 "gather": f"rccl_all_gather_{mode}" if gather_on else "none",
                 "gather_mode_selection": ("auto: the fastest of the timed modes is the headline" if auto_mode else "fixed by --gather-mode") if gather_on else None,
                 "gather_modes": ({m: {"value": total_points * K / t_m, "ms_per_step": t_m / K * 1e3,
-                                      "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1)}
+                                      "link_bytes_per_qp": 8 * per_pt if m == "full" else 8 * (d + 1),
+                                      **({"ms_per_step_batches": other_stats[m]["ms_per_step_batches"]} if m in other_stats else {})}
                                   for m, t_m in {mode: elapsed_, **other_}.items()} if gather_on else None),
                 "gather_modes_meaning": ({"full": "north_star's plain RCCL all-gather of all three output arrays",
                                           "compact": "kernel writes (sigma, dp) only; all-gather of (sigma, dp); every rank rebuilds EVERY block's "
@@ -702,8 +738,9 @@ def main():
                                           "compact_pipelined": "compact in 4 pieces, rebuild overlapped with the link traffic",
                                           "compact_direct": "compact with (sigma, dp) exchanged as ONE batch of point-to-point sends / receives "
                                                             "(every block on its own xGMI link at once) instead of the library's all-gather",
-                                          "library_*": "the same three compact forms through libdxo's own RCCL path (dxo_mgpu_von_mises with "
-                                                       "DXO_GATHER_COMPACT / _COMPACT_DIRECT / _COMPACT_PIPELINED): what a C / MPI caller gets"}
+                                          "library forms": "libdxo's own RCCL path (dxo_mgpu_von_mises, what a C / MPI caller gets) is timed at this "
+                                                           "size AFTER this line is out and reported under gather_check.library_full_size_ms_per_step; "
+                                                           "it is never the headline"}
                                          if gather_on else None),
                 "rccl_ranks": world if dist_on else 0,
                 "collective_backend": (dist.get_backend() if dist_on else None),
@@ -742,28 +779,20 @@ def main():
             write_line(result, "final")
             return
         write_line(result, "headline")      # (1) the contract line exists from here on
-        # the live HBM-counter passes (two child runs of this script under rocprofv3 --pmc: GPU work of OTHER processes, counters
-        # only, nothing timed) run beside the CPU port's timed passes (host cores only) — neither measures what the other uses
-        traffic_box = {}
-
-        def _traffic():
-            try:
-                traffic_box["r"] = measure_traffic(n, d)
-            except Exception as exc:   # noqa: BLE001 — a side leg must never cost the line
-                traffic_box["r"] = (None, repr(exc))
-
-        tt = None
-        if not args.no_traffic:
-            tt = threading.Thread(target=_traffic, daemon=True)
-            tt.start()
+        # first the CPU port's timed passes (host cores only, nothing else of this run active), THEN the live HBM-counter passes (two
+        # child runs of this script under rocprofv3 --pmc: Python + torch imports, input generation — they would take cores and memory
+        # bandwidth from the CPU figure if they ran beside it)
         if not args.no_cpu:
             try:
                 result["cpu_baseline"] = cpu_baseline(d, 2_000_000, budget_s=args.cpu_budget)
             except Exception as exc:   # noqa: BLE001
                 log(f"bench: cpu_baseline failed: {exc!r}")
-        if tt is not None:
-            tt.join(200.0)
-            traffic, traffic_detail = traffic_box.get("r", (None, "counter passes did not come back in time"))
+            write_line(result, "headline+cpu")
+        if not args.no_traffic:
+            try:
+                traffic, traffic_detail = measure_traffic(n, d)      # each child under its own timeout; nothing runs on after it
+            except Exception as exc:   # noqa: BLE001 — a side leg must never cost the line
+                traffic, traffic_detail = None, repr(exc)
             result["roofline"].update(traffic=traffic, traffic_detail=traffic_detail,
                                       traffic_over_algorithmic=(traffic / bytes_per_launch) if traffic else None)
         write_line(result, "headline+cpu+traffic")      # (2)
@@ -804,16 +833,16 @@ def main():
     # prints the line with the headline mode alone, from its own clock, marked `"degraded": true`, and every rank leaves
     # with exit code 3: a process that has touched the GPU and gives up on a hung collective must not report success.
     compare_done = threading.Event()
+    other_elapsed, other_stats = {}, {}
     if gather_on and world > 1:
-        def _compare_watchdog(elapsed_=elapsed, kernel_ms_=kernel_ms_avg, mode_=args.gather_mode):
+        def _compare_watchdog(elapsed_=elapsed, kernel_ms_=kernel_ms_avg, mode_=args.gather_mode, stats_=batch_stats):
             # headline time and mode captured by value before the comparison loop (the main thread reassigns them later)
             if not compare_done.wait(300.0):
                 log(f"bench rank {rank}: the comparison gather modes did not come back in 300 s — reporting the headline mode alone, exit code 3")
-                emit_result(elapsed_, kernel_ms_, {}, note="comparison gather modes abandoned after 300 s; value and kernel time are rank 0's "
-                                                            "own (not the maximum over ranks)", extras=False, degraded=True, mode=mode_)
+                emit_result(elapsed_, kernel_ms_, {}, note="comparison gather modes abandoned after 300 s", extras=False, degraded=True, mode=mode_,
+                            stats=stats_)
                 os._exit(3)
         threading.Thread(target=_compare_watchdog, daemon=True).start()
-    other_elapsed = {}
     if gather_on:
         if world > 1:   # remote tangents rebuilt from (sigma, dp) must be usable: finite and symmetric
             nb = (rank + 1) % world
@@ -821,39 +850,32 @@ def main():
             if not bool(torch.isfinite(chk).all()) or float((chk - chk.transpose(1, 2)).abs().max()) > 1e-9 * E:
                 raise SystemExit("bench: gathered/rebuilt remote C_tang block is not a finite symmetric tangent")
         sums = (float(sigma_full.sum()), float(dp_full.sum()))      # every mode must leave the same gathered arrays
+        # Every form is a sequence of torch.distributed collectives that all ranks enter alike: nothing below can fail on one rank
+        # and not on the others except the collective itself, and a raise out of a collective is FATAL (sharding.py) — there is no
+        # per-mode try: a rank that skipped a mode its peers had entered would leave them waiting in it. (libdxo's own RCCL forms,
+        # whose communicator bootstrap CAN fail locally, are timed after the result line is out: library_gather_check.)
         for mode in MODES:
             if mode == args.gather_mode:
                 continue
-            try:    # comparison figures only: they must never cost the headline line
-                step2 = make_step(mode)
-                for _ in range(min(W, 2)):
-                    step2()
-                fence()
-                t0 = time.perf_counter()
-                for k in range(K):
-                    step2()
-                fence()
-                if (float(sigma_full.sum()), float(dp_full.sum())) != sums:
-                    raise RuntimeError("gathered (sigma, dp) differ from the headline mode's")
-                other_elapsed[mode] = time.perf_counter() - t0
-            except Exception as exc:   # noqa: BLE001
-                log(f"bench: gather mode '{mode}' failed and is left out: {exc!r}")
+            w2, k2, g2 = run_batches(make_step(mode), min(W, 2))
+            if (float(sigma_full.sum()), float(dp_full.sum())) != sums:
+                raise SystemExit(f"bench: gather mode '{mode}' left different (sigma, dp) than the headline mode")
+            w2 = reduce_walls(w2)
+            bm, st = batch_record(w2, k2, g2)
+            other_elapsed[mode], other_stats[mode] = w2[bm], st
 
     if dist_on:
-        t = torch.tensor([elapsed, kernel_ms_avg] + [other_elapsed.get(m, 0.0) for m in MODES], dtype=torch.float64, device=device)
+        t = torch.tensor([kernel_ms_avg], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # a mode that failed on ANY rank is out: its time is only meaningful if every rank ran it
-        ok = torch.tensor([1.0 if m in other_elapsed or m == args.gather_mode else 0.0 for m in MODES], dtype=torch.float64, device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        elapsed, kernel_ms_avg_max = float(t[0]), float(t[1])
-        other_elapsed = {m: float(t[2 + i]) for i, m in enumerate(MODES) if m in other_elapsed and float(ok[i]) > 0.0}
+        kernel_ms_avg_max = float(t[0])
         if auto_mode and gather_on:
             # the reduced times are identical on every rank, so every rank picks the same headline
-            best = min({args.gather_mode: elapsed, **{m: v for m, v in other_elapsed.items() if v > 0.0}}.items(), key=lambda kv: kv[1])
+            best = min({args.gather_mode: elapsed, **other_elapsed}.items(), key=lambda kv: kv[1])
             if best[0] != args.gather_mode:
-                other_elapsed[args.gather_mode] = elapsed
+                other_elapsed[args.gather_mode], other_stats[args.gather_mode] = elapsed, batch_stats
                 args.gather_mode, elapsed = best
                 del other_elapsed[args.gather_mode]
+                batch_stats = other_stats.pop(args.gather_mode)
     else:
         kernel_ms_avg_max = kernel_ms_avg
     compare_done.set()
@@ -871,6 +893,37 @@ def main():
             raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
         if not bool(torch.isfinite(C_tang[lo * d * d:(lo + 4096) * d * d]).all()):
             raise SystemExit("bench: non-finite tangent in the kernel output — refusing to report a number")
+
+    # side figures (never `value`), measured AFTER the timed batches so that their allocations and frees cannot disturb them
+    if rank == 0 and not gather_on:
+        plain = torch.empty(n * per_pt, dtype=torch.float64, device=device)   # what an un-placed allocation gives
+        plain_GBps = time_kernel((plain.data_ptr(), plain.data_ptr() + n * d * d * 8, plain.data_ptr() + n * (d * d + d) * 8), 12)
+        del plain
+        torch.cuda.empty_cache()
+
+    # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
+    # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
+    # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
+    if rank == 0 and not gather_on and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
+        from dolfinx_external_operator_amd import make_von_mises
+
+        deps3 = deps.view(n // args.nq, args.nq, d)
+        rates = []
+        for kw in ({"device_outputs": "arena"}, {}):
+            ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
+            f = ext((1,))
+            f(deps3)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(12):
+                f(deps3)
+            e1.record(stream)
+            torch.cuda.synchronize(device)
+            rates.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
+            del ext, f
+            torch.cuda.empty_cache()
+        factory_GBps, factory_fresh_GBps = rates
+
 
     # stream probe: a no-arithmetic kernel moving the same read:write mix (13 : 43 sixteen-byte rows per tile) from the
     # input slab into the SAME output block, persistent grid of 16 workgroups per CU. A reference point beside the
@@ -896,7 +949,7 @@ def main():
         if world == 1 and not args.no_e2e:
             del C_tang, sigma, dp, C_full, sigma_full, dp_full, in_slab, deps, sigma_n, p
             torch.cuda.empty_cache()
-        emit_result(elapsed, kernel_ms_avg_max, other_elapsed, probe_GBps)
+        emit_result(elapsed, kernel_ms_avg_max, other_elapsed, probe_GBps, stats=batch_stats)
     if dist_on:
         # the result line is out; whatever is still running 180 s from now (a collective of the cross-check or the final
         # barrier that does not come back) is abandoned — with exit code 3, so that a hang is never recorded as success
@@ -910,13 +963,11 @@ def main():
         try:    # evidence for dxo_mgpu_* with more than one rank; stderr only, after the result line
             C_tang = sigma = dp = C_full = sigma_full = dp_full = None
             torch.cuda.empty_cache()
-            rec = library_gather_check(torch, dist, ctx, prm, d, rank, world, device)
+            rec = library_gather_check(torch, dist, ctx, prm, d, rank, world, device, n_full=n if gather_on else 0, steps_full=K)
             emit_gather_check({"status": rec["library_gather_check"], **{k: v for k, v in rec.items() if k not in ("library_gather_check", "rank")}})
         except Exception as exc:   # noqa: BLE001
             log(f"bench rank {rank}: library_gather_check failed: {exc!r}")
             emit_gather_check({"status": "error", "why": repr(exc)})
-    if mg is not None:
-        mg.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -96,6 +96,28 @@ def test_n_gt_1_record_with_gather_modes_and_check():
     assert rec["gather_check"]["status"] == "ok" and len(rec["gather_check"]["why"]) <= 120
 
 
+def test_batch_timing_keys_reach_the_line():
+    """SURVEY 8d's protocol (median of 5 batches): the per-batch step and kernel times and the largest step gap are on the line."""
+    full = canned()
+    full.update(batches=5, ms_per_step_batches=[0.7251234567, 0.7249, 0.8181, 0.7253, 0.7250], kernel_ms_batches=[0.7181234567, 0.718, 0.7179, 0.7182, 0.718],
+                step_gap_us_max=1934.56789,
+                timing={"protocol": "p" * 500, "median_batch": 0, "step_gap_us_max_at": {"batch": 2, "after_step": 7}, "step_gap_us_median": 5.9,
+                        "step_gap_meaning": "m" * 300})
+    for stage in ("headline", "headline+cpu", "headline+cpu+traffic", "final"):
+        line = compact_line(full, stage)
+        assert len(line) < LINE_BUDGET
+        rec = json.loads(line)
+        assert rec["batches"] == 5 and len(rec["ms_per_step_batches"]) == 5 and len(rec["kernel_ms_batches"]) == 5
+        assert abs(rec["ms_per_step_batches"][2] - 0.8181) < 1e-9 and abs(rec["step_gap_us_max"] - 1934.6) < 0.1
+        assert rec["timing"]["median_batch"] == 0 and rec["timing"]["step_gap_us_max_at"] == {"batch": 2, "after_step": 7}
+        assert len(rec["timing"]["protocol"]) < 200 and "step_gap_meaning" not in rec["timing"]
+    # the inflated record keeps them too: they are never among the parts dropped to fit the budget
+    for i in range(40):
+        full["secondary"][f"extra_leg_{i}"] = copy.deepcopy(full["secondary"]["device_loop_q2hex"])
+    rec = json.loads(compact_line(full))
+    assert rec.get("truncated") is True and len(rec["ms_per_step_batches"]) == 5 and "step_gap_us_max" in rec
+
+
 def test_compact_record_is_plain_json_types():
     rec = compact_record(canned())
     json.loads(json.dumps(rec, allow_nan=False))      # no NaN / Infinity tokens a strict parser would refuse

@@ -5,7 +5,7 @@ rates) and the driver could not read it back. The contract line is now a bounded
 
     compact_line(full)  ->  one JSON line, <= LINE_BUDGET bytes (asserted), carrying the contract keys (metric, value, unit,
                             n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config with
-                            `workload`, roofline, cpu_baseline) plus one short record per secondary leg.
+                            `workload`, roofline, cpu_baseline) the `timing` block (per-batch step and kernel times, largest step gap) plus one short record per secondary leg.
 
 The full record goes to `bench_full.json` beside bench.py and to stderr (bench.py does that); nothing here touches the GPU
 or imports torch, so tests/test_bench_line.py builds the line from canned records on the CPU.
@@ -149,6 +149,21 @@ def compact_record(full, stage="final"):
         if cfg.get("mode_status"):
             c["mode_status"] = {m: ("timed" if s == "timed" else "failed") for m, s in cfg["mode_status"].items()}
     out["config"] = c
+    # the timing protocol's evidence: every batch's step time and kernel-event time, the largest gap between two launches
+    if full.get("batches") is not None:
+        out["batches"] = full["batches"]
+    for k in ("ms_per_step_batches", "kernel_ms_batches"):
+        if isinstance(full.get(k), list):
+            out[k] = [_r(float(x), 6) for x in full[k]]
+    if full.get("step_gap_us_max") is not None:
+        out["step_gap_us_max"] = _r(float(full["step_gap_us_max"]), 5)
+    tm = full.get("timing")
+    if isinstance(tm, dict):
+        t = _pick(tm, ("median_batch", "step_gap_us_median"), 5)
+        if isinstance(tm.get("step_gap_us_max_at"), dict):
+            t["step_gap_us_max_at"] = tm["step_gap_us_max_at"]
+        t["protocol"] = "warm-up, then `batches` batches of `steps` steps, each between fences; value and ms_per_step = the median batch"
+        out["timing"] = t
     roof = full.get("roofline") or {}
     r = {k: (roof[k] if k in ("bound", "unit", "kernel", "achieved", "frac", "kernel_ms_avg") else _r(roof[k], 7))
          for k in _ROOF_KEYS if k in roof}
@@ -181,7 +196,8 @@ def compact_record(full, stage="final"):
     if isinstance(gc, dict):
         out["gather_check"] = {k: (v if not isinstance(v, str) else v[:120]) for k, v in gc.items()
                                if k in ("status", "why", "rccl_ranks_in_libdxo", "full_ms_per_step", "compact_ms_per_step",
-                                        "direct_ms_per_step", "overlap_ms_per_step", "compact_replicas_bit_identical")}
+                                        "direct_ms_per_step", "overlap_ms_per_step", "compact_replicas_bit_identical",
+                                        "library_full_size_ms_per_step")}
     out["line"] = stage
     out["full_record"] = "bench_full.json (beside bench.py) and stderr"
     return _finite(out)
