@@ -543,7 +543,7 @@ def main():
     sigma = sigma_full[own * n * d:(own + 1) * n * d]
     dp = dp_full[own * n:(own + 1) * n]
 
-    plain_GBps = factory_GBps = factory_fresh_GBps = None      # side figures, filled in after the timed batches
+    plain_GBps = factory_GBps = factory_fresh_GBps = factory_placement = None      # side figures, filled in after the timed batches
 
     def bytes_per_launch_of(d_, n_):
         return BYTES_PER_QP[d_] * n_
@@ -764,6 +764,7 @@ def main():
                 "achieved_plain_hipMalloc": plain_GBps,
                 "achieved_factory_device_call_arena_outputs": factory_GBps,
                 "achieved_factory_default_device_call": factory_fresh_GBps,
+                "factory_placement": factory_placement,
                 "stream_probe_GBps": probe_GBps,
             },
             "kernel_only_value": total_points / (kernel_ms_ * 1e-3),
@@ -912,7 +913,10 @@ def main():
         for kw in ({"device_outputs": "arena"}, {}):
             ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
             f = ext((1,))
-            f(deps3)
+            blk_ = getattr(f(deps3)[0], "dxo_block", None)
+            if blk_ is not None and kw:
+                factory_placement = {k: blk_.info.get(k) for k in ("mode", "candidates", "chosen_kind", "chosen_GBps", "rounds", "calibration_ms")}
+            del blk_
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             for _ in range(12):

@@ -67,7 +67,7 @@ class PlacementInfo(C.Structure):
     """dxo_placement_info — what dxo_output_alloc's calibration saw."""
     _fields_ = [("mode", C.c_int16), ("probe_kind", C.c_int16), ("candidates", C.c_int32), ("chosen", C.c_int32), ("vmm_mask", C.c_uint32),
                 ("probe_GBps", C.c_double * PLACEMENT_MAX), ("calibration_ms", C.c_double), ("chosen_GBps", C.c_double),
-                ("tuned_blocks_per_cu", C.c_int32), ("reserved_", C.c_int32)]
+                ("tuned_blocks_per_cu", C.c_int32), ("rounds", C.c_int32)]
 
 
 class DeviceInfo(C.Structure):
@@ -614,7 +614,7 @@ class Context:
                 "kinds": kinds, "probe": {0: "store_stream", 1: "six_stream_mix", 2: "vm_tile", 3: "caller"}.get(info.probe_kind, str(info.probe_kind)),
                 "tuned_blocks_per_cu": info.tuned_blocks_per_cu,
                 "probe_GBps": [round(info.probe_GBps[k], 1) for k in range(info.candidates)],
-                "chosen_GBps": round(info.chosen_GBps, 1), "calibration_ms": info.calibration_ms}
+                "chosen_GBps": round(info.chosen_GBps, 1), "calibration_ms": info.calibration_ms, "rounds": info.rounds}
 
     def output_tensors(self, sizes, dtype=None):
         """Flat torch CUDA tensors of `sizes` elements each (fp64 unless dtype is given), carved from ONE

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -96,6 +97,10 @@ struct dxo_ctx {
     int64_t placement_probe = 1;        // 1: rank candidates with the six-stream read + write sweep of the kernels, 0: one store stream
     int64_t placement_good_mix_GBps = 6250;   // early-exit rate of the six-stream sweep (algorithmic GB/s)
     int64_t placement_good_GBps = 6800; // stop searching at the first candidate whose write sweep reaches this
+    int64_t placement_rounds = 3;       // candidate searches per calibration at most (a rejected winner buys one more, arena.hip)
+    int64_t placement_accept_pct = 97;  // a winner below this share of the best rate ever kept for its (probe, size) class is rejected
+    int64_t placement_standout_pct = 106;   // without such a record: a winner below this share of its crowd's median is rejected once
+    std::map<int64_t, double> placement_best;   // (probe kind, size class) -> best rate a calibration of this context has kept
     std::vector<dxo_arena_block> arena;
     int64_t vm_mark_indeterminate = 0;  // DEVICE-path von Mises: dp = -0.0 at f_elastic == 0 exactly (the reference's 0/0, :318), for
                                         // consumers that rebuild the tangent from (sigma, dp); dxo_vm_clear_marks restores +0

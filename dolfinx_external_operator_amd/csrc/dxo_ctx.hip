@@ -160,6 +160,9 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "placement_min_bytes")) return &c->placement_min_bytes;
     if (!std::strcmp(key, "placement_good_GBps")) return &c->placement_good_GBps;
     if (!std::strcmp(key, "placement_vmm")) return &c->placement_vmm;
+    if (!std::strcmp(key, "placement_rounds")) return &c->placement_rounds;
+    if (!std::strcmp(key, "placement_accept_pct")) return &c->placement_accept_pct;
+    if (!std::strcmp(key, "placement_standout_pct")) return &c->placement_standout_pct;
     if (!std::strcmp(key, "placement_probe")) return &c->placement_probe;
     if (!std::strcmp(key, "placement_good_mix_GBps")) return &c->placement_good_mix_GBps;
     if (!std::strcmp(key, "host_threads")) return &c->host_threads;

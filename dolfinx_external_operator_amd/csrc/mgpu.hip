@@ -66,6 +66,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool is_mock = false;      // the library loaded is tests/mock_rccl (it exports mock_rccl_bytes_moved), not RCCL
     std::string why;
 };
 
@@ -97,6 +98,7 @@ Rccl* rccl() {
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.is_mock = dlsym(r.handle, "mock_rccl_bytes_moved") != nullptr;
     });
     return r.why.empty() ? &r : nullptr;
 }
@@ -120,8 +122,8 @@ int nccl_fail(dxo_mgpu* g, ncclResult_t r, const char* where) {
     } while (0)
 
 // HIP errors are positive hipError_t codes (as everywhere in the C ABI)
-int mg_hip_fail(dxo_mgpu* g, const char* what) {
-    const hipError_t e = hipGetLastError();
+int mg_hip_fail(dxo_mgpu* g, hipError_t e, const char* what) {
+    (void)hipGetLastError();      // clear the sticky copy; `e` is the failing call's own return value
     if (g) g->err = std::string(what) + ": " + hipGetErrorString(e) + " (hipError " + std::to_string((int)e) + ")";
     return (int)e > 0 ? (int)e : 999;
 }
@@ -186,14 +188,17 @@ int dxo_mgpu_create(const int* devices, int n_dev, dxo_mgpu** out) {
     for (int i = 0; i < n_dev; ++i) {
         devs[(size_t)i] = devices ? devices[i] : i;
         if (devs[(size_t)i] < 0 || devs[(size_t)i] >= count) return DXO_E_NODEVICE;
-        // one rank per physical device (RCCL refuses anything else). TEST HOOK: with DXO_MGPU_TEST_SHARE_DEVICE=1 in the environment
-        // several ranks may share a device — only a mock transport (tests/mock_rccl) can carry that; it lets the N > 1 data path run
-        // on a one-GPU box.
-        const char* share = std::getenv("DXO_MGPU_TEST_SHARE_DEVICE");
-        for (int j = 0; j < i; ++j)
-            if (devs[(size_t)j] == devs[(size_t)i] && !(share && share[0] == '1')) return DXO_E_SIZE;
     }
     if (!rccl()) return DXO_E_NODEVICE;
+    // one rank per physical device (RCCL refuses anything else). TEST HOOK: over the MOCK transport only (tests/mock_rccl, recognised by
+    // its marker symbol — never over RCCL, where a shared device would end in an ncclCommInit failure or a hang) and with
+    // DXO_MGPU_TEST_SHARE_DEVICE=1 in the environment, several ranks may share a device: the N > 1 data path on a one-GPU box.
+    const char* share = std::getenv("DXO_MGPU_TEST_SHARE_DEVICE");
+    const bool may_share = rccl()->is_mock && share && share[0] == '1';
+    for (int i = 0; i < n_dev; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i] && !may_share) return DXO_E_SIZE;
+    }
     dxo_mgpu* g = new dxo_mgpu();
     g->world = n_dev;
     g->comm.assign((size_t)n_dev, nullptr);
@@ -416,8 +421,14 @@ static int mg_pipeline_resources(dxo_mgpu* g, int chunks) {
     if (g->xstream.size() != L) {
         g->xstream.assign(L, nullptr);
         for (size_t i = 0; i < L; ++i) {
-            if (hipSetDevice(g->ctx[i]->device) != hipSuccess || hipStreamCreateWithFlags(&g->xstream[i], hipStreamNonBlocking) != hipSuccess) {
-                return mg_hip_fail(g, "dxo_mgpu: could not create the exchange stream");
+            hipError_t e = hipSetDevice(g->ctx[i]->device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->xstream[i], hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                // leave nothing half-made: a later call must create the streams again, never run the exchange on a null (legacy default) stream
+                for (size_t j = 0; j < i; ++j)
+                    if (g->xstream[j]) (void)hipStreamDestroy(g->xstream[j]);
+                g->xstream.clear();
+                return mg_hip_fail(g, e, "dxo_mgpu: could not create the exchange stream");
             }
         }
     }
@@ -428,11 +439,18 @@ static int mg_pipeline_resources(dxo_mgpu* g, int chunks) {
         g->ev_arrived.assign(L * (size_t)chunks, nullptr);
         for (size_t i = 0; i < L; ++i) {
             (void)hipSetDevice(g->ctx[i]->device);
-            for (int k = 0; k < chunks; ++k)
-                if (hipEventCreateWithFlags(&g->ev_kernel[i * chunks + k], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&g->ev_arrived[i * chunks + k], hipEventDisableTiming) != hipSuccess) {
-                    return mg_hip_fail(g, "dxo_mgpu: could not create the pipeline events");
+            for (int k = 0; k < chunks; ++k) {
+                hipError_t e = hipEventCreateWithFlags(&g->ev_kernel[i * chunks + k], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_arrived[i * chunks + k], hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    for (hipEvent_t ev : g->ev_kernel) if (ev) (void)hipEventDestroy(ev);
+                    for (hipEvent_t ev : g->ev_arrived) if (ev) (void)hipEventDestroy(ev);
+                    g->ev_kernel.clear();
+                    g->ev_arrived.clear();
+                    g->ev_chunks = 0;
+                    return mg_hip_fail(g, e, "dxo_mgpu: could not create the pipeline events");
                 }
+            }
         }
         g->ev_chunks = chunks;
     }
@@ -625,19 +643,17 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
             if (g->world == 1) continue;
             for (size_t i = 0; i < L; ++i) {
                 (void)hipSetDevice(g->ctx[i]->device);
-                if (hipEventRecord(g->ev_kernel[i * g->ev_chunks + k], dxo_launch_stream(g->ctx[i])) != hipSuccess ||
-                    hipStreamWaitEvent(g->xstream[i], g->ev_kernel[i * g->ev_chunks + k], 0) != hipSuccess) {
-                    return mg_hip_fail(g, "dxo_mgpu_von_mises: event record / wait failed");
-                }
+                hipError_t he = hipEventRecord(g->ev_kernel[i * g->ev_chunks + k], dxo_launch_stream(g->ctx[i]));
+                if (he == hipSuccess) he = hipStreamWaitEvent(g->xstream[i], g->ev_kernel[i * g->ev_chunks + k], 0);
+                if (he != hipSuccess) return mg_hip_fail(g, he, "dxo_mgpu_von_mises: event record / wait failed");
             }
             rc = mg_exchange_direct(g, (void* const*)sigma, sizeof(double) * (size_t)d, n, b, e - b, &g->xstream);
             if (rc == DXO_OK) rc = mg_exchange_direct(g, (void* const*)dp, sizeof(double), n, b, e - b, &g->xstream);
             if (rc != DXO_OK) return rc;
             for (size_t i = 0; i < L; ++i) {
                 (void)hipSetDevice(g->ctx[i]->device);
-                if (hipEventRecord(g->ev_arrived[i * g->ev_chunks + k], g->xstream[i]) != hipSuccess) {
-                    return mg_hip_fail(g, "dxo_mgpu_von_mises: event record failed");
-                }
+                const hipError_t he = hipEventRecord(g->ev_arrived[i * g->ev_chunks + k], g->xstream[i]);
+                if (he != hipSuccess) return mg_hip_fail(g, he, "dxo_mgpu_von_mises: event record failed");
             }
         }
         for (int k = 0; k < nk; ++k) {
@@ -645,9 +661,8 @@ int dxo_mgpu_von_mises(dxo_mgpu* g, const dxo_vm_params* prm, int d, int64_t n_p
             if (g->world > 1)
                 for (size_t i = 0; i < L; ++i) {
                     (void)hipSetDevice(g->ctx[i]->device);
-                    if (hipStreamWaitEvent(dxo_launch_stream(g->ctx[i]), g->ev_arrived[i * g->ev_chunks + k], 0) != hipSuccess) {
-                        return mg_hip_fail(g, "dxo_mgpu_von_mises: event wait failed");
-                    }
+                    const hipError_t he = hipStreamWaitEvent(dxo_launch_stream(g->ctx[i]), g->ev_arrived[i * g->ev_chunks + k], 0);
+                    if (he != hipSuccess) return mg_hip_fail(g, he, "dxo_mgpu_von_mises: event wait failed");
                 }
             rc = rebuild(b, e);
             if (rc != DXO_OK) return rc;

@@ -67,7 +67,10 @@ namespace {
 // still in registers (dxo_von_mises_residual; node_sum follows). No tangent is written in this form.
 // MODE 0: (C_tang, sigma, dp). MODE 1: (sigma, dp) only — its own instantiation, so that the profiler's kernel names tell the two
 // launches apart (the arithmetic of the stores that remain is the same). MODE 2: RES.
-template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, int MODE = 0>
+// does the instantiation (MODE, ND_CT) fetch the old state by global_load_lds when its slices fit? (host and device agree through this one function)
+constexpr bool vmf_dma_compiled(int mode, int nd_ct) { return DXO_VMF_DMA && !DXO_VMF_PRELOAD && !(mode == 0 && nd_ct == 27); }
+
+template <int G, bool NT, int ND_CT = 0, int NG_CT = 0, int MODE = 0, bool DMA_OK = true>
 __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE == 1 && G == 2) ? DXO_VMF_STATE2D_WAVES : (MODE == 1) ? DXO_VMF_STATE3D_WAVES : DXO_VMF_WAVES) void vm_field(VmConst c, OperandDev m, int wave_doubles, int64_t cell0,
                                                          int64_t n_cells, const double* __restrict__ u,
                                                          const double* __restrict__ sigma_n,
@@ -76,8 +79,9 @@ __global__ __launch_bounds__(DXO_BLOCK, MODE == 2 ? DXO_VMF_RES_WAVES : (MODE ==
                                                          const double* __restrict__ wq, double* __restrict__ fe) {
     constexpr bool RES = MODE == 2;
     // the stress tile by global_load_lds (DXO_VMF_DMA) — not in the one instantiation that sits exactly at its register budget (Q2 hexahedra with
-    // tangent: 168 registers; the two address pairs the copies need spill there and cost 2 %)
-    constexpr bool DMA = DXO_VMF_DMA && !DXO_VMF_PRELOAD && !(MODE == 0 && ND_CT == 27);
+    // tangent: 168 registers; the two address pairs the copies need spill there and cost 2 %), and not when the host found that the landing slices
+    // do not fit the workgroup's 64 KB beside the element's tables and gather regions (DMA_OK = false: e.g. Q2 hexahedra with a 27-point rule)
+    constexpr bool DMA = DMA_OK && vmf_dma_compiled(MODE, ND_CT);
     static_assert(!RES || (G == 3 && ND_CT > 0 && ND_CT <= C8_NODES && NG_CT == 8), "the residual form is the eight-point hexahedron's");
     constexpr int D = G == 2 ? 4 : 6;
     using T = VmTile<D>;
@@ -313,7 +317,19 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
 #endif
     if (wd < tile) wd = tile;
     wd = (wd + 1) & ~1;
-    const size_t shm = (size_t)(m.table_doubles + 4 * wd + (fe ? C8_LDS : 0) + (DXO_VMF_DMA ? 4 * DXO_WAVE * (D + 1) : 0)) * sizeof(double);
+    const int mode = fe ? 2 : (C_tang ? 0 : 1);
+    const bool q2hex = DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8;   // trip counts known at compile time
+    // the landing slices of the global_load_lds prefetch (4 waves x 64 x (D + 1) doubles: 14 KB at d = 6) are requested only by the
+    // instantiations that use them, and only when they fit beside the tables and the four gather regions; a larger element (Q2
+    // hexahedra with the 27-point rule: 57 KB without them) takes the same kernel with the loads in registers
+    const size_t base_doubles = (size_t)m.table_doubles + 4 * (size_t)wd + (fe ? C8_LDS : 0);
+    const size_t slice_doubles = 4 * (size_t)DXO_WAVE * (D + 1);
+    bool dma = vmf_dma_compiled(mode, (mode == 2 || q2hex) ? 27 : 0);
+    if (dma && (base_doubles + slice_doubles) * sizeof(double) > 64 * 1024) {
+        if (mode == 2 || q2hex) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");   // cannot happen: their sizes are fixed
+        dma = false;
+    }
+    const size_t shm = (base_doubles + (dma ? slice_doubles : 0)) * sizeof(double);
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");
     const int64_t n_groups = (n_cells + m.cells_per_wave - 1) / m.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
@@ -326,19 +342,27 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
         hipLaunchKernelGGL((vm_field<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, L.c, m, wd, cell0, n_cells, L.d_u,  \
                            sigma_n, p, C_tang, sigma, dp, L.mesh->d_wq, fe);                                                       \
     } while (0)
-    const int mode = fe ? 2 : (C_tang ? 0 : 1);
-    const bool q2hex = DXO_OP_CT && L.mesh->gdim == 3 && m.ndofs == 27 && m.ngeom == 8;   // trip counts known at compile time
     if (mode == 2) {            // residual form (dxo_vmf_residual_eligible has been checked by the caller)
         if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 2); else DXO_VMF_LAUNCH(3, false, 27, 8, 2);
     } else if (q2hex) {
         if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 0); else DXO_VMF_LAUNCH(3, false, 27, 8, 0); }
         else           { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 1); else DXO_VMF_LAUNCH(3, false, 27, 8, 1); }
     } else if (L.mesh->gdim == 2) {
-        if (mode == 0) { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 0); else DXO_VMF_LAUNCH(2, false, 0, 0, 0); }
-        else           { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 1); else DXO_VMF_LAUNCH(2, false, 0, 0, 1); }
+        if (dma) {
+            if (mode == 0) { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 0); else DXO_VMF_LAUNCH(2, false, 0, 0, 0); }
+            else           { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 1); else DXO_VMF_LAUNCH(2, false, 0, 0, 1); }
+        } else {
+            if (mode == 0) { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 0, false); else DXO_VMF_LAUNCH(2, false, 0, 0, 0, false); }
+            else           { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 1, false); else DXO_VMF_LAUNCH(2, false, 0, 0, 1, false); }
+        }
     } else {
-        if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 0); else DXO_VMF_LAUNCH(3, false, 0, 0, 0); }
-        else           { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 1); else DXO_VMF_LAUNCH(3, false, 0, 0, 1); }
+        if (dma) {
+            if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 0); else DXO_VMF_LAUNCH(3, false, 0, 0, 0); }
+            else           { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 1); else DXO_VMF_LAUNCH(3, false, 0, 0, 1); }
+        } else {
+            if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 0, false); else DXO_VMF_LAUNCH(3, false, 0, 0, 0, false); }
+            else           { if (nt) DXO_VMF_LAUNCH(3, true, 0, 0, 1, false); else DXO_VMF_LAUNCH(3, false, 0, 0, 1, false); }
+        }
     }
 #undef DXO_VMF_LAUNCH
     return DXO_OK;

@@ -158,7 +158,11 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
  * that must be shareable through hipIpcGetMemHandle); "placement_probe" (default 1: candidates are ranked with a sweep in
  * the constitutive kernels' own pattern — three input streams read, three output streams written, 13 : 43 KiB per
  * 64-point tile, rates in algorithmic GB/s, early exit at "placement_good_mix_GBps" = 6250; 0: one stream of stores,
- * early exit at "placement_good_GBps"). The
+ * early exit at "placement_good_GBps"). A search can come up without a fast block: the winner is REJECTED — and one more search
+ * with fresh candidates made while it stays allocated, the two winners then timed head to head — when it is below
+ * "placement_accept_pct" (97) per cent of the best rate a calibration of this context ever kept for the same probe and
+ * block size, or, without such a record, when it does not stand out from its own candidates (below
+ * "placement_standout_pct" = 106 per cent of their median; once); "placement_rounds" (3) bounds the searches. The
  * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
 #define DXO_PLACEMENT_MAX 32
 typedef struct dxo_placement_info {
@@ -179,7 +183,9 @@ typedef struct dxo_placement_info {
                                                kept (0 one tile per wave, k persistent workgroups per CU); the kernel
                                                uses it whenever it writes into this block and option "blocks_per_cu"
                                                is 0                                                                 */
-    int32_t reserved_;
+    int32_t rounds;                         /* candidate searches this calibration made (1-3): a winner below 0.97 of the best
+                                               rate the context ever kept for this probe and size, or one that does not stand
+                                               out from its own candidates, buys one more search with fresh candidates      */
 } dxo_placement_info;
 int dxo_output_alloc(dxo_ctx* ctx, int64_t bytes, void** ptr);
 int dxo_output_free(dxo_ctx* ctx, void* ptr);

@@ -254,6 +254,48 @@ def test_fused_operand_plus_von_mises(ctx, oracle, cell, n, chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("with_tangent", [True, False])
+def test_fused_von_mises_on_a_27_point_rule(ctx, oracle, with_tangent):
+    """Q2 hexahedra with the 3x3x3 Gauss rule: tables 28.7 KB + four gather regions 28.7 KB leave no room for the landing slices of the
+    global_load_lds prefetch (14 KB) inside 64 KB — the launch must take the same kernel with the loads in registers, not refuse the mesh
+    (round-5 advisor finding; csrc/vm_field.hip field_launch)."""
+    import torch
+
+    from dolfinx_external_operator_amd import MEM_DEVICE, DeviceMesh, VmParams
+    from tools.synthetic import gauss_tensor_rule, with_rule
+
+    E = 70e3
+    prm = VmParams(E, 0.3, 250.0, E * (E / 100) / (E - E / 100))
+    m = with_rule(structured_mesh("hexahedron", (5, 4, 3), 2, distort=0.2, seed=11), *gauss_tensor_rule("hexahedron", 3))
+    assert m.nq == 27 and abs(m.weights.sum() - 1.0) < 1e-14
+    d, npts = 6, m.num_cells * m.nq
+    rng = np.random.Generator(np.random.PCG64(5))
+    u = rng.normal(size=m.node_x.shape[0] * m.gdim)
+    u *= 1.5e-3 / eval_operand(EPS_MANDEL, m.gdim, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi).std()
+    sigma_n, p = _vm_state(npts, d, seed=2)
+    e_ref = eval_operand(EPS_MANDEL, m.gdim, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
+    C_o, s_o, dp_o = oracle.von_mises(e_ref.reshape(-1, d), sigma_n, p)
+    assert 0.05 < (dp_o > 0).mean() < 0.98
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        t = [torch.from_numpy(a).cuda() for a in (u, sigma_n.reshape(-1), p)]
+        Ct = torch.full((npts * d * d,), -7.0, dtype=torch.float64, device="cuda") if with_tangent else None
+        st = torch.empty(npts * d, dtype=torch.float64, device="cuda")
+        dpt = torch.empty(npts, dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dm.von_mises(prm, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), Ct.data_ptr() if with_tangent else None, st.data_ptr(),
+                     dpt.data_ptr(), mem=MEM_DEVICE)
+        torch.cuda.synchronize()
+        tol = 1e-12
+        assert np.abs(st.cpu().numpy().reshape(-1, d) - s_o).max() <= tol * np.abs(s_o).max()
+        assert np.abs(dpt.cpu().numpy() - dp_o).max() <= tol * np.abs(dp_o).max()
+        if with_tangent:
+            assert np.abs(Ct.cpu().numpy().reshape(-1, d, d) - C_o).max() <= tol * np.abs(C_o).max()
+    finally:
+        dm.close()
+
+
+@pytest.mark.gpu
 def test_lazy_operand_takes_the_fused_path_inside_the_reference_call_sequence(ctx, oracle):
     from dolfinx_external_operator_amd import (DeviceMesh, LazyOperand, QuadratureExternalOperator,
                                                evaluate_external_operators, evaluate_operands, make_von_mises)

@@ -404,6 +404,35 @@ def test_default_factory_path_reproduces_the_reference_nan_points(ctx, oracle, g
     assert np.array_equal(outs["rebuild"][1], outs["copy"][1]) and np.array_equal(outs["rebuild"][2], outs["copy"][2])
 
 
+def test_arena_calibration_retries_a_rejected_winner_bounded(ctx):
+    """Round 6 (csrc/arena.hip): a calibration whose winner is below `placement_accept_pct` of the best rate the context ever kept
+    for the same probe and size buys one more search, `placement_rounds` at most; the block kept is the head-to-head winner."""
+    n, d = 3_300_000, 6
+    keys = ("placement_candidates", "placement_rounds", "placement_accept_pct", "placement_standout_pct")
+    old = {k: ctx.get_option(k) for k in keys}
+    try:
+        ctx.set_option("placement_candidates", 4)
+        ctx.set_option("placement_standout_pct", 0)          # first calibration of the class: accepted whatever its crowd looks like
+        a = ctx.vm_output_tensors(n, d)
+        assert a[0].dxo_block.info["rounds"] == 1, a[0].dxo_block.info
+        ctx.set_option("placement_accept_pct", 1000)         # nothing reaches ten times the record: every winner is rejected
+        b = ctx.vm_output_tensors(n, d)
+        info = b[0].dxo_block.info
+        assert info["rounds"] == 3 and info["chosen_GBps"] > 1000.0, info
+        ctx.set_option("placement_rounds", 1)
+        c = ctx.vm_output_tensors(n, d)
+        assert c[0].dxo_block.info["rounds"] == 1
+        ctx.set_option("placement_accept_pct", 1)            # anything passes
+        ctx.set_option("placement_rounds", 3)
+        e = ctx.vm_output_tensors(n, d)
+        assert e[0].dxo_block.info["rounds"] == 1
+        ptrs = {t[0].data_ptr() for t in (a, b, c, e)}
+        assert len(ptrs) == 4                                   # four live blocks, none handed out twice
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+
+
 def test_vm_output_alloc_calibrates_with_the_kernel_itself(ctx, oracle):
     """dxo_vm_output_alloc: candidates are timed running vm_tile; the record names the probe, the kinds and the launch
     shape that was fastest on the block kept; a later dxo_von_mises into that block (which picks the shape up) gives the

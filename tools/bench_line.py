@@ -176,10 +176,13 @@ def compact_record(full, stage="final"):
         r["traffic_detail"] = td[:160]
     pl = roof.get("placement")
     if isinstance(pl, dict):
-        r["placement"] = _pick(pl, ("mode", "candidates", "chosen_kind", "chosen_GBps", "calibration_ms"))
+        r["placement"] = _pick(pl, ("mode", "candidates", "chosen_kind", "chosen_GBps", "calibration_ms", "rounds"))
         gb = pl.get("probe_GBps")
         if isinstance(gb, list) and gb:
             r["placement"]["probe_GBps_min_max"] = [min(gb), max(gb)]
+    fp = roof.get("factory_placement")
+    if isinstance(fp, dict):
+        r["factory_placement"] = _pick(fp, ("candidates", "chosen_kind", "chosen_GBps", "rounds"))
     out["roofline"] = r
     cpu = full.get("cpu_baseline")
     if isinstance(cpu, dict):
@@ -218,7 +221,7 @@ def compact_line(full, stage="final", budget=LINE_BUDGET):
     """One JSON line <= budget bytes. If a record ever outgrows the budget, the least important parts are dropped in a
     fixed order (never a contract key) until it fits; the final assert is the guarantee the driver relies on."""
     rec = compact_record(full, stage)
-    drops = [("secondary_summary", "_keys"), ("roofline", "placement"), ("roofline", "traffic_method"), ("end_to_end_summary", None),
+    drops = [("secondary_summary", "_keys"), ("roofline", "placement"), ("roofline", "factory_placement"), ("roofline", "traffic_method"), ("end_to_end_summary", None),
              ("config", "gather_modes"), ("secondary_summary", None), ("gather_check", None)]
     line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
     # per-call arrays of the device-loop legs go first, one leg at a time

@@ -81,6 +81,25 @@ def quadrature_degree2(cell: str):
     raise ValueError(cell)
 
 
+def gauss_tensor_rule(cell: str, npd: int):
+    """npd-point Gauss-Legendre rule per direction on the quadrilateral / hexahedron (x fastest): npd = 3 on the hexahedron is the
+    27-point rule DOLFINx picks for `quadrature_degree` 4-5."""
+    t, w = np.polynomial.legendre.leggauss(npd)
+    t, w = 0.5 * (t + 1.0), 0.5 * w
+    gdim = {"quadrilateral": 2, "hexahedron": 3}[cell]
+    idx = [c[::-1] for c in itertools.product(range(npd), repeat=gdim)]
+    return np.array([[t[i] for i in c] for c in idx]), np.array([np.prod([w[i] for i in c]) for c in idx])
+
+
+def with_rule(mesh: "SyntheticMesh", points: np.ndarray, weights: np.ndarray) -> "SyntheticMesh":
+    """The same mesh tabulated at another quadrature rule."""
+    import dataclasses
+
+    phi, dphi = LagrangeElement(mesh.cell, mesh.degree).tabulate(points)
+    _, dpsi = LagrangeElement(mesh.cell, 1).tabulate(points)
+    return dataclasses.replace(mesh, points=np.ascontiguousarray(points), phi=phi, dphi=dphi, dpsi=dpsi, weights=np.ascontiguousarray(weights))
+
+
 @dataclass
 class SyntheticMesh:
     """Arrays of a structured mesh in the layout `dxo_mesh_desc` takes."""
