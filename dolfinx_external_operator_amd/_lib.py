@@ -142,7 +142,6 @@ _SIGNATURES = {
     "dxo_assign_plan_destroy": (None, [_P, _P]),
     "dxo_assign_apply": (C.c_int, [_P, _P, _P, _P]),
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),
-    "dxo_mesh_patch_info": (C.c_int, [_P, _P, _P]),
     "dxo_operand_adjoint": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
     "dxo_tangent_diagonal": (C.c_int, [_P, _P, _P, _P]),

@@ -46,6 +46,10 @@ bool dxo_arena_alloc_calibrated(dxo_ctx* ctx, size_t bytes, const dxo_arena_prob
 void dxo_arena_register(dxo_ctx* ctx, const dxo_arena_block& blk);
 // tuned launch shape of the arena block that contains `ptr`, or -1
 int dxo_arena_tuned_shape(dxo_ctx* ctx, const void* ptr);
+// Kernel variants that were measured and not shipped live under scripts/exp/ and are compiled into their translation unit only with
+// -DDXO_EXPERIMENTS; dxo_ctx_set_option asks the owning unit whether a value is available in this build (DXO_E_OPTION otherwise).
+int dxo_icnn_variant_max();            // icnn.hip: 2 in the product build, 4 with the experiments
+bool dxo_adjoint_patch_available();    // adjoint.hip
 // does `ptr` lie in an arena block backed by 2 MB physical chunks (not shareable with peers / RCCL)?
 bool dxo_arena_is_vmm(dxo_ctx* ctx, const void* ptr);
 

@@ -177,6 +177,10 @@ int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
     int64_t* slot = option_slot(c, key);
     if (!slot) return dxo_fail(c, DXO_E_OPTION, "unknown option");
     if (value < 0) return dxo_fail(c, DXO_E_OPTION, "option value must be >= 0");
+    if (slot == &c->icnn_variant && value > dxo_icnn_variant_max())
+        return dxo_fail(c, DXO_E_OPTION, "icnn_variant: 0 (VALU), 1 (fp32 MFMA), 2 (split-bf16 MFMA); 3 and 4 exist only in a -DDXO_EXPERIMENTS build (scripts/exp/icnn_variants.h)");
+    if (slot == &c->adjoint_patch && value != 0 && !dxo_adjoint_patch_available())
+        return dxo_fail(c, DXO_E_OPTION, "adjoint_patch: the patch form exists only in a -DDXO_EXPERIMENTS build (scripts/exp/adjoint_patch.h)");
     if (slot == &c->mc_blocks_per_cu && value < 1) return dxo_fail(c, DXO_E_OPTION, "mc_blocks_per_cu < 1");
     if (slot == &c->vm_rebuild_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "vm_rebuild_chunk_points < 64");
     if (slot == &c->host_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "host_chunk_points < 64");

@@ -17,7 +17,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import MEM_DEVICE, MEM_HOST, Context, default_context
+from ._lib import MEM_DEVICE, MEM_HOST, Context, DxoError, default_context
 
 KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3, "value_grad": 4}
 
@@ -199,11 +199,17 @@ class DeviceMesh:
 
 
     def patch_info(self) -> dict:
-        """The patches of the full-mesh consumer-side calls (dxo_mesh_patch_info; built on first use)."""
+        """The patches of the patch form of the internal force — an experiment that is NOT in the product library: the entry point
+        (dxo_mesh_patch_info, scripts/exp/adjoint_patch_kernels.h) exists only in a -DDXO_EXPERIMENTS build (scripts/exp/build_variant.py,
+        loaded through DXO_HIP_LIBRARY) and is bound here on demand."""
         import numpy as np
 
+        fn = getattr(self.ctx.lib, "dxo_mesh_patch_info", None)
+        if fn is None:
+            raise DxoError("dxo_mesh_patch_info: the patch form is not part of this build of libdxo_hip.so (-DDXO_EXPERIMENTS only)")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]
         info = np.zeros(8, dtype=np.int64)
-        self.ctx.check(self.ctx.lib.dxo_mesh_patch_info(self.ctx._h, self._h, info.ctypes.data), "dxo_mesh_patch_info")
+        self.ctx.check(fn(self.ctx._h, self._h, info.ctypes.data), "dxo_mesh_patch_info")
         keys = ("patches", "groups_per_wave", "wave_groups", "max_patch_nodes", "patch_nodes", "shared_nodes", "shared_entry_ppm", "waves_per_patch")
         out = dict(zip(keys, (int(x) for x in info)))
         out["max_wave_nodes"] = out["groups_per_wave"] >> 32

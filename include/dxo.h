@@ -474,18 +474,6 @@ int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_mesh* 
  * C_tang of dxo_tangent_apply / dxo_tangent_diagonal must be 16-byte aligned (the operator kernels' outputs are).
  * dxo_mesh_set_weights: the nq reference quadrature weights (basix.make_quadrature(...)[1]), host pointer. */
 int dxo_mesh_set_weights(dxo_ctx* ctx, dxo_mesh* mesh, const double* weights);
-/* The PATCH form of the internal force on hexahedra (dxo_operand_adjoint, kind EPS_MANDEL, 2x2x2 rule; option "adjoint_patch"
- * = 1, default 0 — an experiment that is correct and bit-reproducible but measured slower than the two-pass form,
- * profiles/r05_patch_form.txt): the wave groups (64 / nq consecutive cells) are cut into compact patches by recursive coordinate
- * bisection; one workgroup adds a patch's element-vector entries in LDS (per-wave accumulators merged in a fixed order: no
- * atomics) and only nodes shared between patches leave a partial in HBM, summed by a second kernel. The reference adds element vectors cell by cell (DOLFINx assembly
- * of the forms of external_operator.py:463-486).
- * dxo_mesh_patch_info builds the patches if needed and reports them: info[0] patches, [1] low 32 bits: wave groups per wave and
- * patch, high 32 bits: largest number of nodes in one wave's accumulator, [2] wave groups, [3] largest number of nodes of a
- * patch, [4] patch nodes in total, [5] nodes shared between patches (second-pass list), [6] 1e6 x (shared patch nodes / (cell,
- * node) incidences): the share of the element-vector entries that still travels through HBM, [7] waves per patch workgroup.
- * Returns DXO_E_SIZE when the mesh cannot use the patch form (the calls then keep the two-pass form). */
-int dxo_mesh_patch_info(dxo_ctx* ctx, dxo_mesh* mesh, int64_t info[8]);
 int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, const double* S, const int32_t* cells,
                         int64_t n_cells, double* out);
 int dxo_tangent_apply(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const double* v, double* out);

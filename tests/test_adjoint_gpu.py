@@ -276,15 +276,21 @@ def test_lane_per_cell_kernel_equals_wave_group_kernel(ctx, cell, n, degree):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n, overwrite", [((5, 4, 3), 0), ((12, 9, 7), 1), ((20, 20, 20), 1)])
-def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overwrite):
-    """Option adjoint_patch = 1 (csrc/adjoint_patch.h, an opt-in experiment): the element-vector entries of Q2 hexahedra are added in
+def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overwrite, experiments_build):
+    """Experiments build only (scripts/exp/adjoint_patch.h, -DDXO_EXPERIMENTS: measured slower, profiles/r05_patch_form.txt); the product
+    library refuses the option, which is what this test checks there. Option adjoint_patch = 1: the element-vector entries of Q2 hexahedra are added in
     LDS patch by patch and only patch-border partials go through HBM. Same sums in another (fixed) order: equal to the two-pass form
     to rounding, identical bits run to run, untouched entries handled like the two-pass form does (accumulate / overwrite)."""
     import torch
 
-    from dolfinx_external_operator_amd import DeviceMesh
+    from dolfinx_external_operator_amd import DeviceMesh, DxoError
     from tools.synthetic import structured_mesh
 
+    if not experiments_build:
+        with pytest.raises(DxoError, match="adjoint_patch"):
+            ctx.set_option("adjoint_patch", 1)
+        assert ctx.get_option("adjoint_patch") == 0
+        return
     m = structured_mesh("hexahedron", n, 2, distort=0.2, seed=3)
     dm = DeviceMesh.from_synthetic(m, ctx=ctx)
     dev = torch.device("cuda", ctx.device)

@@ -127,13 +127,20 @@ def test_mfma_and_valu_kernels_agree(ctx, weights):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 20_001, 300_000])
-def test_pipelined_and_hybrid_kernels_are_bit_identical_to_the_packed_one(ctx, weights, n):
-    """icnn_variant 3 (scalar fp32 arithmetic, phase 1 of the next half-tile issued between the vector instructions of this one's
+def test_pipelined_and_hybrid_kernels_are_bit_identical_to_the_packed_one(ctx, weights, n, experiments_build):
+    """Experiments build only (scripts/exp/icnn_variants.h, -DDXO_EXPERIMENTS; the product library refuses the options, checked here).
+    icnn_variant 3 (scalar fp32 arithmetic, phase 1 of the next half-tile issued between the vector instructions of this one's
     phases 2, one wave per SIMD) and 4 (scalar operands inside phase 1's MFMAs, packed phases 2 and 3) run the same operations in
     the same order per accumulator as variant 2 (packed fp32, phases in sequence): same bits, at sizes with one tile per wave,
     ragged tails and several tiles per wave."""
-    from dolfinx_external_operator_amd import MEM_HOST
+    from dolfinx_external_operator_amd import MEM_HOST, DxoError
 
+    if not experiments_build:
+        for variant in (3, 4):
+            with pytest.raises(DxoError, match="icnn_variant"):
+                ctx.set_option("icnn_variant", variant)
+        assert ctx.get_option("icnn_variant") == DEFAULT_VARIANT
+        return
     rng = np.random.default_rng(21)
     F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
     model = ctx.icnn_create(state_dict(weights))
@@ -155,12 +162,16 @@ def test_pipelined_and_hybrid_kernels_are_bit_identical_to_the_packed_one(ctx, w
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant):
+def test_non_finite_points_stay_in_their_own_rows(ctx, weights, variant, experiments_build):
     """The MFMA kernels evaluate 64 points per wave through shared matrix products: a point is one COLUMN of every product, so
     a NaN / inf / singular deformation gradient must poison its own 20 outputs and nothing else — the other points come out
     bit for bit as in a batch where the bad points are replaced by the identity."""
-    from dolfinx_external_operator_amd import MEM_HOST
+    from dolfinx_external_operator_amd import MEM_HOST, DxoError
 
+    if variant > 2 and not experiments_build:      # scripts/exp/icnn_variants.h: the product library refuses these values
+        with pytest.raises(DxoError, match="icnn_variant"):
+            ctx.set_option("icnn_variant", variant)
+        return
     rng = np.random.default_rng(5)
     n = 1000
     F = np.array([1.0, 0.0, 0.0, 1.0]) + 0.1 * rng.normal(size=(n, 4))
