@@ -14,9 +14,9 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from tools.mc_inputs import mc_tracing_inputs  # noqa: E402
+from tools.mc_inputs import mc_pool  # noqa: E402
 from dolfinx_external_operator_amd import MEM_DEVICE, Context, McParams  # noqa: E402
-from oracle import load_oracle  # noqa: E402  (input generation only: states after k tracing loads)
+from oracle import load_oracle  # noqa: E402  (the --cpu leg only; inputs come from the frozen pool tests/golden/mc_tracing_pool.npz)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
@@ -32,7 +32,8 @@ ap.add_argument("--arena", type=int, default=0, help="(no gain measured: the cal
 args = ap.parse_args()
 n = args.n
 o = load_oracle()
-pool_d, pool_s = mc_tracing_inputs(o, args.pool, seed=2)
+pool_d, pool_s = mc_pool()
+args.pool = pool_d.shape[0]
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(2)

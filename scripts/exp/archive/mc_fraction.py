@@ -5,7 +5,7 @@ import argparse, json, pathlib, statistics, sys, time
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch  # noqa: E402
-from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device  # noqa: E402
+from tools.mc_inputs import mc_default_params, mc_pool_inputs_device  # noqa: E402
 from dolfinx_external_operator_amd import MEM_DEVICE, Context  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
@@ -20,7 +20,7 @@ stream = torch.cuda.current_stream()
 ctx.set_stream(stream.cuda_stream)
 # a pool of tracing states (advanced by the library's own kernel), split into elastic and plastic by the library's yield value
 m = 50_000
-pd, ps = mc_tracing_inputs_device(ctx, m, seed=2)
+pd, ps = mc_pool_inputs_device(torch, torch.device('cuda', ctx.device), m, seed=2)
 pC, psig = torch.empty(m * 16, dtype=torch.float64, device=dev), torch.empty(m * 4, dtype=torch.float64, device=dev)
 pit = torch.empty(m, dtype=torch.int32, device=dev)
 py, pnr, pdl = (torch.empty(m, dtype=torch.float64, device=dev) for _ in range(3))

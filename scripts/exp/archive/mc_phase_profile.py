@@ -6,7 +6,7 @@ import json, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch  # noqa: E402
-from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device  # noqa: E402
+from tools.mc_inputs import mc_default_params, mc_pool_inputs_device  # noqa: E402
 from dolfinx_external_operator_amd import MEM_DEVICE, Context  # noqa: E402
 n = 10_000_000
 dev = torch.device("cuda:0")
@@ -14,7 +14,7 @@ ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 prm = mc_default_params()
 m = 50_000
-pd, ps = mc_tracing_inputs_device(ctx, m, seed=2)
+pd, ps = mc_pool_inputs_device(torch, torch.device('cuda', ctx.device), m, seed=2)
 bufs = lambda k: (torch.empty(k * 16, dtype=torch.float64, device=dev), torch.empty(k * 4, dtype=torch.float64, device=dev), torch.empty(k, dtype=torch.int32, device=dev),
                   torch.empty(k, dtype=torch.float64, device=dev), torch.empty(k, dtype=torch.float64, device=dev), torch.zeros(k, dtype=torch.float64, device=dev))
 C, s, it, y, nr, dl = bufs(m)

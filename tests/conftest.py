@@ -115,8 +115,37 @@ def assert_close_scaled(actual, expected, rtol, what=""):
 
 
 # ------------------------------------------------------------------------------- Mohr-Coulomb inputs
-# the generator of the config-4 tracing distribution lives in tools/mc_inputs.py (bench.py's secondary block uses it too)
-from tools.mc_inputs import MC_E, MC_NU, mc_elastic_matrices, mc_path_increment, mc_tracing_inputs  # noqa: E402,F401
+# constants and the path increment live in tools/mc_inputs.py (bench legs draw from the frozen pool there, without the checker); the seeded
+# generator below is the tests' own and DOES use the checker to advance the states along the tracing loads
+from tools.mc_inputs import MC_E, MC_NU, mc_elastic_matrices, mc_path_increment  # noqa: E402,F401
+
+
+def mc_tracing_inputs(oracle, n, seed, shear=0.0):
+    """SURVEY.md 8(d) config 4 distribution: random Lode angle theta ~ U(-pi/6, pi/6), states after
+    k in {0..8} tracing loads of R = 0.7 from the hydrostatic state p = 0.1 (:854-929), then an increment of
+    R ~ U(0, 0.7) along the same path. `shear` > 0 adds a Mandel shear component to state and increment.
+    Returns deps (n,4), sigma_n (n,4)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    _, S = mc_elastic_matrices()
+    tr = np.array([1.0, 1.0, 1.0, 0.0])
+    theta = rng.uniform(-np.pi / 6 + 1e-5, np.pi / 6 - 1e-5, n)
+    k_loads = rng.integers(0, 9, n)
+    sn = np.zeros((n, 4))
+    sn[:, :3] = 0.1
+    if shear > 0:
+        sn[:, 3] = rng.normal(0, shear, n)
+    for k in range(8):
+        active = k_loads > k
+        if not active.any():
+            break
+        d = mc_path_increment(theta[active], 0.7)
+        _, s, *_ = oracle.mohr_coulomb(d @ S.T, sn[active], nthreads=8, tangent=False)
+        dp = s @ tr / 3.0 - 0.1
+        sn[active] = s - np.outer(dp, tr)          # :922-923
+    dsig = mc_path_increment(theta, rng.uniform(0.0, 0.7, n))
+    if shear > 0:
+        dsig[:, 3] = rng.normal(0, shear, n)
+    return dsig @ S.T, sn
 
 
 # C_tang entries are O(E) = 8e3: agreement is asked relative to the tangent's scale (see mc_compare).

@@ -16,7 +16,7 @@ Tolerances are the ones of the small-size parity tests (1e-13 x scale von Mises;
 import numpy as np
 import pytest
 
-from conftest import assert_close_scaled, mc_compare_all, mc_elastic_matrices, mc_tracing_inputs
+from conftest import assert_close_scaled, mc_compare_all, mc_elastic_matrices
 from dolfinx_external_operator_amd import MEM_DEVICE, McParams, VmParams
 
 pytestmark = pytest.mark.gpu
@@ -81,11 +81,9 @@ def test_mohr_coulomb_at_ten_million_points(ctx, oracle):
     import torch
 
     n = 10_000_000
-    pool_d, pool_s = mc_tracing_inputs(oracle, 20_000, seed=2)
-    rng = np.random.default_rng(0)
-    idx = rng.integers(0, 20_000, n)
-    deps = pool_d[idx] * rng.uniform(0.5, 1.0, (n, 1))
-    sn = pool_s[idx]
+    from tools.mc_inputs import mc_pool_inputs
+
+    deps, sn = mc_pool_inputs(n, seed=0)      # drawn from the frozen pool (tests/golden/mc_tracing_pool.npz): inputs need no checker
     dev = torch.device("cuda:0")
     d_deps, d_sn = torch.from_numpy(deps).to(dev), torch.from_numpy(sn).to(dev)
     Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
@@ -199,13 +197,13 @@ def test_mohr_coulomb_schedules_agree_bitwise_at_ten_million_points(ctx, oracle)
     in different orders on different lanes — every one of the 10^7 x 24 outputs is the same bit pattern."""
     import torch
 
-    from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device
+    from tools.mc_inputs import mc_default_params, mc_pool_inputs_device
 
     n = 10_000_000
     dev = torch.device("cuda:0")
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     prm = mc_default_params()
-    deps, sn = mc_tracing_inputs_device(ctx, n, seed=5)
+    deps, sn = mc_pool_inputs_device(torch, dev, n, seed=5)
     out = {}
     try:
         for variant in (2, 1):

@@ -260,3 +260,25 @@ def test_lode_angle_sine_and_cosine_without_library_calls(mc_core):
     assert np.all(np.abs(sn - np.sin(th)) <= 2e-15 * np.abs(np.sin(th)))
     assert np.all(np.abs(cs - np.cos(th)) <= 1e-15)
     assert np.array_equal(np.signbit(sn), np.signbit(u))
+
+
+def test_frozen_config4_pool_is_the_seeded_tracing_distribution(oracle):
+    """tests/golden/mc_tracing_pool.npz (written by make_golden_mc_inputs.py) is what this suite's own seeded generator gives: the bench
+    leg of config 4 and the 10^7-point test draw from the fixture, so that nothing under tools/ needs the checker to make inputs."""
+    import ast
+    import pathlib
+
+    from tools import mc_inputs
+
+    pool_d, pool_s = mc_inputs.mc_pool()
+    deps, sn = mc_tracing_inputs(oracle, 20_000, seed=2)
+    assert np.array_equal(pool_s, sn) and np.array_equal(pool_d, deps)
+    d, s = mc_inputs.mc_pool_inputs(1000, seed=7)
+    assert d.shape == (1000, 4) and s.shape == (1000, 4) and np.isfinite(d).all()
+    yielding = oracle.mohr_coulomb(d, s, nthreads=2, tangent=False)[3]
+    assert 0.1 < float((yielding > 0).mean()) < 0.9          # a mix of elastic and plastic points, as config 4 asks
+    tree = ast.parse(pathlib.Path(mc_inputs.__file__).read_text())
+    imported = {a.name for n in ast.walk(tree) if isinstance(n, ast.Import) for a in n.names} | \
+               {n.module or "" for n in ast.walk(tree) if isinstance(n, ast.ImportFrom)}
+    assert not any(m.split(".")[0] == "oracle" for m in imported), imported
+    assert "oracle" not in {n.id for n in ast.walk(tree) if isinstance(n, ast.Name)}

@@ -79,11 +79,11 @@ def _avail():
 
 def mohr_coulomb_cfg4(torch, ctx, stream, n, cpu):
     from dolfinx_external_operator_amd import MEM_DEVICE
-    from tools.mc_inputs import mc_default_params, mc_tracing_inputs_device
+    from tools.mc_inputs import mc_default_params, mc_pool_inputs_device
 
     dev = torch.device("cuda", ctx.device)
     prm = mc_default_params()
-    deps, sn = mc_tracing_inputs_device(ctx, n, seed=2)
+    deps, sn = mc_pool_inputs_device(torch, dev, n, seed=2)      # drawn from the frozen pool tests/golden/mc_tracing_pool.npz
     Ct = torch.empty(n * 16, dtype=torch.float64, device=dev)
     s = torch.empty(n * 4, dtype=torch.float64, device=dev)
     it = torch.empty(n, dtype=torch.int32, device=dev)

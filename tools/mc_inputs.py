@@ -1,7 +1,9 @@
 """Synthetic Mohr-Coulomb inputs of BASELINE config 4: the demo's yield-surface tracing distribution
-(doc/demo/demo_plasticity_mohr_coulomb.py:854-929). Used by the tests (through tests/conftest.py), scripts/bench_mc.py and
-bench.py's secondary block. `oracle` is the CPU checker (oracle/mc_oracle.cpp): it only advances the STATES along the
-tracing loads so that the batch mixes elastic points and points sitting on the yield surface; nothing measured calls it."""
+(doc/demo/demo_plasticity_mohr_coulomb.py:854-929). Used by scripts/bench_mc.py, bench.py's secondary block and the 10^7-point
+test. The states of that distribution (stress after k tracing loads) need a return map to produce: that was done ONCE, by the CPU
+checker, into the fixture tests/golden/mc_tracing_pool.npz (tests/golden/make_golden_mc_inputs.py); this module only reads the
+fixture — it never imports or calls anything under oracle/. (The tests' own seeded generator, which does call the checker, lives
+in tests/conftest.py: mc_tracing_inputs.)"""
 from __future__ import annotations
 
 import numpy as np
@@ -25,32 +27,41 @@ def mc_path_increment(theta, R):
     return d
 
 
-def mc_tracing_inputs(oracle, n, seed, shear=0.0):
-    """SURVEY.md 8(d) config 4 distribution: random Lode angle theta ~ U(-pi/6, pi/6), states after
-    k in {0..8} tracing loads of R = 0.7 from the hydrostatic state p = 0.1 (:854-929), then an increment of
-    R ~ U(0, 0.7) along the same path. `shear` > 0 adds a Mandel shear component to state and increment.
-    Returns deps (n,4), sigma_n (n,4)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    _, S = mc_elastic_matrices()
-    tr = np.array([1.0, 1.0, 1.0, 0.0])
-    theta = rng.uniform(-np.pi / 6 + 1e-5, np.pi / 6 - 1e-5, n)
-    k_loads = rng.integers(0, 9, n)
-    sn = np.zeros((n, 4))
-    sn[:, :3] = 0.1
-    if shear > 0:
-        sn[:, 3] = rng.normal(0, shear, n)
-    for k in range(8):
-        active = k_loads > k
-        if not active.any():
-            break
-        d = mc_path_increment(theta[active], 0.7)
-        _, s, *_ = oracle.mohr_coulomb(d @ S.T, sn[active], nthreads=8, tangent=False)
-        dp = s @ tr / 3.0 - 0.1
-        sn[active] = s - np.outer(dp, tr)          # :922-923
-    dsig = mc_path_increment(theta, rng.uniform(0.0, 0.7, n))
-    if shear > 0:
-        dsig[:, 3] = rng.normal(0, shear, n)
-    return dsig @ S.T, sn
+_POOL = None
+
+
+def mc_pool():
+    """(deps, sigma_n), each (20 000, 4): the frozen pool of the tracing distribution (tests/golden/mc_tracing_pool.npz, written once by
+    tests/golden/make_golden_mc_inputs.py: the states after k tracing loads need a return map, which the CPU checker did THERE). Nothing
+    in this module calls the checker; bench legs, scripts and the 10^7-point test draw from this pool."""
+    global _POOL
+    if _POOL is None:
+        import pathlib
+
+        g = np.load(pathlib.Path(__file__).resolve().parents[1] / "tests" / "golden" / "mc_tracing_pool.npz")
+        _, S = mc_elastic_matrices()
+        sn = np.zeros((g["theta"].size, 4))
+        sn[:, :3] = g["sigma_n3"]
+        _POOL = (mc_path_increment(g["theta"], g["R"]) @ S.T, sn)      # deps = S_elas dsigma (:903)
+    return _POOL
+
+
+def mc_pool_inputs(n, seed=0):
+    """n points of BASELINE config 4 drawn from the frozen pool (NumPy, host): a seeded pick with the increment scaled by U(0.5, 1)."""
+    pool_d, pool_s = mc_pool()
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, pool_d.shape[0], n)
+    return pool_d[idx] * rng.uniform(0.5, 1.0, (n, 1)), pool_s[idx]
+
+
+def mc_pool_inputs_device(torch, device, n, seed=2):
+    """The same draw made on the device (CUDA tensors deps (n, 4), sigma_n (n, 4)): what the bench leg of config 4 times."""
+    pool_d, pool_s = mc_pool()
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pick = torch.randint(0, pool_d.shape[0], (n,), generator=g, device=device)
+    scale = torch.rand(n, 1, generator=g, device=device, dtype=torch.float64) * 0.5 + 0.5
+    return (torch.from_numpy(pool_d).to(device)[pick] * scale).contiguous(), torch.from_numpy(pool_s).to(device)[pick].contiguous()
 
 
 def mc_default_params():
@@ -59,45 +70,3 @@ def mc_default_params():
 
     c, phi = 3.45, np.pi / 6
     return McParams(MC_E, MC_NU, c, phi, phi, 26 * np.pi / 180, 0.26 * c / np.tan(phi), 1e-8, 200, 0)
-
-
-def mc_tracing_inputs_device(ctx, n, seed, pool=50_000):
-    """The same distribution produced WITHOUT the CPU checker: the states after k tracing loads are advanced by the
-    library's own kernel (dxo_mohr_coulomb on device memory, `pool` seeded points x 8 loads), then `n` points are drawn
-    from the pool with the increment scaled by U(0.5, 1). Returns torch CUDA tensors deps (n,4), sigma_n (n,4).
-    This is what bench.py's secondary block times (no oracle call outside its cpu_baseline leg)."""
-    import torch
-
-    from dolfinx_external_operator_amd import MEM_DEVICE
-
-    dev = torch.device("cuda", ctx.device)
-    prm = mc_default_params()
-    rng = np.random.Generator(np.random.PCG64(seed))
-    _, S = mc_elastic_matrices()
-    St = torch.from_numpy(S.T.copy()).to(dev)
-    tr = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
-    theta = rng.uniform(-np.pi / 6 + 1e-5, np.pi / 6 - 1e-5, pool)
-    k_loads = torch.from_numpy(rng.integers(0, 9, pool)).to(dev)
-    sn = torch.zeros(pool, 4, dtype=torch.float64, device=dev)
-    sn[:, :3] = 0.1
-    d_full = torch.from_numpy(mc_path_increment(theta, 0.7)).to(dev)
-    for k in range(8):
-        idx = torch.nonzero(k_loads > k).squeeze(1)
-        m = int(idx.numel())
-        if m == 0:
-            break
-        de = (d_full[idx] @ St).contiguous()
-        s_in = sn[idx].contiguous()
-        Ct = torch.empty(m * 16, dtype=torch.float64, device=dev)
-        s_out = torch.empty(m, 4, dtype=torch.float64, device=dev)
-        ctx.mohr_coulomb(prm, m, MEM_DEVICE, de.data_ptr(), s_in.data_ptr(), Ct.data_ptr(), s_out.data_ptr())
-        ctx.synchronize()
-        dpv = s_out @ tr / 3.0 - 0.1
-        sn[idx] = s_out - torch.outer(dpv, tr)          # :922-923
-    dsig = torch.from_numpy(mc_path_increment(theta, rng.uniform(0.0, 0.7, pool))).to(dev)
-    pool_d = dsig @ St
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    pick = torch.randint(0, pool, (n,), generator=g, device=dev)
-    scale = torch.rand(n, 1, generator=g, device=dev, dtype=torch.float64) * 0.5 + 0.5
-    return (pool_d[pick] * scale).contiguous(), sn[pick].contiguous()
