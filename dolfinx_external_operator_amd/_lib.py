@@ -42,10 +42,13 @@ class IsiharaParams(C.Structure):
     _fields_ = [("c1", C.c_double), ("c2", C.c_double), ("c3", C.c_double), ("c4", C.c_double)]
 
 
+ABI_VERSION = 2      # include/dxo.h DXO_ABI_VERSION (2: dxo_assign_desc::elem_bytes)
+
+
 class AssignDesc(C.Structure):
     """dxo_assign_desc — one subspace of a dofmap assigner (external_operator.py:286-335)."""
     _fields_ = [("n_cells", C.c_int64), ("n_pts", C.c_int32), ("val_size", C.c_int32), ("offset", C.c_int32),
-                ("n_points_total", C.c_int32), ("comp_size", C.c_int32), ("_pad", C.c_int32)]
+                ("n_points_total", C.c_int32), ("comp_size", C.c_int32), ("elem_bytes", C.c_int32)]
 
 
 class IcnnWeights(C.Structure):
@@ -228,8 +231,8 @@ def load_library(path: str | pathlib.Path | None = None) -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, let it propagate
             fn.restype = res
             fn.argtypes = args
-        if lib.dxo_abi_version() != 1:
-            raise DxoError(f"ABI version mismatch: library {lib.dxo_abi_version()}, binding 1")
+        if lib.dxo_abi_version() != ABI_VERSION:
+            raise DxoError(f"ABI version mismatch: library {lib.dxo_abi_version()}, binding {ABI_VERSION}")
         if path is None:
             _lib = lib
         return lib

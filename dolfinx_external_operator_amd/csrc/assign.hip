@@ -14,6 +14,10 @@
 // shared between cells) the LAST one wins. A parallel scatter would leave whichever store lands last; to return the
 // same array as the reference, pass 1 records for every dof the largest source position that targets it
 // (atomicMax), pass 2 stores only from that position. HBM/atomic-bound index traffic, no arithmetic.
+//
+// The reference's assigners are dtype-agnostic (`coeff.x.array[dofs] = values` for whatever scalar type the function space has:
+// float32 / float64 / complex128 in test/test_multiaction.py:15-23): values are MOVED, never computed on, so the kernels are
+// templates on the element WIDTH — 4, 8 or 16 bytes (dxo_assign_desc::elem_bytes), moved as unsigned words of that width.
 #include "dxo_common.h"
 
 namespace {
@@ -45,9 +49,12 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_owner(AssignDev a, const int
     }
 }
 
+struct alignas(16) assign_u128 { unsigned long long lo, hi; };      // complex128: one 16-byte move
+
+template <typename T>
 __global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int32_t* __restrict__ dofs,
                                                           const unsigned long long* __restrict__ owner,
-                                                          const double* __restrict__ values, double* __restrict__ coeff,
+                                                          const T* __restrict__ values, T* __restrict__ coeff,
                                                           int64_t coeff_size) {
     const int64_t n = a.n_cells * a.n_pts * a.val_size;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -71,9 +78,9 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_plan_finish(AssignDev a, con
     }
 }
 
-template <typename I>
-__global__ __launch_bounds__(DXO_BLOCK) void assign_apply(const I* __restrict__ src, const double* __restrict__ values,
-                                                          double* __restrict__ coeff, int64_t coeff_size) {
+template <typename I, typename T>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_apply(const I* __restrict__ src, const T* __restrict__ values,
+                                                          T* __restrict__ coeff, int64_t coeff_size) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < coeff_size; d += stride) {
         const I s = src[d];
@@ -83,8 +90,13 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_apply(const I* __restrict__ 
 
 }  // namespace
 
+// element width of a descriptor: 0 (a caller of ABI version 1, where the field was padding it zeroed) means 8
+static int assign_elem_bytes(const dxo_assign_desc* d) { return d->elem_bytes == 0 ? 8 : d->elem_bytes; }
+static bool assign_elem_ok(int eb) { return eb == 4 || eb == 8 || eb == 16; }
+
 struct dxo_assign_plan {
     int64_t coeff_size = 0, n_values = 0;
+    int elem_bytes = 8;
     bool wide = false;          // int64 source positions (values array beyond 2^31 entries)
     void* src = nullptr;        // device: int32 or int64 per coefficient entry
 };
@@ -98,12 +110,14 @@ extern "C" int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* d, co
     if (d->n_cells < 0 || d->n_pts < 1 || d->val_size < 1 || d->offset < 0 || d->comp_size < d->val_size ||
         d->n_points_total < d->offset + d->n_pts || coeff_size < 0)
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_assign_plan_create: inconsistent sizes");
+    if (!assign_elem_ok(assign_elem_bytes(d))) return dxo_fail(ctx, DXO_E_DIM, "dxo_assign_plan_create: elem_bytes must be 4, 8 or 16 (0 = 8)");
     const int64_t n = d->n_cells * d->n_pts * d->val_size;
     if (n > 0 && !flat_dofs) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_plan_create: flat_dofs is NULL");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     dxo_assign_plan* pl = new dxo_assign_plan;
     pl->coeff_size = coeff_size;
+    pl->elem_bytes = assign_elem_bytes(d);
     pl->n_values = d->n_cells * (int64_t)d->n_points_total * d->comp_size;
     pl->wide = pl->n_values > 0x7fffffffLL;
     const size_t sb = (size_t)(coeff_size ? coeff_size : 1) * (pl->wide ? 8 : 4);
@@ -149,12 +163,14 @@ extern "C" void dxo_assign_plan_destroy(dxo_ctx* ctx, dxo_assign_plan* plan) {
     delete plan;
 }
 
-extern "C" int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const double* values, double* coeff) {
+extern "C" int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const void* values, void* coeff) {
     if (!ctx) return DXO_E_NULL;
     DXO_LOCK(ctx);
     if (!plan) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_apply: plan is NULL");
     if (plan->coeff_size == 0) return DXO_OK;
     if (!values || !coeff) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign_apply: NULL array");
+    if (((uintptr_t)values | (uintptr_t)coeff) & (uintptr_t)(plan->elem_bytes - 1))
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_assign_apply: values and coeff must be aligned to the element width");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     int rc = dxo_device_begin(ctx, s);
@@ -162,22 +178,31 @@ extern "C" int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const
     int64_t blocks = (plan->coeff_size + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
-    if (plan->wide) hipLaunchKernelGGL(assign_apply<int64_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, (const int64_t*)plan->src, values, coeff, plan->coeff_size);
-    else            hipLaunchKernelGGL(assign_apply<int32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, (const int32_t*)plan->src, values, coeff, plan->coeff_size);
+#define DXO_APPLY(I, T) hipLaunchKernelGGL((assign_apply<I, T>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, (const I*)plan->src, (const T*)values, (T*)coeff, plan->coeff_size)
+    if (plan->wide) {
+        if (plan->elem_bytes == 4) DXO_APPLY(int64_t, uint32_t); else if (plan->elem_bytes == 8) DXO_APPLY(int64_t, unsigned long long); else DXO_APPLY(int64_t, assign_u128);
+    } else {
+        if (plan->elem_bytes == 4) DXO_APPLY(int32_t, uint32_t); else if (plan->elem_bytes == 8) DXO_APPLY(int32_t, unsigned long long); else DXO_APPLY(int32_t, assign_u128);
+    }
+#undef DXO_APPLY
     return dxo_device_end(ctx, s);
 }
 
-extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, const double* values,
-                          double* coeff, int64_t coeff_size) {
+extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t* flat_dofs, const void* values,
+                          void* coeff, int64_t coeff_size) {
     if (!ctx) return DXO_E_NULL;
     DXO_LOCK(ctx);
     if (!d) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: descriptor is NULL");
     if (d->n_cells < 0 || d->n_pts < 1 || d->val_size < 1 || d->offset < 0 || d->comp_size < d->val_size ||
         d->n_points_total < d->offset + d->n_pts || coeff_size < 0)
         return dxo_fail(ctx, DXO_E_SIZE, "dxo_assign: inconsistent sizes");
+    const int eb = assign_elem_bytes(d);
+    if (!assign_elem_ok(eb)) return dxo_fail(ctx, DXO_E_DIM, "dxo_assign: elem_bytes must be 4, 8 or 16 (0 = 8)");
     const int64_t n = d->n_cells * d->n_pts * d->val_size;
     if (n == 0) return DXO_OK;
     if (!flat_dofs || !values || !coeff) return dxo_fail(ctx, DXO_E_NULL, "dxo_assign: NULL array");
+    if (((uintptr_t)values | (uintptr_t)coeff) & (uintptr_t)(eb - 1))
+        return dxo_fail(ctx, DXO_E_ALIGN, "dxo_assign: values and coeff must be aligned to the element width");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
     // owner table: one 8-byte word per coefficient entry + the error word, in the context's device-path scratch
@@ -192,7 +217,9 @@ extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t*
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, coeff_size);
-    hipLaunchKernelGGL(assign_store, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, values, coeff, coeff_size);
+    if (eb == 4)      hipLaunchKernelGGL(assign_store<uint32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const uint32_t*)values, (uint32_t*)coeff, coeff_size);
+    else if (eb == 8) hipLaunchKernelGGL(assign_store<unsigned long long>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const unsigned long long*)values, (unsigned long long*)coeff, coeff_size);
+    else              hipLaunchKernelGGL(assign_store<assign_u128>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const assign_u128*)values, (assign_u128*)coeff, coeff_size);
     rc = dxo_device_end(ctx, s);
     if (rc != DXO_OK || !ctx->assign_validate) return rc;
     unsigned long long bad = 0;

@@ -326,7 +326,7 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
     const size_t slice_doubles = 4 * (size_t)DXO_WAVE * (D + 1);
     bool dma = vmf_dma_compiled(mode, (mode == 2 || q2hex) ? 27 : 0);
     if (dma && (base_doubles + slice_doubles) * sizeof(double) > 64 * 1024) {
-        if (mode == 2 || q2hex) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");   // cannot happen: their sizes are fixed
+        if (mode == 2) return dxo_fail(ctx, DXO_E_SIZE, "dxo_von_mises_field: element too large for the LDS budget");   // cannot happen: the residual form is the 8-point rule's
         dma = false;
     }
     const size_t shm = (base_doubles + (dma ? slice_doubles : 0)) * sizeof(double);
@@ -346,7 +346,8 @@ int field_launch(dxo_ctx* ctx, const FieldLaunch& L, int64_t cell0, int64_t n_ce
         if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 2); else DXO_VMF_LAUNCH(3, false, 27, 8, 2);
     } else if (q2hex) {
         if (mode == 0) { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 0); else DXO_VMF_LAUNCH(3, false, 27, 8, 0); }
-        else           { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 1); else DXO_VMF_LAUNCH(3, false, 27, 8, 1); }
+        else if (dma)  { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 1); else DXO_VMF_LAUNCH(3, false, 27, 8, 1); }
+        else           { if (nt) DXO_VMF_LAUNCH(3, true, 27, 8, 1, false); else DXO_VMF_LAUNCH(3, false, 27, 8, 1, false); }     // a larger rule than 2x2x2
     } else if (L.mesh->gdim == 2) {
         if (dma) {
             if (mode == 0) { if (nt) DXO_VMF_LAUNCH(2, true, 0, 0, 0); else DXO_VMF_LAUNCH(2, false, 0, 0, 0); }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DXO_ABI_VERSION 1
+#define DXO_ABI_VERSION 2
 
 /* error codes (negative = caller error) */
 #define DXO_OK 0
@@ -512,10 +512,14 @@ int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, dou
  * "assign_validate" = 0 skips it (entries are still never written out of bounds). */
 typedef struct dxo_assign_desc {
     int64_t n_cells;
-    int32_t n_pts, val_size, offset, n_points_total, comp_size, _pad;
+    int32_t n_pts, val_size, offset, n_points_total, comp_size;
+    int32_t elem_bytes;     /* width of one scalar of `values` / `coeff`: 4 (float32), 8 (float64), 16 (complex128); 0 = 8. The
+                               reference's assigners take whatever scalar type the function space has (float32 / float64 /
+                               complex128 in test/test_multiaction.py:15-23): values are moved, never computed on. ABI version 2
+                               (version 1 had padding here and moved 8-byte elements only) */
 } dxo_assign_desc;
-int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, const double* values,
-               double* coeff, int64_t coeff_size);
+int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, const void* values,
+               void* coeff, int64_t coeff_size);
 /* The same assignment as a PLAN (round 4). Which entry wins a shared dof depends on the dofmap alone, and the dofmap of a
  * function space does not change between the calls of a solve (the reference builds its unrolled dofmaps once, in the
  * operator's constructor, external_operator.py:203-209): dxo_assign_plan_create runs the ownership pass once and keeps, per
@@ -527,7 +531,7 @@ typedef struct dxo_assign_plan dxo_assign_plan;
 int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, int64_t coeff_size,
                            dxo_assign_plan** out);
 void dxo_assign_plan_destroy(dxo_ctx* ctx, dxo_assign_plan* plan);
-int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const double* values, double* coeff);
+int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const void* values, void* coeff);   /* elements of the width the plan's descriptor named */
 
 /* Operand evaluation FUSED in front of the heat-flux kernel: T and sigma = grad T of a scalar Lagrange field on
  * `mesh` are formed per quadrature point and fed to q_impl / dqdT_impl / dqdsigma_impl

@@ -34,7 +34,7 @@ def test_binding_covers_every_declared_symbol(hip_library):
 
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "dxo.h"\nint main(void){ dxo_vm_params p = {70e3, 0.3, 250.0, 707.07}; (void)p; return DXO_ABI_VERSION - 1; }\n')
+    src.write_text('#include "dxo.h"\nint main(void){ dxo_vm_params p = {70e3, 0.3, 250.0, 707.07}; (void)p; return DXO_ABI_VERSION - 2; }\n')
     res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", "-c", str(src), "-o",
                           str(tmp_path / "t.o")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
@@ -50,7 +50,7 @@ def test_code_object_targets_gfx950(hip_library):
 
 def test_argument_errors_without_a_device(hip_library):
     lib = hip_library
-    assert lib.dxo_abi_version() == 1
+    assert lib.dxo_abi_version() == 2          # 2: dxo_assign_desc::elem_bytes (float32 / float64 / complex128 through the device assigner)
     assert lib.dxo_ctx_create(0, None) == -1                       # DXO_E_NULL
     assert lib.dxo_von_mises(None, None, 4, 0, 0, None, None, None, None, None, None) == -1
     assert lib.dxo_heat(None, 1.0, 1.0, 2, 0, 0, None, None, None, None, None) == -1

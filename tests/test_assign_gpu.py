@@ -10,13 +10,28 @@ from dolfinx_external_operator_amd import (AssignDesc, MixedExternalOperator, Qu
 pytestmark = pytest.mark.gpu
 
 
+DTYPES = [np.float32, np.float64, np.complex128]      # the scalar types the reference's own tests run (test/test_multiaction.py:15-23)
+
+
+def as_dtype(rng, shape, dtype):
+    """Seeded values of `dtype` (complex: independent real and imaginary parts)."""
+    v = rng.normal(size=shape)
+    if np.issubdtype(dtype, np.complexfloating):
+        v = v + 1j * rng.normal(size=shape)
+    return v.astype(dtype)
+
+
 def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
     """dxo_assign, and the same assignment through a plan (dxo_assign_plan_create + dxo_assign_apply, applied twice: a plan
-    is made once per dofmap and reused): both must leave the same bits."""
+    is made once per dofmap and reused): both must leave the same bits. The element width travels in desc.elem_bytes and is
+    taken from `values`' dtype here (float32 / float64 / complex128: the device moves 4 / 8 / 16-byte words)."""
     import torch
 
+    values = np.ascontiguousarray(values).reshape(-1)
+    assert initial.dtype == values.dtype
+    desc.elem_bytes = values.dtype.itemsize
     d = torch.from_numpy(np.ascontiguousarray(flat_dofs, dtype=np.int32)).cuda()
-    v = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64).reshape(-1)).cuda()
+    v = torch.from_numpy(values).cuda()
     c = torch.from_numpy(initial.copy()).cuda()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.assign(desc, d.data_ptr(), v.data_ptr(), c.data_ptr(), coeff_size)
@@ -27,13 +42,14 @@ def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
         c2 = torch.from_numpy(initial.copy()).cuda()
         plan.apply(v.data_ptr(), c2.data_ptr())
         torch.cuda.synchronize()
-        assert torch.equal(c2, c)
+        assert torch.equal(torch.view_as_real(c2) if c2.is_complex() else c2, torch.view_as_real(c) if c.is_complex() else c)
     plan.close()
     return c.cpu().numpy()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("bs", [1, 2, 3])
-def test_non_mixed_unrolled_dofmap_with_shared_dofs(ctx, bs):
+def test_non_mixed_unrolled_dofmap_with_shared_dofs(ctx, bs, dtype):
     """A P1-like continuous space on a strip of cells: neighbouring cells share nodes, values differ per cell, so
     the result depends on the write order — it must be NumPy's."""
     rng = np.random.Generator(np.random.PCG64(bs))
@@ -43,16 +59,18 @@ def test_non_mixed_unrolled_dofmap_with_shared_dofs(ctx, bs):
     unrolled = get_unrolled_dofmap(dofmap, bs)
     size = (n_cells + n_pts) * bs
     op = QuadratureExternalOperator(num_cells=n_cells, num_points=n_pts, value_shape=(bs,) if bs > 1 else (),
-                                    unrolled_dofmap=unrolled, coefficient_size=size)
-    values = rng.normal(size=n_cells * n_pts * bs)
+                                    unrolled_dofmap=unrolled, coefficient_size=size, dtype=dtype)
+    values = as_dtype(rng, n_cells * n_pts * bs, dtype)
     op.ref_coefficient.x.array[:] = -3.0
     op._assign_func(values)
+    assert op.ref_coefficient.x.array.dtype == dtype
     desc = AssignDesc(n_cells, n_pts, bs, 0, n_pts, bs, 0)
-    got = device_assign(ctx, desc, unrolled, values, size, np.full(size, -3.0))
-    assert np.array_equal(got, op.ref_coefficient.x.array)
+    got = device_assign(ctx, desc, unrolled, values, size, np.full(size, -3.0, dtype=dtype))
+    assert got.dtype == dtype and np.array_equal(got, op.ref_coefficient.x.array)
 
 
-def test_mixed_scalar_and_padded_vector_subspaces(ctx):
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mixed_scalar_and_padded_vector_subspaces(ctx, dtype):
     rng = np.random.Generator(np.random.PCG64(11))
     n_cells = 1200
     # subspace 0: vector (2 components, 3 points), subspace 1: scalar (4 points); comp_size = 2 (padded), :151-161
@@ -60,21 +78,21 @@ def test_mixed_scalar_and_padded_vector_subspaces(ctx):
     dm1 = (n_cells * 6 + rng.integers(0, n_cells, size=(n_cells, 4))).astype(np.int32)        # shared scalar dofs
     size = n_cells * 7
     sub = [{"n_pts": 3, "val_size": 2, "dofmap": dm0}, {"n_pts": 4, "val_size": 1, "dofmap": dm1}]
-    op = MixedExternalOperator(num_cells=n_cells, subspaces=sub, coefficient_size=size)
-    values = rng.normal(size=n_cells * 7 * 2)
+    op = MixedExternalOperator(num_cells=n_cells, subspaces=sub, coefficient_size=size, dtype=dtype)
+    values = as_dtype(rng, n_cells * 7 * 2, dtype)
     op.ref_coefficient.x.array[:] = 9.0
     op._assign_func(values)                                                                    # _assign_mixed_3d
-    coeff = np.full(size, 9.0)
+    coeff = np.full(size, 9.0, dtype=dtype)
     for info in op._mixed_subspace_info:
         desc = AssignDesc(n_cells, info["n_pts"], info["val_size"], info["offset"], op._n_points_total, op._comp_size, 0)
         coeff = device_assign(ctx, desc, info["flat_dofs"], values, size, coeff)
     assert np.array_equal(coeff, op.ref_coefficient.x.array)
     # all-scalar mixed space -> _assign_mixed_2d
     sub2 = [{"n_pts": 3, "val_size": 1, "dofmap": dm0[:, :3]}, {"n_pts": 4, "val_size": 1, "dofmap": dm1}]
-    op2 = MixedExternalOperator(num_cells=n_cells, subspaces=sub2, coefficient_size=size)
-    v2 = rng.normal(size=n_cells * 7)
+    op2 = MixedExternalOperator(num_cells=n_cells, subspaces=sub2, coefficient_size=size, dtype=dtype)
+    v2 = as_dtype(rng, n_cells * 7, dtype)
     op2._assign_func(v2)
-    coeff = np.zeros(size)
+    coeff = np.zeros(size, dtype=dtype)
     for info in op2._mixed_subspace_info:
         desc = AssignDesc(n_cells, info["n_pts"], 1, info["offset"], op2._n_points_total, 1, 0)
         coeff = device_assign(ctx, desc, info["flat_dofs"], v2, size, coeff)
@@ -98,3 +116,10 @@ def test_argument_checks_and_empty(ctx):
         ctx.assign_plan(AssignDesc(2, 2, 1, 0, 2, 1, 0), bad.data_ptr(), 8)                        # NumPy raises IndexError here
     empty = ctx.assign_plan(AssignDesc(0, 2, 1, 0, 2, 1, 0), None, 0)
     empty.apply(None, None)
+    for eb in (1, 2, 3, 12, 32):                                                                   # element widths: 4, 8, 16 (0 = 8)
+        with pytest.raises(ValueError, match="elem_bytes"):
+            ctx.assign(AssignDesc(2, 2, 1, 0, 2, 1, eb), i.data_ptr(), t.data_ptr(), t.data_ptr(), 8)
+        with pytest.raises(ValueError, match="elem_bytes"):
+            ctx.assign_plan(AssignDesc(2, 2, 1, 0, 2, 1, eb), i.data_ptr(), 8)
+    with pytest.raises(ValueError, match="aligned"):                                               # complex128 moves 16-byte words
+        ctx.assign(AssignDesc(2, 2, 1, 0, 2, 1, 16), i.data_ptr(), t.data_ptr() + 8, t.data_ptr(), 4)
