@@ -405,6 +405,13 @@ class Context:
 
     def set_option(self, key: str, value: int) -> None:
         self.check(self.lib.dxo_ctx_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+        self.__dict__.setdefault("_opt_mirror", {})[key] = int(value)
+
+    def option_is(self, key: str, value: int) -> bool:
+        """Is the option known (from this binding's own set_option calls) to hold `value` already? Saves the per-call pair of
+        set_option round trips on latency-bound batches; an option never set through the binding counts as its library default."""
+        m = self.__dict__.get("_opt_mirror")
+        return (m.get(key, None) if m else None) == int(value)
 
     def get_option(self, key: str) -> int:
         v = C.c_int64()

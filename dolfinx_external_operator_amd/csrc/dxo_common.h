@@ -89,6 +89,7 @@ struct dxo_ctx {
     int64_t adjoint_patch = 0;          // internal force on hexahedra, whole mesh: 1 = patch form (entries meet in LDS, adjoint_patch.h; measured SLOWER, profiles/r05_patch_form.txt), 0 = element vectors + node sums
     int64_t mgpu_chunks = 4;            // DXO_GATHER_COMPACT_PIPELINED: pieces of a rank's block (kernel of piece k + 1 beside the exchange of piece k)
     int64_t adjoint_mfma = 1;           // Q2 / Q1 hexahedra, 2x2x2 rule: the consumer-side scatter B^T t as f64 MFMAs (c8m_contract in adjoint.hip); 0 = DPP reduce-scatter (cell8_dpp.h)
+    int64_t adjoint_brick = 1;          // hexahedra, 2x2x2 rule, matrix-pipe scatter: 1 = brick form (cells in the library's Morton order, a wave group's element vectors reduced in the wave: cell8_brick.h), 0 = element vectors per cell
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and
@@ -116,8 +117,9 @@ struct dxo_ctx {
     void* small_pinned = nullptr;
     size_t small_pinned_bytes = 0;
     hipEvent_t small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int64_t host_small_bytes = 2 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
-    int64_t host_zero_copy_bytes = 2 << 20;   // ... and below this many bytes the kernel reads / writes the pinned staging block itself (no DMA)
+    int64_t host_small_bytes = 8 << 20;   // batches whose inputs + outputs fit this many bytes take the small path
+    int64_t host_zero_copy_bytes = 8 << 20;   // ... and below this many bytes the kernel reads / writes page-locked host memory itself (no DMA)
+    int64_t host_zero_copy_piece_bytes = 1 << 20;   // ... in pieces of about this many bytes (at most 4): piece k + 1 is packed while piece k runs
     void* scratch[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     void* stage[DXO_HOST_SLOTS + 1] = {nullptr, nullptr, nullptr, nullptr};   // dxo_stage: operand values in front of a pointwise kernel
@@ -188,6 +190,9 @@ typedef int (*dxo_chunk_post)(dxo_ctx* ctx, void* user, int64_t first, int64_t m
 
 // Run fn(begin, end) over [0, n) split into contiguous ranges on the context's host threads; returns when all are done.
 void dxo_host_parallel_for(dxo_ctx* ctx, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& fn);
+// registry of page-locked host ranges (dxo_ctx.hip): noted by dxo_host_alloc / dxo_host_register, forgotten by their counterparts
+void dxo_pinned_note(void* base, size_t bytes, bool add);
+void* dxo_pinned_mapped(const void* p, size_t bytes);
 
 // Every extern "C" entry point that takes a ctx starts with this (ctx may be NULL: the guard is then a no-op).
 #define DXO_LOCK(ctx) std::unique_lock<std::recursive_mutex> dxo_lock_guard_ = (ctx) ? std::unique_lock<std::recursive_mutex>((ctx)->mu) : std::unique_lock<std::recursive_mutex>()

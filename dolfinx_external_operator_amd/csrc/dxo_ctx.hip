@@ -22,7 +22,37 @@ struct SlotEvents {
 
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Page-locked host ranges this library has handed out or registered (dxo_host_alloc, dxo_host_register), process-wide: the
+// small-batch path of the host pipeline lets the kernel read / write such arrays IN PLACE (they are device-mapped) instead of
+// copying them through its staging block. Keyed by base address.
+std::mutex g_pinned_mu;
+std::map<uintptr_t, size_t> g_pinned;
+
 }  // namespace
+
+void dxo_pinned_note(void* base, size_t bytes, bool add) {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    if (add) g_pinned[(uintptr_t)base] = bytes;
+    else g_pinned.erase((uintptr_t)base);
+}
+
+// device-side address of [p, p + bytes) when that range lies inside a page-locked block of the registry, else nullptr
+void* dxo_pinned_mapped(const void* p, size_t bytes) {
+    if (!p) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        auto it = g_pinned.upper_bound((uintptr_t)p);
+        if (it == g_pinned.begin()) return nullptr;
+        --it;
+        if ((uintptr_t)p + bytes > it->first + it->second) return nullptr;
+    }
+    void* m = nullptr;
+    if (hipHostGetDevicePointer(&m, const_cast<void*>(p), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return m;
+}
 
 extern "C" {
 
@@ -144,6 +174,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "adjoint_atomics")) return &c->adjoint_atomics;
     if (!std::strcmp(key, "adjoint_patch")) return &c->adjoint_patch;
     if (!std::strcmp(key, "adjoint_mfma")) return &c->adjoint_mfma;
+    if (!std::strcmp(key, "adjoint_brick")) return &c->adjoint_brick;
     if (!std::strcmp(key, "mgpu_chunks")) return &c->mgpu_chunks;
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
     if (!std::strcmp(key, "vm_residual_fused")) return &c->vm_residual_fused;
@@ -152,6 +183,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "mc_part_points")) return &c->mc_part_points;
     if (!std::strcmp(key, "host_small_bytes")) return &c->host_small_bytes;
     if (!std::strcmp(key, "host_zero_copy_bytes")) return &c->host_zero_copy_bytes;
+    if (!std::strcmp(key, "host_zero_copy_piece_bytes")) return &c->host_zero_copy_piece_bytes;
     if (!std::strcmp(key, "vm_host_tangent")) return &c->vm_host_tangent;
     if (!std::strcmp(key, "vm_mark_indeterminate")) return &c->vm_mark_indeterminate;
     if (!std::strcmp(key, "assign_validate")) return &c->assign_validate;
@@ -224,6 +256,7 @@ int dxo_host_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     *ptr = nullptr;
     if (c) DXO_HIP(c, hipSetDevice(c->device));
     DXO_HIP(c, hipHostMalloc(ptr, bytes > 0 ? (size_t)bytes : 1, hipHostMallocDefault));
+    dxo_pinned_note(*ptr, bytes > 0 ? (size_t)bytes : 1, true);
     return DXO_OK;
 }
 
@@ -235,12 +268,14 @@ int dxo_host_register(dxo_ctx* c, void* ptr, int64_t bytes) {
     if (bytes <= 0) return dxo_fail(c, DXO_E_SIZE, "dxo_host_register: size must be positive");
     if (c) DXO_HIP(c, hipSetDevice(c->device));
     DXO_HIP(c, hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    dxo_pinned_note(ptr, (size_t)bytes, true);
     return DXO_OK;
 }
 
 int dxo_host_unregister(dxo_ctx* c, void* ptr) {
     DXO_LOCK(c);
     if (!ptr) return DXO_OK;
+    dxo_pinned_note(ptr, 0, false);
     DXO_HIP(c, hipHostUnregister(ptr));
     return DXO_OK;
 }
@@ -248,6 +283,7 @@ int dxo_host_unregister(dxo_ctx* c, void* ptr) {
 int dxo_host_free(dxo_ctx* c, void* ptr) {
     DXO_LOCK(c);
     if (!ptr) return DXO_OK;
+    dxo_pinned_note(ptr, 0, false);
     DXO_HIP(c, hipHostFree(ptr));
     return DXO_OK;
 }
@@ -420,30 +456,59 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                     (void)hipGetLastError();
                     zero_copy = false;
                 } else {
+                    // Every span is either DIRECT — the caller's array is page-locked memory this library handed out or registered
+                    // (the factories' output arrays are: Context.pinned_recycled), the kernel reads / writes it in place and no
+                    // host copy is made — or STAGED in the context's pinned block (packed before the launch / unpacked after it).
+                    // The batch runs in up to 4 PIECES on 64-unit borders: piece k + 1 is packed by this thread while the kernel
+                    // of piece k moves its bytes over PCIe, so the pack of all but the first piece is hidden.
                     char* mbase = static_cast<char*>(mapped);
-                    std::vector<void*> z_in(inputs.size()), z_out(outputs.size());
+                    const size_t ni = inputs.size(), no = outputs.size();
+                    std::vector<char*> z_in(ni), z_out(no), st_in(ni, nullptr), st_out(no, nullptr);
                     size_t zo = 0;
-                    for (size_t k = 0; k < inputs.size(); ++k) {
-                        std::memcpy(hbase + zo, inputs[k].in, inputs[k].bytes_pp * (size_t)n);
-                        z_in[k] = mbase + zo;
-                        zo += round_up(inputs[k].bytes_pp * (size_t)n, 256);
+                    for (size_t k = 0; k < ni; ++k) {
+                        const size_t bytes = inputs[k].bytes_pp * (size_t)n;
+                        if (void* m = dxo_pinned_mapped(inputs[k].in, bytes)) {
+                            z_in[k] = static_cast<char*>(m);
+                        } else {
+                            st_in[k] = hbase + zo;
+                            z_in[k] = mbase + zo;
+                        }
+                        zo += round_up(bytes, 256);
                     }
-                    const size_t z_out_base = zo;
-                    for (size_t k = 0; k < outputs.size(); ++k) {
-                        z_out[k] = mbase + zo;
-                        zo += round_up(outputs[k].bytes_pp * (size_t)n, 256);
+                    for (size_t k = 0; k < no; ++k) {
+                        const size_t bytes = outputs[k].bytes_pp * (size_t)n;
+                        void* m = outputs[k].out ? dxo_pinned_mapped(outputs[k].out, bytes) : nullptr;
+                        if (m) {
+                            z_out[k] = static_cast<char*>(m);
+                        } else {
+                            st_out[k] = hbase + zo;
+                            z_out[k] = mbase + zo;
+                        }
+                        zo += round_up(bytes, 256);
                     }
-                    int rcz = launch(c, user, n, z_in.data(), z_out.data(), s);
-                    if (rcz != DXO_OK) return rcz;
+                    int64_t pieces = c->host_zero_copy_piece_bytes > 0 ? (int64_t)(need / (size_t)c->host_zero_copy_piece_bytes) : 1;
+                    if (pieces > 4) pieces = 4;
+                    if (pieces < 1) pieces = 1;
+                    int64_t step = (n + pieces - 1) / pieces;
+                    step = (step + DXO_WAVE - 1) / DXO_WAVE * DXO_WAVE;
+                    std::vector<void*> a_in(ni), a_out(no);
+                    for (int64_t b0 = 0; b0 < n; b0 += step) {
+                        const int64_t m = b0 + step < n ? step : n - b0;
+                        for (size_t k = 0; k < ni; ++k) {
+                            const size_t o = inputs[k].bytes_pp * (size_t)b0;
+                            if (st_in[k]) std::memcpy(st_in[k] + o, static_cast<const char*>(inputs[k].in) + o, inputs[k].bytes_pp * (size_t)m);
+                            a_in[k] = z_in[k] + o;
+                        }
+                        for (size_t k = 0; k < no; ++k) a_out[k] = z_out[k] + outputs[k].bytes_pp * (size_t)b0;
+                        const int rcz = launch(c, user, m, a_in.data(), a_out.data(), s);
+                        if (rcz != DXO_OK) return rcz;
+                    }
                     DXO_HIP(c, hipGetLastError());
                     DXO_HIP(c, hipStreamSynchronize(s));
-                    zo = z_out_base;
-                    for (size_t k = 0; k < outputs.size(); ++k) {
-                        if (outputs[k].out) std::memcpy(outputs[k].out, hbase + zo, outputs[k].bytes_pp * (size_t)n);
-                        zo += round_up(outputs[k].bytes_pp * (size_t)n, 256);
-                    }
+                    for (size_t k = 0; k < no; ++k)
+                        if (st_out[k] && outputs[k].out) std::memcpy(outputs[k].out, st_out[k], outputs[k].bytes_pp * (size_t)n);
                     if (post) {
-                        rcz = post(c, user, 0, n);
+                        const int rcz = post(c, user, 0, n);
                         if (rcz != DXO_OK) return rcz;
                     }
                     c->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0s).count();

@@ -89,6 +89,19 @@ class _Outputs:
         self._cache: dict[tuple[str, int], np.ndarray] = {}
         self._retired: list[np.ndarray] = []   # reuse=True buffers of an earlier batch size: never freed under a live view
 
+    def get_many(self, keys, sizes) -> list[np.ndarray]:
+        """Several fp64 outputs of one call. Without targets / reuse they are views of ONE recycled page-locked block (each on a
+        256-byte border): one trip to the pool per call instead of one per array — the fixed cost that matters at the demos' sizes.
+        The block returns to the pool when the last view is gone, exactly like single arrays."""
+        if self.targets or self.reuse:
+            return [self.get(k, n) for k, n in zip(keys, sizes)]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 31) // 32 * 32
+        block = self.ctx.pinned_recycled(total, np.float64)
+        return [block[o:o + n] for o, n in zip(offs, sizes)]
+
     def get(self, key: str, size: int, dtype=np.float64) -> np.ndarray:
         if key in self.targets:
             a = _state_array(self.targets[key])
@@ -261,10 +274,7 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
         if sigma_n_.size != n * d or p_.size != n:
             # the reference's reshape at :347-348 raises ValueError on a size mismatch
             raise ValueError(f"state size mismatch: sigma_n {sigma_n_.size} (want {n * d}), p {p_.size} (want {n})")
-        out = holder["out"]
-        C_tang_ = out.get("C_tang", n * d * d)
-        sigma_ = out.get("sigma", n * d)
-        dp_ = out.get("dp", n)
+        C_tang_, sigma_, dp_ = holder["out"].get_many(("C_tang", "sigma", "dp"), (n * d * d, n * d, n))
         if devices is not None:   # one cell block per GPU, each over its own PCIe link, no collective
             if holder["mgpu"] is None:
                 from ._lib import MultiGpu
@@ -274,16 +284,21 @@ def make_von_mises(sigma_n, p, *, E: float = 70e3, nu: float = 0.3, sigma_0: flo
             g.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
             g.von_mises_host(prm, d, n, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
             return _like(deps, C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1))
+        want = 1 if host_tangent == "rebuild" else 0
         with c._lock:   # the option is per context: set, call, restore without another thread's call in between
-            c.set_option("vm_host_tangent", 1 if host_tangent == "rebuild" else 0)
+            if not c.option_is("vm_host_tangent", want):
+                c.set_option("vm_host_tangent", want)
             try:
                 if mirror is not None:
                     mirror.sync(c, d, n, sigma_n_, p_).call(prm, MEM_HOST, deps_, C_tang_, sigma_, dp_)
                 else:
                     c.von_mises(prm, d, n, MEM_HOST, deps_, sigma_n_, p_, C_tang_, sigma_, dp_)
             finally:
-                c.set_option("vm_host_tangent", 0)
-        return _like(deps, C_tang_.reshape(-1), sigma_.reshape(-1), dp_.reshape(-1))   # :352
+                if want:
+                    c.set_option("vm_host_tangent", 0)
+        if deps.dtype == np.float32:
+            return _like(deps, C_tang_, sigma_, dp_)
+        return C_tang_, sigma_, dp_   # :352 (flat already)
 
     def sigma_external(derivatives):
         if derivatives == (1,):
@@ -440,7 +455,7 @@ def von_mises_commit_state(p, dp, sigma_n, sigma, *, ctx: Context | None = None,
 
 
 def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, device: int = 0,
-              fuse_by_identity: bool = False) -> Callable:
+              fuse_by_identity: bool | None = None) -> Callable:
     """`q_external` of the nonlinear-heat demo (demo_nonlinear_heat_equation_part2.py:276-284) on the GPU.
 
     external_function((0, 0))(T, sigma) -> q        flat (N*gdim,)        (:219-230)
@@ -449,26 +464,46 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     T: (num_cells, nq); sigma: (num_cells, nq*gdim) or (num_cells, nq, gdim) (:222-225); gdim is
     sigma.size / T.size.
 
-    By default every call launches the kernel with only the requested output (the other output pointers
-    are NULL). With fuse_by_identity=True the first call for a given pair of operand OBJECTS computes all
-    three outputs in one launch and the next two calls (part2.py:307-309 evaluates F- and J-operators
-    from the same `evaluated_operands` dict) are served from that result. Only enable it if the operand
-    arrays are not modified in place between those calls (evaluate_operands returns fresh arrays).
-    Why this is not the default: a NumPy array carries no modification stamp, so "the same operands came back" can
-    only be PROVEN by comparing contents, which at BASELINE config 1 (6 144 points) costs as much as the launch it
-    would save (two np.array_equal + two copies, ~30 us against ~29 us per call), and at large sizes far more. The
-    caller knows: `external_function.bind(q_operator, dqdT_operator, dqdsigma_operator)` is the one-line statement
-    "this function is driven by evaluate_external_operators with ONE evaluated_operands dict per pass" (part2.py:307-309).
-    It (i) turns identity fusion on and (ii) installs the three operators' coefficient arrays as output targets (entries
-    may be None), so one launch per pass fills all three coefficients and the reference's `x.array[:] = values`
-    (external_operator.py:441) finds source == destination: 36-45 us per step at config 1 against 63 us for the reference's
-    NumPy statements and 87 us for three separate launches.
+    One pass of the reference evaluates the F- and the J-operators from ONE `evaluated_operands` dict (part2.py:307-309): the three
+    derivatives are asked for the SAME operand array objects, one after the other. With fuse_by_identity=None (the default since
+    round 6: fusion for NumPy operands, guarded as described below; CUDA-tensor operands are fused only with an explicit True, as
+    a tripwire on device memory would cost a synchronisation) the first call for a pair of operand OBJECTS computes all three
+    outputs in one launch and the next calls with the very
+    same objects are served from that result — three launches become one (config 1: 80 -> about 50 us per pass). A NumPy array
+    carries no modification stamp, so an operand modified IN PLACE between two such calls cannot be proven unchanged without
+    comparing contents (which costs as much as the launch saved); what guards the served result is (i) object identity (the kept
+    arrays stay alive, their ids cannot be recycled), (ii) equal shapes and (iii) a TRIPWIRE: 48 strided entries of each operand
+    are compared with what the fused launch saw — any whole-array update (`T *= 2`, `T[:] = ...`, a new solution written in place)
+    trips it and the call recomputes. A caller that pokes single entries of an operand between the derivative calls of one pass
+    must pass fuse_by_identity=False (every call then launches the kernel with only the requested output). evaluate_operands
+    returns fresh arrays at every pass (external_operator.py:386-402), so the reference's own flow never relies on the tripwire.
+    `external_function.bind(q_operator, dqdT_operator, dqdsigma_operator)` additionally installs the three operators' coefficient
+    arrays as output targets (entries may be None), so the one launch per pass fills all three coefficients and the reference's
+    `x.array[:] = values` (external_operator.py:441) finds source == destination: 36-45 us per step at config 1 against 63 us for
+    the reference's NumPy statements.
     """
-    holder = {"ctx": ctx, "keep": None, "val": None, "targets": None, "fuse": bool(fuse_by_identity)}
+    holder = {"ctx": ctx, "keep": None, "val": None, "targets": None, "fuse": fuse_by_identity, "probe": None}
     names = ("q", "dqdT", "dqdsigma")
+
+    def _probe(T, sigma):
+        """(shapes, 48 strided entries of each operand): the tripwire of the identity fusion."""
+        tf, sf = T.reshape(-1), sigma.reshape(-1)
+        return (T.shape, sigma.shape, tf[:: max(tf.size // 48, 1)][:48].copy(), sf[:: max(sf.size // 48, 1)][:48].copy())
+
+    def _probe_same(a, b):
+        return a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
 
     def _host_outs(sizes, which, fuse):
         tg = holder["targets"]
+        if tg is None or all(t is None for t in tg):
+            # no targets: views of ONE recycled page-locked block (the kernel writes it in place, no staging copy)
+            want = [k for k in range(3) if fuse or k == which]
+            offs, total = {}, 0
+            for k in want:
+                offs[k] = total
+                total += (sizes[k] + 31) // 32 * 32
+            block = holder["ctx"].pinned_recycled(total, np.float64)
+            return [block[offs[k]:offs[k] + sizes[k]] if k in offs else None for k in range(3)]
         outs = []
         for k, sz in enumerate(sizes):
             if not (fuse or k == which):
@@ -489,8 +524,12 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
             holder["ctx"] = default_context(device)
         c = holder["ctx"]
         fuse_by_identity = holder["fuse"]
+        if fuse_by_identity is None:      # default: NumPy operands only (tripwire-guarded)
+            fuse_by_identity = isinstance(T, np.ndarray) and isinstance(sigma, np.ndarray)
         if fuse_by_identity and holder["keep"] is not None and holder["keep"][0] is T and holder["keep"][1] is sigma:
-            return holder["val"][which]
+            if holder["probe"] is None or _probe_same(holder["probe"], _probe(T, sigma)):
+                return holder["val"][which]
+            holder["keep"] = holder["val"] = holder["probe"] = None      # the operands were modified in place: recompute
         if (isinstance(T, LazyOperand) and isinstance(sigma, LazyOperand) and T.kind == "value" and sigma.kind == "grad"
                 and T.bs == 1 and sigma.bs == 1 and T.mesh is sigma.mesh and T.mesh.ctx is c and np.array_equal(T.u, sigma.u)):
             # both operands are still unevaluated views of the SAME scalar field: T, grad T and the requested output
@@ -540,6 +579,7 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
         if fuse_by_identity:
             holder["keep"] = (T, sigma)
             holder["val"] = outs
+            holder["probe"] = _probe(T, sigma) if isinstance(T, np.ndarray) and isinstance(sigma, np.ndarray) else None
         return outs[which]
 
     def q_impl(T, sigma):
@@ -563,7 +603,7 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     def bind(q_operator=None, dqdT_operator=None, dqdsigma_operator=None):
         holder["targets"] = tuple(None if o is None else _coefficient_of(o) for o in (q_operator, dqdT_operator, dqdsigma_operator))
         holder["fuse"] = True
-        holder["keep"] = holder["val"] = None
+        holder["keep"] = holder["val"] = holder["probe"] = None
         return q_external
 
     q_external.bind = bind

@@ -50,9 +50,38 @@ def test_fused_by_identity_gives_same_values(ctx, golden):
     g = golden("heat_c1.npz")
     T, s = g["T"], g["sigma"]
     fused = make_heat(ctx=ctx, fuse_by_identity=True)
-    plain = make_heat(ctx=ctx)
+    plain = make_heat(ctx=ctx, fuse_by_identity=False)
     for idx in ((0, 0), (1, 0), (0, 1)):
         assert np.array_equal(fused(idx)(T, s), plain(idx)(T, s))
+
+
+def test_default_fuses_one_pass_of_numpy_operands_and_the_tripwire_catches_in_place_updates(ctx, golden):
+    """Round 6 default (fuse_by_identity=None): the three derivative calls of one pass on the SAME NumPy operand objects are one
+    launch (part2.py:307-309 drives them from one evaluated_operands dict); fresh arrays, other shapes or an in-place update of an
+    operand (caught by the 48-entry tripwire) launch again, and the values are those of the unfused calls bit for bit."""
+    g = golden("heat_c1.npz")
+    T, s = g["T"].copy(), g["sigma"].copy()
+    q_external = make_heat(A=float(g["A"]), B=float(g["B"]), ctx=ctx)
+    plain = make_heat(A=float(g["A"]), B=float(g["B"]), ctx=ctx, fuse_by_identity=False)
+    launches = []
+    real = ctx.heat
+    ctx.heat = lambda *a, **k: (launches.append(1), real(*a, **k))[1]
+    try:
+        got = [q_external(idx)(T, s) for idx in ((0, 0), (1, 0), (0, 1))]
+        assert len(launches) == 1
+        T2, s2 = T.copy(), s.copy()                      # the next pass: fresh operand arrays
+        got2 = [q_external(idx)(T2, s2) for idx in ((0, 0), (1, 0), (0, 1))]
+        assert len(launches) == 2
+        T2 *= 1.5                                        # a new solution written IN PLACE between two derivative calls
+        stale_guard = q_external((1, 0))(T2, s2)
+        assert len(launches) == 3
+    finally:
+        ctx.heat = real
+    for k, idx in enumerate(((0, 0), (1, 0), (0, 1))):
+        ref = plain(idx)(T, s)
+        assert np.array_equal(got[k], ref) and np.array_equal(got2[k], ref)
+    assert np.array_equal(stale_guard, plain((1, 0))(T2, s2)) and not np.array_equal(stale_guard, got2[1])
+    assert rel(got[0], g["q"]) <= RTOL and rel(got[2], g["dqdsigma"]) <= RTOL
 
 
 def test_bind_fuses_one_pass_and_writes_the_three_coefficients_in_place(ctx, golden):

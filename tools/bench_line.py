@@ -79,6 +79,9 @@ def leg_summary(leg):
         out["ms"] = _r(float(ms), 5)
     if isinstance(leg.get("value"), (int, float)):
         out["value"] = _r(float(leg["value"]), 5)
+    for k in ("us_per_call", "us_per_step", "us_per_step_bind", "us_per_step_three_calls"):      # the latency-bound legs (demo sizes)
+        if isinstance(leg.get(k), (int, float)):
+            out[k] = _r(float(leg[k]), 4)
     rs = _roof_short(leg.get("roofline"))
     if rs:
         out.update(rs)
@@ -87,6 +90,9 @@ def leg_summary(leg):
         out["cpu"] = _r(float(cpu["value"]), 4)
         if cpu.get("cores") is not None:
             out["cpu_cores"] = cpu["cores"]
+        for k in ("us_per_call", "us_per_step"):
+            if isinstance(cpu.get(k), (int, float)):
+                out["cpu_" + k] = _r(float(cpu[k]), 4)
     if isinstance(leg.get("calls"), dict):
         out["calls"] = _calls_short(leg["calls"])
     wo = leg.get("without_tangent_array")
