@@ -37,7 +37,6 @@
 #include "cell8_mfma.h"
 #include "scatter_mfma.h"
 #include "vm_core.h"
-#include "cell8_brick.h"
 #ifdef DXO_EXPERIMENTS
 #include "../../scripts/exp/adjoint_patch.h"
 #endif
@@ -549,11 +548,9 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8(OperandDev m, co
 constexpr int C8M_FTAB = 0;
 #endif
 
-// BR: the brick form (cell8_brick.h) — `m` carries the brick-ordered dofmaps, S is reached through br.orig, and the group's element
-// vectors leave the wave as one partial per node it touches (br.part) instead of 8 x ND entries of `fe`
-template <int ND, bool BR = false>
+template <int ND>
 __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8_mfma(OperandDev m, const double* __restrict__ wq, const double* __restrict__ S,
-                                                                     int64_t n_cells, double* __restrict__ out, double* __restrict__ fe, BrickDev br = BrickDev()) {
+                                                                     int64_t n_cells, double* __restrict__ out, double* __restrict__ fe) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // geometry rows only (the dphi table lives in the A fragments): [q][vertex][dpsi_x, dpsi_y, dpsi_z, 0] at the offset C8Lane expects
     for (int e = threadIdx.x; e < C8_GEO; e += blockDim.x) {
@@ -593,16 +590,8 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8_mfma(OperandDev 
         const int ncell = cells_in(grp);
         const bool has_point = c_l < ncell;
         dxo_f64x2 s2[3];
-        BrickTabReg tabw;
-        int64_t slot0 = 0;
         {
-            int64_t pt = c0 * 8 + lane;
-            if constexpr (BR) {
-                pt = has_point ? (int64_t)br.orig[c0 + c_l] * 8 + q_l : 0;      // the stress lives in the caller's cell order
-                tabw = brick_request_table(br, grp, lane);
-                slot0 = br.slot0[grp];
-            }
-            const dxo_f64x2* Sp = reinterpret_cast<const dxo_f64x2*>(S + pt * 6);
+            const dxo_f64x2* Sp = reinterpret_cast<const dxo_f64x2*>(S + (c0 * 8 + lane) * 6);
 #pragma unroll
             for (int k = 0; k < 3; ++k) s2[k] = has_point ? Sp[k] : dxo_f64x2{0.0, 0.0};
         }
@@ -626,8 +615,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8_mfma(OperandDev 
             }
         c8m_d4 acc[2][2];
         c8m_contract(Tl, lane, T, Afr, acc);
-        if constexpr (BR) c8m_store_brick<ND>(Tl, lane, acc, tabw, slot0, br.part);
-        else c8m_store<ND>(m, lane, acc, c0, ncell, fe, out);
+        c8m_store<ND>(m, lane, acc, c0, ncell, fe, out);
     }
 }
 
@@ -646,13 +634,11 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_adjoint_c8_mfma(OperandDev 
 // (iii) the parked tensors have an odd stride (adjoint_scatter). ND_CT / NG_CT as in operand_compute_geo.
 // VM: the tangent's action comes from the von Mises state (VmStateSrc) instead of from C_tang rows.
 // MF (option adjoint_mfma, Q2 hexahedra): the scatter's contraction as f64 MFMAs (c8m_contract) instead of the DPP reduce-scatter.
-// BR (hexahedra, VM, MF): the brick form of the scatter (cell8_brick.h) — `m` carries the brick-ordered dofmaps, the state is reached through br.orig.
-template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false, bool MF = false, bool BR = false>
+template <int G, int ND_CT = 0, int NG_CT = 0, bool VM = false, bool MF = false>
 __global__ __launch_bounds__(DXO_BLOCK, (MF && ND_CT != 27) ? DXO_TA_GM_WAVES : VM ? (MF ? DXO_TA_VM_MF_WAVES : DXO_TA_VM_WAVES) : DXO_TA_WAVES) void tangent_apply(OperandDev m, const double* __restrict__ wq, int lds_wave,
                                                               const double* __restrict__ C_tang, VmStateSrc vs,
                                                               const double* __restrict__ v, int64_t n_cells,
-                                                              double* __restrict__ out, double* __restrict__ fe, BrickDev br = BrickDev()) {
-    static_assert(!BR || (VM && MF && G == 3 && NG_CT == 8), "the brick form is the state-based matrix-pipe kernel's on hexahedra");
+                                                              double* __restrict__ out, double* __restrict__ fe) {
     constexpr int D = G == 2 ? 4 : 6;
     constexpr int CV = D * D / 2;        // 16-byte pieces of a point's tangent
     // cells of 8 points and at most 32 nodes (launched so only for nq = 8): the scatter phase runs in registers, a DPP
@@ -704,13 +690,7 @@ __global__ __launch_bounds__(DXO_BLOCK, (MF && ND_CT != 27) ? DXO_TA_GM_WAVES : 
 #if DXO_TA_STAGE
         TangentRows<D> rows;
         VmPoint<D> vp;
-        BrickTabReg tabw;
-        int64_t slot0 = 0;
-        if constexpr (BR) {
-            vp.request(vs, has_point ? (int64_t)br.orig[c0 + (lane >> 3)] * 8 + (lane & 7) : 0, has_point);      // the state lives in the caller's cell order
-            tabw = brick_request_table(br, grp, lane);
-            slot0 = br.slot0[grp];
-        } else if constexpr (VM) vp.request(vs, c0 * m.nq + lane, has_point);
+        if constexpr (VM) vp.request(vs, c0 * m.nq + lane, has_point);
 #if DXO_TA_EARLY_C
         if constexpr (!VM) rows.request(C_tang, c0 * m.nq, ncell * m.nq, lane);
 #endif
@@ -803,8 +783,7 @@ __global__ __launch_bounds__(DXO_BLOCK, (MF && ND_CT != 27) ? DXO_TA_GM_WAVES : 
                 c8m_d4 acc[2][2];
                 const double none[2][6] = {};
                 c8m_contract<true>(W, lane, T, none, acc, tabP);       // compute_geo / rows.times have fenced: the gather buffer is free
-                if constexpr (BR) c8m_store_brick<ND_CT>(W, lane, acc, tabw, slot0, br.part);
-                else c8m_store<ND_CT>(m, lane, acc, c0, ncell, fe, out);
+                c8m_store<ND_CT>(m, lane, acc, c0, ncell, fe, out);
                 continue;
             }
             const int64_t cell = c0 + (lane >> 3);
@@ -1144,65 +1123,6 @@ int ensure_transpose(dxo_ctx* ctx, dxo_mesh* m) {
     return DXO_OK;
 }
 
-// brick form (cell8_brick.h): built once per mesh on first use
-bool ensure_bricks(dxo_ctx* ctx, dxo_mesh* m) {
-    BrickSet& bs = m->brick;
-    if (!bs.built) {
-        bs.built = true;
-        BrickHost H;
-        if (!brick_build_host(m->h_dofmap, m->h_geom_dofmap, m->h_cell_xyz, m->h_cell_ext, m->num_cells, m->dev.ndofs, m->num_field_nodes, H)) return false;
-        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t sz[] = {H.orig.size() * 4, H.dofmap.size() * 4, H.geom.size() * 4, H.tab_id.size() * 4, H.slot0.size() * 8, H.tabs.size(),
-                             H.node_ptr.size() * 8, (H.node_ent.size() + 4) * 4};
-        const void* src[] = {H.orig.data(), H.dofmap.data(), H.geom.data(), H.tab_id.data(), H.slot0.data(), H.tabs.data(), H.node_ptr.data(), H.node_ent.data()};
-        const size_t real[] = {sz[0], sz[1], sz[2], sz[3], sz[4], sz[5], sz[6], H.node_ent.size() * 4};
-        size_t off[8], total = 0;
-        for (int k = 0; k < 8; ++k) { off[k] = total; total += al(sz[k] ? sz[k] : 1); }
-        if (hipMalloc(&bs.blob, total) != hipSuccess) { (void)hipGetLastError(); bs.blob = nullptr; return false; }
-        char* b = static_cast<char*>(bs.blob);
-        for (int k = 0; k < 8; ++k)
-            if (real[k] && hipMemcpy(b + off[k], src[k], real[k], hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
-        BrickDev& d = bs.dev;
-        d.orig = reinterpret_cast<const int32_t*>(b + off[0]);
-        d.dofmap = reinterpret_cast<const int32_t*>(b + off[1]);
-        d.geom_dofmap = reinterpret_cast<const int32_t*>(b + off[2]);
-        d.tab_id = reinterpret_cast<const int32_t*>(b + off[3]);
-        d.slot0 = reinterpret_cast<const int64_t*>(b + off[4]);
-        d.tabs = reinterpret_cast<const uint8_t*>(b + off[5]);
-        bs.d_node_ptr = reinterpret_cast<int64_t*>(b + off[6]);
-        bs.d_node_ent = reinterpret_cast<uint32_t*>(b + off[7]);
-        bs.n_slots = H.n_slots;
-        bs.n_tables = (int64_t)(H.tabs.size() / BRICK_TAB_BYTES);
-        bs.usable = true;
-    }
-    if (!bs.usable) return false;
-    const size_t need = (size_t)bs.n_slots * 3 * sizeof(double);
-    if (bs.part_cap < need) {
-        if (bs.dev.part) (void)hipFree(bs.dev.part);
-        bs.dev.part = nullptr;
-        bs.part_cap = 0;
-        if (hipMalloc((void**)&bs.dev.part, need ? need : 8) != hipSuccess) { (void)hipGetLastError(); return false; }
-        bs.part_cap = need;
-    }
-    return true;
-}
-
-// does this call take the brick form? (hexahedra with the 2x2x2 rule, whole mesh, matrix-pipe scatter, no atomics)
-bool use_bricks(dxo_ctx* ctx, dxo_mesh* m, const int32_t* cells, int64_t n_cells) {
-    if (!ctx->adjoint_brick || !ctx->adjoint_mfma || ctx->adjoint_atomics || cells || n_cells != m->num_cells) return false;
-    if (m->gdim != 3 || m->dev.nq != 8 || m->dev.ngeom != 8 || (m->dev.ndofs != 27 && m->dev.ndofs != 8)) return false;
-    return ensure_bricks(ctx, m);
-}
-
-OperandDev brick_dev(const dxo_mesh* m) {
-    OperandDev v = m->dev;
-    v.dofmap = m->brick.dev.dofmap;
-    v.geom_dofmap = m->brick.dev.geom_dofmap;
-    return v;
-}
-
-void launch_node_sum_brick(const dxo_ctx* ctx, const dxo_mesh* m, double* out, hipStream_t s);
-
 #ifdef DXO_EXPERIMENTS
 #define DXO_PATCH_PART 2
 #include "../../scripts/exp/adjoint_patch_kernels.h"
@@ -1239,16 +1159,6 @@ void launch_node_sum(const dxo_ctx* ctx, const dxo_mesh* m, int bs, double* out,
     if (bs == 1) hipLaunchKernelGGL(node_sum<1>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
     else if (bs == 2) hipLaunchKernelGGL(node_sum<2>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
     else hipLaunchKernelGGL(node_sum<3>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->d_node_ptr, m->d_node_ent, m->d_fe, out, (int)(ctx->consumer_overwrite != 0));
-}
-
-// the brick form's second pass: the same kernel over the groups' partials (at most 8 per node on structured hexahedra)
-void launch_node_sum_brick(const dxo_ctx* ctx, const dxo_mesh* m, double* out, hipStream_t s) {
-    int64_t blocks = (m->num_field_nodes + DXO_BLOCK - 1) / DXO_BLOCK;
-    const int64_t cap = (int64_t)ctx->compute_units * DXO_NS_BLOCKS_PER_CU;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(node_sum<3>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->num_field_nodes, m->brick.d_node_ptr, m->brick.d_node_ent, m->brick.dev.part, out,
-                       (int)(ctx->consumer_overwrite != 0));
 }
 
 template <int G, int BS, int KIND>
@@ -1342,22 +1252,6 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
         return dxo_device_end(ctx, s);
     }
 #endif
-    if (c8 && use_bricks(ctx, mesh, cells, n_cells)) {
-        // brick form (cell8_brick.h): the group's element vectors meet in the wave, one partial per touched node leaves it
-        int rc = dxo_device_begin(ctx, s);
-        if (rc != DXO_OK) return rc;
-        const int64_t n_groups = (n_cells + 7) / 8;
-        int64_t blocks = (n_groups + 3) / 4;
-        const int64_t cap = (int64_t)ctx->compute_units * DXO_C8_ADJ_BLOCKS_PER_CU;
-        if (blocks > cap) blocks = cap;
-        blocks = (blocks + 7) / 8 * 8;
-        const size_t shm = (size_t)(C8_LDS + (DXO_BLOCK / DXO_WAVE) * C8M_WAVE) * sizeof(double);
-        const OperandDev mb = brick_dev(mesh);
-        if (mesh->dev.ndofs == 27) hipLaunchKernelGGL((operand_adjoint_c8_mfma<27, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mb, mesh->d_wq, S, n_cells, out, nullptr, mesh->brick.dev);
-        else                       hipLaunchKernelGGL((operand_adjoint_c8_mfma<8, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mb, mesh->d_wq, S, n_cells, out, nullptr, mesh->brick.dev);
-        launch_node_sum_brick(ctx, mesh, out, s);
-        return dxo_device_end(ctx, s);
-    }
     double* fe = two_pass_buffer(ctx, mesh, bs, cells, n_cells);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
@@ -1485,6 +1379,11 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     if (shm > 64 * 1024) return dxo_fail(ctx, DXO_E_SIZE, "dxo_tangent_apply: element too large for the LDS budget");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
+    double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    rc = clear_for_atomics(ctx, mesh, mesh->gdim, out, fe, s);
+    if (rc != DXO_OK) return rc;
     const int64_t n_groups = (mesh->num_cells + mesh->dev.cells_per_wave - 1) / mesh->dev.cells_per_wave;
     int64_t blocks = (n_groups + 3) / 4;
     const int64_t cap = (int64_t)ctx->compute_units * (vs ? DXO_TA_VM_BLOCKS_PER_CU : DXO_TA_BLOCKS_PER_CU);
@@ -1492,21 +1391,6 @@ int tangent_apply_impl(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, const
     blocks = (blocks + 7) / 8 * 8;
     const VmStateSrc none{};
     const VmStateSrc& src = vs ? *vs : none;
-    if (vs && (q1 || (rs && ctx->adjoint_mfma)) && wd >= C8M_WAVE && use_bricks(ctx, mesh, nullptr, mesh->num_cells)) {
-        // brick form (cell8_brick.h): the group's element vectors are reduced in the wave, one partial per touched node leaves it
-        int rcb = dxo_device_begin(ctx, s);
-        if (rcb != DXO_OK) return rcb;
-        const OperandDev mb = brick_dev(mesh);
-        if (q1) hipLaunchKernelGGL((tangent_apply<3, 8, 8, true, true, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mb, mesh->d_wq, wd, C_tang, src, v, mesh->num_cells, out, nullptr, mesh->brick.dev);
-        else    hipLaunchKernelGGL((tangent_apply<3, 27, 8, true, true, true>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mb, mesh->d_wq, wd, C_tang, src, v, mesh->num_cells, out, nullptr, mesh->brick.dev);
-        launch_node_sum_brick(ctx, mesh, out, s);
-        return dxo_device_end(ctx, s);
-    }
-    double* fe = two_pass_buffer(ctx, mesh, mesh->gdim, nullptr, mesh->num_cells);
-    int rc = dxo_device_begin(ctx, s);
-    if (rc != DXO_OK) return rc;
-    rc = clear_for_atomics(ctx, mesh, mesh->gdim, out, fe, s);
-    if (rc != DXO_OK) return rc;
 #define DXO_APPLY_LAUNCH(...) hipLaunchKernelGGL((tangent_apply<__VA_ARGS__>), dim3((int)blocks), dim3(DXO_BLOCK), shm, s, mesh->dev, mesh->d_wq, wd, C_tang, src, v, mesh->num_cells, out, fe)
 #ifdef DXO_EXPERIMENTS
     if (!vs && DXO_TANGENT_CELL && fe && ctx->adjoint_cell && launch_tangent_cell(ctx, mesh, C_tang, v, fe, s)) {

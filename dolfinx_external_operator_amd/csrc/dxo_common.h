@@ -89,7 +89,6 @@ struct dxo_ctx {
     int64_t adjoint_patch = 0;          // internal force on hexahedra, whole mesh: 1 = patch form (entries meet in LDS, adjoint_patch.h; measured SLOWER, profiles/r05_patch_form.txt), 0 = element vectors + node sums
     int64_t mgpu_chunks = 4;            // DXO_GATHER_COMPACT_PIPELINED: pieces of a rank's block (kernel of piece k + 1 beside the exchange of piece k)
     int64_t adjoint_mfma = 1;           // Q2 / Q1 hexahedra, 2x2x2 rule: the consumer-side scatter B^T t as f64 MFMAs (c8m_contract in adjoint.hip); 0 = DPP reduce-scatter (cell8_dpp.h)
-    int64_t adjoint_brick = 1;          // hexahedra, 2x2x2 rule, matrix-pipe scatter: 1 = brick form (cells in the library's Morton order, a wave group's element vectors reduced in the wave: cell8_brick.h), 0 = element vectors per cell
     int64_t adjoint_atomics = 0;        // adjoint kernels: 1 = fp64 atomics into the dof vector, 0 = element vectors + node sums
     int64_t mc_part_points = (int64_t)1 << 30;   // Mohr-Coulomb: points per classify/Newton pass (int32 list entries)
     int64_t mc_waves_per_simd = 1;      // kept for option compatibility: mc_newton keeps its lane state in LDS (mc_core.h LaneLds) and

@@ -174,7 +174,6 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "adjoint_atomics")) return &c->adjoint_atomics;
     if (!std::strcmp(key, "adjoint_patch")) return &c->adjoint_patch;
     if (!std::strcmp(key, "adjoint_mfma")) return &c->adjoint_mfma;
-    if (!std::strcmp(key, "adjoint_brick")) return &c->adjoint_brick;
     if (!std::strcmp(key, "mgpu_chunks")) return &c->mgpu_chunks;
     if (!std::strcmp(key, "adjoint_cell")) return &c->adjoint_cell;
     if (!std::strcmp(key, "vm_residual_fused")) return &c->vm_residual_fused;
@@ -413,7 +412,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
         for (const auto& s : inputs)
             if (!s.dev) in_bytes += round_up(s.bytes_pp * (size_t)n, 256);
         for (const auto& s : outputs) out_bytes += round_up(s.bytes_pp * (size_t)n, 256);
-        if ((int64_t)(in_bytes + out_bytes) <= c->host_small_bytes) {
+        // (a batch the caller's chunk size would split — option host_chunk_points below the batch — takes the chunked ring it asks for)
+        if ((int64_t)(in_bytes + out_bytes) <= c->host_small_bytes && n * (points_per_unit > 0 ? points_per_unit : 1) <= c->host_chunk_points) {
             const size_t need = in_bytes + out_bytes;
             if (need > c->small_pinned_bytes) {
                 if (c->small_pinned) DXO_HIP(c, hipHostFree(c->small_pinned));

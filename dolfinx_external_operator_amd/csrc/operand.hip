@@ -244,20 +244,6 @@ extern "C" int dxo_mesh_create(dxo_ctx* ctx, const dxo_mesh_desc* d, dxo_mesh** 
     const int32_t* bi = reinterpret_cast<const int32_t*>(v.x + n_x);
     v.dofmap = bi; v.geom_dofmap = bi + n_dm;
     if (n_dm) m->h_dofmap.assign(d->dofmap, d->dofmap + n_dm);
-    if (n_gm && G == 3 && d->ngeom == 8 && d->nq == 8) {      // brick order of the consumer-side kernels (cell8_brick.h), built on first use
-        m->h_geom_dofmap.assign(d->geom_dofmap, d->geom_dofmap + n_gm);
-        // mean spacing of the cells along every global axis: edge vector k of a hexahedron = mean of the vertices whose local index has
-        // bit k set minus mean of the others (tensor-product vertex order); per axis the largest component over the three edge vectors
-        double acc[3] = {0.0, 0.0, 0.0};
-        for (int64_t c = 0; c < d->num_cells; ++c) {
-            double ev[3][3] = {};
-            for (int v2 = 0; v2 < 8; ++v2)
-                for (int k = 0; k < 3; ++k)
-                    for (int j = 0; j < 3; ++j) ev[k][j] += ((v2 >> k) & 1 ? 0.25 : -0.25) * hx[(int64_t)d->geom_dofmap[c * 8 + v2] * 3 + j];
-            for (int j = 0; j < 3; ++j) acc[j] += std::max(std::fabs(ev[0][j]), std::max(std::fabs(ev[1][j]), std::fabs(ev[2][j])));
-        }
-        for (int j = 0; j < 3; ++j) m->h_cell_ext[j] = d->num_cells ? acc[j] / (double)d->num_cells : 0.0;
-    }
     m->h_cell_xyz.assign((size_t)d->num_cells * 3, 0.0f);      // vertex mean of every cell: orders the wave groups (adjoint_patch.h)
     for (int64_t c = 0; c < d->num_cells; ++c)
         for (int v2 = 0; v2 < d->ngeom; ++v2)
@@ -282,8 +268,6 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_node_ptr) (void)hipFree(m->d_node_ptr);
     if (m->d_node_ent) (void)hipFree(m->d_node_ent);
     if (m->d_fe) (void)hipFree(m->d_fe);
-    if (m->brick.blob) (void)hipFree(m->brick.blob);
-    if (m->brick.dev.part) (void)hipFree(m->brick.dev.part);
     if (m->patch.blob) (void)hipFree(m->patch.blob);
     if (m->patch.dev.bpart) (void)hipFree(m->patch.dev.bpart);
     delete m;

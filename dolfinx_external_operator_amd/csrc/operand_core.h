@@ -386,34 +386,6 @@ struct PatchSet {
     double shared_fraction = 0.0;        // shared patch nodes / (cell, node) incidences: what still travels through HBM
 };
 
-// ---- brick form of the consumer-side scatter on hexahedra with the 2x2x2 rule (adjoint.hip, cell8_brick.h; option adjoint_brick).
-// The library keeps a SECOND cell order for those kernels: cells sorted along a Morton curve of their centroids, eight consecutive
-// ones per wave group — on a structured mesh a 2 x 2 x 2 brick. A group's eight element vectors (8 x ND entries) meet in the wave
-// before they leave it: entries of the same node are added in LDS in a fixed order and the group writes ONE partial per node it touches
-// (125 instead of 216 on Q2 bricks) as one contiguous run; node_sum then adds at most 8 group partials per node instead of up to 27
-// element-vector entries. Per-point arrays (stress, state) stay in the CALLER's cell order: the kernels reach them through `orig`.
-struct BrickDev {
-    const int32_t* orig = nullptr;       // [num_cells] caller's index of the cell at brick-order position k
-    const int32_t* dofmap = nullptr;     // [num_cells][ndofs] the dofmap in brick order
-    const int32_t* geom_dofmap = nullptr;   // [num_cells][8]
-    const int32_t* tab_id = nullptr;     // [n_groups] which reduction table the group uses (equal tables are stored once)
-    const int64_t* slot0 = nullptr;      // [n_groups] first partial slot of the group (its U partials follow each other)
-    const uint8_t* tabs = nullptr;       // reduction tables, BRICK_TAB_BYTES each
-    double* part = nullptr;              // [n_slots][3] the groups' partials (the `fe` of node_sum)
-};
-constexpr int BRICK_TAB_BYTES = 704;     // [0] U; [4, 4 + 217) start[u] (entries of slot u: start[u] .. start[u + 1]); [224, 224 + 2 * 216) uint16 LDS index of each entry
-constexpr int BRICK_TAB_START = 4, BRICK_TAB_SRC = 224;
-
-struct BrickSet {
-    bool built = false, usable = false;
-    BrickDev dev;
-    void* blob = nullptr;                // one device allocation for the index arrays
-    size_t part_cap = 0;
-    int64_t n_slots = 0, n_tables = 0;
-    int64_t* d_node_ptr = nullptr;       // transposed map node -> its group partials (slot ids), ascending group order
-    uint32_t* d_node_ent = nullptr;
-};
-
 struct dxo_mesh {
     int gdim = 0;
     OperandDev dev{};
@@ -440,7 +412,4 @@ struct dxo_mesh {
     // adjoint kernels, patch form (adjoint_patch.h): a representative point per cell for the Morton order of the wave groups
     std::vector<float> h_cell_xyz;     // [num_cells][3]
     PatchSet patch;
-    std::vector<int32_t> h_geom_dofmap;   // host copy of the geometry dofmap (brick order of the consumer-side kernels, built on first use)
-    double h_cell_ext[3] = {0.0, 0.0, 0.0};   // mean spacing of the cells along the global axes (Morton quantisation of the brick order)
-    BrickSet brick;
 };

@@ -495,9 +495,10 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
 
     def _host_outs(sizes, which, fuse):
         tg = holder["targets"]
-        if tg is None or all(t is None for t in tg):
-            # no targets: views of ONE recycled page-locked block (the kernel writes it in place, no staging copy)
-            want = [k for k in range(3) if fuse or k == which]
+        if fuse and (tg is None or all(t is None for t in tg)):
+            # no targets, all three outputs: views of ONE recycled page-locked block (the kernel writes it in place, no staging copy; one
+            # block size per batch size, so the pool hands the same blocks back pass after pass)
+            want = [0, 1, 2]
             offs, total = {}, 0
             for k in want:
                 offs[k] = total

@@ -7,7 +7,7 @@ import pathlib
 import statistics
 import sys
 
-ROOT = pathlib.Path(__file__).resolve().parents[2]
+ROOT = pathlib.Path(__file__).resolve().parents[3]
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 

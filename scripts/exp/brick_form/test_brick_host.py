@@ -9,14 +9,14 @@ import pytest
 
 from tools.synthetic import structured_mesh
 
-ROOT = pathlib.Path(__file__).resolve().parents[1]
+ROOT = pathlib.Path(__file__).resolve().parents[3]
 
 
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = tmp_path_factory.mktemp("brick") / "brick_host"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", f"-I{ROOT / 'dolfinx_external_operator_amd' / 'csrc'}",
-                    str(ROOT / "tests" / "helpers" / "brick_host.cpp"), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", f"-I{ROOT / 'scripts' / 'exp' / 'brick_form'}",
+                    str(ROOT / "scripts" / "exp" / "brick_form" / "brick_host.cpp"), "-o", str(exe)], check=True)
     return exe
 
 

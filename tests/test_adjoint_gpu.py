@@ -319,56 +319,6 @@ def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overw
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n, degree, shuffle", [((2, 2, 2), 2, False), ((5, 4, 3), 2, False), ((12, 10, 8), 2, True), ((7, 5, 3), 1, True),
-                                               ((20, 20, 22), 2, False), ((1, 1, 3), 2, False)])
-def test_brick_form_equals_the_per_cell_form_and_the_oracle(ctx, n, degree, shuffle):
-    """Option adjoint_brick (default 1, csrc/cell8_brick.h): hexahedra with the 2x2x2 rule are processed in the library's own Morton
-    order, eight cells per wave group, and a group's element vectors are reduced in the wave — one partial per touched node leaves it.
-    Per-point arrays stay in the CALLER's cell order: with the cells of the mesh shuffled (`shuffle`) the result must not change.
-    Same sums in another fixed order: equal to the per-cell form (0) to rounding, to the NumPy oracle, identical bits run to run; cell
-    counts that are not multiples of 8, meshes whose Morton runs are not bricks (odd sizes), Q1 and Q2."""
-    import torch
-
-    from dolfinx_external_operator_amd import DeviceMesh
-    from oracle.operand_oracle import EPS_MANDEL, operand_adjoint
-    from tools.synthetic import structured_mesh
-
-    m = structured_mesh("hexahedron", n, degree, distort=0.2, seed=8)
-    rng = np.random.Generator(np.random.PCG64(3))
-    if shuffle:      # the caller's cell order is arbitrary: permute cells (dofmaps) — per-point data below is generated in THAT order
-        perm = rng.permutation(m.num_cells)
-        m.dofmap, m.geom_dofmap = np.ascontiguousarray(m.dofmap[perm]), np.ascontiguousarray(m.geom_dofmap[perm])
-    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
-    dev = torch.device("cuda", ctx.device)
-    npts, nn = m.num_cells * m.nq, m.node_x.shape[0]
-    S_h = rng.normal(size=(m.num_cells, m.nq, 6))
-    S = torch.from_numpy(S_h.reshape(-1)).to(dev)
-    ref = operand_adjoint(EPS_MANDEL, 3, S_h, m.weights, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, nn).reshape(-1)
-    saved = (ctx.get_option("adjoint_brick"), ctx.get_option("consumer_overwrite"))
-    try:
-        outs = {}
-        for ow in (0, 1):
-            ctx.set_option("consumer_overwrite", ow)
-            for mode in (0, 1, 1):
-                ctx.set_option("adjoint_brick", mode)
-                out = torch.full((nn * 3,), 0.25, dtype=torch.float64, device=dev)
-                dm.adjoint("eps", 3, S.data_ptr(), out.data_ptr())
-                torch.cuda.synchronize()
-                outs.setdefault((ow, mode), []).append(out)
-        scale = float(np.abs(ref).max())
-        for ow in (0, 1):
-            base = 0.0 if ow else 0.25
-            a, b1, b2 = outs[(ow, 0)][0], outs[(ow, 1)][0], outs[(ow, 1)][1]
-            assert float((b1 - a).abs().max()) <= 1e-13 * scale
-            assert torch.equal(b1, b2)
-            assert np.abs(b1.cpu().numpy() - base - ref).max() <= 1e-12 * scale
-    finally:
-        ctx.set_option("adjoint_brick", saved[0])
-        ctx.set_option("consumer_overwrite", saved[1])
-        dm.close()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("n, degree, atomics", [((5, 4, 3), 2, 0), ((12, 9, 7), 2, 0), ((7, 5, 3), 1, 0), ((6, 5, 5), 2, 1), ((20, 20, 21), 2, 0)])
 def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree, atomics):
     """Option adjoint_mfma (default 1): on hexahedra with the 2x2x2 rule the element vectors of a wave's 8 cells are formed by 24
