@@ -448,8 +448,6 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
             // memcpys, one launch and one stream wait (option "host_zero_copy_bytes", 0 = off; spans that live on the
             // device take the copy path). At a few hundred points the two hipMemcpyAsync were half of the call.
             bool zero_copy = stream_once && !timed && (int64_t)need <= c->host_zero_copy_bytes;
-            for (const auto& sp : inputs) zero_copy = zero_copy && !sp.dev;
-            for (const auto& sp : outputs) zero_copy = zero_copy && !sp.dev;
             if (zero_copy) {
                 void* mapped = nullptr;
                 if (hipHostGetDevicePointer(&mapped, hbase, 0) != hipSuccess || !mapped) {
@@ -467,6 +465,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                     size_t zo = 0;
                     for (size_t k = 0; k < ni; ++k) {
                         const size_t bytes = inputs[k].bytes_pp * (size_t)n;
+                        if (inputs[k].dev) {                  // lives on the device (dxo_vm_state): read where it is
+                            z_in[k] = static_cast<char*>(inputs[k].dev);
+                            continue;
+                        }
                         if (void* m = dxo_pinned_mapped(inputs[k].in, bytes)) {
                             z_in[k] = static_cast<char*>(m);
                         } else {
@@ -475,10 +477,17 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                         }
                         zo += round_up(bytes, 256);
                     }
+                    std::vector<char*> dev_to_host(no, nullptr);      // outputs the kernel writes on the DEVICE and the caller wants too
                     for (size_t k = 0; k < no; ++k) {
                         const size_t bytes = outputs[k].bytes_pp * (size_t)n;
                         void* m = outputs[k].out ? dxo_pinned_mapped(outputs[k].out, bytes) : nullptr;
-                        if (m) {
+                        if (outputs[k].dev) {                 // result stays in the device mirror; one D2H copy brings the caller's copy
+                            z_out[k] = static_cast<char*>(outputs[k].dev);
+                            if (outputs[k].out) {
+                                if (m) dev_to_host[k] = static_cast<char*>(outputs[k].out);
+                                else { st_out[k] = hbase + zo; dev_to_host[k] = hbase + zo; }
+                            }
+                        } else if (m) {
                             z_out[k] = static_cast<char*>(m);
                         } else {
                             st_out[k] = hbase + zo;
@@ -504,6 +513,8 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
                         if (rcz != DXO_OK) return rcz;
                     }
                     DXO_HIP(c, hipGetLastError());
+                    for (size_t k = 0; k < no; ++k)
+                        if (dev_to_host[k]) DXO_HIP(c, hipMemcpyAsync(dev_to_host[k], outputs[k].dev, outputs[k].bytes_pp * (size_t)n, hipMemcpyDeviceToHost, s));
                     DXO_HIP(c, hipStreamSynchronize(s));
                     for (size_t k = 0; k < no; ++k)
                         if (st_out[k] && outputs[k].out) std::memcpy(outputs[k].out, st_out[k], outputs[k].bytes_pp * (size_t)n);

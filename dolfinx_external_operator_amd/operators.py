@@ -486,12 +486,13 @@ def make_heat(*, A: float = 1.0, B: float = 1.0, ctx: Context | None = None, dev
     names = ("q", "dqdT", "dqdsigma")
 
     def _probe(T, sigma):
-        """(shapes, 48 strided entries of each operand): the tripwire of the identity fusion."""
+        """(shapes, the BYTES of 48 strided entries of each operand): the tripwire of the identity fusion. Compared as bytes: bit
+        patterns, NaNs included, at 2 us per check (np.array_equal(..., equal_nan=True) on the same entries costs 16 us)."""
         tf, sf = T.reshape(-1), sigma.reshape(-1)
-        return (T.shape, sigma.shape, tf[:: max(tf.size // 48, 1)][:48].copy(), sf[:: max(sf.size // 48, 1)][:48].copy())
+        return (T.shape, sigma.shape, tf[:: max(tf.size // 48, 1)][:48].tobytes(), sf[:: max(sf.size // 48, 1)][:48].tobytes())
 
     def _probe_same(a, b):
-        return a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[3], b[3], equal_nan=True)
+        return a == b
 
     def _host_outs(sizes, which, fuse):
         tg = holder["targets"]

@@ -58,6 +58,16 @@ ctx.pin(sigma_n); ctx.pin(p)
 us, c_us, r = time_vm()
 print(json.dumps({"form": "default + state arrays pinned by the caller (Context.pin)", "us_per_call": us, "c_us": c_us,
                   "bit_identical": all(np.array_equal(a, b, equal_nan=True) for a, b in zip(r, ref))}), flush=True)
+# (sigma, dp) over PCIe and the tangent rebuilt by host threads (0.6 instead of 2.5 MB come back; default only from 2^18 points on)
+old_min, old_thr = ctx.get_option("vm_rebuild_min_points"), ctx.get_option("host_threads")
+ctx.set_option("vm_rebuild_min_points", 0)
+for thr in (1, 4, 8):
+    ctx.set_option("host_threads", thr)
+    us, c_us, r = time_vm(host_tangent="rebuild")
+    err = max(float(np.nanmax(np.abs(a - b))) / float(np.nanmax(np.abs(b))) for a, b in zip(r, ref))
+    print(json.dumps({"form": f'host_tangent="rebuild", vm_rebuild_min_points = 0, {thr} host threads', "us_per_call": us, "c_us": c_us, "max_rel_err_vs_copy": err}), flush=True)
+ctx.set_option("vm_rebuild_min_points", old_min)
+ctx.set_option("host_threads", old_thr)
 us, c_us, r = time_vm(state="resident")
 print(json.dumps({"form": 'state="resident"', "us_per_call": us, "c_us": c_us}), flush=True)
 
