@@ -133,7 +133,7 @@ def measure_traffic(n, d, timeout_s=90):
         with tempfile.TemporaryDirectory(prefix="dxo_pmc_", dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
             cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "t", "--", sys.executable, str(pathlib.Path(__file__).resolve()),
                    "--steps", "3", "--warmup", "1", "--batches", "1", "--nqp", str(n), "--d", str(d), "--placement", "0", "--no-cpu", "--no-probe", "--no-e2e",
-                   "--no-secondary", "--no-traffic"]
+                   "--no-secondary", "--no-traffic", "--no-side"]
             try:
                 res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, cwd=tmp)
             except (subprocess.TimeoutExpired, OSError) as exc:
@@ -418,6 +418,9 @@ def main():
                          "(experiment; default 0 = hipMalloc candidates only, see the comment at placement_vmm below); sets "
                          "DXO_ALLOW_VMM_COLLECTIVE=1 on every rank, without which sharding.py refuses such buffers; libdxo's own "
                          "forms (the cross-check after the line) refuse them always")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side figures measured after the timed batches (plain-allocation and factory launches of the same kernel): "
+                         "profiled runs use it so that the LAST batches x steps dispatches of the headline kernel are the timed ones")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the no-arithmetic stream probe")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (H2D + kernel + D2H) leg")
@@ -896,7 +899,7 @@ def main():
             raise SystemExit("bench: non-finite tangent in the kernel output — refusing to report a number")
 
     # side figures (never `value`), measured AFTER the timed batches so that their allocations and frees cannot disturb them
-    if rank == 0 and not gather_on:
+    if rank == 0 and not gather_on and not args.no_side:
         plain = torch.empty(n * per_pt, dtype=torch.float64, device=device)   # what an un-placed allocation gives
         plain_GBps = time_kernel((plain.data_ptr(), plain.data_ptr() + n * d * d * 8, plain.data_ptr() + n * (d * d + d) * 8), 12)
         del plain
@@ -905,7 +908,7 @@ def main():
     # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
     # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
     # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
-    if rank == 0 and not gather_on and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
+    if rank == 0 and not gather_on and not args.no_side and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
         from dolfinx_external_operator_amd import make_von_mises
 
         deps3 = deps.view(n // args.nq, args.nq, d)

@@ -19,9 +19,9 @@ S0=$(date +%s)
 timeout 900 python3 bench.py > "$OUT/bench_stdout.txt" 2> "$OUT/bench.err"; echo "bench rc=$? wall=$(( $(date +%s) - S0 )) s, stdout $(wc -c < "$OUT/bench_stdout.txt") bytes in $(wc -l < "$OUT/bench_stdout.txt") lines"
 cp bench_full.json "$OUT/bench.json" 2>/dev/null        # the full record (the stdout lines are bounded extracts of it)
 tail -1 "$OUT/bench_stdout.txt" > "$OUT/${TAG}_bench_line.json"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e --no-traffic > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o b -- python3 bench.py --no-cpu --no-probe --no-e2e --no-traffic --no-side > "$OUT/bench_profiled.json" 2> "$OUT/stats.log"; echo "kernel-trace rc=$?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic --no-side > "$OUT/prof_fetch.log" 2>&1; echo "fetch rc=$?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o vm -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-probe --no-e2e --no-secondary --no-traffic --no-side > "$OUT/prof_write.log" 2>&1; echo "write rc=$?"
 if [ -z "$QUICK" ]; then
   pass() {  # dir, script + args..., -- counters...
     local name=$1; shift

@@ -68,11 +68,17 @@ if trace:
             # first dispatch of any secondary kernel
             first_secondary = min((dd[0][0] for nn, dd in disp.items() if nn.startswith(("mc_", "icnn_", "vm_field", "vm_tile<4", "heat_", "isihara", "tangent_", "adjoint", "assign"))), default=1 << 62)
             head = [d for d in ds if d[0] < first_secondary]
-            timed = head[-K:]
-            lines.append(f"{name}: {len(ds)} dispatches; the K = {K} timed steps (last {K} before the secondary legs): mean {sum(d[1] for d in timed) / len(timed) / 1e3:.1f} us "
-                         f"(min {min(d[1] for d in timed) / 1e3:.1f}, max {max(d[1] for d in timed) / 1e3:.1f}); all others (calibration, plain-allocation leg, warm-up): "
-                         f"mean {sum(d[1] for d in head[:-K]) / max(len(head) - K, 1) / 1e3:.1f} us; VGPR {timed[0][3]}+{timed[0][4]} LDS {timed[0][5]} scratch {timed[0][6]}")
-            lines.append("  timed steps, us: " + " ".join(f"{d[1] / 1e3:.0f}" for d in timed))
+            B = int(prof.get("batches") or 1)
+            timed = head[-B * K:]           # bench.py --no-side: nothing launches this kernel between the last timed batch and the secondary legs
+            per_batch = [timed[b * K:(b + 1) * K] for b in range(B)]
+            lines.append(f"{name}: {len(ds)} dispatches; the {B} x {K} timed steps (last {B * K} before the secondary legs): mean {sum(d[1] for d in timed) / len(timed) / 1e3:.1f} us "
+                         f"(min {min(d[1] for d in timed) / 1e3:.1f}, max {max(d[1] for d in timed) / 1e3:.1f}); all others (calibration, warm-up): "
+                         f"mean {sum(d[1] for d in head[:-B * K]) / max(len(head) - B * K, 1) / 1e3:.1f} us; VGPR {timed[0][3]}+{timed[0][4]} LDS {timed[0][5]} scratch {timed[0][6]}")
+            lines.append("  per batch, mean us: " + " ".join(f"{sum(d[1] for d in pb) / max(len(pb), 1) / 1e3:.1f}" for pb in per_batch)
+                         + "   (the bench line's kernel_ms_batches, HIP events of the same process: "
+                         + " ".join(f"{x * 1e3:.1f}" for x in (prof.get("kernel_ms_batches") or [])) + ")")
+            lines.append("  gaps between consecutive timed launches inside a batch, us (max per batch): "
+                         + " ".join(f"{max((pb[k + 1][0] - pb[k][0] - pb[k][1]) / 1e3 for k in range(len(pb) - 1)):.1f}" for pb in per_batch if len(pb) > 1))
         else:
             lines.append(f"{name}: {len(ds)} dispatches, {len(sel)} at the largest grid ({big} threads): mean {sum(d[1] for d in sel) / len(sel) / 1e3:.1f} us "
                          f"(min {min(d[1] for d in sel) / 1e3:.1f}); VGPR {sel[0][3]}+{sel[0][4]} LDS {sel[0][5]} scratch {sel[0][6]}")

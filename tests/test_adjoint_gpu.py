@@ -323,7 +323,10 @@ def test_patch_form_of_the_internal_force_equals_the_two_pass_form(ctx, n, overw
 def test_matrix_pipe_scatter_equals_the_dpp_scatter_on_hexahedra(ctx, n, degree, atomics):
     """Option adjoint_mfma (default 1): on hexahedra with the 2x2x2 rule the element vectors of a wave's 8 cells are formed by 24
     v_mfma_f64_16x16x4_f64 (csrc/adjoint.hip c8m_contract) instead of the DPP reduce-scatter (0). The same sums in another fixed order:
-    equal to rounding, identical bits run to run; cell counts that are not a multiple of 8, Q1 and Q2, the atomics form."""
+    equal to rounding, identical bits run to run; cell counts that are not a multiple of 8, Q1 and Q2, the atomics form.
+    This test compares HIP with HIP (two forms of the scatter). What pins the DEFAULT (matrix-pipe) form to the NumPy oracle are the
+    tests above, which run with the library's defaults: test_adjoint_identity_patch_test_and_oracle (adjointness, patch test, oracle on
+    all four cell types), test_matrix_free_tangent / _diagonal (oracle) and the Newton-Krylov convergence test."""
     import torch
 
     from dolfinx_external_operator_amd import DeviceMesh, VmParams
