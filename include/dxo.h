@@ -110,16 +110,22 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * entries; variant 2 splits batches beyond 2^30 points by itself), "icnn_variant"
  * (fp32 network: 0 lane-per-point VALU kernel; 1 MFMA kernel on fp32-input MFMA; 2 — the default — the same GEMMs with
  * every fp32 operand split exactly into three bf16 numbers and six partial products on the bf16 MFMA pipe: fp32-level
- * results (it agrees with the oracle as closely as variant 1) in about 0.68 of the time), "host_small_bytes" (host batches whose inputs + outputs
- * fit this many bytes, default 2 MiB, go through one pinned staging buffer with ONE H2D and ONE D2H copy instead of
- * the chunked pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase
- * dxo_timing is recorded on it only with "timing" = 1), "host_zero_copy_bytes" (default 2 MiB: on that path, batches up
- * to this size are not copied by DMA at all — the kernel reads its inputs from and writes its outputs to the page-locked,
- * device-mapped staging block over PCIe directly, which removes the two copy launches from the call: 49 -> 34 us at 600
- * points, 153 -> 86 us at 6 144 points (von Mises d = 4), 39 -> 24 us for the heat flux of config 1; results are
- * bit-identical; 0 = off; with "timing" = 1 the copy form is used so that the phases can be timed; only the operators whose
- * kernels read every input once and store whole lines take this path — von Mises, heat, conductivity, Isihara and their
- * fused-operand forms; the Mohr-Coulomb and network kernels re-read inputs / store partial lines and keep the DMA copies), "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
+ * results (it agrees with the oracle as closely as variant 1) in about 0.68 of the time; 3 and 4 — two kernels measured
+ * slower in round 5 — exist only in a -DDXO_EXPERIMENTS build, scripts/exp/icnn_variants.h: this library answers them, like
+ * "adjoint_patch" = 1, with DXO_E_OPTION), "host_small_bytes" (host batches whose inputs + outputs
+ * fit this many bytes — default 8 MiB — and are not split by "host_chunk_points" take the SMALL path instead of the chunked
+ * pipeline: the fixed cost per call at the reference's demo sizes; 0 switches the path off; per-phase dxo_timing is recorded
+ * on it only with "timing" = 1, through one packed H2D and one packed D2H copy), "host_zero_copy_bytes" (default 8 MiB: on
+ * that path, batches up to this size are not copied by DMA at all — the kernel reads and writes page-locked, device-mapped
+ * HOST memory over PCIe directly: a caller's array that lies in a page-locked block this library handed out or registered
+ * (dxo_host_alloc, dxo_host_register) is used IN PLACE, any other array goes through the context's pinned staging block (one
+ * host memcpy each way); arrays that live on the device (dxo_vm_state) are used where they are; the batch runs in up to four
+ * pieces of about "host_zero_copy_piece_bytes" (default 1 MiB, 0 = one piece), piece k + 1 being packed while piece k's kernel
+ * runs. Results are bit-identical; 0 = off; with "timing" = 1 the copy form is used so that the phases can be timed; only the
+ * operators whose kernels read every input once and store whole lines take this form — von Mises, heat, conductivity, Isihara
+ * and their fused-operand forms; the Mohr-Coulomb and network kernels re-read inputs / store partial lines and keep the two
+ * packed DMA copies. Measured (profiles/r06_demo_latency.txt): the von Mises demo's 15 000 points 194 -> 98 us per call),
+ * "vm_host_tangent" (DXO_MEM_HOST dxo_von_mises: 0 = C_tang comes
  * back over PCIe, bit-identical to a device call; 1 = only (sigma, dp) cross PCIe and the caller's C_tang array is
  * rebuilt from them by the context's host threads while later chunks are in flight — same formulas as
  * dxo_vm_expand_tangent, agrees with the device tangent to rounding (5e-16 of its scale measured); the reference's 0/0
