@@ -546,7 +546,7 @@ def main():
     sigma = sigma_full[own * n * d:(own + 1) * n * d]
     dp = dp_full[own * n:(own + 1) * n]
 
-    plain_GBps = factory_GBps = factory_fresh_GBps = factory_placement = None      # side figures, filled in after the timed batches
+    plain_GBps = factory_GBps = factory_fresh_GBps = factory_placement = factory_detail = None      # side figures, filled in after the timed batches
 
     def bytes_per_launch_of(d_, n_):
         return BYTES_PER_QP[d_] * n_
@@ -767,7 +767,7 @@ def main():
                 "achieved_plain_hipMalloc": plain_GBps,
                 "achieved_factory_device_call_arena_outputs": factory_GBps,
                 "achieved_factory_default_device_call": factory_fresh_GBps,
-                "factory_placement": factory_placement,
+                "factory_placement": factory_placement, "factory_detail": factory_detail,
                 "stream_probe_GBps": probe_GBps,
             },
             "kernel_only_value": total_points / (kernel_ms_ * 1e-3),
@@ -913,21 +913,29 @@ def main():
 
         deps3 = deps.view(n // args.nq, args.nq, d)
         rates = []
+        factory_detail = {}
         for kw in ({"device_outputs": "arena"}, {}):
             ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
             f = ext((1,))
-            blk_ = getattr(f(deps3)[0], "dxo_block", None)
+            res_ = f(deps3)
+            blk_ = getattr(res_[0], "dxo_block", None)
             if blk_ is not None and kw:
                 factory_placement = {k: blk_.info.get(k) for k in ("mode", "candidates", "chosen_kind", "chosen_GBps", "rounds", "calibration_ms")}
-            del blk_
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(12):
-                f(deps3)
-            e1.record(stream)
-            torch.cuda.synchronize(device)
-            rates.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
-            del ext, f
+            reps = []
+            for _ in range(3):      # three runs of 12 launches: a transient (host hiccup) shows as one low run, a slow block as three
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(12):
+                    f(deps3)
+                e1.record(stream)
+                torch.cuda.synchronize(device)
+                reps.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
+            rates.append(statistics.median(reps))
+            factory_detail["arena" if kw else "fresh"] = {"runs_GBps": reps}
+            if blk_ is not None and kw:
+                # the same block through the thin entry point (no factory code between the launches): separates the block from the path
+                factory_detail["arena"]["direct_entry_point_GBps"] = time_kernel(tuple(t.data_ptr() for t in res_), 12)
+            del ext, f, res_, blk_
             torch.cuda.empty_cache()
         factory_GBps, factory_fresh_GBps = rates
 
