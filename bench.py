@@ -100,15 +100,22 @@ def cpu_baseline(d, n_sample, budget_s=10.0):
         nt *= 2
     if avail not in scan:
         scan[avail] = max(one_pass(avail), one_pass(avail))
-    threads = max(scan, key=scan.get)
-    rates, t_all = [], time.perf_counter()
-    while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 200):
-        rates.append(one_pass(threads))
+    # the two best thread counts of the scan are then run SUSTAINED (half the budget each) and the better median is the figure: a count
+    # that wins two short passes can lose over seconds (a cgroup quota throttles 128 spinning threads: one lease in ten read 20x low)
+    best_two = sorted(scan, key=scan.get, reverse=True)[:2]
+    sustained = {}
+    for nt_ in best_two:
+        rr, t_all = [], time.perf_counter()
+        while len(rr) < 3 or (time.perf_counter() - t_all < budget_s / len(best_two) and len(rr) < 200):
+            rr.append(one_pass(nt_))
+        sustained[nt_] = rr
+    threads = max(sustained, key=lambda k: statistics.median(sustained[k]))
+    rates = sustained[threads]
     return {
         "value": statistics.median(rates), "unit": "qp/s", "cores": threads, "kind": "port",
         "sample": f"{n_sample} points x {len(rates)} passes (median of passes), d={d}, same input distribution; "
                   f"oracle/dxo_oracle.c (C port of the reference's Numba kernel) with OpenMP over points, "
-                  f"fastest of thread counts {sorted(scan)} on {avail} visible cores",
+                  f"fastest of thread counts {sorted(scan)} on {avail} visible cores (the two best of the scan run sustained, the better median kept)",
         "value_1core": scan[1], "thread_scan": {str(k): v for k, v in scan.items()},
     }
 
