@@ -495,3 +495,57 @@ def test_other_material_parameters(ctx, oracle, E_, nu_, s0_, H_):
         Cx = np.empty(n * d * d)
         ctx.vm_expand_tangent(prm, d, n, MEM_HOST, s, dp, Cx)
         assert_close_scaled(Cx, Co, RTOL, "tangent from state")
+
+
+@pytest.mark.parametrize("n, d", [(10_001, 6), (4_097, 4), (63, 6), (30_000, 4)])
+def test_small_host_path_in_place_pieces_and_staging_give_the_device_result(ctx, n, d):
+    """Round 6 (csrc/dxo_ctx.hip, small path of the host pipeline): batches up to 8 MiB run as kernels on page-locked host memory.
+    Every mixture must leave the bits a device call leaves: (a) pageable arrays through the pinned staging block, one piece; (b) four
+    pieces on ragged borders; (c) output arrays that are page-locked blocks of the library (written in place) with pageable inputs;
+    (d) everything page-locked — inputs registered by the caller (Context.pin), outputs from the pool — nothing is copied at all;
+    (e) the DMA form (host_zero_copy_bytes = 0: one packed H2D + one packed D2H). Guard words behind every output."""
+    deps, sigma_n, p = vm_inputs(n, d, seed=31)
+    Cd, sd, dpd = run_device(ctx, deps, sigma_n, p)
+    keys = ("host_zero_copy_bytes", "host_zero_copy_piece_bytes", "host_small_bytes")
+    old = {k: ctx.get_option(k) for k in keys}
+    sizes = (n * d * d, n * d, n)
+
+    def check(outs, what):
+        for got, ref, m in zip(outs, (Cd, sd, dpd), sizes):
+            assert np.array_equal(got[:m], np.asarray(ref).reshape(-1), equal_nan=True), what
+            assert np.all(got[m:] == -7.0), what + ": guard words"
+
+    def pageable():
+        return [np.full(m + 8, -7.0) for m in sizes]
+
+    try:
+        for label, opts in (("one piece", {"host_zero_copy_piece_bytes": 0}), ("four pieces", {"host_zero_copy_piece_bytes": 4096}),
+                            ("DMA form", {"host_zero_copy_bytes": 0})):
+            for k, v in {**old, **opts}.items():
+                ctx.set_option(k, v)
+            outs = pageable()
+            ctx.von_mises(PRM, d, n, MEM_HOST, deps, sigma_n, p, *outs)
+            check(outs, label + ", pageable arrays")
+            pool = [ctx.pinned_recycled(m + 8) for m in sizes]          # what the factories hand out: written in place
+            for a in pool:
+                a[:] = -7.0
+            ctx.von_mises(PRM, d, n, MEM_HOST, deps, sigma_n, p, *pool)
+            check(pool, label + ", page-locked outputs")
+        for k, v in {**old, "host_zero_copy_piece_bytes": 4096}.items():
+            ctx.set_option(k, v)
+        ins = [np.ascontiguousarray(a).copy() for a in (deps, sigma_n, p)]
+        for a in ins:
+            ctx.pin(a)
+        try:
+            pool = [ctx.pinned_recycled(m + 8) for m in sizes]
+            for a in pool:
+                a[:] = -7.0
+            ctx.von_mises(PRM, d, n, MEM_HOST, *ins, *pool)
+            check(pool, "everything page-locked")
+            assert all(np.array_equal(a, b) for a, b in zip(ins, (deps, sigma_n, p)))      # inputs read in place, untouched
+        finally:
+            for a in ins:
+                ctx.unpin(a)
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
