@@ -234,7 +234,7 @@ def end_to_end(ctx, prm, d, sizes=(1_000_000, 10_000_000), calls=3):
     return out
 
 
-def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=2):
+def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=3):
     """One level above the C ABI: the factory called the way the reference calls it, through the value-side mirror of
     evaluate_external_operators (external_operator.py:407-448), which ends with `coefficient.x.array[:] = values` (:289-290)
     — a 36 N-double single-threaded host copy unless the factory was given the coefficient as its output (`outputs=`:
@@ -261,7 +261,8 @@ def through_dispatcher(ctx, n, d, deps, sigma_n, p, nq=8, calls=2):
             t0 = time.perf_counter()
             evaluate_external_operators([op], ev)
             ts.append(time.perf_counter() - t0)
-        res[label] = round(sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, 2)
+        res[label] = round(statistics.median(ts[1:]) * 1e3, 2)
+        res.setdefault("calls_ms", {})[label] = [round(t * 1e3, 1) for t in ts]      # the first is the warm-up (first touch of the coefficient's pages)
         del op
     return res
 

@@ -373,7 +373,8 @@ int field_chunk(dxo_ctx* ctx, void* user, int64_t n_chunk, void* const* d_in, vo
     FieldLaunch& L = *static_cast<FieldLaunch*>(user);
     const int64_t cell0 = L.next_cell;
     L.next_cell += n_chunk;
-    return field_launch(ctx, L, cell0, n_chunk, (const double*)d_in[0], (const double*)d_in[1], (double*)d_out[0],
+    // host-rebuild mode: the tangent is rebuilt from (sigma, dp) on the host, the device writes none (the (sigma, dp)-only launch)
+    return field_launch(ctx, L, cell0, n_chunk, (const double*)d_in[0], (const double*)d_in[1], L.h_C_tang ? nullptr : (double*)d_out[0],
                         (double*)d_out[1], (double*)d_out[2], s);
 }
 
@@ -467,7 +468,7 @@ extern "C" int dxo_von_mises_field_state(dxo_ctx* ctx, const dxo_vm_params* prm,
         L.h_dp = dp;
         L.h_C_tang = C_tang;
         L.c.mark_indeterminate = 1;
-        std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        std::vector<dxo_span> out = {{nullptr, nullptr, 0}, {nullptr, sigma, D * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
         rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild, true);
@@ -517,7 +518,7 @@ extern "C" int dxo_von_mises_field(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_m
         L.h_dp = dp;
         L.h_C_tang = C_tang;
         L.c.mark_indeterminate = 1;
-        std::vector<dxo_span> out = {{nullptr, nullptr, D * D * sd}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
+        std::vector<dxo_span> out = {{nullptr, nullptr, 0}, {nullptr, sigma, D * sd}, {nullptr, dp, sd}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
         rc = dxo_run_host_pipeline(ctx, nc, in, out, field_chunk, &L, nq, field_host_rebuild, true);

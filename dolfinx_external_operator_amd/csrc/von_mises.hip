@@ -268,8 +268,10 @@ int vm_launch(dxo_ctx* ctx, const VmLaunch& L, int64_t n, const double* deps, co
 
 int vm_chunk(dxo_ctx* ctx, void* user, int64_t m, void* const* d_in, void* const* d_out, hipStream_t s) {
     const VmLaunch& L = *static_cast<const VmLaunch*>(user);
-    return vm_launch(ctx, L, m, (const double*)d_in[0], (const double*)d_in[1], (const double*)d_in[2],
-                     (double*)d_out[0], (double*)d_out[1], (double*)d_out[2], s);
+    // host-rebuild mode (option vm_host_tangent): the tangent is rebuilt from (sigma, dp) on the host, so the device writes none — the
+    // (sigma, dp)-only form of the kernel: 160 instead of 448 B/point of stores, and on the small path no tangent crosses PCIe
+    double* C_tang = L.h_C_tang ? nullptr : (double*)d_out[0];
+    return vm_launch(ctx, L, m, (const double*)d_in[0], (const double*)d_in[1], (const double*)d_in[2], C_tang, (double*)d_out[1], (double*)d_out[2], s);
 }
 
 // ------------------------------------------------------------------ tangent from (sigma, dp)
@@ -461,7 +463,7 @@ extern "C" int dxo_von_mises(dxo_ctx* ctx, const dxo_vm_params* prm, int d, int6
         L.h_dp = dp;
         L.h_C_tang = C_tang;
         L.c.mark_indeterminate = 1;
-        std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};
+        std::vector<dxo_span> out = {{nullptr, nullptr, 0}, {nullptr, sigma, d * sd}, {nullptr, dp, sd}};      // no tangent on the device side (vm_chunk)
         // smaller chunks than the copy mode: the host half of a chunk runs on the calling thread between two enqueues,
         // so the un-overlapped tail of the call is the rebuild of the last DXO_HOST_SLOTS chunks
         const int64_t saved_chunk = ctx->host_chunk_points;
@@ -680,7 +682,7 @@ extern "C" int dxo_von_mises_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_v
         L.h_dp = dp;
         L.h_C_tang = C_tang;
         L.c.mark_indeterminate = 1;   // the mark (dp = -0.0) stays in the mirror's dp: p + (-0.0) == p at the commit
-        std::vector<dxo_span> out = {{nullptr, nullptr, d * d * sd}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
+        std::vector<dxo_span> out = {{nullptr, nullptr, 0}, {nullptr, sigma, d * sd, st->sigma}, {nullptr, dp, sd, st->dp}};
         const int64_t saved_chunk = ctx->host_chunk_points;
         if (ctx->host_chunk_points > ctx->vm_rebuild_chunk_points) ctx->host_chunk_points = ctx->vm_rebuild_chunk_points;
         rc = dxo_run_host_pipeline(ctx, n, in, out, vm_chunk, &L, 1, vm_host_rebuild, true);
