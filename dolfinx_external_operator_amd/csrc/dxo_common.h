@@ -111,7 +111,8 @@ struct dxo_ctx {
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
     int64_t host_threads = 32;          // worker threads of the host half of the pipeline (capped by the hardware's)
     int64_t vm_rebuild_chunk_points = 1 << 17;   // pipeline chunk of the vm_host_tangent = 1 mode
-    int64_t vm_rebuild_min_points = 1 << 18;     // smaller batches are latency-bound, not PCIe-bound: they take the copy mode
+    int64_t vm_rebuild_min_points = 1 << 16;     // smaller batches take the copy mode (round 6: the rebuild wins back to back from 15 000 points on — profiles/r06_demo_latency.txt —,
+                                                 // but a solver's calls are milliseconds apart and then pay the wake-up of the host threads: 2^16 keeps a margin of 0.1 ms)
     // small-batch path of the host pipeline: one pinned staging buffer, one H2D, one D2H, events made once
     void* small_pinned = nullptr;
     size_t small_pinned_bytes = 0;

@@ -134,7 +134,7 @@ int dxo_ctx_synchronize(dxo_ctx* ctx);
  * with f_elastic == 0 EXACTLY, where the reference's n_elas is 0/0 and its tangent all NaN, demo_plasticity_von_mises.py:318,
  * so that dxo_vm_expand_tangent can reproduce that NaN from (sigma, dp); dxo_vm_clear_marks turns the marks back into +0;
  * the compact multi-GPU gathers set it themselves), "host_threads" (worker threads of that host half, default 32, capped by the CPUs the process may use: affinity mask and
- * cgroup CPU quota, minus two; DXO_HOST_CPU_BUDGET in the environment overrides the detection), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^18: smaller batches are latency-bound and take the copy mode), and the "placement_*" options
+ * cgroup CPU quota, minus two; DXO_HOST_CPU_BUDGET in the environment overrides the detection), "vm_rebuild_chunk_points" (pipeline chunk of that mode, default 2^17), "vm_rebuild_min_points" (default 2^16: smaller batches take the copy mode — back to back the rebuild wins from 15 000 points on, but calls that are milliseconds apart pay the wake-up of the host threads), and the "placement_*" options
  * of the output arena below. */
 int dxo_ctx_set_option(dxo_ctx* ctx, const char* key, int64_t value);
 int dxo_ctx_get_option(dxo_ctx* ctx, const char* key, int64_t* value);

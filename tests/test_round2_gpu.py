@@ -117,7 +117,7 @@ def test_host_tangent_rebuild_matches_the_device_tangent(ctx, d, n):
     outs = {}
     old_chunk, old_min = ctx.get_option("host_chunk_points"), ctx.get_option("vm_rebuild_min_points")
     ctx.set_option("host_chunk_points", 65536)     # several chunks at the largest size: the hook runs per chunk
-    ctx.set_option("vm_rebuild_min_points", 0)     # also the small sizes go through the rebuild (default: >= 2^18 points)
+    ctx.set_option("vm_rebuild_min_points", 0)     # also the small sizes go through the rebuild (default: >= 2^16 points)
     try:
         for mode in (0, 1):
             ctx.set_option("vm_host_tangent", mode)
