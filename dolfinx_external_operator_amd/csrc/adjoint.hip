@@ -1225,6 +1225,8 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
     DXO_LOCK(ctx);
     if (!mesh) return dxo_fail(ctx, DXO_E_NULL, "dxo_operand_adjoint: mesh is NULL");
     if (!mesh->d_wq) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: quadrature weights not set (dxo_mesh_set_weights)");
+    if (kind == DXO_OPERAND_CAUCHY_GREEN || kind == DXO_OPERAND_I1 || kind == DXO_OPERAND_DETF)
+        return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: a nonlinear operand (C, I1, det F) has no adjoint — its linearisation is a form UFL derives on the reference side");
     const int D = dxo_operand_value_size(mesh->gdim, bs, kind);
     if (D == DXO_E_OPTION) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: unknown operand kind");
     if (D < 0) return dxo_fail(ctx, DXO_E_DIM, "dxo_operand_adjoint: block size does not fit the operand kind / gdim");

@@ -128,6 +128,15 @@ int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double*
         case DXO_OPERAND_DEFGRAD:
             if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
             return DXO_E_DIM;
+        case DXO_OPERAND_CAUCHY_GREEN:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_CAUCHY_GREEN>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_I1:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_I1>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_DETF:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DETF>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }
@@ -175,6 +184,9 @@ extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
         case DXO_OPERAND_VALUE_GRAD: return bs == 1 || bs == gdim ? bs * (1 + gdim) : DXO_E_DIM;
         case DXO_OPERAND_EPS_MANDEL: return bs == gdim ? (gdim == 2 ? 4 : 6) : DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD: return bs == gdim ? gdim * gdim : DXO_E_DIM;
+        case DXO_OPERAND_CAUCHY_GREEN: return bs == gdim ? gdim * gdim : DXO_E_DIM;
+        case DXO_OPERAND_I1: return bs == gdim ? 1 : DXO_E_DIM;
+        case DXO_OPERAND_DETF: return bs == gdim ? 1 : DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }

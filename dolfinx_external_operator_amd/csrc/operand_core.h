@@ -62,7 +62,8 @@ struct OperandShape {
                            : KIND == DXO_OPERAND_VALUE_GRAD ? BS * (1 + G)
                            : KIND == DXO_OPERAND_GRAD ? BS * G
                            : KIND == DXO_OPERAND_EPS_MANDEL ? (G == 2 ? 4 : 6)
-                           : G * G;   // DXO_OPERAND_DEFGRAD
+                           : (KIND == DXO_OPERAND_I1 || KIND == DXO_OPERAND_DETF) ? 1
+                           : G * G;   // DXO_OPERAND_DEFGRAD, DXO_OPERAND_CAUCHY_GREEN
 };
 
 // grad u (BS x G, row = field component, column = direction) -> operand components
@@ -92,11 +93,40 @@ __device__ __forceinline__ void shape_operand(const double (&val)[BS], const dou
             o[0] = g[0][0]; o[1] = g[1][1]; o[2] = g[2][2];
             o[3] = r2 * (g[0][1] + g[1][0]); o[4] = r2 * (g[0][2] + g[2][0]); o[5] = r2 * (g[1][2] + g[2][1]);
         }
-    } else {
+    } else if constexpr (KIND == DXO_OPERAND_DEFGRAD) {
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int j = 0; j < G; ++j) o[i * G + j] = g[i][j] + (i == j ? 1.0 : 0.0);
+    } else {
+        // nonlinear operands of F = I + grad u (test/test_operands_evaluation.py:32-36); BS == G
+        double F[G][G];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) F[i][j] = g[i % BS][j] + (i == j ? 1.0 : 0.0);
+        if constexpr (KIND == DXO_OPERAND_CAUCHY_GREEN) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    double c = 0.0;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) c += F[k][i] * F[k][j];      // (F^T F)_ij
+                    o[i * G + j] = c;
+                }
+        } else if constexpr (KIND == DXO_OPERAND_I1) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int j = 0; j < G; ++j) t += F[i][j] * F[i][j];
+            o[0] = t;
+        } else {
+            if constexpr (G == 2) o[0] = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+            else o[0] = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) +
+                        F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+        }
     }
 }
 

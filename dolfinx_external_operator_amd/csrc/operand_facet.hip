@@ -112,6 +112,15 @@ int dispatch_facets(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const doubl
         case DXO_OPERAND_DEFGRAD:
             if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, u, ents, n, out, s); return DXO_OK; }
             return DXO_E_DIM;
+        case DXO_OPERAND_CAUCHY_GREEN:
+            if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_CAUCHY_GREEN>(ctx, m, u, ents, n, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_I1:
+            if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_I1>(ctx, m, u, ents, n, out, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_DETF:
+            if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_DETF>(ctx, m, u, ents, n, out, s); return DXO_OK; }
+            return DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }

@@ -19,7 +19,9 @@ import numpy as np
 
 from ._lib import MEM_DEVICE, MEM_HOST, Context, DxoError, default_context
 
-KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3, "value_grad": 4}
+KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3, "value_grad": 4,
+         # nonlinear operands of F = I + grad u (the reference's own operand test, test/test_operands_evaluation.py:32-36): forward only
+         "C": 5, "I1": 6, "detF": 7}
 
 
 class MeshDesc(C.Structure):
@@ -297,7 +299,7 @@ class DeviceOperand:
         else:
             out = self.mesh.evaluate(self.kind, self.bs, self.field, entities)
         g = self.mesh.gdim
-        if self.kind == "F":
+        if self.kind in ("F", "C"):
             return out.reshape(out.shape[0], out.shape[1], g, g)
         if self.kind == "grad" and self.bs > 1:
             return out.reshape(out.shape[0], out.shape[1], self.bs, g)

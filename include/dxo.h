@@ -404,7 +404,14 @@ enum {
     DXO_OPERAND_EPS_MANDEL = 2,  /* [g00,g11,0,r(g01+g10)] (2-D, demo_plasticity_von_mises.py:225-227),
                                     [g00,g11,g22,r(g01+g10),r(g02+g20),r(g12+g21)] (3-D), r = sqrt(2)/2; bs = gdim   */
     DXO_OPERAND_DEFGRAD = 3,     /* I + grad u, row-major   value_size = gdim*gdim (demo_hyperelasticity.py:479)      */
-    DXO_OPERAND_VALUE_GRAD = 4   /* [u (bs), grad u (bs*gdim)] in one pass, value_size = bs*(1+gdim) (heat: T and grad T)   */
+    DXO_OPERAND_VALUE_GRAD = 4,  /* [u (bs), grad u (bs*gdim)] in one pass, value_size = bs*(1+gdim) (heat: T and grad T)   */
+    /* NONLINEAR operands of one vector field (bs = gdim), formed per point from F = I + grad u — the operand of the reference's own
+     * operand test, test/test_operands_evaluation.py:32-36 (F = Identity(d) + grad(u); C = F.T * F; J = det(F); I1 = tr(C)).
+     * Forward evaluation only (dxo_eval_operand, dxo_eval_operand_facets): dxo_operand_adjoint answers DXO_E_OPTION for them
+     * (the adjoint of a nonlinear operand is a linearisation, which UFL derives on the reference side). */
+    DXO_OPERAND_CAUCHY_GREEN = 5,/* C = F^T F, row-major     value_size = gdim*gdim                                          */
+    DXO_OPERAND_I1 = 6,          /* tr(F^T F) = sum F_ij^2   value_size = 1                                                  */
+    DXO_OPERAND_DETF = 7         /* det F                    value_size = 1                                                  */
 };
 typedef struct dxo_mesh_desc {
     int32_t gdim;               /* 2 or 3 (= topological dimension) */

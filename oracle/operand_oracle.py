@@ -17,6 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 VALUE, GRAD, EPS_MANDEL, DEFGRAD, VALUE_GRAD = 0, 1, 2, 3, 4
+CAUCHY_GREEN, I1, DETF = 5, 6, 7      # nonlinear operands of F = I + grad u: C = F.T * F, tr(C), det(F) (test/test_operands_evaluation.py:32-36)
 
 
 def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=None):
@@ -46,8 +47,15 @@ def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=Non
             return np.stack([g[..., 0, 0], g[..., 1, 1], np.zeros((nc, nq)), r * (g[..., 0, 1] + g[..., 1, 0])], axis=-1)
         return np.stack([g[..., 0, 0], g[..., 1, 1], g[..., 2, 2], r * (g[..., 0, 1] + g[..., 1, 0]),
                          r * (g[..., 0, 2] + g[..., 2, 0]), r * (g[..., 1, 2] + g[..., 2, 1])], axis=-1)
+    F = g + np.eye(gdim)
     if kind == DEFGRAD:
-        return (g + np.eye(gdim)).reshape(nc, nq, gdim * gdim)
+        return F.reshape(nc, nq, gdim * gdim)
+    if kind == CAUCHY_GREEN:
+        return np.einsum("cqki,cqkj->cqij", F, F).reshape(nc, nq, gdim * gdim)      # F.T * F (:33)
+    if kind == I1:
+        return np.einsum("cqij,cqij->cq", F, F)[..., None]                          # tr(F.T * F) (:35)
+    if kind == DETF:
+        return np.linalg.det(F)[..., None]                                          # det(F) (:34)
     raise ValueError(kind)
 
 

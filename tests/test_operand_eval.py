@@ -8,7 +8,7 @@ from tools.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
 from oracle.operand_oracle import DEFGRAD, EPS_MANDEL, GRAD, VALUE, eval_operand
 
 CELLS = {"triangle": (5, 4), "quadrilateral": (4, 3), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 2)}
-KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "C": 5, "I1": 6, "detF": 7}
 
 
 def poly_field(gdim, bs, degree, seed):
@@ -36,6 +36,13 @@ def expected(kind, g, val):
         return g.reshape(*g.shape[:2], -1)
     if kind == "F":
         return (g + np.eye(gdim)).reshape(*g.shape[:2], -1)
+    if kind in ("C", "I1", "detF"):      # the reference's own operand test: F = Identity(d) + grad(u); C = F.T * F; J = det(F); I1 = tr(C)
+        F = g + np.eye(gdim)             # (test/test_operands_evaluation.py:32-36)
+        if kind == "C":
+            return np.einsum("...ki,...kj->...ij", F, F).reshape(*g.shape[:2], -1)
+        if kind == "I1":
+            return np.einsum("...ij,...ij->...", F, F)[..., None]
+        return np.linalg.det(F)[..., None]
     if gdim == 2:
         return np.stack([g[..., 0, 0], g[..., 1, 1], 0 * g[..., 0, 0], r * (g[..., 0, 1] + g[..., 1, 0])], axis=-1)
     return np.stack([g[..., 0, 0], g[..., 1, 1], g[..., 2, 2], r * (g[..., 0, 1] + g[..., 1, 0]),
@@ -66,7 +73,7 @@ def test_oracle_known_answers_on_distorted_meshes(cell, degree):
     for bs in (1, m.gdim):
         u, grad = poly_field(m.gdim, bs, degree, seed=bs)
         uvec = u(m.node_x).reshape(-1)                                     # nodal interpolation is exact
-        for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
             got = eval_operand(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
             want = expected(kind, grad(xq), u(xq))
             assert got.shape == want.shape
@@ -103,7 +110,7 @@ def test_hip_matches_oracle_and_known_answers(ctx, cell, degree, strain_kernels)
             u, grad = poly_field(m.gdim, bs, degree, seed=10 + bs)
             uvec = u(m.node_x).reshape(-1)
             rough = rng.normal(size=uvec.size)                             # not a polynomial: oracle comparison only
-            for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
                 got = dm.evaluate(kind, bs, uvec)
                 want = expected(kind, grad(xq), u(xq))
                 assert got.shape == want.shape
@@ -416,7 +423,7 @@ def test_oracle_on_cell_facet_pairs(cell, degree):
     for bs in (1, m.gdim):
         u, grad = poly_field(m.gdim, bs, degree, seed=20 + bs)
         uvec = u(m.node_x).reshape(-1)
-        for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
             got = eval_operand_facets(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, phi_f, dphi_f, dpsi_f, ents)
             want = expected(kind, grad(xq), u(xq))
             assert got.shape == want.shape == (len(ents), phi_f.shape[1], want.shape[2])
@@ -441,7 +448,7 @@ def test_hip_on_cell_facet_pairs(ctx, cell, degree):
             u, grad = poly_field(m.gdim, bs, degree, seed=30 + bs)
             uvec = u(m.node_x).reshape(-1)
             rough = rng.normal(size=uvec.size)
-            for kind in ("value", "grad") + (("eps", "F") if bs == m.gdim else ()):
+            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
                 got = dm.evaluate_facets(kind, bs, uvec, ents)
                 want = expected(kind, grad(xq), u(xq))
                 assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
@@ -482,3 +489,40 @@ def test_lazy_operand_snapshot_or_live_field(ctx):
     assert np.array_equal(np.asarray(snap), before)             # the snapshot still is the old value
     assert np.max(np.abs(np.asarray(live) - 2.0 * before)) <= 1e-14 * np.max(np.abs(before))   # the live operand follows the field
     dm.close()
+
+
+@pytest.mark.gpu
+def test_the_reference_operand_test_pattern_on_the_device(ctx):
+    """test/test_operands_evaluation.py:19-66 restated on the device: N = FEMExternalOperator(I1, slope) with I1 = tr(F.T * F),
+    F = Identity(d) + grad(u) of a P1 vector field u = (0.1 x, 0.3 y), and `slope` a P1 scalar function equal to 1: evaluate_operands
+    must return I1 at every quadrature point (known answer: F = diag(1.1, 1.3), I1 = 2.9, det F = 1.43, C = diag(1.21, 1.69)) and the
+    slope's values, with the reference's shapes (scalar operands are 2-D: (num_cells, nq)). Nonlinear operands are forward-only: the
+    adjoint refuses them."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceMesh, QuadratureExternalOperator, evaluate_operands
+
+    m = structured_mesh("triangle", (4, 4), 1, distort=0.2, seed=2)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        u = np.stack([0.1 * m.node_x[:, 0], 0.3 * m.node_x[:, 1]], axis=1).reshape(-1)        # :20
+        slope = np.ones(m.node_x.shape[0])                                                      # :39
+        I1_op, slope_op = dm.operand("I1", u), dm.operand("value", slope, bs=1)
+        N = QuadratureExternalOperator(I1_op, slope_op, num_cells=m.num_cells, num_points=m.nq, value_shape=(),
+                                       external_function=lambda d: (lambda a, b: (a * b).reshape(-1)))
+        ev = evaluate_operands([N])
+        assert ev[I1_op].shape == ev[slope_op].shape == (m.num_cells, m.nq)
+        np.testing.assert_allclose(ev[I1_op], 1.1 ** 2 + 1.3 ** 2, rtol=1e-13)                  # :65
+        np.testing.assert_allclose(ev[slope_op], 1.0, rtol=1e-13)                               # :66
+        np.testing.assert_allclose(dm.operand("detF", u).eval(None), 1.1 * 1.3, rtol=1e-13)
+        C = dm.operand("C", u).eval(None)
+        assert C.shape == (m.num_cells, m.nq, 2, 2)
+        np.testing.assert_allclose(C, np.broadcast_to(np.diag([1.21, 1.69]), C.shape), atol=1e-13)
+        S = torch.zeros(m.num_cells * m.nq, dtype=torch.float64, device="cuda")
+        out = torch.zeros(m.node_x.shape[0] * 2, dtype=torch.float64, device="cuda")
+        with pytest.raises(ValueError, match="nonlinear operand"):
+            dm.adjoint("I1", 2, S.data_ptr(), out.data_ptr())
+        with pytest.raises(ValueError):
+            dm.value_size("I1", 1)                                                              # needs a vector field, bs = gdim
+    finally:
+        dm.close()
