@@ -443,10 +443,10 @@ int dxo_run_host_pipeline(dxo_ctx* c, int64_t n, const std::vector<dxo_span>& in
             hipStream_t s = c->slot_stream[0];
             char* hbase = static_cast<char*>(c->small_pinned);
             char* dbase = static_cast<char*>(c->slot_buf[0]);
-            // ---- tiny batches: no DMA at all. The staging block is page-locked, device-mapped host memory, so the kernel
-            // reads its inputs from it and writes its outputs into it over PCIe directly; what is left of a call is two host
-            // memcpys, one launch and one stream wait (option "host_zero_copy_bytes", 0 = off; spans that live on the
-            // device take the copy path). At a few hundred points the two hipMemcpyAsync were half of the call.
+            // ---- no DMA at all (option "host_zero_copy_bytes", 0 = off): the kernel reads and writes page-locked, device-mapped HOST
+            // memory over PCIe directly — the caller's own arrays where they are page-locked blocks of this library, the context's
+            // staging block otherwise; spans that live on the device (dxo_vm_state) are used where they are. What is left of a call
+            // is the pack of the pageable inputs, one launch per piece and one stream wait.
             bool zero_copy = stream_once && !timed && (int64_t)need <= c->host_zero_copy_bytes;
             if (zero_copy) {
                 void* mapped = nullptr;
