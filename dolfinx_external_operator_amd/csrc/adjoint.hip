@@ -226,6 +226,9 @@ __device__ __forceinline__ void dual_tensor(const double (&s)[OperandShape<G, BS
 #pragma unroll
             for (int j = 0; j < G; ++j) gh[i][j] = s[BS + i * G + j];
         }
+    } else if constexpr (KIND == DXO_OPERAND_DIV) {      // pairing s div v: Ghat = s I
+#pragma unroll
+        for (int i = 0; i < G; ++i) gh[i % BS][i] = s[0];
     } else {   // EPS_MANDEL: e = [g00, g11, (g22 | 0), r(g01+g10), r(g02+g20), r(g12+g21)]
         if constexpr (G == 2) {
             gh[0][0] = s[0]; gh[1][1] = s[1]; gh[0][1] = gh[1][0] = r2 * s[3];
@@ -1187,6 +1190,9 @@ int dispatch_adjoint(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const doub
             return DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD:
             if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_DEFGRAD>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK; }
+            return DXO_E_DIM;
+        case DXO_OPERAND_DIV:
+            if constexpr (BS == G) { launch_adjoint<G, BS, DXO_OPERAND_DIV>(ctx, m, S, cells, n_cells, out, fe, s); return DXO_OK; }
             return DXO_E_DIM;
     }
     return DXO_E_OPTION;

@@ -137,6 +137,9 @@ int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double*
         case DXO_OPERAND_DETF:
             if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DETF>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
             return DXO_E_DIM;
+        case DXO_OPERAND_DIV:
+            if constexpr (BS == G) { launch_operand<G, BS, DXO_OPERAND_DIV>(ctx, m, u, cells, n_cells, out, s); return DXO_OK; }
+            return DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }
@@ -187,6 +190,7 @@ extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
         case DXO_OPERAND_CAUCHY_GREEN: return bs == gdim ? gdim * gdim : DXO_E_DIM;
         case DXO_OPERAND_I1: return bs == gdim ? 1 : DXO_E_DIM;
         case DXO_OPERAND_DETF: return bs == gdim ? 1 : DXO_E_DIM;
+        case DXO_OPERAND_DIV: return bs == gdim ? 1 : DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }

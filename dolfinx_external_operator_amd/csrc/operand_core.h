@@ -62,7 +62,7 @@ struct OperandShape {
                            : KIND == DXO_OPERAND_VALUE_GRAD ? BS * (1 + G)
                            : KIND == DXO_OPERAND_GRAD ? BS * G
                            : KIND == DXO_OPERAND_EPS_MANDEL ? (G == 2 ? 4 : 6)
-                           : (KIND == DXO_OPERAND_I1 || KIND == DXO_OPERAND_DETF) ? 1
+                           : (KIND == DXO_OPERAND_I1 || KIND == DXO_OPERAND_DETF || KIND == DXO_OPERAND_DIV) ? 1
                            : G * G;   // DXO_OPERAND_DEFGRAD, DXO_OPERAND_CAUCHY_GREEN
 };
 
@@ -98,6 +98,11 @@ __device__ __forceinline__ void shape_operand(const double (&val)[BS], const dou
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int j = 0; j < G; ++j) o[i * G + j] = g[i][j] + (i == j ? 1.0 : 0.0);
+    } else if constexpr (KIND == DXO_OPERAND_DIV) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) t += g[i % BS][i];      // BS == G
+        o[0] = t;
     } else {
         // nonlinear operands of F = I + grad u (test/test_operands_evaluation.py:32-36); BS == G
         double F[G][G];

@@ -121,6 +121,9 @@ int dispatch_facets(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const doubl
         case DXO_OPERAND_DETF:
             if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_DETF>(ctx, m, u, ents, n, out, s); return DXO_OK; }
             return DXO_E_DIM;
+        case DXO_OPERAND_DIV:
+            if constexpr (BS == G) { launch_facets<G, BS, DXO_OPERAND_DIV>(ctx, m, u, ents, n, out, s); return DXO_OK; }
+            return DXO_E_DIM;
     }
     return DXO_E_OPTION;
 }

@@ -21,7 +21,8 @@ from ._lib import MEM_DEVICE, MEM_HOST, Context, DxoError, default_context
 
 KINDS = {"value": 0, "grad": 1, "eps": 2, "F": 3, "value_grad": 4,
          # nonlinear operands of F = I + grad u (the reference's own operand test, test/test_operands_evaluation.py:32-36): forward only
-         "C": 5, "I1": 6, "detF": 7}
+         "C": 5, "I1": 6, "detF": 7,
+         "div": 8}        # div u (linear: forward and adjoint), test/test_external_operators_evaluation.py:141
 
 
 class MeshDesc(C.Structure):

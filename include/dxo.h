@@ -411,7 +411,9 @@ enum {
      * (the adjoint of a nonlinear operand is a linearisation, which UFL derives on the reference side). */
     DXO_OPERAND_CAUCHY_GREEN = 5,/* C = F^T F, row-major     value_size = gdim*gdim                                          */
     DXO_OPERAND_I1 = 6,          /* tr(F^T F) = sum F_ij^2   value_size = 1                                                  */
-    DXO_OPERAND_DETF = 7         /* det F                    value_size = 1                                                  */
+    DXO_OPERAND_DETF = 7,        /* det F                    value_size = 1                                                  */
+    DXO_OPERAND_DIV = 8          /* div u = tr(grad u)       value_size = 1, bs = gdim; LINEAR: forward and adjoint
+                                    (the operand of test/test_external_operators_evaluation.py:141)                           */
 };
 typedef struct dxo_mesh_desc {
     int32_t gdim;               /* 2 or 3 (= topological dimension) */

@@ -17,6 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 VALUE, GRAD, EPS_MANDEL, DEFGRAD, VALUE_GRAD = 0, 1, 2, 3, 4
+DIV = 8                                # div u = tr(grad u) (test/test_external_operators_evaluation.py:141)
 CAUCHY_GREEN, I1, DETF = 5, 6, 7      # nonlinear operands of F = I + grad u: C = F.T * F, tr(C), det(F) (test/test_operands_evaluation.py:32-36)
 
 
@@ -47,6 +48,8 @@ def eval_operand(kind, bs, u, dofmap, geom_dofmap, x, phi, dphi, dpsi, cells=Non
             return np.stack([g[..., 0, 0], g[..., 1, 1], np.zeros((nc, nq)), r * (g[..., 0, 1] + g[..., 1, 0])], axis=-1)
         return np.stack([g[..., 0, 0], g[..., 1, 1], g[..., 2, 2], r * (g[..., 0, 1] + g[..., 1, 0]),
                          r * (g[..., 0, 2] + g[..., 2, 0]), r * (g[..., 1, 2] + g[..., 2, 1])], axis=-1)
+    if kind == DIV:
+        return np.einsum("cqii->cq", g)[..., None]
     F = g + np.eye(gdim)
     if kind == DEFGRAD:
         return F.reshape(nc, nq, gdim * gdim)
@@ -97,6 +100,9 @@ def operand_adjoint(kind, bs, S, weights, dofmap, geom_dofmap, x, phi, dphi, dps
             gh[..., 0, 1] = gh[..., 1, 0] = r * S[..., 3]
             gh[..., 0, 2] = gh[..., 2, 0] = r * S[..., 4]
             gh[..., 1, 2] = gh[..., 2, 1] = r * S[..., 5]
+    elif kind == DIV:
+        for i in range(gdim):
+            gh[..., i, i] = S[..., 0]
     else:
         raise ValueError(kind)
     contrib = np.einsum("cq,cqi,qa->cai", scale, vh, phi) + np.einsum("cq,cqij,cqaj->cai", scale, gh, gphys)

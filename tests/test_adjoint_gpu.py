@@ -11,7 +11,7 @@ from oracle.operand_oracle import (DEFGRAD, EPS_MANDEL, GRAD, VALUE, VALUE_GRAD,
 
 pytestmark = pytest.mark.gpu
 CELLS = {"triangle": (6, 5), "quadrilateral": (4, 4), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 3)}
-KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "value_grad": VALUE_GRAD}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "value_grad": VALUE_GRAD, "div": 8}
 
 
 def device_adjoint(ctx, dm, kind, bs, S, n_nodes, cells=None):
@@ -40,7 +40,7 @@ def test_adjoint_identity_patch_test_and_oracle(ctx, cell, degree):
     wdet = m.weights[None, :] * np.abs(det)
     try:
         for bs in (1, G):
-            for kind in ("value", "grad", "value_grad") + (("eps", "F") if bs == G else ()):
+            for kind in ("value", "grad", "value_grad") + (("eps", "F", "div") if bs == G else ()):
                 u = rng.normal(size=nn * bs)
                 e = dm.evaluate(kind, bs, u)                               # B u on the device
                 if kind == "F":

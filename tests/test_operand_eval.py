@@ -8,7 +8,7 @@ from tools.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
 from oracle.operand_oracle import DEFGRAD, EPS_MANDEL, GRAD, VALUE, eval_operand
 
 CELLS = {"triangle": (5, 4), "quadrilateral": (4, 3), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 2)}
-KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "C": 5, "I1": 6, "detF": 7}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "C": 5, "I1": 6, "detF": 7, "div": 8}
 
 
 def poly_field(gdim, bs, degree, seed):
@@ -36,6 +36,8 @@ def expected(kind, g, val):
         return g.reshape(*g.shape[:2], -1)
     if kind == "F":
         return (g + np.eye(gdim)).reshape(*g.shape[:2], -1)
+    if kind == "div":
+        return np.einsum("...ii->...", g)[..., None]
     if kind in ("C", "I1", "detF"):      # the reference's own operand test: F = Identity(d) + grad(u); C = F.T * F; J = det(F); I1 = tr(C)
         F = g + np.eye(gdim)             # (test/test_operands_evaluation.py:32-36)
         if kind == "C":
@@ -73,7 +75,7 @@ def test_oracle_known_answers_on_distorted_meshes(cell, degree):
     for bs in (1, m.gdim):
         u, grad = poly_field(m.gdim, bs, degree, seed=bs)
         uvec = u(m.node_x).reshape(-1)                                     # nodal interpolation is exact
-        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
+        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF", "div") if bs == m.gdim else ()):
             got = eval_operand(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi)
             want = expected(kind, grad(xq), u(xq))
             assert got.shape == want.shape
@@ -110,7 +112,7 @@ def test_hip_matches_oracle_and_known_answers(ctx, cell, degree, strain_kernels)
             u, grad = poly_field(m.gdim, bs, degree, seed=10 + bs)
             uvec = u(m.node_x).reshape(-1)
             rough = rng.normal(size=uvec.size)                             # not a polynomial: oracle comparison only
-            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
+            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF", "div") if bs == m.gdim else ()):
                 got = dm.evaluate(kind, bs, uvec)
                 want = expected(kind, grad(xq), u(xq))
                 assert got.shape == want.shape
@@ -423,7 +425,7 @@ def test_oracle_on_cell_facet_pairs(cell, degree):
     for bs in (1, m.gdim):
         u, grad = poly_field(m.gdim, bs, degree, seed=20 + bs)
         uvec = u(m.node_x).reshape(-1)
-        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
+        for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF", "div") if bs == m.gdim else ()):
             got = eval_operand_facets(KIND_ID[kind], bs, uvec, m.dofmap, m.geom_dofmap, m.x, phi_f, dphi_f, dpsi_f, ents)
             want = expected(kind, grad(xq), u(xq))
             assert got.shape == want.shape == (len(ents), phi_f.shape[1], want.shape[2])
@@ -448,7 +450,7 @@ def test_hip_on_cell_facet_pairs(ctx, cell, degree):
             u, grad = poly_field(m.gdim, bs, degree, seed=30 + bs)
             uvec = u(m.node_x).reshape(-1)
             rough = rng.normal(size=uvec.size)
-            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF") if bs == m.gdim else ()):
+            for kind in ("value", "grad") + (("eps", "F", "C", "I1", "detF", "div") if bs == m.gdim else ()):
                 got = dm.evaluate_facets(kind, bs, uvec, ents)
                 want = expected(kind, grad(xq), u(xq))
                 assert np.abs(got - want).max() <= 5e-12 * max(1.0, np.abs(want).max()), (cell, degree, bs, kind)
