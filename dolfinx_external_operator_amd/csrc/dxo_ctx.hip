@@ -25,8 +25,10 @@ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Page-locked host ranges this library has handed out or registered (dxo_host_alloc, dxo_host_register), process-wide: the
 // small-batch path of the host pipeline lets the kernel read / write such arrays IN PLACE (they are device-mapped) instead of
 // copying them through its staging block. Keyed by base address.
-std::mutex g_pinned_mu;
-std::map<uintptr_t, size_t> g_pinned;
+// (heap objects that are never destroyed: a page-locked block may be released by a finaliser that runs while the process is exiting,
+// after the destructors of this library's statics)
+std::mutex& g_pinned_mu = *new std::mutex;
+std::map<uintptr_t, size_t>& g_pinned = *new std::map<uintptr_t, size_t>;
 
 }  // namespace
 
