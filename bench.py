@@ -657,19 +657,11 @@ def main():
         gaps = [[batch[k][1].elapsed_time(batch[k + 1][0]) * 1e3 for k in range(K - 1)] for batch in evs]
         return walls, kern, gaps
 
+    from tools.bench_timing import batch_record as _batch_record
+
     def batch_record(walls, kern, gaps):
-        """The median batch and what the line says about all of them (walls: already the maximum over ranks under torch.distributed)."""
-        b_med = sorted(range(B), key=lambda b_: walls[b_])[B // 2]
-        gap_max = max(((g, b_, k) for b_, row in enumerate(gaps) for k, g in enumerate(row)), default=(0.0, 0, 0))
-        return b_med, {
-            "batches": B, "median_batch": b_med,
-            "ms_per_step_batches": [t / K * 1e3 for t in walls],
-            "kernel_ms_batches": kern,
-            "step_gap_us_max": gap_max[0], "step_gap_us_max_at": {"batch": gap_max[1], "after_step": gap_max[2]},
-            "step_gap_us_median": statistics.median([g for row in gaps for g in row]) if K > 1 else 0.0,
-            "step_gap_meaning": ("interval between the end of one step's kernel and the start of the next step's, from the launch stream's own events"
-                                 + (" (with the gather on it contains the exchange)" if gather_on else "")),
-        }
+        """The median batch and what the line says about all of them (tools/bench_timing.py; walls: already the maximum over ranks)."""
+        return _batch_record(walls, kern, gaps, K, gather_on)
 
     def reduce_walls(walls):
         if not dist_on:     # one batch time for the job = the slowest rank's
