@@ -304,7 +304,8 @@ void block_free(dxo_arena_block& b) {
 //   (i)  the context remembers the best rate a calibration of this (probe kind, block size) ever kept: a winner below
 //        0.97 of it is rejected (option "placement_accept_pct", 97);
 //   (ii) without a record, a winner that does not stand out from its own crowd (below 1.06 x the median candidate, option
-//        "placement_standout_pct", 106: a fast block among ordinary ones reads 1.15-1.2 x) is rejected ONCE.
+//        "placement_standout_pct", 106: a fast block among ordinary ones reads 1.15-1.2 x) is rejected ONCE — unless it runs at the
+//        rate fast blocks are known to reach ("placement_good_mix_GBps": on a box whose candidates are all fast nothing stands out).
 // Bounded by option "placement_rounds" (3 searches at most); the winner of every search meets the winner so far head to head
 // (same number of blocks alive for both timings) and the slower one is freed. info.rounds reports the searches made.
 int64_t class_key(int kind, size_t bytes) {
@@ -363,6 +364,9 @@ bool alloc_by_candidates(dxo_ctx* c, size_t bytes, const dxo_arena_probe& pr, dx
             if (rate >= 0.01 * (double)c->placement_accept_pct * best_seen) break;
             continue;
         }
+        // a winner at the rate fast blocks are known to reach (option "placement_good_mix_GBps", 6250: 0.78 of the spec peak) needs no
+        // second opinion: on a box whose candidates are ALL fast nothing stands out and the retry would only cost its two seconds
+        if (rate >= (double)c->placement_good_mix_GBps) break;
         const double med = crowd_median(held.info);
         if (held.info.candidates < 4 || med <= 0.0 || rate >= 0.01 * (double)c->placement_standout_pct * med || standout_retry_used) break;
         standout_retry_used = true;

@@ -168,7 +168,8 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
  * with fresh candidates made while it stays allocated, the two winners then timed head to head — when it is below
  * "placement_accept_pct" (97) per cent of the best rate a calibration of this context ever kept for the same probe and
  * block size, or, without such a record, when it does not stand out from its own candidates (below
- * "placement_standout_pct" = 106 per cent of their median; once); "placement_rounds" (3) bounds the searches. The
+ * "placement_standout_pct" = 106 per cent of their median; once; not if it already runs at "placement_good_mix_GBps"); "placement_rounds" (3)
+ * bounds the searches; the rate tested is the winner's rate AFTER the other candidates have been freed. The
  * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
 #define DXO_PLACEMENT_MAX 32
 typedef struct dxo_placement_info {
