@@ -35,25 +35,28 @@ __device__ __forceinline__ int64_t assign_src(const AssignDev& a, int64_t e) {
     return (c * a.n_points_total + a.offset + p) * a.comp_size + v;
 }
 
-// owner[coeff_size] is the error word: number of flat_dofs entries outside [0, coeff_size). Such entries are skipped by
+// The error word (the 8 bytes in front of the owner table): number of flat_dofs entries outside [0, coeff_size). Such entries are skipped by
 // both passes (the NumPy assigner the kernel mirrors raises IndexError, external_operator.py:287; here the call
 // returns DXO_E_SIZE and coeff holds the in-range part).
-__global__ __launch_bounds__(DXO_BLOCK) void assign_owner(AssignDev a, const int32_t* __restrict__ dofs,
-                                                          unsigned long long* __restrict__ owner, int64_t coeff_size) {
+// The owner words are 32-bit while the entry count fits (W = uint32_t, every reference-sized mesh) and 64-bit beyond: the pass is bound by
+// the NUMBER of device-scope atomics (77 G/s measured, scripts/exp/assign_owner_probe.hip: 0.44 against 0.51 ms on 3.4e7 entries; a load-first
+// filter, descending order and atomic-free fixed-point rounds are all slower), the narrow word only halves the table.
+template <typename W>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_owner(AssignDev a, const int32_t* __restrict__ dofs, W* __restrict__ owner,
+                                                          unsigned long long* __restrict__ bad, int64_t coeff_size) {
     const int64_t n = a.n_cells * a.n_pts * a.val_size;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const int64_t d = dofs[e];
-        if (d < 0 || d >= coeff_size) atomicAdd(owner + coeff_size, 1ull);
-        else atomicMax(owner + d, (unsigned long long)(e + 1));
+        if (d < 0 || d >= coeff_size) atomicAdd(bad, 1ull);
+        else atomicMax(owner + d, (W)(e + 1));
     }
 }
 
 struct alignas(16) assign_u128 { unsigned long long lo, hi; };      // complex128: one 16-byte move
 
-template <typename T>
-__global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int32_t* __restrict__ dofs,
-                                                          const unsigned long long* __restrict__ owner,
+template <typename W, typename T>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int32_t* __restrict__ dofs, const W* __restrict__ owner,
                                                           const T* __restrict__ values, T* __restrict__ coeff,
                                                           int64_t coeff_size) {
     const int64_t n = a.n_cells * a.n_pts * a.val_size;
@@ -61,16 +64,15 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_store(AssignDev a, const int
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const int64_t d = dofs[e];
         if (d < 0 || d >= coeff_size) continue;
-        if (owner[d] == (unsigned long long)(e + 1)) coeff[d] = values[assign_src(a, e)];
+        if (owner[d] == (W)(e + 1)) coeff[d] = values[assign_src(a, e)];
     }
 }
 
 // ---- assignment plans. Which entry wins a shared dof depends on the dofmap alone, and a function space's dofmap never changes
 // between the calls of a solve: the plan keeps, for every coefficient entry, the position in `values` of the LAST entry that
 // targets it (-1: none), so applying it is one gather with coalesced stores, no atomics and no owner table.
-template <typename I>
-__global__ __launch_bounds__(DXO_BLOCK) void assign_plan_finish(AssignDev a, const unsigned long long* __restrict__ owner,
-                                                                I* __restrict__ src, int64_t coeff_size) {
+template <typename W, typename I>
+__global__ __launch_bounds__(DXO_BLOCK) void assign_plan_finish(AssignDev a, const W* __restrict__ owner, I* __restrict__ src, int64_t coeff_size) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < coeff_size; d += stride) {
         const unsigned long long o = owner[d];
@@ -93,6 +95,26 @@ __global__ __launch_bounds__(DXO_BLOCK) void assign_apply(const I* __restrict__ 
 // element width of a descriptor: 0 (a caller of ABI version 1, where the field was padding it zeroed) means 8
 static int assign_elem_bytes(const dxo_assign_desc* d) { return d->elem_bytes == 0 ? 8 : d->elem_bytes; }
 static bool assign_elem_ok(int eb) { return eb == 4 || eb == 8 || eb == 16; }
+
+// Scratch of the owner pass: [error word (8 bytes)][owner table: coeff_size words of 4 or 8 bytes], zeroed on the stream.
+struct OwnerTable {
+    unsigned long long* bad = nullptr;
+    void* words = nullptr;
+    bool narrow = true;
+};
+static bool assign_owner_table(dxo_ctx* ctx, hipStream_t s, int64_t n_entries, int64_t coeff_size, OwnerTable* t) {
+    t->narrow = n_entries < 0xffffffffLL;
+    const size_t need = 8 + (size_t)coeff_size * (t->narrow ? 4 : 8);
+    char* base = static_cast<char*>(dxo_scratch(ctx, s, need));
+    if (!base) return false;
+    t->bad = reinterpret_cast<unsigned long long*>(base);
+    t->words = base + 8;
+    return hipMemsetAsync(base, 0, need, s) == hipSuccess;
+}
+static void assign_owner_launch(const OwnerTable& t, const AssignDev& a, const int32_t* flat_dofs, int64_t coeff_size, int blocks, hipStream_t s) {
+    if (t.narrow) hipLaunchKernelGGL(assign_owner<uint32_t>, dim3(blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, (uint32_t*)t.words, t.bad, coeff_size);
+    else          hipLaunchKernelGGL(assign_owner<unsigned long long>, dim3(blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, (unsigned long long*)t.words, t.bad, coeff_size);
+}
 
 struct dxo_assign_plan {
     int64_t coeff_size = 0, n_values = 0;
@@ -126,26 +148,26 @@ extern "C" int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* d, co
         delete pl;
         return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign_plan_create: plan allocation");
     }
-    const size_t need = ((size_t)coeff_size + 1) * sizeof(unsigned long long);
-    unsigned long long* owner = static_cast<unsigned long long*>(dxo_scratch(ctx, s, need));
+    OwnerTable t;
     auto bail = [&](int rc) { (void)hipFree(pl->src); delete pl; return rc; };
-    if (!owner) return bail(dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign_plan_create: scratch allocation"));
-    if (hipMemsetAsync(owner, 0, need, s) != hipSuccess) return bail(dxo_hip_fail(ctx, hipGetLastError(), "dxo_assign_plan_create: memset"));
+    if (!assign_owner_table(ctx, s, n, coeff_size, &t)) return bail(dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign_plan_create: owner table"));
     AssignDev a{d->n_cells, d->n_pts, d->val_size, d->offset, d->n_points_total, d->comp_size};
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (n > 0) {
         int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, coeff_size);
+        assign_owner_launch(t, a, flat_dofs, coeff_size, (int)blocks, s);
     }
     if (coeff_size > 0) {
         int64_t blocks = (coeff_size + DXO_BLOCK - 1) / DXO_BLOCK;
         if (blocks > cap) blocks = cap;
-        if (pl->wide) hipLaunchKernelGGL(assign_plan_finish<int64_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, owner, (int64_t*)pl->src, coeff_size);
-        else          hipLaunchKernelGGL(assign_plan_finish<int32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, owner, (int32_t*)pl->src, coeff_size);
+#define DXO_FINISH(W, I) hipLaunchKernelGGL((assign_plan_finish<W, I>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, (const W*)t.words, (I*)pl->src, coeff_size)
+        if (t.narrow) { if (pl->wide) DXO_FINISH(uint32_t, int64_t); else DXO_FINISH(uint32_t, int32_t); }
+        else          { if (pl->wide) DXO_FINISH(unsigned long long, int64_t); else DXO_FINISH(unsigned long long, int32_t); }
+#undef DXO_FINISH
     }
     unsigned long long bad = 0;
-    if (hipMemcpyAsync(&bad, owner + coeff_size, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    if (hipMemcpyAsync(&bad, t.bad, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return bail(dxo_hip_fail(ctx, hipGetLastError(), "dxo_assign_plan_create: synchronisation"));
     if (bad) {   // the NumPy assigner raises IndexError (external_operator.py:287); no plan is made
         char msg[160];
@@ -205,25 +227,24 @@ extern "C" int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* d, const int32_t*
         return dxo_fail(ctx, DXO_E_ALIGN, "dxo_assign: values and coeff must be aligned to the element width");
     hipStream_t s = dxo_launch_stream(ctx);
     DXO_HIP(ctx, hipSetDevice(ctx->device));
-    // owner table: one 8-byte word per coefficient entry + the error word, in the context's device-path scratch
-    const size_t need = ((size_t)coeff_size + 1) * sizeof(unsigned long long);
-    unsigned long long* owner = static_cast<unsigned long long*>(dxo_scratch(ctx, s, need));
-    if (!owner) return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign: scratch allocation");
+    // owner table: one word per coefficient entry behind the error word, in the context's device-path scratch
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
-    DXO_HIP(ctx, hipMemsetAsync(owner, 0, need, s));
+    OwnerTable t;
+    if (!assign_owner_table(ctx, s, n, coeff_size, &t)) return dxo_hip_fail(ctx, hipErrorOutOfMemory, "dxo_assign: owner table");
     AssignDev a{d->n_cells, d->n_pts, d->val_size, d->offset, d->n_points_total, d->comp_size};
     int64_t blocks = (n + DXO_BLOCK - 1) / DXO_BLOCK;
     const int64_t cap = (int64_t)ctx->compute_units * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(assign_owner, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, coeff_size);
-    if (eb == 4)      hipLaunchKernelGGL(assign_store<uint32_t>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const uint32_t*)values, (uint32_t*)coeff, coeff_size);
-    else if (eb == 8) hipLaunchKernelGGL(assign_store<unsigned long long>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const unsigned long long*)values, (unsigned long long*)coeff, coeff_size);
-    else              hipLaunchKernelGGL(assign_store<assign_u128>, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, owner, (const assign_u128*)values, (assign_u128*)coeff, coeff_size);
+    assign_owner_launch(t, a, flat_dofs, coeff_size, (int)blocks, s);
+#define DXO_STORE(W, T) hipLaunchKernelGGL((assign_store<W, T>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, a, flat_dofs, (const W*)t.words, (const T*)values, (T*)coeff, coeff_size)
+    if (t.narrow) { if (eb == 4) DXO_STORE(uint32_t, uint32_t); else if (eb == 8) DXO_STORE(uint32_t, unsigned long long); else DXO_STORE(uint32_t, assign_u128); }
+    else          { if (eb == 4) DXO_STORE(unsigned long long, uint32_t); else if (eb == 8) DXO_STORE(unsigned long long, unsigned long long); else DXO_STORE(unsigned long long, assign_u128); }
+#undef DXO_STORE
     rc = dxo_device_end(ctx, s);
     if (rc != DXO_OK || !ctx->assign_validate) return rc;
     unsigned long long bad = 0;
-    DXO_HIP(ctx, hipMemcpyAsync(&bad, owner + coeff_size, sizeof bad, hipMemcpyDeviceToHost, s));
+    DXO_HIP(ctx, hipMemcpyAsync(&bad, t.bad, sizeof bad, hipMemcpyDeviceToHost, s));
     DXO_HIP(ctx, hipStreamSynchronize(s));
     if (bad) {
         char msg[160];

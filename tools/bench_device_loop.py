@@ -320,5 +320,6 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
                      "roofline": {**_hbm(size * (4 + 8 + 8), ms_plan),
                                   "note": "algorithmic bytes of the planned form: a 4-byte source position, the winning value and the coefficient entry per dof"}},
             "roofline": {**_hbm(by, ms), "algorithmic_bytes_per_call": by,
-                         "note": "implementation traffic is higher by construction: an 8-byte owner word per dof is cleared, updated with atomicMax "
-                                 "(one per entry) and read back per entry so that the result is the reference's sequential one, not a race"}}
+                         "note": "implementation traffic is higher by construction: a 4-byte owner word per dof is cleared, updated with atomicMax "
+                                 "(one per entry: the pass is bound by the atomic rate, ~77 G/s) and read back per entry so that the result is the "
+                                 "reference's sequential one, not a race"}}
