@@ -103,7 +103,7 @@ struct OwnerTable {
     bool narrow = true;
 };
 static bool assign_owner_table(dxo_ctx* ctx, hipStream_t s, int64_t n_entries, int64_t coeff_size, OwnerTable* t) {
-    t->narrow = n_entries < 0xffffffffLL;
+    t->narrow = n_entries < 0xffffffffLL && ctx->assign_owner_bits != 64;
     const size_t need = 8 + (size_t)coeff_size * (t->narrow ? 4 : 8);
     char* base = static_cast<char*>(dxo_scratch(ctx, s, need));
     if (!base) return false;

@@ -188,6 +188,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "vm_host_tangent")) return &c->vm_host_tangent;
     if (!std::strcmp(key, "vm_mark_indeterminate")) return &c->vm_mark_indeterminate;
     if (!std::strcmp(key, "assign_validate")) return &c->assign_validate;
+    if (!std::strcmp(key, "assign_owner_bits")) return &c->assign_owner_bits;
     if (!std::strcmp(key, "placement_mode")) return &c->placement_mode;
     if (!std::strcmp(key, "placement_candidates")) return &c->placement_candidates;
     if (!std::strcmp(key, "placement_min_bytes")) return &c->placement_min_bytes;

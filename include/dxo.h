@@ -525,7 +525,9 @@ int dxo_tangent_diagonal(dxo_ctx* ctx, dxo_mesh* mesh, const double* C_tang, dou
  * fancy assignment, so the result is the reference's array, not a race. flat_dofs entries must lie in
  * [0, coeff_size): out-of-range entries are skipped on the device and the call returns DXO_E_SIZE (the NumPy
  * assigner raises IndexError, :287); the check costs one stream synchronisation per call, option
- * "assign_validate" = 0 skips it (entries are still never written out of bounds). */
+ * "assign_validate" = 0 skips it (entries are still never written out of bounds). The pass that finds the last writer
+ * keeps one word per coefficient entry: 32-bit while the entry count is below 2^32 - 1, 64-bit beyond (option
+ * "assign_owner_bits" = 64 takes the wide words at any size: the same result, for tests). */
 typedef struct dxo_assign_desc {
     int64_t n_cells;
     int32_t n_pts, val_size, offset, n_points_total, comp_size;
@@ -541,8 +543,8 @@ int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_do
  * operator's constructor, external_operator.py:203-209): dxo_assign_plan_create runs the ownership pass once and keeps, per
  * coefficient entry, the position in `values` of the last entry that targets it; dxo_assign_apply is then ONE gather
  * (coeff[d] = values[src[d]] for the targeted entries, the others keep their value) with coalesced stores and no atomics —
- * bit-identical to dxo_assign at a fraction of its traffic (0.67 -> see profiles/README.md ms for 3.4*10^7 entries into 10^7
- * dofs). flat_dofs is device memory and is not kept; out-of-range entries make the creation fail with DXO_E_SIZE. */
+ * bit-identical to dxo_assign at a fraction of its cost (0.60 -> 0.11 ms for 3.4*10^7 entries into 10^7 dofs,
+ * profiles/r06_assign_owner.txt). flat_dofs is device memory and is not kept; out-of-range entries make the creation fail with DXO_E_SIZE. */
 typedef struct dxo_assign_plan dxo_assign_plan;
 int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, int64_t coeff_size,
                            dxo_assign_plan** out);

@@ -36,6 +36,21 @@ def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.assign(desc, d.data_ptr(), v.data_ptr(), c.data_ptr(), coeff_size)
     torch.cuda.synchronize()
+    # the last-writer pass keeps 32-bit owner words at these sizes; the 64-bit words that > 2^32 - 2 entries take must give the same
+    # array and the same plan (option assign_owner_bits = 64 forces them)
+    ctx.set_option("assign_owner_bits", 64)
+    try:
+        c_wide = torch.from_numpy(initial.copy()).cuda()
+        ctx.assign(desc, d.data_ptr(), v.data_ptr(), c_wide.data_ptr(), coeff_size)
+        plan_wide = ctx.assign_plan(desc, d.data_ptr(), coeff_size)
+        c_wide_plan = torch.from_numpy(initial.copy()).cuda()
+        plan_wide.apply(v.data_ptr(), c_wide_plan.data_ptr())
+        torch.cuda.synchronize()
+        plan_wide.close()
+    finally:
+        ctx.set_option("assign_owner_bits", 0)
+    as_real = lambda t: torch.view_as_real(t) if t.is_complex() else t
+    assert torch.equal(as_real(c_wide), as_real(c)) and torch.equal(as_real(c_wide_plan), as_real(c))
     plan = ctx.assign_plan(desc, d.data_ptr(), coeff_size)
     del d                                                   # the plan does not keep the dofmap
     for _ in range(2):
