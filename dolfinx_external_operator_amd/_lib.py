@@ -144,6 +144,7 @@ _SIGNATURES = {
     "dxo_assign_plan_create": (C.c_int, [_P, C.POINTER(AssignDesc), _P, C.c_int64, C.POINTER(_P)]),
     "dxo_assign_plan_destroy": (None, [_P, _P]),
     "dxo_assign_apply": (C.c_int, [_P, _P, _P, _P]),
+    "dxo_assign_plan_form": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),
     "dxo_operand_adjoint": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
@@ -756,6 +757,13 @@ class AssignPlan:
 
     def apply(self, values, coeff) -> None:
         self.ctx.check(self.ctx.lib.dxo_assign_apply(self.ctx._h, self._h, _ptr(values), _ptr(coeff)), "dxo_assign_apply")
+
+    def form(self) -> dict:
+        """dxo_assign_plan_form: which order the plan is applied in (0 = a large plan before its first apply, 1 = by coefficient entry,
+        2 = by position in `values`) and the two timings its first apply took."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        f = self.ctx.lib.dxo_assign_plan_form(self._h, C.byref(a), C.byref(b))
+        return {"form": int(f), "ms_dof_order": a.value, "ms_source_order": b.value}
 
     def close(self) -> None:
         self._fin()

@@ -127,6 +127,7 @@ struct dxo_ctx {
     hipStream_t scratch_stream = nullptr;   // stream of the last DEVICE-path launch that used scratch[DXO_HOST_SLOTS]
     bool scratch_stream_set = false;
     int64_t assign_validate = 1;        // dxo_assign: check flat_dofs against coeff_size on the device (one sync per call)
+    int64_t assign_plan_form = 0;       // dxo_assign_plan_create: 0 = keep both forms of a large plan and let the first apply time them, 1 = dof order only, 2 = source order
     int64_t assign_owner_bits = 0;      // owner words of the last-writer pass: 0 = 32-bit while the entry count fits, 64 = always wide (what > 2^32 - 2 entries take)
     dxo_timing last = {0, 0, 0, 0};
     std::string err;

@@ -189,6 +189,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "vm_mark_indeterminate")) return &c->vm_mark_indeterminate;
     if (!std::strcmp(key, "assign_validate")) return &c->assign_validate;
     if (!std::strcmp(key, "assign_owner_bits")) return &c->assign_owner_bits;
+    if (!std::strcmp(key, "assign_plan_form")) return &c->assign_plan_form;
     if (!std::strcmp(key, "placement_mode")) return &c->placement_mode;
     if (!std::strcmp(key, "placement_candidates")) return &c->placement_candidates;
     if (!std::strcmp(key, "placement_min_bytes")) return &c->placement_min_bytes;
@@ -215,6 +216,8 @@ int dxo_ctx_set_option(dxo_ctx* c, const char* key, int64_t value) {
         return dxo_fail(c, DXO_E_OPTION, "icnn_variant: 0 (VALU), 1 (fp32 MFMA), 2 (split-bf16 MFMA); 3 and 4 exist only in a -DDXO_EXPERIMENTS build (scripts/exp/icnn_variants.h)");
     if (slot == &c->adjoint_patch && value != 0 && !dxo_adjoint_patch_available())
         return dxo_fail(c, DXO_E_OPTION, "adjoint_patch: the patch form exists only in a -DDXO_EXPERIMENTS build (scripts/exp/adjoint_patch.h)");
+    if (slot == &c->assign_plan_form && value > 2) return dxo_fail(c, DXO_E_OPTION, "assign_plan_form: 0 (both, the first apply chooses), 1 (dof order), 2 (source order)");
+    if (slot == &c->assign_owner_bits && value != 0 && value != 64) return dxo_fail(c, DXO_E_OPTION, "assign_owner_bits: 0 (32-bit while the entry count fits) or 64");
     if (slot == &c->mc_blocks_per_cu && value < 1) return dxo_fail(c, DXO_E_OPTION, "mc_blocks_per_cu < 1");
     if (slot == &c->vm_rebuild_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "vm_rebuild_chunk_points < 64");
     if (slot == &c->host_chunk_points && value < DXO_WAVE) return dxo_fail(c, DXO_E_OPTION, "host_chunk_points < 64");

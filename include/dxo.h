@@ -543,13 +543,21 @@ int dxo_assign(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_do
  * operator's constructor, external_operator.py:203-209): dxo_assign_plan_create runs the ownership pass once and keeps, per
  * coefficient entry, the position in `values` of the last entry that targets it; dxo_assign_apply is then ONE gather
  * (coeff[d] = values[src[d]] for the targeted entries, the others keep their value) with coalesced stores and no atomics —
- * bit-identical to dxo_assign at a fraction of its cost (0.60 -> 0.11 ms for 3.4*10^7 entries into 10^7 dofs,
- * profiles/r06_assign_owner.txt). flat_dofs is device memory and is not kept; out-of-range entries make the creation fail with DXO_E_SIZE. */
+ * bit-identical to dxo_assign at a fraction of its cost (0.60 -> 0.083 ms for 3.4*10^7 entries into 10^7 dofs,
+ * profiles/r06_assign_sorted.txt). flat_dofs is device memory and is not kept; out-of-range entries make the creation fail with DXO_E_SIZE. */
 typedef struct dxo_assign_plan dxo_assign_plan;
 int dxo_assign_plan_create(dxo_ctx* ctx, const dxo_assign_desc* desc, const int32_t* flat_dofs, int64_t coeff_size,
                            dxo_assign_plan** out);
 void dxo_assign_plan_destroy(dxo_ctx* ctx, dxo_assign_plan* plan);
 int dxo_assign_apply(dxo_ctx* ctx, const dxo_assign_plan* plan, const void* values, void* coeff);   /* elements of the width the plan's descriptor named */
+/* A plan of 2^20 coefficient entries or more carries the assignment in two orders (round 6): by coefficient entry (sequential stores, gathered
+ * loads) and by position in `values` (near-sequential loads, scattered stores). Which is faster depends on how the caller's dofs are numbered
+ * against its cells (Q2 hexahedra 108^3: 0.089 / 0.090 ms with one numbering, 0.107 / 0.085 with another, profiles/r06_assign_sorted.txt), so the
+ * FIRST dxo_assign_apply of such a plan launches each form twice on the caller's arrays (every launch leaves the same coefficient), times the
+ * second launches and keeps the faster form from then on; a call made while its stream is being captured takes the first form and decides
+ * later. Option "assign_plan_form" at creation: 0 = as described, 1 = entry order only, 2 = source order (any size). Returns the form in use
+ * (0 = not decided yet, 1, 2) and the two timings in ms (0 until measured); pointers may be NULL. */
+int dxo_assign_plan_form(const dxo_assign_plan* plan, double* ms_dof_order, double* ms_source_order);
 
 /* Operand evaluation FUSED in front of the heat-flux kernel: T and sigma = grad T of a scalar Lagrange field on
  * `mesh` are formed per quadrature point and fed to q_impl / dqdT_impl / dqdsigma_impl

@@ -2,10 +2,11 @@
 # scripts/exp/assign_sorted_probe.sh — run the probe and its two counter passes on the GPU box (repo root).
 mkdir -p gpurun_out/assign6
 export TMPDIR=/tmp
-scripts/exp/assign_sorted_probe | tee gpurun_out/assign6/probe.txt
+Z=${1:-0}      # 1: the bench leg's numbering (z fastest)
+scripts/exp/assign_sorted_probe 108 $Z | tee gpurun_out/assign6/probe_$Z.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/assign6/$c -o p -- scripts/exp/assign_sorted_probe > /dev/null 2>&1
-  python3 - "$c" <<'PY' | tee -a gpurun_out/assign6/probe.txt
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/assign6/$c -o p -- scripts/exp/assign_sorted_probe 108 $Z > /dev/null 2>&1
+  python3 - "$c" <<'PY' | tee -a gpurun_out/assign6/probe_$Z.txt
 import csv, glob, collections, sys
 c = sys.argv[1]
 acc = collections.defaultdict(list)

@@ -51,6 +51,18 @@ def device_assign(ctx, desc, flat_dofs, values, coeff_size, initial):
         ctx.set_option("assign_owner_bits", 0)
     as_real = lambda t: torch.view_as_real(t) if t.is_complex() else t
     assert torch.equal(as_real(c_wide), as_real(c)) and torch.equal(as_real(c_wide_plan), as_real(c))
+    # the plan in SOURCE order (what a large plan may choose at its first apply; assign_plan_form = 2 builds it at any size)
+    ctx.set_option("assign_plan_form", 2)
+    try:
+        plan_src = ctx.assign_plan(desc, d.data_ptr(), coeff_size)
+    finally:
+        ctx.set_option("assign_plan_form", 0)
+    assert plan_src.form()["form"] == (2 if np.asarray(flat_dofs).size else 1)
+    c_src = torch.from_numpy(initial.copy()).cuda()
+    plan_src.apply(v.data_ptr(), c_src.data_ptr())
+    torch.cuda.synchronize()
+    plan_src.close()
+    assert torch.equal(as_real(c_src), as_real(c))
     plan = ctx.assign_plan(desc, d.data_ptr(), coeff_size)
     del d                                                   # the plan does not keep the dofmap
     for _ in range(2):
@@ -112,6 +124,57 @@ def test_mixed_scalar_and_padded_vector_subspaces(ctx, dtype):
         desc = AssignDesc(n_cells, info["n_pts"], 1, info["offset"], op2._n_points_total, 1, 0)
         coeff = device_assign(ctx, desc, info["flat_dofs"], v2, size, coeff)
     assert np.array_equal(coeff, op2.ref_coefficient.x.array)
+
+
+def test_large_plan_times_both_orders_at_its_first_apply_and_keeps_one(ctx):
+    """A plan of 2^20 coefficient entries or more carries the assignment by coefficient entry AND by position in `values`; its first apply
+    launches both on the caller's arrays, times them and keeps the faster (include/dxo.h: dxo_assign_plan_form). Whatever it keeps, the
+    coefficient is NumPy's `coeff[dofs] = values` (external_operator.py:286-287), on a Q2-hexahedra dofmap whose neighbouring cells share nodes."""
+    import torch
+
+    from tools.synthetic import structured_mesh_cached
+
+    m = structured_mesh_cached("hexahedron", (52, 52, 52), 2, distort=0.0, seed=0)
+    nc, npt = m.dofmap.shape
+    size = m.node_x.shape[0]
+    assert size >= 1 << 20
+    rng = np.random.Generator(np.random.PCG64(11))
+    values = rng.normal(size=nc * npt)
+    expect = np.full(size, -7.0)
+    expect[m.dofmap.reshape(-1)] = values                      # NumPy: the last writer wins
+    d = torch.from_numpy(np.ascontiguousarray(m.dofmap.reshape(-1), dtype=np.int32)).cuda()
+    v = torch.from_numpy(values).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    desc = AssignDesc(nc, npt, 1, 0, npt, 1, 8)
+    plan = ctx.assign_plan(desc, d.data_ptr(), size)
+    assert plan.form()["form"] == 0                            # both orders on board, none chosen yet
+    forms = []
+    for _ in range(3):
+        c = torch.full((size,), -7.0, dtype=torch.float64, device="cuda")
+        plan.apply(v.data_ptr(), c.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy(), expect)
+        forms.append(plan.form())
+    assert forms[0]["form"] in (1, 2) and forms[0] == forms[1] == forms[2]      # decided once
+    assert forms[0]["ms_dof_order"] > 0.0 and forms[0]["ms_source_order"] > 0.0
+    fast = min(forms[0]["ms_dof_order"], forms[0]["ms_source_order"])
+    assert (forms[0]["ms_source_order"] == fast) == (forms[0]["form"] == 2)
+    plan.close()
+    # either order on its own gives the same array
+    for f in (1, 2):
+        ctx.set_option("assign_plan_form", f)
+        try:
+            pf = ctx.assign_plan(desc, d.data_ptr(), size)
+        finally:
+            ctx.set_option("assign_plan_form", 0)
+        assert pf.form()["form"] == f
+        c = torch.full((size,), -7.0, dtype=torch.float64, device="cuda")
+        pf.apply(v.data_ptr(), c.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy(), expect)
+        pf.close()
+    with pytest.raises(ValueError):
+        ctx.set_option("assign_plan_form", 3)
 
 
 def test_argument_checks_and_empty(ctx):

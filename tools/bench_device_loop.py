@@ -301,6 +301,7 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
     coeff_p = torch.zeros(size, dtype=torch.float64, device=dev)
     ms_plan, _ = _time(torch, stream, lambda: plan.apply(vals.data_ptr(), coeff_p.data_ptr()), launches, warm=2)
     plan_equal = bool(torch.equal(coeff_p, coeff))
+    plan_form = plan.form()
     plan.close()
     # NumPy's answer on a sample of dofs: the last (cell, node) entry that targets the dof
     h_d = m.dofmap.reshape(-1)
@@ -315,8 +316,11 @@ def assign_leg(torch, ctx, stream, cells_per_side=108, launches=10):
                         "NumPy last-writer-wins order, fp64", "entries": nc * npt, "dofs": size, "value": nc * npt / ms * 1e3, "unit": "entries/s",
             "ms_per_call": ms, "ms_per_call_with_range_check_sync": res[1], "last_writer_spot_check": "ok" if ok else "MISMATCH",
             "kernels": ["hipMemsetAsync(owner)", "assign_owner", "assign_store"], "dtype": "f64 values / int32 dofs",
-            "plan": {"ms_per_call": ms_plan, "equal_to_dxo_assign": plan_equal, "kernels": ["assign_apply"],
-                     "meaning": "dxo_assign_plan_create once per dofmap, then dxo_assign_apply per call: one gather coeff[d] = values[src[d]]",
+            "plan": {"ms_per_call": ms_plan, "equal_to_dxo_assign": plan_equal, "kernels": ["assign_apply_pairs" if plan_form["form"] == 2 else "assign_apply"],
+                     "order": {1: "by coefficient entry", 2: "by position in values"}.get(plan_form["form"], "undecided"),
+                     "first_apply_ms": {"by_coefficient_entry": plan_form["ms_dof_order"], "by_position_in_values": plan_form["ms_source_order"]},
+                     "meaning": "dxo_assign_plan_create once per dofmap, then dxo_assign_apply per call: one gather coeff[d] = values[src[d]], in "
+                                "whichever of its two orders the plan's first apply timed faster on these arrays",
                      "roofline": {**_hbm(size * (4 + 8 + 8), ms_plan),
                                   "note": "algorithmic bytes of the planned form: a 4-byte source position, the winning value and the coefficient entry per dof"}},
             "roofline": {**_hbm(by, ms), "algorithmic_bytes_per_call": by,

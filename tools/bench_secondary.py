@@ -639,7 +639,7 @@ TRAFFIC_KEYS = {
     ("device_loop_p2tri", ("calls", "tangent_diagonal", "roofline")): ("tangent_diag<2, *, false, *>", "all"),
     ("device_loop_p2tri", ("calls", "state_commit", "roofline")): ("vm_commit(", "second_half"),
     ("assign_cg", ("roofline",)): ("assign_owner<", "all"),
-    ("assign_cg", ("plan", "roofline")): ("assign_apply<", "all"),
+    ("assign_cg", ("plan", "roofline")): ("assign_apply", "all"),
 }
 FOLLOWERS = ("node_sum<", "assign_store<")
 # FETCH_SIZE on gfx950 tallies the 128-byte requests of wide coalesced reads (16 bytes per lane) at 64 bytes: x2 for the streaming
@@ -647,7 +647,7 @@ FOLLOWERS = ("node_sum<", "assign_store<")
 # requests, which the counter tallies in full: x1 (checked on dxo_operand_adjoint: counter 1.74 GB against 1.87 GB of reads by
 # count — the stress field, the element vectors read back by node_sum, its index arrays, geometry; x2 would claim 3.5 GB).
 # tangent_apply / tangent_diag read their 2.9 GB of tangent rows lane-linear (x2) and gather the rest: x2 is an upper bound there.
-FETCH_X1 = ("node_sum<", "assign_owner<", "assign_store<", "assign_apply<", "adjoint_cell_eps<", "operand_adjoint<", "operand_adjoint_c8", "tangent_cell<")
+FETCH_X1 = ("node_sum<", "assign_owner<", "assign_store<", "assign_apply<", "assign_apply_pairs<", "adjoint_cell_eps<", "operand_adjoint<", "operand_adjoint_c8", "tangent_cell<")
 
 
 def _name_has(key, name):
