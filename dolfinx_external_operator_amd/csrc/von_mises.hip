@@ -699,6 +699,13 @@ extern "C" int dxo_von_mises_state(dxo_ctx* ctx, const dxo_vm_params* prm, dxo_v
 // End of a load step in the reference: `p.x.petsc_vec.axpy(1.0, dp.x.petsc_vec)` and
 // `sigma_n.x.array[:] = sigma.ref_coefficient.x.array` (demo_plasticity_von_mises.py:564-565). With the state
 // resident on the device this is one fused lane-linear pass instead of two host loops plus two uploads.
+#ifndef DXO_COMMIT_X2
+#define DXO_COMMIT_X2 1
+#endif
+#ifndef DXO_COMMIT_BLOCKS_PER_CU
+#define DXO_COMMIT_BLOCKS_PER_CU 256   // 10^7 points, d = 6 (1.2 GB per call), scripts/exp/commit_ab.py: 16 workgroups per CU 0.215-0.237 ms, 64 0.202-0.223, 128 0.212,
+                                       // 256 0.198-0.203, 512 0.197-0.204 (8-byte accesses at 256: 0.201) — the grid, not the access width
+#endif
 namespace {
 __global__ __launch_bounds__(DXO_BLOCK) void vm_commit(int64_t n_p, int64_t n_s, double* __restrict__ p,
                                                        const double* __restrict__ dp, double* __restrict__ sigma_n,
@@ -707,6 +714,23 @@ __global__ __launch_bounds__(DXO_BLOCK) void vm_commit(int64_t n_p, int64_t n_s,
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = i0; i < n_p; i += stride) p[i] += dp[i];
     for (int64_t i = i0; i < n_s; i += stride) sigma_n[i] = sigma[i];
+}
+// the same pass in 16-byte accesses (arrays 16-byte aligned, which every allocation of the library and of torch is): n_p2 / n_s2 pairs, then the
+// odd tail of p. Same additions, same bits.
+__global__ __launch_bounds__(DXO_BLOCK) void vm_commit_x2(int64_t n_p, int64_t n_s2, dxo_f64x2* __restrict__ p2, const dxo_f64x2* __restrict__ dp2,
+                                                          dxo_f64x2* __restrict__ sigma_n2, const dxo_f64x2* __restrict__ sigma2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_p2 = n_p >> 1;
+    for (int64_t i = i0; i < n_s2; i += stride) sigma_n2[i] = sigma2[i];
+    for (int64_t i = i0; i < n_p2; i += stride) {
+        dxo_f64x2 a = p2[i];
+        const dxo_f64x2 b = dp2[i];
+        a.x += b.x;
+        a.y += b.y;
+        p2[i] = a;
+    }
+    if ((n_p & 1) && i0 == 0) reinterpret_cast<double*>(p2)[n_p - 1] += reinterpret_cast<const double*>(dp2)[n_p - 1];
 }
 }  // namespace
 
@@ -723,10 +747,13 @@ extern "C" int dxo_vm_commit_state(dxo_ctx* ctx, int d, int64_t n, double* p, co
     hipStream_t s = dxo_launch_stream(ctx);
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
-    int64_t blocks = (n * d + DXO_BLOCK - 1) / DXO_BLOCK;
-    const int64_t cap = (int64_t)ctx->compute_units * 16;
+    const bool x2 = ((((uintptr_t)p | (uintptr_t)dp | (uintptr_t)sigma_n | (uintptr_t)sigma) & 15u) == 0) && DXO_COMMIT_X2;   // n * d is even (d = 4, 6)
+    int64_t blocks = ((x2 ? n * d / 2 : n * d) + DXO_BLOCK - 1) / DXO_BLOCK;
+    const int64_t cap = (int64_t)ctx->compute_units * DXO_COMMIT_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(vm_commit, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, n * d, p, dp, sigma_n, sigma);
+    if (x2) hipLaunchKernelGGL(vm_commit_x2, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, n * d / 2, reinterpret_cast<dxo_f64x2*>(p), reinterpret_cast<const dxo_f64x2*>(dp),
+                               reinterpret_cast<dxo_f64x2*>(sigma_n), reinterpret_cast<const dxo_f64x2*>(sigma));
+    else hipLaunchKernelGGL(vm_commit, dim3((int)blocks), dim3(DXO_BLOCK), 0, s, n, n * d, p, dp, sigma_n, sigma);
     return dxo_device_end(ctx, s);
 }
 
