@@ -177,6 +177,44 @@ def test_large_plan_times_both_orders_at_its_first_apply_and_keeps_one(ctx):
         ctx.set_option("assign_plan_form", 3)
 
 
+def test_large_plan_applied_inside_a_graph_capture_decides_later(ctx):
+    """The first apply of a two-order plan waits on events, which a stream under capture cannot do: a captured apply takes the entry-order form
+    and leaves the plan undecided; the replayed graph assigns like NumPy, and the next ordinary apply makes the choice."""
+    import torch
+
+    from tools.synthetic import structured_mesh_cached
+
+    m = structured_mesh_cached("hexahedron", (52, 52, 52), 2, distort=0.0, seed=0)
+    nc, npt = m.dofmap.shape
+    size = m.node_x.shape[0]
+    rng = np.random.Generator(np.random.PCG64(12))
+    values = rng.normal(size=nc * npt)
+    expect = np.full(size, 2.5)
+    expect[m.dofmap.reshape(-1)] = values
+    d = torch.from_numpy(np.ascontiguousarray(m.dofmap.reshape(-1), dtype=np.int32)).cuda()
+    v = torch.from_numpy(values).cuda()
+    c = torch.full((size,), 2.5, dtype=torch.float64, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    plan = ctx.assign_plan(AssignDesc(nc, npt, 1, 0, npt, 1, 8), d.data_ptr(), size)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(graph):
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)      # the capture stream
+            plan.apply(v.data_ptr(), c.data_ptr())
+    finally:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert plan.form()["form"] == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), expect)
+    c.fill_(2.5)
+    plan.apply(v.data_ptr(), c.data_ptr())
+    torch.cuda.synchronize()
+    assert plan.form()["form"] in (1, 2) and np.array_equal(c.cpu().numpy(), expect)
+    plan.close()
+
+
 def test_argument_checks_and_empty(ctx):
     import torch
 
