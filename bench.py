@@ -438,7 +438,7 @@ def main():
                     help="skip the `secondary` block (BASELINE configs 4 and 5, the reference's d = 4 layout, the fused operand + "
                          "return-map kernel: tools/bench_secondary.py)")
     ap.add_argument("--secondary-points", type=int, default=10_000_000)
-    ap.add_argument("--secondary-budget", type=float, default=70.0,
+    ap.add_argument("--secondary-budget", type=float, default=90.0,
                     help="seconds of wall the secondary legs (and their counter passes) may use: a leg that would start after the deadline is skipped and "
                          "named in secondary.skipped (the default run must finish well inside the driver's patience)")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of timed passes of the headline's cpu_baseline leg")

@@ -14,13 +14,14 @@ from .evaluation import (
     evaluate_operands,
     get_unrolled_dofmap,
 )
+from .device_assign import DeviceAssigner
 from .operand_eval import DeviceMesh, DeviceOperand, LazyOperand
 from .operators import make_conductivity, make_heat, make_icnn, make_isihara, make_mohr_coulomb, make_von_mises, von_mises_commit_state
 
 __version__ = "0.1.0"
 
 __all__ = [
-    "AssignPlan",
+    "AssignPlan", "DeviceAssigner",
     "Context", "DxoError", "VmParams", "MEM_HOST", "MEM_DEVICE", "default_context", "load_library",
     "make_von_mises", "make_heat", "make_conductivity", "make_mohr_coulomb", "make_icnn", "make_isihara", "McParams", "IsiharaParams", "von_mises_commit_state",
     "QuadratureExternalOperator", "MixedExternalOperator", "Operand", "Coefficient",

@@ -126,6 +126,50 @@ def test_mixed_scalar_and_padded_vector_subspaces(ctx, dtype):
     assert np.array_equal(coeff, op2.ref_coefficient.x.array)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_device_assigner_is_the_operators_assign_func_on_device_arrays(ctx, dtype):
+    """DeviceAssigner(op, ctx).apply(values, coeff) against op._assign_func(values) for the four assigners the reference's constructor chooses
+    from (external_operator.py:195-209): contiguous, unrolled dofmap (block size 2, shared dofs), mixed all-scalar (2-D), mixed padded (3-D)."""
+    import torch
+
+    from dolfinx_external_operator_amd import DeviceAssigner
+
+    rng = np.random.Generator(np.random.PCG64(21))
+    n_cells = 900
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dm = np.stack([np.arange(n_cells) + k for k in range(3)], axis=1).astype(np.int32)
+    rng.shuffle(dm, axis=0)
+    dm0 = rng.permutation(n_cells * 6).reshape(n_cells, 6).astype(np.int32)
+    dm1 = (n_cells * 6 + rng.integers(0, n_cells, size=(n_cells, 4))).astype(np.int32)
+    ops = {
+        "contiguous": QuadratureExternalOperator(num_cells=n_cells, num_points=3, value_shape=(2, 2), dtype=dtype),
+        "non_mixed": QuadratureExternalOperator(num_cells=n_cells, num_points=3, value_shape=(2,), unrolled_dofmap=get_unrolled_dofmap(dm, 2),
+                                                coefficient_size=(n_cells + 3) * 2, dtype=dtype),
+        "mixed_2d": MixedExternalOperator(num_cells=n_cells, subspaces=[{"n_pts": 3, "val_size": 1, "dofmap": dm0[:, :3]}, {"n_pts": 4, "val_size": 1, "dofmap": dm1}],
+                                          coefficient_size=n_cells * 7, dtype=dtype),
+        "mixed_3d": MixedExternalOperator(num_cells=n_cells, subspaces=[{"n_pts": 3, "val_size": 2, "dofmap": dm0}, {"n_pts": 4, "val_size": 1, "dofmap": dm1}],
+                                          coefficient_size=n_cells * 7, dtype=dtype),
+    }
+    for kind, op in ops.items():
+        da = DeviceAssigner(op, ctx)
+        assert da.kind == kind and da.dtype == dtype
+        values = as_dtype(rng, da.values_size, dtype)
+        op.ref_coefficient.x.array[:] = 4.0
+        op._assign_func(values)
+        v = torch.from_numpy(values).cuda()
+        c = torch.from_numpy(np.full(da.coeff_size, 4.0, dtype=dtype)).cuda()
+        da.apply(v.data_ptr(), c.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy(), op.ref_coefficient.x.array), kind
+        if kind == "contiguous":
+            da.apply(c.data_ptr(), c.data_ptr())             # the operator wrote in place: nothing to move
+        else:
+            assert all(f["form"] == 1 for f in da.forms())    # small plans keep the entry-order form
+        da.close()
+    with pytest.raises(TypeError):
+        DeviceAssigner(QuadratureExternalOperator(num_cells=4, num_points=2, dtype=np.float16), ctx)
+
+
 def test_large_plan_times_both_orders_at_its_first_apply_and_keeps_one(ctx):
     """A plan of 2^20 coefficient entries or more carries the assignment by coefficient entry AND by position in `values`; its first apply
     launches both on the caller's arrays, times them and keeps the faster (include/dxo.h: dxo_assign_plan_form). Whatever it keeps, the
