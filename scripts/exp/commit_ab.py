@@ -11,7 +11,7 @@ from dolfinx_external_operator_amd import Context
 
 ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-n, d = 10_000_000, 6
+n, d = 10_000_000, (int(sys.argv[1]) if len(sys.argv) > 1 else 6)
 g = torch.Generator(device="cuda").manual_seed(0)
 p = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
 dp = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
@@ -30,4 +30,4 @@ for _ in range(5):
     e1.record()
     e1.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
-print(json.dumps({"lib": os.environ.get("DXO_HIP_LIBRARY", "product"), "ms": round(best, 4), "TBps": round(n * 120 / best / 1e9, 2), "bits_ok": ok}))
+print(json.dumps({"lib": os.environ.get("DXO_HIP_LIBRARY", "product"), "ms": round(best, 4), "d": d, "TBps": round(n * (16 * d + 24) / best / 1e9, 2), "bits_ok": ok}))
