@@ -1235,7 +1235,7 @@ extern "C" int dxo_operand_adjoint(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int b
         return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: a nonlinear operand (C, I1, det F) has no adjoint — its linearisation is a form UFL derives on the reference side");
     const int D = dxo_operand_value_size(mesh->gdim, bs, kind);
     if (D == DXO_E_OPTION) return dxo_fail(ctx, DXO_E_OPTION, "dxo_operand_adjoint: unknown operand kind");
-    if (D < 0) return dxo_fail(ctx, DXO_E_DIM, "dxo_operand_adjoint: block size does not fit the operand kind / gdim");
+    if (D < 0 || (bs != 1 && bs != mesh->gdim)) return dxo_fail(ctx, DXO_E_DIM, "dxo_operand_adjoint: block size does not fit the operand kind / gdim (the adjoint takes bs = 1 or gdim)");
     if (!cells) n_cells = n_cells < 0 ? mesh->num_cells : n_cells;
     if (n_cells < 0 || (!cells && n_cells > mesh->num_cells)) return dxo_fail(ctx, DXO_E_SIZE, "dxo_operand_adjoint: bad n_cells");
     if (n_cells == 0) return DXO_OK;

@@ -51,8 +51,13 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval(OperandDev m, const do
         }
         op_fence();
         const int nval = ncell * m.nq * D;
-        double* g_o = out + c0 * m.nq * D;
-        for (int idx = lane; idx < nval; idx += DXO_WAVE) __builtin_nontemporal_store(W[idx], g_o + idx);
+        if (m.out_stride) {      // one component of a wider operand: D values per point, out_stride apart
+            double* g_s = out + c0 * m.nq * m.out_stride;
+            for (int idx = lane; idx < nval; idx += DXO_WAVE) g_s[(int64_t)(idx / D) * m.out_stride + idx % D] = W[idx];
+        } else {
+            double* g_o = out + c0 * m.nq * D;
+            for (int idx = lane; idx < nval; idx += DXO_WAVE) __builtin_nontemporal_store(W[idx], g_o + idx);
+        }
         op_fence();
     };
     int64_t grp = walk.first;
@@ -144,6 +149,25 @@ int dispatch_kind(const dxo_ctx* ctx, const dxo_mesh* m, int kind, const double*
     return DXO_E_OPTION;
 }
 
+// A Lagrange field of ANY block size (the reference evaluates whatever `fem.Expression` is handed: test/test_nested_ex_op.py:113-118 uses a
+// 4-component DG field as an operand) for the kinds that act on each component alone — value, grad, value_grad: one scalar launch per
+// component (two for value_grad: its values and its gradients are not adjacent in the operand), reading u at stride bs and writing its slice of
+// every point. bs = 1 and bs = gdim take the dense kernels above.
+template <int G>
+int dispatch_components(const dxo_ctx* ctx, const dxo_mesh* m, int kind, int bs, const double* u, const int32_t* cells, int64_t n_cells,
+                        double* out, hipStream_t s) {
+    OperandDev dev = m->dev;
+    dev.u_stride = bs;
+    dev.out_stride = kind == DXO_OPERAND_VALUE ? bs : kind == DXO_OPERAND_GRAD ? bs * G : bs * (1 + G);
+    for (int c = 0; c < bs; ++c) {
+        if (kind == DXO_OPERAND_VALUE || kind == DXO_OPERAND_VALUE_GRAD)
+            launch_operand_dev<G, 1, DXO_OPERAND_VALUE>(ctx, dev, u + c, cells, n_cells, out + c, s);
+        if (kind == DXO_OPERAND_GRAD || kind == DXO_OPERAND_VALUE_GRAD)
+            launch_operand_dev<G, 1, DXO_OPERAND_GRAD>(ctx, dev, u + c, cells, n_cells, out + (kind == DXO_OPERAND_GRAD ? 0 : bs) + c * G, s);
+    }
+    return DXO_OK;
+}
+
 int ensure(dxo_ctx* ctx, void** p, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return DXO_OK;
     if (*p) DXO_HIP(ctx, hipFree(*p));
@@ -182,9 +206,9 @@ int dxo_operand_launch_range(dxo_ctx* ctx, const dxo_mesh* mesh, int kind, int b
 extern "C" int dxo_operand_value_size(int gdim, int bs, int kind) {
     if (gdim != 2 && gdim != 3) return DXO_E_DIM;
     switch (kind) {
-        case DXO_OPERAND_VALUE: return bs == 1 || bs == gdim ? bs : DXO_E_DIM;
-        case DXO_OPERAND_GRAD: return bs == 1 || bs == gdim ? bs * gdim : DXO_E_DIM;
-        case DXO_OPERAND_VALUE_GRAD: return bs == 1 || bs == gdim ? bs * (1 + gdim) : DXO_E_DIM;
+        case DXO_OPERAND_VALUE: return bs >= 1 && bs <= DXO_OPERAND_MAX_BS ? bs : DXO_E_DIM;                      // any block size: per-component kinds
+        case DXO_OPERAND_GRAD: return bs >= 1 && bs <= DXO_OPERAND_MAX_BS ? bs * gdim : DXO_E_DIM;
+        case DXO_OPERAND_VALUE_GRAD: return bs >= 1 && bs <= DXO_OPERAND_MAX_BS ? bs * (1 + gdim) : DXO_E_DIM;
         case DXO_OPERAND_EPS_MANDEL: return bs == gdim ? (gdim == 2 ? 4 : 6) : DXO_E_DIM;
         case DXO_OPERAND_DEFGRAD: return bs == gdim ? gdim * gdim : DXO_E_DIM;
         case DXO_OPERAND_CAUCHY_GREEN: return bs == gdim ? gdim * gdim : DXO_E_DIM;
@@ -331,7 +355,8 @@ extern "C" int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* m, int kind, int bs, int
     }
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
-    if (m->gdim == 2) rc = bs == 1 ? dispatch_kind<2, 1>(ctx, m, kind, du, dc, n_cells, dout, s) : dispatch_kind<2, 2>(ctx, m, kind, du, dc, n_cells, dout, s);
+    if (bs != 1 && bs != m->gdim) rc = m->gdim == 2 ? dispatch_components<2>(ctx, m, kind, bs, du, dc, n_cells, dout, s) : dispatch_components<3>(ctx, m, kind, bs, du, dc, n_cells, dout, s);
+    else if (m->gdim == 2) rc = bs == 1 ? dispatch_kind<2, 1>(ctx, m, kind, du, dc, n_cells, dout, s) : dispatch_kind<2, 2>(ctx, m, kind, du, dc, n_cells, dout, s);
     else              rc = bs == 1 ? dispatch_kind<3, 1>(ctx, m, kind, du, dc, n_cells, dout, s) : dispatch_kind<3, 3>(ctx, m, kind, du, dc, n_cells, dout, s);
     if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_eval_operand: unsupported (gdim, bs, kind)");
     rc = dxo_device_end(ctx, s);

@@ -18,6 +18,10 @@ struct OperandDev {
     const int32_t* dofmap;         // [num_cells][ndofs]
     const int32_t* geom_dofmap;    // [num_cells][ngeom]
     const double* x;               // [num_geom_nodes][G]
+    // a field of ANY block size evaluated one component at a time by the scalar (BS = 1) kernels (dxo_eval_operand): component c of node a
+    // sits at u[a * u_stride + c] (the launch passes u + c) and its values go to out[point * out_stride + ...] (the launch passes out + the
+    // component's offset). 0 = the kernel's own block size / value size, i.e. a dense field and a dense output.
+    int u_stride = 0, out_stride = 0;
 };
 
 
@@ -196,7 +200,7 @@ __device__ __forceinline__ void operand_gather(const OperandDev& m, double* W, c
         const int64_t cell = cells ? (int64_t)cells[c0 + c] : c0 + c;
         const int64_t node = m.dofmap[cell * nd + a];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) U[c * su + a * BS + i] = u[node * BS + i];
+        for (int i = 0; i < BS; ++i) U[c * su + a * BS + i] = u[node * (m.u_stride ? m.u_stride : BS) + i];
     }
     for (int idx = lane; idx < ncell * ng; idx += DXO_WAVE) {
         const int c = idx / ng, v = idx - c * ng;
@@ -246,7 +250,7 @@ __device__ __forceinline__ void pipe_load_values(const OperandDev& m, OperandPip
     for (int it = 0; it < OP_GI; ++it)
         if (pf.un[it] >= 0) {
 #pragma unroll
-            for (int i = 0; i < BS; ++i) pf.ud[it][i] = u[(int64_t)pf.un[it] * BS + i];
+            for (int i = 0; i < BS; ++i) pf.ud[it][i] = u[(int64_t)pf.un[it] * (m.u_stride ? m.u_stride : BS) + i];
         }
 #pragma unroll
     for (int it = 0; it < OP_XI; ++it)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval_facets(OperandDev m, i
             const double ph = phi[a];
 #pragma unroll
             for (int i = 0; i < BS; ++i) {
-                const double ua = u[node * BS + i];
+                const double ua = u[node * (m.u_stride ? m.u_stride : BS) + i];
                 val[i] += ua * ph;
 #pragma unroll
                 for (int k = 0; k < G; ++k) gref[i][k] += ua * dphi[a * G + k];
@@ -81,12 +81,13 @@ __global__ __launch_bounds__(DXO_BLOCK) void operand_eval_facets(OperandDev m, i
         double o[D];
         shape_operand<G, BS, KIND>(val, g, o);
 #pragma unroll
-        for (int k = 0; k < D; ++k) out[t * D + k] = o[k];
+        for (int k = 0; k < D; ++k) out[t * (m.out_stride ? m.out_stride : D) + k] = o[k];
     }
 }
 
 template <int G, int BS, int KIND>
-void launch_facets(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, const int32_t* ents, int64_t n, double* out, hipStream_t s) {
+void launch_facets(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, const int32_t* ents, int64_t n, double* out, hipStream_t s,
+                   int u_stride = 0, int out_stride = 0) {
     const size_t nd = (size_t)m->dev.ndofs, nf = (size_t)m->n_local_facets, nqf = (size_t)m->nq_facet;
     const double* phi_f = m->d_facet_tab;
     const double* dphi_f = phi_f + nf * nqf * nd;
@@ -95,8 +96,25 @@ void launch_facets(const dxo_ctx* ctx, const dxo_mesh* m, const double* u, const
     const int64_t cap = (int64_t)ctx->compute_units * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((operand_eval_facets<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, m->dev, (int)nqf, phi_f, dphi_f,
+    OperandDev dev = m->dev;
+    dev.u_stride = u_stride;
+    dev.out_stride = out_stride;
+    hipLaunchKernelGGL((operand_eval_facets<G, BS, KIND>), dim3((int)blocks), dim3(DXO_BLOCK), 0, s, dev, (int)nqf, phi_f, dphi_f,
                        dpsi_f, u, ents, n, out);
+}
+
+// any block size for the per-component kinds, as dispatch_components of operand.hip: one scalar launch per component
+template <int G>
+int dispatch_facet_components(const dxo_ctx* ctx, const dxo_mesh* m, int kind, int bs, const double* u, const int32_t* ents, int64_t n,
+                              double* out, hipStream_t s) {
+    const int os = kind == DXO_OPERAND_VALUE ? bs : kind == DXO_OPERAND_GRAD ? bs * G : bs * (1 + G);
+    for (int c = 0; c < bs; ++c) {
+        if (kind == DXO_OPERAND_VALUE || kind == DXO_OPERAND_VALUE_GRAD)
+            launch_facets<G, 1, DXO_OPERAND_VALUE>(ctx, m, u + c, ents, n, out + c, s, bs, os);
+        if (kind == DXO_OPERAND_GRAD || kind == DXO_OPERAND_VALUE_GRAD)
+            launch_facets<G, 1, DXO_OPERAND_GRAD>(ctx, m, u + c, ents, n, out + (kind == DXO_OPERAND_GRAD ? 0 : bs) + c * G, s, bs, os);
+    }
+    return DXO_OK;
 }
 
 template <int G, int BS>
@@ -201,7 +219,8 @@ extern "C" int dxo_eval_operand_facets(dxo_ctx* ctx, dxo_mesh* m, int kind, int 
     }
     int rc = dxo_device_begin(ctx, s);
     if (rc != DXO_OK) return rc;
-    if (m->gdim == 2) rc = bs == 1 ? dispatch_facets<2, 1>(ctx, m, kind, du, de, n_entities, dout, s) : dispatch_facets<2, 2>(ctx, m, kind, du, de, n_entities, dout, s);
+    if (bs != 1 && bs != m->gdim) rc = m->gdim == 2 ? dispatch_facet_components<2>(ctx, m, kind, bs, du, de, n_entities, dout, s) : dispatch_facet_components<3>(ctx, m, kind, bs, du, de, n_entities, dout, s);
+    else if (m->gdim == 2) rc = bs == 1 ? dispatch_facets<2, 1>(ctx, m, kind, du, de, n_entities, dout, s) : dispatch_facets<2, 2>(ctx, m, kind, du, de, n_entities, dout, s);
     else              rc = bs == 1 ? dispatch_facets<3, 1>(ctx, m, kind, du, de, n_entities, dout, s) : dispatch_facets<3, 3>(ctx, m, kind, du, de, n_entities, dout, s);
     if (rc != DXO_OK) return dxo_fail(ctx, rc, "dxo_eval_operand_facets: unsupported (gdim, bs, kind)");
     rc = dxo_device_end(ctx, s);

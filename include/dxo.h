@@ -398,7 +398,12 @@ int dxo_isihara(dxo_ctx* ctx, const dxo_isihara_params* prm, int64_t n, int mem,
  *   x            = mesh.geometry.x          [num_geom_nodes][x_stride]  (DOLFINx: x_stride = 3), first gdim used
  *   phi, dphi    = V.element.basix_element.tabulate(1, points): values [nq][ndofs], reference gradients
  *                  [nq][ndofs][gdim]; dpsi = the coordinate element's reference gradients [nq][ngeom][gdim]
- * Cells are not assumed affine: J is rebuilt at every point from dpsi. */
+ * Cells are not assumed affine: J is rebuilt at every point from dpsi.
+ * Block sizes: value / grad / value_grad act on each component alone and take ANY bs in 1..DXO_OPERAND_MAX_BS (the reference hands
+ * `fem.Expression` whatever field the operand is: test/test_nested_ex_op.py:113-118 evaluates a 4-component DG field): bs = 1 and bs = gdim run
+ * the dense kernels, any other bs one scalar launch per component. The kinds built from grad u of a displacement-like field need bs = gdim.
+ * The adjoint entry points take bs = 1 or gdim. */
+#define DXO_OPERAND_MAX_BS 64
 enum {
     DXO_OPERAND_VALUE = 0,       /* u                       value_size = bs                         (heat: T)        */
     DXO_OPERAND_GRAD = 1,        /* grad u, [i][j]=du_i/dx_j value_size = bs*gdim                    (heat: grad T)   */

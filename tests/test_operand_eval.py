@@ -8,7 +8,7 @@ from tools.synthetic import LagrangeElement, quadrature_degree2, structured_mesh
 from oracle.operand_oracle import DEFGRAD, EPS_MANDEL, GRAD, VALUE, eval_operand
 
 CELLS = {"triangle": (5, 4), "quadrilateral": (4, 3), "tetrahedron": (2, 3, 2), "hexahedron": (3, 2, 2)}
-KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "C": 5, "I1": 6, "detF": 7, "div": 8}
+KIND_ID = {"value": VALUE, "grad": GRAD, "eps": EPS_MANDEL, "F": DEFGRAD, "value_grad": 4, "C": 5, "I1": 6, "detF": 7, "div": 8}
 
 
 def poly_field(gdim, bs, degree, seed):
@@ -528,3 +528,57 @@ def test_the_reference_operand_test_pattern_on_the_device(ctx):
             dm.value_size("I1", 1)                                                              # needs a vector field, bs = gdim
     finally:
         dm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,degree,bs", [("triangle", 1, 4), ("triangle", 2, 3), ("quadrilateral", 2, 5), ("tetrahedron", 1, 4), ("tetrahedron", 2, 2),
+                                            ("hexahedron", 2, 4), ("hexahedron", 1, 9)])
+def test_fields_of_any_block_size_as_value_and_gradient_operands(ctx, cell, degree, bs):
+    """`evaluate_operands` evaluates whatever field the operand is (external_operator.py:386-402): test/test_nested_ex_op.py:113-118 hands a
+    4-component DG field `theta` to an operator. value / grad / value_grad of a field whose block size is neither 1 nor gdim run as one scalar
+    launch per component (csrc/operand.hip dispatch_components): against the NumPy oracle on all cells, on an entity list, on (cell, facet) pairs,
+    and with Expression.eval's shapes through the dispatcher."""
+    from dolfinx_external_operator_amd import DeviceMesh, QuadratureExternalOperator, evaluate_operands
+    from oracle.operand_oracle import eval_operand_facets
+
+    m = structured_mesh(cell, CELLS[cell], degree, distort=0.15, seed=4)
+    g = m.gdim
+    assert bs not in (1, g)
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    rng = np.random.Generator(np.random.PCG64(40 + bs))
+    u = rng.normal(size=m.node_x.shape[0] * bs)
+    ents = rng.permutation(m.num_cells)[: max(3, m.num_cells // 2)].astype(np.int32)
+    try:
+        for kind in ("value", "grad", "value_grad"):
+            assert dm.value_size(kind, bs) == {"value": bs, "grad": bs * g, "value_grad": bs * (1 + g)}[kind]
+            for cells in (None, ents):
+                ref = eval_operand(KIND_ID[kind], bs, u, m.dofmap, m.geom_dofmap, m.x, m.phi, m.dphi, m.dpsi, cells)
+                got = dm.evaluate(kind, bs, u, cells)
+                assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (kind, cells is None)
+        # each component is the scalar operand of that component (the dense bs = 1 kernel): the same bits
+        one = dm.evaluate("grad", 1, np.ascontiguousarray(u.reshape(-1, bs)[:, bs - 1]))
+        assert np.array_equal(dm.evaluate("grad", bs, u).reshape(m.num_cells, m.nq, bs, g)[:, :, bs - 1, :], one)
+        # Expression.eval's shapes through the dispatcher: (cells, nq, bs) and (cells, nq, bs, gdim)
+        theta, dtheta = dm.operand("value", u, bs=bs), dm.operand("grad", u, bs=bs)
+        N = QuadratureExternalOperator(theta, dtheta, num_cells=m.num_cells, num_points=m.nq, value_shape=(),
+                                       external_function=lambda d: (lambda a, b: (a.sum(axis=2) + b.sum(axis=(2, 3))).reshape(-1)))
+        ev = evaluate_operands([N])
+        assert ev[theta].shape == (m.num_cells, m.nq, bs) and ev[dtheta].shape == (m.num_cells, m.nq, bs, g)
+    finally:
+        dm.close()
+    mf, tabs, fents, _ = _facet_case(cell, degree, seed=6)
+    dmf = DeviceMesh.from_synthetic(mf, ctx=ctx)
+    try:
+        dmf.set_facet_tables(*tabs)
+        uf = rng.normal(size=mf.node_x.shape[0] * bs)
+        for kind in ("value", "grad", "value_grad"):
+            ref = eval_operand_facets(KIND_ID[kind], bs, uf, mf.dofmap, mf.geom_dofmap, mf.x, *tabs, fents)
+            got = dmf.evaluate_facets(kind, bs, uf, fents)
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), kind
+        # the kinds built from a displacement gradient still need bs = gdim, and the adjoint takes 1 or gdim
+        with pytest.raises(ValueError):
+            dmf.value_size("eps", bs)
+        with pytest.raises(ValueError):
+            dmf.value_size("value", 65)
+    finally:
+        dmf.close()
