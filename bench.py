@@ -897,6 +897,7 @@ def main():
             raise SystemExit("bench: yield condition violated by the kernel output — refusing to report a number")
         if not bool(torch.isfinite(C_tang[lo * d * d:(lo + 4096) * d * d]).all()):
             raise SystemExit("bench: non-finite tangent in the kernel output — refusing to report a number")
+    del s_chk, dev_chk, f_chk, plastic      # s_chk is a view into the headline's output block: it must not outlive the block's release below
 
     # side figures (never `value`), measured AFTER the timed batches so that their allocations and frees cannot disturb them
     if rank == 0 and not gather_on and not args.no_side:
@@ -904,41 +905,6 @@ def main():
         plain_GBps = time_kernel((plain.data_ptr(), plain.data_ptr() + n * d * d * 8, plain.data_ptr() + n * (d * d + d) * 8), 12)
         del plain
         torch.cuda.empty_cache()
-
-    # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
-    # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
-    # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
-    if rank == 0 and not gather_on and not args.no_side and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
-        from dolfinx_external_operator_amd import make_von_mises
-
-        deps3 = deps.view(n // args.nq, args.nq, d)
-        rates = []
-        factory_detail = {}
-        for kw in ({"device_outputs": "arena"}, {}):
-            ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
-            f = ext((1,))
-            res_ = f(deps3)
-            blk_ = getattr(res_[0], "dxo_block", None)
-            if blk_ is not None and kw:
-                factory_placement = {k: blk_.info.get(k) for k in ("mode", "candidates", "chosen_kind", "chosen_GBps", "rounds", "calibration_ms")}
-            reps = []
-            for _ in range(3):      # three runs of 12 launches: a transient (host hiccup) shows as one low run, a slow block as three
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(12):
-                    f(deps3)
-                e1.record(stream)
-                torch.cuda.synchronize(device)
-                reps.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
-            rates.append(statistics.median(reps))
-            factory_detail["arena" if kw else "fresh"] = {"runs_GBps": reps}
-            if blk_ is not None and kw:
-                # the same block through the thin entry point (no factory code between the launches): separates the block from the path
-                factory_detail["arena"]["direct_entry_point_GBps"] = time_kernel(tuple(t.data_ptr() for t in res_), 12)
-            del ext, f, res_, blk_
-            torch.cuda.empty_cache()
-        factory_GBps, factory_fresh_GBps = rates
-
 
     # stream probe: a no-arithmetic kernel moving the same read:write mix (13 : 43 sixteen-byte rows per tile) from the
     # input slab into the SAME output block, persistent grid of 16 workgroups per CU. A reference point beside the
@@ -960,9 +926,60 @@ def main():
         ctx.set_option("blocks_per_cu", saved_bpc)
         probe_GBps = tiles * (R + Wc) * 1024 / (e0.elapsed_time(e1) / K * 1e-3) / 1e9
 
+    # The factory leg below is what a USER of make_von_mises gets, and a user does not hold a second 3.4 GB output block: the headline's block goes
+    # back to the context first (dxo_output_free keeps one calibrated block for the next request of its size, csrc/arena.hip — on a box with ONE
+    # fast range among 68 candidates, round 6 lease 14, nothing else could give the factory the headline's rate), and the factory's own
+    # calibration is then handed that block (factory_placement.rounds == 0) or searches afresh.
+    released_headline_block = False
+    if rank == 0 and world == 1 and not dist_on and not gather_on and not args.no_side:
+        del C_tang, sigma, dp, C_full, sigma_full, dp_full
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        released_headline_block = True
+
+    # the same kernel through the drop-in factory with CUDA-tensor operands, make_von_mises(...)((1,))(deps): with its DEFAULTS
+    # (fresh output tensors at every call, the reference's semantics) and with the one-keyword opt-in device_outputs="arena"
+    # (outputs in a persistent arena block of the operator's own, overwritten by its next call)
+    if rank == 0 and not gather_on and not args.no_side and n * per_pt * 8 >= ctx.get_option("placement_min_bytes") and 3 * n * per_pt * 8 < info["total_mem_bytes"] // 4:
+        from dolfinx_external_operator_amd import make_von_mises
+
+        deps3 = deps.view(n // args.nq, args.nq, d)
+        rates = []
+        factory_detail = {}
+        for kw in ({"device_outputs": "arena"}, {}):
+            ext = make_von_mises(sigma_n, p, E=E, nu=nu, sigma_0=sigma_0, H=H, ctx=ctx, **kw)
+            f = ext((1,))
+            res_ = f(deps3)
+            blk_ = getattr(res_[0], "dxo_block", None)
+            if blk_ is not None and kw:
+                factory_placement = {k: blk_.info.get(k) for k in ("mode", "candidates", "chosen_kind", "chosen_GBps", "rounds", "calibration_ms")}
+                factory_placement["block"] = ("the headline's block, handed back by the context's cache (rounds = 0)" if blk_.info.get("rounds") == 0
+                                              else "its own search" + (", made after the headline's block was released" if released_headline_block else ""))
+            reps = []
+            for _ in range(3):      # three runs of 12 launches: a transient (host hiccup) shows as one low run, a slow block as three
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(12):
+                    f(deps3)
+                e1.record(stream)
+                torch.cuda.synchronize(device)
+                reps.append(BYTES_PER_QP[d] * n / (e0.elapsed_time(e1) / 12 * 1e-3) / 1e9)
+            rates.append(statistics.median(reps))
+            factory_detail["arena" if kw else "fresh"] = {"runs_GBps": reps}
+            if blk_ is not None and kw:
+                # the same block through the thin entry point (no factory code between the launches): separates the block from the path
+                factory_detail["arena"]["direct_entry_point_GBps"] = time_kernel(tuple(t.data_ptr() for t in res_), 12)
+            del ext, f, res_, blk_
+            torch.cuda.empty_cache()
+        factory_GBps, factory_fresh_GBps = rates
+
+
     if rank == 0:
         if world == 1 and not args.no_e2e:
-            del C_tang, sigma, dp, C_full, sigma_full, dp_full, in_slab, deps, sigma_n, p
+            if not released_headline_block:
+                del C_tang, sigma, dp, C_full, sigma_full, dp_full
+            del in_slab, deps, sigma_n, p
             torch.cuda.empty_cache()
         emit_result(elapsed, kernel_ms_avg_max, other_elapsed, probe_GBps, stats=batch_stats)
     if dist_on:

@@ -324,7 +324,37 @@ double crowd_median(const dxo_placement_info& info) {
     return v[v.size() / 2];
 }
 
+// ---- the retained block (round 6). A calibration costs 2-7 s and, on some boxes, fast ranges are rare: one lease showed ONE fast block among 68
+// candidates, so an operator created after another one of the same size had been deleted could not find what its predecessor had just given
+// back. dxo_output_free therefore keeps ONE calibrated block (the fastest it has been handed) instead of releasing it, and the next request of
+// exactly its size and probe kind is given that block — re-timed first, and taken only if it still runs at placement_accept_pct of the class
+// record. It is released when a search starts (it must not sit among the candidates), when dxo_device_alloc would otherwise fail, and when the
+// context closes. Option "placement_cache" = 0 turns it off. info.rounds = 0 marks a block that came from here.
+bool cache_take(dxo_ctx* c, size_t bytes, const dxo_arena_probe& pr, dxo_arena_block& blk, hipStream_t s) {
+    for (size_t i = 0; i < c->arena_cache.size(); ++i) {
+        dxo_arena_block& e = c->arena_cache[i];
+        if (e.bytes != bytes || e.info.probe_kind != pr.kind) continue;
+        // the request's rule about chunk-backed ranges holds for a retained block too (placement_vmm = 0: RCCL buffers must be plain hipMalloc blocks)
+        if ((c->placement_vmm == 0 && e.vmm) || (c->placement_vmm >= 2 && !e.vmm)) continue;
+        int sh = e.info.tuned_blocks_per_cu;
+        const double bw = probe_block(c, pr, e.ptr, s, 6, &sh);
+        (void)hipStreamSynchronize(s);
+        const int64_t key = class_key(pr.kind, bytes);
+        const double best_seen = c->placement_best.count(key) ? c->placement_best[key] : 0.0;
+        if (bw <= 0.0 || bw < 0.01 * (double)c->placement_accept_pct * best_seen) return false;      // no longer what it was: the caller drops it and searches
+        blk = e;
+        blk.info.chosen_GBps = bw;
+        blk.info.tuned_blocks_per_cu = sh;
+        blk.info.rounds = 0;
+        c->arena_cache.erase(c->arena_cache.begin() + (long)i);
+        return true;
+    }
+    return false;
+}
+
 bool alloc_by_candidates(dxo_ctx* c, size_t bytes, const dxo_arena_probe& pr, dxo_arena_block& blk, hipStream_t s) {
+    if (c->placement_cache && cache_take(c, bytes, pr, blk, s)) return true;
+    dxo_arena_cache_drop(c);
     const int64_t key = class_key(pr.kind, bytes);
     int max_rounds = (int)c->placement_rounds;
     if (max_rounds < 1) max_rounds = 1;
@@ -404,7 +434,17 @@ bool dxo_arena_is_vmm(dxo_ctx* c, const void* ptr) {
     return false;
 }
 
+void dxo_arena_cache_drop(dxo_ctx* c) {
+    if (c->arena_cache.empty()) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : c->arena_cache)
+        if (b.ptr) block_free(b);
+    c->arena_cache.clear();
+}
+
 void dxo_arena_release_all(dxo_ctx* c) {
+    dxo_arena_cache_drop(c);
     for (auto& b : c->arena)
         if (b.ptr) block_free(b);
     c->arena.clear();
@@ -518,6 +558,14 @@ extern "C" int dxo_output_free(dxo_ctx* c, void* ptr) {
         c->arena.erase(c->arena.begin() + (long)i);
         DXO_HIP(c, hipSetDevice(c->device));
         DXO_HIP(c, hipDeviceSynchronize());
+        if (c->placement_cache && b.info.mode == 2 && b.info.chosen_GBps > 0.0) {
+            // retained for the next request of its size (see cache_take): one block at most, the faster of the two
+            if (c->arena_cache.empty()) {
+                c->arena_cache.push_back(b);
+                return DXO_OK;
+            }
+            if (b.info.chosen_GBps > c->arena_cache[0].info.chosen_GBps) std::swap(b, c->arena_cache[0]);
+        }
         block_free(b);
         return DXO_OK;
     }

@@ -30,6 +30,7 @@ struct dxo_arena_block {
 };
 struct dxo_ctx;
 void dxo_arena_release_all(dxo_ctx* ctx);
+void dxo_arena_cache_drop(dxo_ctx* ctx);      // frees the retained block, if any (a search is about to start, memory ran short, the context closes)
 
 // How dxo_output_alloc's calibration exercises a candidate block (arena.hip). The generic probes are sweeps of
 // arena.hip's own; a kernel family can bring its own launch (dxo_vm_output_alloc: vm_tile itself) and a list of launch
@@ -106,6 +107,7 @@ struct dxo_ctx {
     int64_t placement_standout_pct = 106;   // without such a record: a winner below this share of its crowd's median is rejected once
     std::map<int64_t, double> placement_best;   // (probe kind, size class) -> best rate a calibration of this context has kept
     std::vector<dxo_arena_block> arena;
+    std::vector<dxo_arena_block> arena_cache;   // at most one calibrated block that its owner has freed (arena.hip: handed to the next request of its size)
     int64_t vm_mark_indeterminate = 0;  // DEVICE-path von Mises: dp = -0.0 at f_elastic == 0 exactly (the reference's 0/0, :318), for
                                         // consumers that rebuild the tangent from (sigma, dp); dxo_vm_clear_marks restores +0
     int64_t vm_host_tangent = 0;        // DXO_MEM_HOST von Mises: 0 copy C_tang over PCIe, 1 copy (sigma, dp) and rebuild C_tang on the host
@@ -126,6 +128,7 @@ struct dxo_ctx {
     size_t stage_bytes[DXO_HOST_SLOTS + 1] = {0, 0, 0, 0};
     hipStream_t scratch_stream = nullptr;   // stream of the last DEVICE-path launch that used scratch[DXO_HOST_SLOTS]
     bool scratch_stream_set = false;
+    int64_t placement_cache = 1;        // dxo_output_free keeps ONE calibrated block for the next request of the same size (0: frees at once)
     int64_t assign_validate = 1;        // dxo_assign: check flat_dofs against coeff_size on the device (one sync per call)
     int64_t assign_plan_form = 0;       // dxo_assign_plan_create: 0 = keep both forms of a large plan and let the first apply time them, 1 = dof order only, 2 = source order
     int64_t assign_owner_bits = 0;      // owner words of the last-writer pass: 0 = 32-bit while the entry count fits, 64 = always wide (what > 2^32 - 2 entries take)

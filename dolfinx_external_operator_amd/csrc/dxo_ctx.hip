@@ -196,6 +196,7 @@ static int64_t* option_slot(dxo_ctx* c, const char* key) {
     if (!std::strcmp(key, "placement_good_GBps")) return &c->placement_good_GBps;
     if (!std::strcmp(key, "placement_vmm")) return &c->placement_vmm;
     if (!std::strcmp(key, "placement_rounds")) return &c->placement_rounds;
+    if (!std::strcmp(key, "placement_cache")) return &c->placement_cache;
     if (!std::strcmp(key, "placement_accept_pct")) return &c->placement_accept_pct;
     if (!std::strcmp(key, "placement_standout_pct")) return &c->placement_standout_pct;
     if (!std::strcmp(key, "placement_probe")) return &c->placement_probe;
@@ -299,7 +300,12 @@ int dxo_device_alloc(dxo_ctx* c, int64_t bytes, void** ptr) {
     if (bytes < 0) return dxo_fail(c, DXO_E_SIZE, "negative size");
     *ptr = nullptr;
     DXO_HIP(c, hipSetDevice(c->device));
-    DXO_HIP(c, hipMalloc(ptr, bytes > 0 ? (size_t)bytes : 1));
+    if (hipMalloc(ptr, bytes > 0 ? (size_t)bytes : 1) != hipSuccess && !c->arena_cache.empty()) {
+        (void)hipGetLastError();
+        dxo_arena_cache_drop(c);      // the block dxo_output_free retained gives way to a request that would otherwise fail
+        *ptr = nullptr;
+    }
+    if (!*ptr) DXO_HIP(c, hipMalloc(ptr, bytes > 0 ? (size_t)bytes : 1));
     return DXO_OK;
 }
 

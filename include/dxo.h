@@ -170,7 +170,11 @@ int dxo_host_free(dxo_ctx* ctx, void* ptr);
  * block size, or, without such a record, when it does not stand out from its own candidates (below
  * "placement_standout_pct" = 106 per cent of their median; once; not if it already runs at "placement_good_mix_GBps"); "placement_rounds" (3)
  * bounds the searches; the rate tested is the winner's rate AFTER the other candidates have been freed. The
- * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw. */
+ * calibration WRITES the block (zeros) and is synchronous. dxo_output_info reports what the calibration saw.
+ * dxo_output_free RETAINS one calibrated block (the fastest it has been handed) instead of releasing it, and the next request of
+ * exactly its size and probe is given that block back after a re-timing (rounds = 0 in its record: ~10 ms instead of a 2-7 s
+ * search, and the only way to a fast block on a box where one range in 68 is fast); it is released when a search starts, when
+ * dxo_device_alloc would otherwise fail, and with the context. Option "placement_cache" = 0 frees at once. */
 #define DXO_PLACEMENT_MAX 32
 typedef struct dxo_placement_info {
     int16_t mode;                           /* how the block was obtained: 0 plain hipMalloc, 2 candidates         */

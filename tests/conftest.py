@@ -40,6 +40,9 @@ def ctx(hip_library):
     from dolfinx_external_operator_amd import Context
 
     c = Context(0)
+    # one context serves the whole session: a calibrated block that one test frees must not be handed to the next test's request of the same size
+    # (tests read the calibration's own record); the retained block has a test of its own, which switches it on (tests/test_round2_gpu.py)
+    c.set_option("placement_cache", 0)
     yield c
     c.close()
 

@@ -408,9 +408,10 @@ def test_arena_calibration_retries_a_rejected_winner_bounded(ctx):
     """Round 6 (csrc/arena.hip): a calibration whose winner is below `placement_accept_pct` of the best rate the context ever kept
     for the same probe and size buys one more search, `placement_rounds` at most; the block kept is the head-to-head winner."""
     n, d = 3_300_000, 6
-    keys = ("placement_candidates", "placement_rounds", "placement_accept_pct", "placement_standout_pct")
+    keys = ("placement_candidates", "placement_rounds", "placement_accept_pct", "placement_standout_pct", "placement_cache")
     old = {k: ctx.get_option(k) for k in keys}
     try:
+        ctx.set_option("placement_cache", 0)                 # every request below searches (no block retained from an earlier test is handed back)
         ctx.set_option("placement_candidates", 4)
         ctx.set_option("placement_standout_pct", 0)          # first calibration of the class: accepted whatever its crowd looks like
         a = ctx.vm_output_tensors(n, d)
@@ -431,6 +432,71 @@ def test_arena_calibration_retries_a_rejected_winner_bounded(ctx):
     finally:
         for k, v in old.items():
             ctx.set_option(k, v)
+
+
+def test_a_freed_calibrated_block_is_handed_to_the_next_request_of_its_size(ctx):
+    """Round 6 (csrc/arena.hip, cache_take): dxo_output_free keeps ONE calibrated block; the next request of exactly its size and probe gets that
+    block back (info.rounds == 0, no search: milliseconds instead of seconds) after a re-timing; a request of another size, option
+    placement_cache = 0, or a block that no longer reaches placement_accept_pct of the class record all lead to a fresh search."""
+    import gc
+
+    n, d = 3_300_000, 6
+    keys = ("placement_candidates", "placement_cache", "placement_accept_pct", "placement_standout_pct", "placement_rounds")
+    old = {k: ctx.get_option(k) for k in keys}
+
+    def alloc(points=n):
+        t = list(ctx.vm_output_tensors(points, d))
+        return t, t[0].data_ptr(), dict(t[0].dxo_block.info)
+
+    def free(holder):
+        holder.clear()                 # the last references to the block's tensors
+        gc.collect()
+
+    try:
+        ctx.set_option("placement_candidates", 4)
+        ctx.set_option("placement_standout_pct", 0)
+        ctx.set_option("placement_rounds", 1)
+        ctx.set_option("placement_accept_pct", 50)           # a re-timed block within a factor two of the record is taken back
+        ctx.set_option("placement_cache", 0)
+        a, pa, ia = alloc()                                   # cache off: searches, and its free releases the block
+        assert ia["rounds"] == 1
+        free(a)
+        ctx.set_option("placement_cache", 1)
+        b, pb, ib = alloc()                                   # nothing retained yet: a search
+        assert ib["rounds"] == 1 and ib["calibration_ms"] > 20.0
+        free(b)                                               # retained
+        c, pc, ic = alloc()
+        assert pc == pb and ic["rounds"] == 0 and ic["chosen_GBps"] > 1000.0 and ic["calibration_ms"] < 0.5 * ib["calibration_ms"], (ib, ic)
+        assert ic["tuned_blocks_per_cu"] > 0
+        # the block works as any other: a call into it
+        import torch
+        g = torch.Generator(device="cuda").manual_seed(3)
+        e = torch.empty(n * d, dtype=torch.float64, device="cuda").normal_(0.0, 3e-3, generator=g)
+        sn = torch.empty(n * d, dtype=torch.float64, device="cuda").normal_(0.0, 100.0, generator=g)
+        p = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.von_mises(PRM, d, n, MEM_DEVICE, e.data_ptr(), sn.data_ptr(), p.data_ptr(), c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(c[1]).all())
+        free(c)                                               # retained again
+        other, po, io = alloc(n + 64 * 1024)                  # another size: the retained block is released, a search runs
+        assert io["rounds"] == 1
+        free(other)                                           # ... and this one is retained now
+        f, pf, i_f = alloc()                                  # the first size again: not the retained block's size -> a search
+        assert i_f["rounds"] == 1
+        free(f)
+        ctx.set_option("placement_accept_pct", 1000)          # nothing re-times at ten times the record: the retained block is dropped
+        h, ph, ih = alloc()
+        assert ih["rounds"] == 1
+        free(h)
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+        ctx.set_option("placement_cache", 0)                  # release whatever this test left retained ...
+        try:
+            free(list(ctx.vm_output_tensors(n, d)))
+        finally:
+            ctx.set_option("placement_cache", old["placement_cache"])
 
 
 def test_vm_output_alloc_calibrates_with_the_kernel_itself(ctx, oracle):
