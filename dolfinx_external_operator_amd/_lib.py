@@ -146,6 +146,8 @@ _SIGNATURES = {
     "dxo_assign_apply": (C.c_int, [_P, _P, _P, _P]),
     "dxo_assign_plan_form": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dxo_mesh_set_weights": (C.c_int, [_P, _P, _P]),
+    "dxo_mesh_set_coordinate_values": (C.c_int, [_P, _P, _P]),
+    "dxo_eval_coordinate": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, _P]),
     "dxo_operand_adjoint": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "dxo_tangent_apply": (C.c_int, [_P, _P, _P, _P, _P]),
     "dxo_tangent_diagonal": (C.c_int, [_P, _P, _P, _P]),

@@ -305,12 +305,80 @@ extern "C" int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* m) {
     if (m->d_facet_tab) (void)hipFree(m->d_facet_tab);
     if (m->d_ents) (void)hipFree(m->d_ents);
     if (m->d_wq) (void)hipFree(m->d_wq);
+    if (m->d_psi) (void)hipFree(m->d_psi);
     if (m->d_node_ptr) (void)hipFree(m->d_node_ptr);
     if (m->d_node_ent) (void)hipFree(m->d_node_ent);
     if (m->d_fe) (void)hipFree(m->d_fe);
     if (m->patch.blob) (void)hipFree(m->patch.blob);
     if (m->patch.dev.bpart) (void)hipFree(m->patch.dev.bpart);
     delete m;
+    return DXO_OK;
+}
+
+// ---- the operand `x = ufl.SpatialCoordinate(mesh)` (the first operand of test/test_nested_ex_op.py:113-118): the coordinate element's own
+// interpolation x(xi_q) = sum_v psi_v(xi_q) X_v, i.e. the VALUE operand of the "field" (geometry dofmap, coordinates, psi). The mesh keeps psi
+// once it has been given; the launch is the dense vector-valued kernel on a view of the mesh whose field element is the coordinate element.
+extern "C" int dxo_mesh_set_coordinate_values(dxo_ctx* ctx, dxo_mesh* m, const double* psi) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!m || !psi) return dxo_fail(ctx, DXO_E_NULL, "dxo_mesh_set_coordinate_values: NULL argument");
+    const size_t n = (size_t)m->dev.nq * m->dev.ngeom;
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    DXO_HIP(ctx, hipDeviceSynchronize());
+    if (!m->d_psi) DXO_HIP(ctx, hipMalloc((void**)&m->d_psi, (n ? n : 1) * sizeof(double)));
+    DXO_HIP(ctx, hipMemcpy(m->d_psi, psi, n * sizeof(double), hipMemcpyHostToDevice));
+    return DXO_OK;
+}
+
+extern "C" int dxo_eval_coordinate(dxo_ctx* ctx, dxo_mesh* m, int mem, const int32_t* cells, int64_t n_cells, double* out) {
+    if (!ctx) return DXO_E_NULL;
+    DXO_LOCK(ctx);
+    if (!m) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_coordinate: mesh is NULL");
+    if (!m->d_psi) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_coordinate: call dxo_mesh_set_coordinate_values first");
+    if (mem != DXO_MEM_HOST && mem != DXO_MEM_DEVICE) return dxo_fail(ctx, DXO_E_MEM, "dxo_eval_coordinate: bad mem");
+    if (!cells) n_cells = n_cells < 0 ? m->num_cells : n_cells;
+    if (n_cells < 0 || (!cells && n_cells > m->num_cells)) return dxo_fail(ctx, DXO_E_SIZE, "dxo_eval_coordinate: bad n_cells");
+    if (n_cells == 0) return DXO_OK;
+    if (!out) return dxo_fail(ctx, DXO_E_NULL, "dxo_eval_coordinate: NULL array");
+    if ((uintptr_t)out & 7u) return dxo_fail(ctx, DXO_E_ALIGN, "dxo_eval_coordinate: out must be 8-byte aligned");
+    const int G = m->gdim;
+    OperandDev dev = m->dev;
+    dev.ndofs = dev.ngeom;
+    dev.phi = m->d_psi;
+    dev.dphi = dev.dpsi;
+    dev.dofmap = dev.geom_dofmap;
+    int wd = dev.cells_per_wave * 2 * op_odd(dev.ngeom * G);
+    if (wd < DXO_WAVE * G * (1 + G)) wd = DXO_WAVE * G * (1 + G);
+    dev.wave_doubles = (wd + 1) & ~1;
+    dev.table_doubles = (dev.nq * (op_odd(dev.ngeom) + 2 * op_odd(dev.ngeom * G)) + 1) & ~1;
+    hipStream_t s = dxo_launch_stream(ctx);
+    DXO_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t* dc = cells;
+    double* dout = out;
+    const size_t out_bytes = (size_t)n_cells * dev.nq * G * sizeof(double);
+    if (mem == DXO_MEM_HOST) {
+        if (cells) {
+            for (int64_t i = 0; i < n_cells; ++i)
+                if (cells[i] < 0 || cells[i] >= m->num_cells) return dxo_fail(ctx, DXO_E_SIZE, "dxo_eval_coordinate: entity outside [0, num_cells)");
+            int rc = ensure(ctx, (void**)&m->d_cells, &m->cells_cap, (size_t)n_cells * sizeof(int32_t));
+            if (rc != DXO_OK) return rc;
+            DXO_HIP(ctx, hipMemcpyAsync(m->d_cells, cells, (size_t)n_cells * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            dc = m->d_cells;
+        }
+        int rc = ensure(ctx, (void**)&m->d_out, &m->out_cap, out_bytes);
+        if (rc != DXO_OK) return rc;
+        dout = m->d_out;
+    }
+    int rc = dxo_device_begin(ctx, s);
+    if (rc != DXO_OK) return rc;
+    if (G == 2) launch_operand_dev<2, 2, DXO_OPERAND_VALUE>(ctx, dev, dev.x, dc, n_cells, dout, s);
+    else        launch_operand_dev<3, 3, DXO_OPERAND_VALUE>(ctx, dev, dev.x, dc, n_cells, dout, s);
+    rc = dxo_device_end(ctx, s);
+    if (rc != DXO_OK) return rc;
+    if (mem == DXO_MEM_HOST) {
+        DXO_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
+        DXO_HIP(ctx, hipStreamSynchronize(s));
+    }
     return DXO_OK;
 }
 

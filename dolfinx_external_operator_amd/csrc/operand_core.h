@@ -436,6 +436,7 @@ struct dxo_mesh {
     size_t cells_cap = 0;
     double* d_out = nullptr;    // staging for host-resident outputs
     size_t out_cap = 0;
+    double* d_psi = nullptr;    // [nq][ngeom] values of the coordinate element at the quadrature points (dxo_mesh_set_coordinate_values)
     double* d_wq = nullptr;     // quadrature weights (dxo_mesh_set_weights), needed by the adjoint kernels only
     // codim-1 evaluation (dxo_mesh_set_facet_tables / dxo_eval_operand_facets): tables per LOCAL facet of the cell
     int n_local_facets = 0, nq_facet = 0;

@@ -77,6 +77,8 @@ class DeviceMesh:
                  geom_dofmap=mesh.geom_dofmap, x=mesh.x, num_field_nodes=mesh.node_x.shape[0], **kw)
         if getattr(mesh, "weights", None) is not None:
             dm.set_weights(mesh.weights)
+        if getattr(mesh, "psi", None) is not None:
+            dm.set_coordinate_values(mesh.psi)
         return dm
 
     @staticmethod
@@ -135,6 +137,31 @@ class DeviceMesh:
         self.ctx.check(rc, "dxo_eval_operand")
         return out
 
+    def set_coordinate_values(self, psi) -> None:
+        """Values of the coordinate element's basis at the quadrature points, (nq, ngeom): what the operand `x` (ufl.SpatialCoordinate,
+        test/test_nested_ex_op.py:113-118) needs beside the gradients the mesh already holds. basix: `tabulate(0, points)[0]` of
+        `mesh.geometry.cmap`."""
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        if psi.ndim != 2 or psi.shape[0] != self.nq:
+            raise ValueError("psi must have shape (nq, ngeom)")
+        self.ctx.check(self.ctx.lib.dxo_mesh_set_coordinate_values(self.ctx._h, self._h, psi.ctypes.data), "dxo_mesh_set_coordinate_values")
+
+    def coordinate(self, entities=None, out=None) -> np.ndarray:
+        """x at every quadrature point of the cells: host array (n_cells, nq, gdim) — `Expression(SpatialCoordinate(mesh), points).eval`."""
+        cells = None if entities is None else np.ascontiguousarray(entities, dtype=np.int32)
+        n = self.num_cells if cells is None else cells.size
+        if out is None:
+            out = np.empty((n, self.nq, self.gdim))
+        rc = self.ctx.lib.dxo_eval_coordinate(self.ctx._h, self._h, MEM_HOST, None if cells is None else cells.ctypes.data, n, out.ctypes.data)
+        self.ctx.check(rc, "dxo_eval_coordinate")
+        return out
+
+    def coordinate_device(self, n_cells: int, out_ptr: int, cells_ptr: int | None = None) -> None:
+        """The same into device memory, asynchronous on the context's stream."""
+        rc = self.ctx.lib.dxo_eval_coordinate(self.ctx._h, self._h, MEM_DEVICE, None if cells_ptr is None else C.c_void_p(cells_ptr), int(n_cells),
+                                              C.c_void_p(out_ptr))
+        self.ctx.check(rc, "dxo_eval_coordinate")
+
     def set_facet_tables(self, phi, dphi, dpsi) -> None:
         """Tables for codim-1 entities, one set per LOCAL facet of the cell, tabulated at the facet quadrature points
         mapped into the reference cell (what Expression.eval does with `(cell, local_facet)` entities,
@@ -183,6 +210,8 @@ class DeviceMesh:
         at 10^7 Q2 nodes). False keeps a reference to the live array instead — for the reference's own calling
         sequence, where `evaluate_external_operators` follows `evaluate_operands` at once (demo_plasticity_von_mises.py:
         445-456) and the field does not change in between."""
+        if kind == "x":     # ufl.SpatialCoordinate(mesh): no field (pass None), codim-0 entities
+            return DeviceOperand(self, "x", None, self.gdim, name or "x", False, snapshot)
         return DeviceOperand(self, kind, field, self.gdim if bs is None else bs, name or kind, lazy, snapshot)
 
     def von_mises(self, prm, u, sigma_n, p, C_tang, sigma, dp, mem: int = MEM_HOST) -> None:
@@ -295,6 +324,10 @@ class DeviceOperand:
             else:
                 u = np.ascontiguousarray(_state(self.field), dtype=np.float64).reshape(-1)   # the live array (no copy if fp64)
             return LazyOperand(self.mesh, self.kind, self.bs, u)
+        if self.kind == "x":
+            if entities is not None and np.ndim(entities) == 2:
+                raise NotImplementedError("the operand `x` is evaluated on cells; codim-1 entities go through the host array")
+            return self.mesh.coordinate(entities)                                         # (n, nq, gdim), like any vector operand
         if entities is not None and np.ndim(entities) == 2:
             out = self.mesh.evaluate_facets(self.kind, self.bs, self.field, entities)    # (cell, local facet) pairs
         else:

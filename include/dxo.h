@@ -447,6 +447,11 @@ int dxo_mesh_destroy(dxo_ctx* ctx, dxo_mesh* mesh);
 int dxo_operand_value_size(int gdim, int bs, int kind);
 /* u: field vector (num_field_nodes*bs doubles); cells: entity list or NULL for cells [0, n_cells) (n_cells < 0: all);
  * out: n_cells*nq*value_size doubles. mem applies to u, cells and out alike. */
+/* The operand `x = ufl.SpatialCoordinate(mesh)` (test/test_nested_ex_op.py:113-118): the physical position of every quadrature point,
+ * x(xi_q) = sum_v psi_v(xi_q) X_v with the coordinate element's own basis. psi = its VALUES at the quadrature points, [nq][ngeom] (the mesh
+ * description carries the gradients only), given once; out: n_cells*nq*gdim doubles, cells / n_cells / mem as for dxo_eval_operand. */
+int dxo_mesh_set_coordinate_values(dxo_ctx* ctx, dxo_mesh* mesh, const double* psi);
+int dxo_eval_coordinate(dxo_ctx* ctx, dxo_mesh* mesh, int mem, const int32_t* cells, int64_t n_cells, double* out);
 int dxo_eval_operand(dxo_ctx* ctx, dxo_mesh* mesh, int kind, int bs, int mem, const double* u,
                      const int32_t* cells, int64_t n_cells, double* out);
 

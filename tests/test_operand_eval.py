@@ -582,3 +582,50 @@ def test_fields_of_any_block_size_as_value_and_gradient_operands(ctx, cell, degr
             dmf.value_size("value", 65)
     finally:
         dmf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", list(CELLS))
+def test_the_operands_of_the_nested_operator_test_x_and_a_four_component_field(ctx, cell):
+    """test/test_nested_ex_op.py:113-130: N = FEMExternalOperator(x, theta, ...) with x = ufl.SpatialCoordinate(mesh) and theta a 4-component
+    DG field, the kernel u_NN_impl(gdim, x, theta) of :60-83 reading x[..., j] and theta[..., k]. Both operands on the device: x against the
+    coordinate map of the synthetic mesh (distorted, so tensor cells are genuinely non-affine), theta = 0.32 as in :109, shapes
+    (cells, nq, gdim) and (cells, nq, 4), all cells and an entity list; the dispatcher deduplicates x when two operators share it (:383-399)."""
+    from dolfinx_external_operator_amd import DeviceMesh, QuadratureExternalOperator, evaluate_operands
+
+    m = structured_mesh(cell, CELLS[cell], 1, distort=0.2, seed=9)
+    g = m.gdim
+    dm = DeviceMesh.from_synthetic(m, ctx=ctx)
+    try:
+        xq = m.physical_points()                                             # (cells, nq, gdim), NumPy
+        got = dm.coordinate()
+        assert got.shape == xq.shape and np.abs(got - xq).max() <= 1e-14 * np.abs(xq).max()
+        ents = np.arange(m.num_cells - 1, -1, -2, dtype=np.int32)
+        assert np.array_equal(dm.coordinate(ents), got[ents])
+        theta = np.full(m.node_x.shape[0] * 4, 0.32)                         # :109
+        x_op, th_op = dm.operand("x", None), dm.operand("value", theta, bs=4)
+
+        def u_nn(derivatives):                                               # the shape logic of :60-83: one value per point from x and theta
+            return lambda x, th: (np.tanh(x[..., 0] * th[..., 0] + th[..., 1]) * th[..., 2] + th[..., 3] * x[..., g - 1]).reshape(-1)
+
+        N1 = QuadratureExternalOperator(x_op, th_op, num_cells=m.num_cells, num_points=m.nq, value_shape=(), external_function=u_nn)
+        N2 = QuadratureExternalOperator(x_op, num_cells=m.num_cells, num_points=m.nq, value_shape=(), external_function=lambda d: (lambda x: x[..., 0].reshape(-1)))
+        ev = evaluate_operands([N1, N2])
+        assert x_op.eval_count == 1                                          # evaluated once for both operators
+        assert ev[x_op].shape == (m.num_cells, m.nq, g) and ev[th_op].shape == (m.num_cells, m.nq, 4)
+        np.testing.assert_allclose(ev[th_op], 0.32, rtol=1e-14)
+        want = np.tanh(xq[..., 0] * 0.32 + 0.32) * 0.32 + 0.32 * xq[..., g - 1]
+        from dolfinx_external_operator_amd import evaluate_external_operators
+        vals = evaluate_external_operators([N1, N2], ev)
+        np.testing.assert_allclose(N1.ref_coefficient.x.array.reshape(m.num_cells, m.nq), want, rtol=1e-13)
+        np.testing.assert_allclose(N2.ref_coefficient.x.array.reshape(m.num_cells, m.nq), xq[..., 0], rtol=1e-13, atol=1e-15)
+        assert len(vals) == 2
+        bare = DeviceMesh(gdim=g, phi=m.phi, dphi=m.dphi, dpsi=m.dpsi, dofmap=m.dofmap, geom_dofmap=m.geom_dofmap, x=m.x,
+                          num_field_nodes=m.node_x.shape[0], ctx=ctx)
+        try:
+            with pytest.raises(ValueError, match="dxo_mesh_set_coordinate_values"):
+                bare.coordinate()
+        finally:
+            bare.close()
+    finally:
+        dm.close()

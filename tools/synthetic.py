@@ -96,8 +96,8 @@ def with_rule(mesh: "SyntheticMesh", points: np.ndarray, weights: np.ndarray) ->
     import dataclasses
 
     phi, dphi = LagrangeElement(mesh.cell, mesh.degree).tabulate(points)
-    _, dpsi = LagrangeElement(mesh.cell, 1).tabulate(points)
-    return dataclasses.replace(mesh, points=np.ascontiguousarray(points), phi=phi, dphi=dphi, dpsi=dpsi, weights=np.ascontiguousarray(weights))
+    psi, dpsi = LagrangeElement(mesh.cell, 1).tabulate(points)
+    return dataclasses.replace(mesh, points=np.ascontiguousarray(points), phi=phi, dphi=dphi, dpsi=dpsi, weights=np.ascontiguousarray(weights), psi=psi)
 
 
 @dataclass
@@ -115,6 +115,7 @@ class SyntheticMesh:
     dphi: np.ndarray
     dpsi: np.ndarray
     weights: np.ndarray | None = None   # (nq,) reference quadrature weights
+    psi: np.ndarray | None = None       # (nq, ngeom) values of the coordinate element at the points (the operand `x`, SpatialCoordinate)
 
     @property
     def num_cells(self) -> int:
@@ -210,12 +211,12 @@ def structured_mesh(cell: str, n: tuple[int, ...], degree: int = 2, distort: flo
     geo = LagrangeElement(cell, 1)
     points, weights = quadrature_degree2(cell)
     phi, dphi = fe.tabulate(points)
-    _, dpsi = geo.tabulate(points)
+    psi, dpsi = geo.tabulate(points)
     # physical position of field nodes: image of the reference nodes under each cell's map (shared nodes agree)
     psi_nodes, _ = geo.tabulate(fe.nodes)
     node_x = np.zeros((int(np.prod(fshape)), gdim))
     node_x[dm.reshape(-1)] = np.einsum("av,cvj->caj", psi_nodes, x[geom]).reshape(-1, gdim)
-    return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi, weights)
+    return SyntheticMesh(cell, gdim, degree, np.ascontiguousarray(x), geom, dm, node_x, points, phi, dphi, dpsi, weights, psi)
 
 
 # ---------------------------------------------------------------------------------------------- codim-1 (facets)
