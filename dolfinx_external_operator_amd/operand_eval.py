@@ -47,7 +47,7 @@ class DeviceMesh:
     """Element tables, dofmaps and coordinates resident on the GPU (uploaded once)."""
 
     def __init__(self, *, gdim: int, phi, dphi, dpsi, dofmap, geom_dofmap, x, num_field_nodes: int | None = None,
-                 ctx: Context | None = None, device: int = 0):
+                 ctx: Context | None = None, device: int = 0, psi=None):
         self.ctx = ctx if ctx is not None else default_context(device)
         phi = np.ascontiguousarray(phi, dtype=np.float64)
         dphi = np.ascontiguousarray(dphi, dtype=np.float64)
@@ -69,6 +69,8 @@ class DeviceMesh:
         h = C.c_void_p()
         self.ctx.check(self.ctx.lib.dxo_mesh_create(self.ctx._h, C.byref(d), C.byref(h)), "dxo_mesh_create")
         self._h = h
+        if psi is not None:     # values of the coordinate element at the points: the operand `x` (set_coordinate_values)
+            self.set_coordinate_values(psi)
 
     @classmethod
     def from_synthetic(cls, mesh, **kw):
@@ -108,7 +110,7 @@ class DeviceMesh:
         n_nodes = V.dofmap.index_map.size_local + V.dofmap.index_map.num_ghosts
         return dict(gdim=gdim, phi=tab[0, :, :, 0], dphi=np.moveaxis(tab[1:, :, :, 0], 0, 2),
                     dpsi=np.moveaxis(ctab[1:, :, :, 0], 0, 2), dofmap=V.dofmap.list, geom_dofmap=mesh.geometry.dofmap,
-                    x=mesh.geometry.x, num_field_nodes=n_nodes)
+                    x=mesh.geometry.x, num_field_nodes=n_nodes, psi=ctab[0, :, :, 0])
 
     @classmethod
     def from_dolfinx(cls, V, quadrature_points, **kw):

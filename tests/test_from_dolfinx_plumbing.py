@@ -68,6 +68,7 @@ def test_tables_from_dolfinx_match_the_synthetic_tables(fake_basix, cell, n):
     np.testing.assert_array_equal(kw["phi"], m.phi)
     np.testing.assert_array_equal(kw["dphi"], m.dphi)                              # (nq, ndofs, gdim)
     np.testing.assert_array_equal(kw["dpsi"], m.dpsi)                              # degree-1 coordinate element from cmap
+    np.testing.assert_array_equal(kw["psi"], m.psi)                                # its values: the operand `x` (SpatialCoordinate)
     assert fake_basix.calls == [("P", cell, 1, 2)]
     assert kw["x"].shape[1] == 3 and kw["dofmap"] is m.dofmap and kw["geom_dofmap"] is m.geom_dofmap
 
@@ -87,3 +88,5 @@ def test_from_dolfinx_evaluates_like_from_synthetic(fake_basix, ctx, cell, n):
     a = DeviceMesh.from_dolfinx(_space(m), m.points, ctx=ctx).evaluate("eps", m.gdim, u)
     b = DeviceMesh.from_synthetic(m, ctx=ctx).evaluate("eps", m.gdim, u)
     np.testing.assert_array_equal(a, b)                                            # 3-column coordinates, same kernel
+    xa = DeviceMesh.from_dolfinx(_space(m), m.points, ctx=ctx).coordinate()
+    np.testing.assert_allclose(xa, m.physical_points(), rtol=1e-14, atol=1e-16)    # x = SpatialCoordinate from the cmap's values
